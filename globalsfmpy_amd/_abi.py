@@ -1,0 +1,158 @@
+"""ctypes mirror of include/gsfm_rot.h (the C-ABI drop-in boundary).
+
+The shared library is the product: if libgsfm_rot.so is missing or does not load,
+importing the solver fails loudly -- there is no CPU fallback.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgsfm_rot.so")
+
+# gsfm_status
+OK, ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_EMPTY, ERR_COMM, ERR_UNSUPPORTED = range(7)
+
+# gsfm_rot_error_type == RotationErrorType (reference include/pairwise_rotation_error_quat.hpp:50-61)
+QUATERNION_NORM = 0
+ROTATION_MAT_FNORM = 1
+QUATERNION_COSINE = 2
+ANGLE_AXIS_COVARIANCE = 3
+ANGLE_AXIS = 4
+ANGLE_AXIS_INLIERS = 5
+ANGLE_AXIS_COV_INLIERS = 6
+ANGLE_AXIS_COVTRACE = 7
+ANGLE_AXIS_COVNORM = 8
+
+# gsfm_loss_kind
+LOSS_TRIVIAL, LOSS_HUBER, LOSS_SOFT_L1, LOSS_CAUCHY, LOSS_ARCTAN, LOSS_TOLERANT, LOSS_TUKEY, \
+    LOSS_LONE_HALF, LOSS_LTWO, LOSS_GEMAN_MCCLURE, LOSS_MAGSAC = range(11)
+LOSS_OP_SCALE, LOSS_OP_PUSH_ARG, LOSS_OP_COMPOSE = 32, 33, 34
+LOSS_MAX_NODES = 16
+
+TERMINATION_NAMES = ["FUNCTION_TOLERANCE", "GRADIENT_TOLERANCE", "PARAMETER_TOLERANCE", "NO_CONVERGENCE", "FAILURE"]
+
+
+class LossNode(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("reserved", C.c_int32), ("p", C.c_double * 3)]
+
+
+class Options(C.Structure):
+    _fields_ = [
+        ("max_num_iterations", C.c_int32), ("num_threads", C.c_int32),
+        ("function_tolerance", C.c_double), ("gradient_tolerance", C.c_double),
+        ("parameter_tolerance", C.c_double), ("initial_trust_region_radius", C.c_double),
+        ("max_trust_region_radius", C.c_double), ("min_trust_region_radius", C.c_double),
+        ("min_relative_decrease", C.c_double), ("min_lm_diagonal", C.c_double),
+        ("max_lm_diagonal", C.c_double), ("jacobi_scaling", C.c_int32),
+        ("max_cg_iterations", C.c_int32), ("cg_relative_tolerance", C.c_double),
+        ("cg_check_interval", C.c_int32), ("verbose", C.c_int32),
+    ]
+
+
+class Summary(C.Structure):
+    _fields_ = [
+        ("termination", C.c_int32), ("num_iterations", C.c_int32),
+        ("num_successful_steps", C.c_int32), ("num_unsuccessful_steps", C.c_int32),
+        ("num_residual_sweeps", C.c_int32), ("num_linearizations", C.c_int32),
+        ("num_cg_iterations", C.c_int32), ("iters_to_1e6", C.c_int32),
+        ("nonfinite", C.c_int32), ("outer_iterations", C.c_int32),
+        ("num_edges_used", C.c_uint64),
+        ("initial_cost", C.c_double), ("final_cost", C.c_double),
+        ("final_gradient_max_norm", C.c_double), ("final_radius", C.c_double),
+        ("last_weight_change", C.c_double),
+        ("t_total_ms", C.c_double), ("t_linearize_ms", C.c_double),
+        ("t_sweep_ms", C.c_double), ("t_cg_ms", C.c_double),
+    ]
+
+    def as_dict(self):
+        d = {name: getattr(self, name) for name, _ in self._fields_}
+        d["termination_name"] = TERMINATION_NAMES[self.termination] if 0 <= self.termination < 5 else "?"
+        return d
+
+
+ALL_GATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+ALL_REDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+LOSS_CALLBACK_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_double, C.POINTER(C.c_double))
+
+
+class Shard(C.Structure):
+    _fields_ = [
+        ("rank", C.c_int32), ("world_size", C.c_int32),
+        ("slice_width", C.c_uint32), ("reserved", C.c_uint32),
+        ("ctx", C.c_void_p), ("all_gather", ALL_GATHER_FN), ("all_reduce_sum", ALL_REDUCE_FN),
+    ]
+
+
+def make_program(nodes):
+    """nodes: list of (kind, p0, p1, p2) -> (LossNode array, n)."""
+    n = len(nodes)
+    if n > LOSS_MAX_NODES:
+        raise ValueError("loss program too long (%d > %d nodes)" % (n, LOSS_MAX_NODES))
+    arr = (LossNode * max(n, 1))()
+    for k, nd in enumerate(nodes):
+        arr[k].kind = int(nd[0])
+        arr[k].reserved = 0
+        ps = list(nd[1:]) + [0.0] * (3 - len(nd[1:]))
+        for c in range(3):
+            arr[k].p[c] = float(ps[c])
+    return arr, n
+
+
+_DP = C.POINTER(C.c_double)
+_U32P = C.POINTER(C.c_uint32)
+
+
+def declare_solver_signatures(lib, prefix, problem_ptr=C.c_void_p):
+    """Shared by the product library (prefix 'gsfm_rot_') and the oracle (prefix 'orc_'):
+    the oracle deliberately mirrors the product's argument lists."""
+    f = getattr(lib, prefix + "set_loss")
+    f.argtypes = [problem_ptr, C.POINTER(LossNode), C.c_int32]; f.restype = C.c_int
+    f = getattr(lib, prefix + "set_loss_callback")
+    f.argtypes = [problem_ptr, LOSS_CALLBACK_FN, C.c_void_p]; f.restype = C.c_int
+    f = getattr(lib, prefix + "set_edge_weights")
+    f.argtypes = [problem_ptr, _DP]; f.restype = C.c_int
+    f = getattr(lib, prefix + "residuals")
+    f.argtypes = [problem_ptr, _DP, _DP, _DP, _DP, _DP]; f.restype = C.c_int
+    f = getattr(lib, prefix + "linearize")
+    f.argtypes = [problem_ptr, _DP, _DP, _DP, _DP]; f.restype = C.c_int
+    f = getattr(lib, prefix + "normal_matvec")
+    f.argtypes = [problem_ptr, _DP, _DP]; f.restype = C.c_int
+    f = getattr(lib, prefix + "solve")
+    f.argtypes = [problem_ptr, _DP, C.POINTER(Options), C.POINTER(Summary)]; f.restype = C.c_int
+    f = getattr(lib, prefix + "solve_sigma_consensus")
+    f.argtypes = [problem_ptr, _DP, C.c_int32, C.c_double, C.POINTER(Options), C.POINTER(Summary)]; f.restype = C.c_int
+    f = getattr(lib, prefix + "get_trace")
+    f.argtypes = [problem_ptr, _DP, C.c_int32]; f.restype = C.c_int32
+    f = getattr(lib, prefix + "problem_destroy")
+    f.argtypes = [problem_ptr]; f.restype = None
+
+
+_lib = None
+
+
+def load_library():
+    """Load libgsfm_rot.so (built by __graft_entry__.build()). Fails loudly."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "globalsfmpy_amd: %s not found. The HIP extension is the product and has no CPU fallback; "
+            "build it with `python -c 'import __graft_entry__ as g; g.build()'`." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    if lib.gsfm_rot_abi_version() != 1:
+        raise ImportError("globalsfmpy_amd: ABI version mismatch in %s" % LIB_PATH)
+    lib.gsfm_last_error.restype = C.c_char_p
+    lib.gsfm_rot_options_default.argtypes = [C.POINTER(Options)]
+    lib.gsfm_rot_problem_create.argtypes = [C.c_uint32, C.c_uint64, _U32P, _U32P, _DP, C.c_int32, _DP, _DP,
+                                            C.POINTER(Shard), C.POINTER(C.c_void_p)]
+    lib.gsfm_rot_problem_create.restype = C.c_int
+    declare_solver_signatures(lib, "gsfm_rot_")
+    lib.gsfm_rot_set_stream.argtypes = [C.c_void_p, C.c_void_p]; lib.gsfm_rot_set_stream.restype = C.c_int
+    lib.gsfm_rot_residual_dim.argtypes = [C.c_int32]; lib.gsfm_rot_residual_dim.restype = C.c_int32
+    lib.gsfm_rot_time_sweep.argtypes = [C.c_void_p, _DP, C.c_int32, _DP]; lib.gsfm_rot_time_sweep.restype = C.c_int
+    lib.gsfm_rot_sweep_bytes.argtypes = [C.c_void_p, _DP, _DP]; lib.gsfm_rot_sweep_bytes.restype = C.c_int
+    lib.gsfm_magsac_table.argtypes = [C.c_int32, _DP, C.c_int32]; lib.gsfm_magsac_table.restype = C.c_int32
+    lib.gsfm_magsac_constants.argtypes = [C.c_int32, _DP, _DP, _DP]; lib.gsfm_magsac_constants.restype = C.c_int
+    _lib = lib
+    return lib

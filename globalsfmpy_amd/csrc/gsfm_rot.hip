@@ -1,0 +1,917 @@
+// C-ABI implementation (include/gsfm_rot.h): problem assembly, Levenberg-Marquardt control with
+// Ceres 1.14 trust-region semantics, block-Jacobi PCG orchestration.  All arithmetic on the edges
+// and cameras runs in the kernels of kernels.hpp; the host only sequences launches and reads a
+// handful of scalars per LM iteration.  Built with hipcc --offload-arch=gfx950 into libgsfm_rot.so.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+#include "../../include/gsfm_rot.h"
+#include "kernels.hpp"
+
+using namespace gsfm;
+
+namespace {
+
+thread_local std::string g_err;
+int fail(gsfm_status st, const std::string& msg) { g_err = msg; return st; }
+
+#define HIPCHK(expr)                                                                              \
+  do {                                                                                            \
+    hipError_t _e = (expr);                                                                       \
+    if (_e != hipSuccess) {                                                                       \
+      return fail(GSFM_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));               \
+    }                                                                                             \
+  } while (0)
+
+double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// ---- MAGSAC constants / tables (include/gamma_values.cpp; regenerated, see oracle/ref_loss.hpp) ----
+struct MagsacConst { double nu, C, q, gk; int n; };
+MagsacConst magsac_const(int nu) {
+  switch (nu) {
+    case 3: return {3.0, 4.029720004054876e-01, 3.368214175218727, 3.439485560754856e-03, 36843};
+    case 4: return {4.0, 2.525252525252525e-01, 3.643721193503644e+00, 3.611260617758625e-03, 38683};
+    default: return {9.0, 3.837828575290349e-03, 4.654674460524809e+00, 3.344206155099048e-02, 48553};
+  }
+}
+double upper_gamma_closed_form(int nu, double x) {
+  if (nu == 3) return std::exp(-x);
+  if (nu == 4) return 0.5 * std::sqrt(M_PI) * std::erfc(std::sqrt(x)) + std::sqrt(x) * std::exp(-x);
+  return 6.0 * std::exp(-x) * (1.0 + x + x * x / 2.0 + x * x * x / 6.0);
+}
+std::vector<double> make_magsac_table(int nu) {
+  const MagsacConst c = magsac_const(nu);
+  std::vector<double> t(c.n);
+  for (int x = 0; x < c.n; ++x) t[x] = upper_gamma_closed_form(nu, x / 1000.0);
+  return t;
+}
+const std::vector<double>& magsac_table(int nu) {
+  static const std::vector<double> t3 = make_magsac_table(3);
+  static const std::vector<double> t4 = make_magsac_table(4);
+  static const std::vector<double> t9 = make_magsac_table(9);
+  return (nu == 3) ? t3 : (nu == 4) ? t4 : t9;
+}
+
+template <typename T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  hipError_t alloc(size_t count, bool zero = false) {
+    release();
+    n = count;
+    if (count == 0) return hipSuccess;
+    hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
+    if (e != hipSuccess) { p = nullptr; return e; }
+    if (zero) { e = hipMemset(p, 0, count * sizeof(T)); if (e == hipSuccess) e = hipDeviceSynchronize(); }
+    return e;
+  }
+  hipError_t upload(const std::vector<T>& h) {
+    hipError_t e = alloc(h.size());
+    if (e != hipSuccess || h.empty()) return e;
+    return hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice);
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+  ~DevBuf() { release(); }
+};
+
+// one set of per-edge planes (cost edges or directed entries)
+struct EdgePlanes {
+  size_t n = 0;
+  DevBuf<uint32_t> eid;
+  DevBuf<double2> qr0, qr1, w0, w1, w2;
+  DevBuf<double> ws;
+};
+
+inline int grid_for(size_t n) { return (int)((n + GSFM_BLOCK - 1) / GSFM_BLOCK); }
+
+struct EventTimer {  // GPU time per phase, resolved at host syncs
+  static constexpr int NPAIR = 96;
+  hipEvent_t ev[2 * NPAIR];
+  int cat[NPAIR];
+  int used = 0;
+  bool ok = false;
+  double acc[3] = {0, 0, 0};
+  hipStream_t stream = nullptr;
+  void init() { ok = true; for (int k = 0; k < 2 * NPAIR; ++k) if (hipEventCreate(&ev[k]) != hipSuccess) ok = false; }
+  void destroy() { if (ok) for (int k = 0; k < 2 * NPAIR; ++k) (void)hipEventDestroy(ev[k]); ok = false; }
+  int begin(int category) {
+    if (!ok) return -1;
+    if (used == NPAIR) { (void)hipStreamSynchronize(stream); resolve(); }
+    const int k = used++;
+    cat[k] = category;
+    (void)hipEventRecord(ev[2 * k], stream);
+    return k;
+  }
+  void end(int k) { if (k >= 0) (void)hipEventRecord(ev[2 * k + 1], stream); }
+  void resolve() {  // only after a stream sync
+    for (int k = 0; k < used; ++k) { float ms = 0; if (hipEventElapsedTime(&ms, ev[2 * k], ev[2 * k + 1]) == hipSuccess) acc[cat[k]] += ms; }
+    used = 0;
+  }
+};
+
+}  // namespace
+
+struct gsfm_rot_problem {
+  uint32_t n_cams = 0;
+  uint64_t n_edges_in = 0;
+  int error_type = 0, functor = F_AA, wmode = W_NONE, param_dim = 3, res_dim = 3;
+  bool sharded = false;
+  gsfm_rot_shard shard{};
+  uint32_t own_begin = 0, own_end = 0, n_rows = 0, n_pad = 0;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+
+  EdgePlanes cost;            // cost-owned edges
+  DevBuf<uint2> cost_idx;
+  EdgePlanes dir;             // directed entries (rows = owned cameras)
+  DevBuf<uint32_t> row_ptr, col;
+  uint32_t G = 16;
+  DevBuf<double2> h0, h1, h2, h3;
+  DevBuf<double> h4;
+  std::vector<uint32_t> h_cost_eid;  // host copies for weight re-upload
+
+  // cameras
+  DevBuf<double> x, x_trial, aa_io, active, scale, gD, Mblk, Minv, Lam, Tinv, b, D6;
+  DevBuf<double2> q, q_trial;
+  DevBuf<double> xcg, r, z, p, Ap;
+  DevBuf<double> part_a, part_b, part_cost, part_cam, scal;
+  DevBuf<CgScalars> cgsc;
+  int nb_cam = 1, nb_cost = 1;
+
+  // loss
+  DevLoss h_loss{};
+  DevBuf<DevLoss> d_loss;
+  DevBuf<double> tables[3];
+  gsfm_loss_callback cb = nullptr;
+  void* cb_user = nullptr;
+  DevBuf<double> rho_ext, s_ext, w_orig;
+  std::vector<double> h_s, h_rho;
+
+  bool have_lin = false;
+  std::vector<double> trace;
+  EventTimer timer;
+};
+
+namespace {
+
+// ---- kernel dispatch on (functor, whitening mode) -----------------------------------------
+template <typename ArgsT, template <int, int> class Launcher>
+int dispatch(const gsfm_rot_problem* P, const ArgsT& args, int grid) {
+  const int f = P->functor, w = P->wmode;
+#define GSFM_CASE(F, W) if (f == F && w == W) { Launcher<F, W>::go(args, grid, P->stream); return 0; }
+  GSFM_CASE(F_AA, W_NONE) GSFM_CASE(F_AA, W_SCALAR) GSFM_CASE(F_AA, W_MATRIX)
+  GSFM_CASE(F_QCOS, W_NONE) GSFM_CASE(F_QNORM, W_NONE) GSFM_CASE(F_RFNORM, W_NONE)
+#undef GSFM_CASE
+  return 1;
+}
+template <int F, int W> struct CostLauncher { static void go(const CostArgs& a, int grid, hipStream_t s) { hipLaunchKernelGGL((k_cost<F, W>), dim3(grid), dim3(GSFM_BLOCK), 0, s, a); } };
+template <int F, int W> struct LinLauncher { static void go(const LinArgs& a, int grid, hipStream_t s) { hipLaunchKernelGGL((k_lin<F, W>), dim3(grid), dim3(GSFM_BLOCK), 0, s, a); } };
+
+int sync_check(gsfm_rot_problem* P, const char* what) {
+  hipError_t e = hipStreamSynchronize(P->stream);
+  if (e != hipSuccess) return fail(GSFM_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+  e = hipGetLastError();
+  if (e != hipSuccess) return fail(GSFM_ERR_HIP, std::string(what) + " (launch): " + hipGetErrorString(e));
+  P->timer.resolve();
+  return 0;
+}
+
+// ---- loss preparation ---------------------------------------------------------------------
+int prepare_loss(gsfm_rot_problem* P, const gsfm_loss_node* prog, int n) {
+  if (n < 0 || n > GSFM_LOSS_MAX_NODES) return fail(GSFM_ERR_INVALID_ARG, "loss program length out of range");
+  DevLoss L;
+  std::memset(&L, 0, sizeof(L));
+  L.n = n;
+  int nr = 0, na = 1;
+  for (int k = 0; k < n; ++k) {
+    const gsfm_loss_node& s = prog[k];
+    DevLossNode& d = L.nodes[k];
+    d.kind = s.kind; d.p[0] = s.p[0]; d.p[1] = s.p[1]; d.p[2] = s.p[2];
+    switch (s.kind) {
+      case GSFM_LOSS_OP_SCALE: if (nr < 1) return fail(GSFM_ERR_INVALID_ARG, "loss program: SCALE on empty stack"); break;
+      case GSFM_LOSS_OP_PUSH_ARG:
+        if (nr < 1 || na >= GSFM_LOSS_MAX_STACK) return fail(GSFM_ERR_INVALID_ARG, "loss program: bad PUSH_ARG");
+        ++na; break;
+      case GSFM_LOSS_OP_COMPOSE:
+        if (nr < 2 || na < 2) return fail(GSFM_ERR_INVALID_ARG, "loss program: bad COMPOSE");
+        --nr; --na; break;
+      case GSFM_LOSS_TRIVIAL: case GSFM_LOSS_HUBER: case GSFM_LOSS_SOFT_L1: case GSFM_LOSS_CAUCHY: case GSFM_LOSS_ARCTAN:
+      case GSFM_LOSS_TUKEY: case GSFM_LOSS_LONE_HALF: case GSFM_LOSS_LTWO: case GSFM_LOSS_GEMAN_MCCLURE:
+        if (nr >= GSFM_LOSS_MAX_STACK) return fail(GSFM_ERR_INVALID_ARG, "loss program: stack overflow");
+        ++nr; break;
+      case GSFM_LOSS_TOLERANT:
+        if (!(s.p[0] >= 0) || !(s.p[1] > 0)) return fail(GSFM_ERR_INVALID_ARG, "TolerantLoss needs a >= 0, b > 0");
+        if (nr >= GSFM_LOSS_MAX_STACK) return fail(GSFM_ERR_INVALID_ARG, "loss program: stack overflow");
+        d.p[2] = s.p[1] * std::log(1 + std::exp(-s.p[0] / s.p[1]));  // c (loss_functions.py:147)
+        ++nr; break;
+      case GSFM_LOSS_MAGSAC: {
+        const int nu = (int)s.p[1];
+        if (nu != 3 && nu != 4 && nu != 9) return fail(GSFM_ERR_INVALID_ARG, "MAGSAC loss: nu must be 3, 4 or 9");
+        if (nr >= GSFM_LOSS_MAX_STACK) return fail(GSFM_ERR_INVALID_ARG, "loss program: stack overflow");
+        const MagsacConst c = magsac_const(nu);
+        const double sigma = s.p[0];
+        // loss_functions.py:286-298 (constructor constants)
+        const double squared_sigma = sigma * sigma;
+        const double dof_minus_one_per_two = (c.nu - 1.0) / 2.0;
+        const double C_times_two_ad_dof = c.C * std::pow(2.0, dof_minus_one_per_two);
+        const double one_over_sigma = C_times_two_ad_dof / sigma;
+        const double gamma_difference = std::tgamma(dof_minus_one_per_two) - c.gk;
+        d.nu = nu; d.inverse = s.p[2] != 0.0;
+        d.aux[0] = squared_sigma; d.aux[1] = 2.0 * squared_sigma; d.aux[2] = squared_sigma * sigma;
+        d.aux[3] = C_times_two_ad_dof; d.aux[4] = one_over_sigma; d.aux[5] = one_over_sigma * gamma_difference;
+        d.aux[6] = c.q * c.q * squared_sigma; d.aux[7] = c.gk;
+        const int ti = nu == 3 ? 0 : nu == 4 ? 1 : 2;
+        if (!P->tables[ti].p) {
+          if (P->tables[ti].upload(magsac_table(nu)) != hipSuccess) return fail(GSFM_ERR_HIP, "uploading MAGSAC table failed");
+        }
+        d.table = P->tables[ti].p; d.table_len = c.n;
+        ++nr; break; }
+      default: return fail(GSFM_ERR_INVALID_ARG, "loss program: unknown node kind");
+    }
+  }
+  if (n > 0 && (nr != 1 || na != 1)) return fail(GSFM_ERR_INVALID_ARG, "loss program does not reduce to one value");
+  P->h_loss = L;
+  if (!P->d_loss.p && P->d_loss.alloc(1) != hipSuccess) return fail(GSFM_ERR_HIP, "alloc loss");
+  HIPCHK(hipMemcpy(P->d_loss.p, &P->h_loss, sizeof(DevLoss), hipMemcpyHostToDevice));
+  return 0;
+}
+
+// ---- collectives --------------------------------------------------------------------------
+int all_gather(gsfm_rot_problem* P, double* buf, size_t count_per_rank) {
+  if (!P->sharded) return 0;
+  if (P->shard.all_gather(P->shard.ctx, buf, count_per_rank, (void*)P->stream) != 0) return fail(GSFM_ERR_COMM, "all_gather callback failed");
+  return 0;
+}
+int all_reduce(gsfm_rot_problem* P, double* buf, size_t count) {
+  if (!P->sharded) return 0;
+  if (P->shard.all_reduce_sum(P->shard.ctx, buf, count, (void*)P->stream) != 0) return fail(GSFM_ERR_COMM, "all_reduce callback failed");
+  return 0;
+}
+
+// ---- launches -----------------------------------------------------------------------------
+enum { SC_COST = 0, SC_GMAX = 1, SC_STEP = 2 /* ..6 */, SC_XNORM2 = 7, SC_TRIAL = 8, SC_N = 16 };
+enum { T_LIN = 0, T_SWEEP = 1, T_CG = 2 };
+
+void launch_cache(gsfm_rot_problem* P, const double* x, double2* q) {
+  hipLaunchKernelGGL(k_cam_cache, dim3(grid_for(P->n_cams)), dim3(GSFM_BLOCK), 0, P->stream, x, P->n_cams, P->param_dim, q);
+}
+
+// host-callback loss: s per original edge -> host -> rho triples -> device
+int refresh_external_rho(gsfm_rot_problem* P, const double2* q) {
+  CostArgs a{};
+  a.n = P->cost.n; a.idx = P->cost_idx.p; a.qr0 = P->cost.qr0.p; a.qr1 = P->cost.qr1.p;
+  a.w0 = P->cost.w0.p; a.w1 = P->cost.w1.p; a.w2 = P->cost.w2.p; a.ws = P->cost.ws.p;
+  a.q = q; a.loss = P->d_loss.p; a.eid = P->cost.eid.p; a.partials = P->part_cost.p; a.s_out = P->s_ext.p; a.s_only = 1;
+  if (dispatch<CostArgs, CostLauncher>(P, a, P->nb_cost)) return fail(GSFM_ERR_UNSUPPORTED, "no kernel for this error type");
+  const size_t E = P->n_edges_in;
+  P->h_s.resize(E); P->h_rho.resize(3 * E);
+  HIPCHK(hipMemcpyAsync(P->h_s.data(), P->s_ext.p, 8 * E, hipMemcpyDeviceToHost, P->stream));
+  if (int st = sync_check(P, "callback loss: read s")) return st;
+  for (size_t e = 0; e < E; ++e) P->cb(P->cb_user, P->h_s[e], &P->h_rho[3 * e]);
+  HIPCHK(hipMemcpyAsync(P->rho_ext.p, P->h_rho.data(), 24 * E, hipMemcpyHostToDevice, P->stream));
+  return 0;
+}
+
+// K1: cost at quaternion cache q -> scal[slot] (all-reduced when sharded)
+int launch_cost(gsfm_rot_problem* P, const double2* q, int slot, double* s_out = nullptr, double* rho_out = nullptr, double* r_out = nullptr) {
+  if (P->cb) { if (int st = refresh_external_rho(P, q)) return st; }
+  CostArgs a{};
+  a.n = P->cost.n; a.idx = P->cost_idx.p; a.qr0 = P->cost.qr0.p; a.qr1 = P->cost.qr1.p;
+  a.w0 = P->cost.w0.p; a.w1 = P->cost.w1.p; a.w2 = P->cost.w2.p; a.ws = P->cost.ws.p;
+  a.q = q; a.loss = P->d_loss.p; a.rho_ext = P->cb ? P->rho_ext.p : nullptr; a.eid = P->cost.eid.p;
+  a.partials = P->part_cost.p; a.s_out = s_out; a.rho_out = rho_out; a.r_out = r_out; a.s_only = 0;
+  const int tk = P->timer.begin(T_SWEEP);
+  if (dispatch<CostArgs, CostLauncher>(P, a, P->nb_cost)) return fail(GSFM_ERR_UNSUPPORTED, "no kernel for this error type");
+  P->timer.end(tk);
+  hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(GSFM_BLOCK), 0, P->stream, P->part_cost.p, P->nb_cost, P->scal.p + slot);
+  return all_reduce(P, P->scal.p + slot, 1);
+}
+
+// K2: linearise at q -> gD (all-gathered), H blocks
+int launch_lin(gsfm_rot_problem* P, const double2* q) {
+  if (P->cb) { if (int st = refresh_external_rho(P, q)) return st; }
+  LinArgs a{};
+  a.n_rows = P->n_rows; a.row_base = P->own_begin; a.G = P->G; a.row_ptr = P->row_ptr.p; a.col = P->col.p; a.eid = P->dir.eid.p;
+  a.qr0 = P->dir.qr0.p; a.qr1 = P->dir.qr1.p; a.w0 = P->dir.w0.p; a.w1 = P->dir.w1.p; a.w2 = P->dir.w2.p; a.ws = P->dir.ws.p;
+  a.q = q; a.loss = P->d_loss.p; a.rho_ext = P->cb ? P->rho_ext.p : nullptr;
+  a.h0 = P->h0.p; a.h1 = P->h1.p; a.h2 = P->h2.p; a.h3 = P->h3.p; a.h4 = P->h4.p; a.gD = P->gD.p;
+  const int tk = P->timer.begin(T_LIN);
+  if (dispatch<LinArgs, LinLauncher>(P, a, grid_for((size_t)P->n_rows * P->G))) return fail(GSFM_ERR_UNSUPPORTED, "no kernel for this error type");
+  P->timer.end(tk);
+  P->have_lin = true;
+  return all_gather(P, P->gD.p, (size_t)P->shard.slice_width * 9);
+}
+
+void launch_prep(gsfm_rot_problem* P, const gsfm_rot_options& o, double radius, bool init_scale) {
+  PrepArgs a{};
+  a.n = P->n_cams; a.param_dim = P->param_dim; a.x = P->x.p; a.gD = P->gD.p; a.scale = P->scale.p;
+  a.init_scale = init_scale; a.jacobi_scaling = o.jacobi_scaling; a.radius = radius; a.min_diag = o.min_lm_diagonal; a.max_diag = o.max_lm_diagonal;
+  a.Mblk = P->Mblk.p; a.Minv = P->Minv.p; a.Lam = P->Lam.p; a.Tinv = P->Tinv.p; a.b = P->b.p; a.gmax_partials = P->part_cam.p;
+  hipLaunchKernelGGL(k_cam_prep, dim3(P->nb_cam), dim3(GSFM_BLOCK), 0, P->stream, a);
+  hipLaunchKernelGGL(k_max_partials, dim3(1), dim3(GSFM_BLOCK), 0, P->stream, P->part_cam.p, P->nb_cam, P->scal.p + SC_GMAX);
+}
+
+int launch_matvec(gsfm_rot_problem* P, const double* Mblk, const double* p, double* y, const int* done) {
+  MatvecArgs a{};
+  a.n_rows = P->n_rows; a.row_base = P->own_begin; a.G = P->G; a.row_ptr = P->row_ptr.p; a.col = P->col.p;
+  a.h0 = P->h0.p; a.h1 = P->h1.p; a.h2 = P->h2.p; a.h3 = P->h3.p; a.h4 = P->h4.p; a.Mblk = Mblk; a.p = p; a.y = y; a.done = done;
+  hipLaunchKernelGGL(k_matvec, dim3(grid_for((size_t)P->n_rows * P->G)), dim3(GSFM_BLOCK), 0, P->stream, a);
+  return all_gather(P, y, (size_t)P->shard.slice_width * 3);
+}
+
+// block-Jacobi PCG on (J^T J + Lambda) eta = -g; returns iterations
+int run_pcg(gsfm_rot_problem* P, const gsfm_rot_options& o, int* iters_out, double* rel_out) {
+  CgArgs a{};
+  a.n = P->n_cams; a.nb = P->nb_cam; a.par = 0; a.tol = o.cg_relative_tolerance; a.max_iters = o.max_cg_iterations;
+  a.Minv = P->Minv.p; a.b = P->b.p; a.xcg = P->xcg.p; a.r = P->r.p; a.z = P->z.p; a.p = P->p.p; a.Ap = P->Ap.p;
+  a.part_a = P->part_a.p; a.part_b = P->part_b.p; a.sc = P->cgsc.p;
+  const dim3 g(P->nb_cam), blk(GSFM_BLOCK);
+  const int tk0 = P->timer.begin(T_CG);
+  hipLaunchKernelGGL(k_cg_init, g, blk, 0, P->stream, a);
+  hipLaunchKernelGGL(k_cg_init_fin, dim3(1), blk, 0, P->stream, a);
+  P->timer.end(tk0);
+  CgScalars h{};
+  const int chunk = std::max(1, o.cg_check_interval);
+  int launched = 0;
+  while (true) {
+    const int tk = P->timer.begin(T_CG);
+    for (int c = 0; c < chunk; ++c) {
+      if (int st = launch_matvec(P, P->Mblk.p, P->p.p, P->Ap.p, &P->cgsc.p->done)) return st;
+      hipLaunchKernelGGL(k_cg_dot, g, blk, 0, P->stream, a);
+      hipLaunchKernelGGL(k_cg_update, g, blk, 0, P->stream, a);
+      hipLaunchKernelGGL(k_cg_pupdate, g, blk, 0, P->stream, a);
+      a.par ^= 1;
+      ++launched;
+    }
+    P->timer.end(tk);
+    HIPCHK(hipMemcpyAsync(&h, P->cgsc.p, sizeof(h), hipMemcpyDeviceToHost, P->stream));
+    if (int st = sync_check(P, "pcg")) return st;
+    if (h.done || launched >= o.max_cg_iterations + chunk) break;
+  }
+  *iters_out = h.iters; *rel_out = h.last_rel;
+  return 0;
+}
+
+int launch_step(gsfm_rot_problem* P) {
+  StepArgs a{};
+  a.n = P->n_cams; a.param_dim = P->param_dim; a.x = P->x.p; a.active = P->active.p; a.eta = P->xcg.p; a.b = P->b.p; a.rcg = P->r.p;
+  a.Lam = P->Lam.p; a.Tinv = P->Tinv.p; a.x_trial = P->x_trial.p; a.q_trial = P->q_trial.p; a.partials = P->part_cam.p;
+  hipLaunchKernelGGL(k_cam_step, dim3(P->nb_cam), dim3(GSFM_BLOCK), 0, P->stream, a);
+  hipLaunchKernelGGL(k_sum_partials_multi, dim3(1), dim3(GSFM_BLOCK), 0, P->stream, P->part_cam.p, P->nb_cam, 5, P->scal.p + SC_STEP);
+  return 0;
+}
+
+int read_scalars(gsfm_rot_problem* P, double* h) {
+  HIPCHK(hipMemcpyAsync(h, P->scal.p, SC_N * sizeof(double), hipMemcpyDeviceToHost, P->stream));
+  return sync_check(P, "read scalars");
+}
+
+int upload_state(gsfm_rot_problem* P, const double* rot_aa) {
+  const size_t N = P->n_cams;
+  HIPCHK(hipMemcpyAsync(P->aa_io.p, rot_aa, 24 * N, hipMemcpyHostToDevice, P->stream));
+  if (P->param_dim == 3) { HIPCHK(hipMemcpyAsync(P->x.p, P->aa_io.p, 24 * N, hipMemcpyDeviceToDevice, P->stream)); }
+  else {  // estimator.cpp:130-136: angle-axis -> quaternion state
+    hipLaunchKernelGGL(k_cam_cache, dim3(grid_for(N)), dim3(GSFM_BLOCK), 0, P->stream, P->aa_io.p, P->n_cams, 3, (double2*)P->x.p);
+  }
+  launch_cache(P, P->x.p, P->q.p);
+  return 0;
+}
+int download_state(gsfm_rot_problem* P, double* rot_aa) {
+  const size_t N = P->n_cams;
+  if (P->param_dim == 3) { HIPCHK(hipMemcpyAsync(rot_aa, P->x.p, 24 * N, hipMemcpyDeviceToHost, P->stream)); }
+  else {
+    hipLaunchKernelGGL(k_quat_to_aa, dim3(grid_for(N)), dim3(GSFM_BLOCK), 0, P->stream, P->x.p, P->active.p, P->n_cams, P->aa_io.p);
+    HIPCHK(hipMemcpyAsync(rot_aa, P->aa_io.p, 24 * N, hipMemcpyDeviceToHost, P->stream));
+  }
+  return sync_check(P, "download rotations");
+}
+
+// ---- TrustRegionMinimizer::Minimize + LevenbergMarquardtStrategy (ceres 1.14 semantics) ----
+int lm_solve(gsfm_rot_problem* P, const gsfm_rot_options& o, gsfm_rot_summary* sum) {
+  const double t0 = now_ms();
+  std::memset(sum, 0, sizeof(*sum));
+  sum->iters_to_1e6 = -1;
+  sum->num_edges_used = P->cost.n;
+  P->trace.clear();
+  P->timer.acc[0] = P->timer.acc[1] = P->timer.acc[2] = 0;
+  double h[SC_N];
+  double radius = o.initial_trust_region_radius, decrease_factor = 2.0;
+  int num_invalid = 0, iteration = 0;
+  double x_cost = 0, x_norm = 0, gmax = 0;
+
+  auto record = [&](double cost, double dc, double sn, double rd, int cg) {
+    const double row[GSFM_ROT_TRACE_COLS] = {(double)iteration, cost, dc, gmax, sn, rd, radius, (double)cg};
+    P->trace.insert(P->trace.end(), row, row + GSFM_ROT_TRACE_COLS);
+    if (o.verbose) fprintf(stderr, "[gsfm] it %3d cost %.12e dcost %.3e |g| %.3e |dx| %.3e rho %.3e radius %.3e cg %d\n",
+                           iteration, cost, dc, gmax, sn, rd, radius, cg);
+  };
+  auto finish = [&](int term) {
+    sum->termination = term; sum->num_iterations = iteration; sum->final_cost = x_cost; sum->final_gradient_max_norm = gmax;
+    sum->final_radius = radius; sum->t_total_ms = now_ms() - t0;
+    sum->t_linearize_ms = P->timer.acc[T_LIN]; sum->t_sweep_ms = P->timer.acc[T_SWEEP]; sum->t_cg_ms = P->timer.acc[T_CG];
+    if (!std::isfinite(x_cost)) sum->nonfinite = 1;
+    return 0;
+  };
+
+  // Init + IterationZero
+  hipLaunchKernelGGL(k_cam_norm, dim3(P->nb_cam), dim3(GSFM_BLOCK), 0, P->stream, P->x.p, P->active.p, P->n_cams, P->param_dim, P->part_cam.p);
+  hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(GSFM_BLOCK), 0, P->stream, P->part_cam.p, P->nb_cam, P->scal.p + SC_XNORM2);
+  if (int st = launch_cost(P, P->q.p, SC_COST)) return st;
+  if (int st = launch_lin(P, P->q.p)) return st;
+  sum->num_residual_sweeps++; sum->num_linearizations++;
+  launch_prep(P, o, radius, true);
+  bool prep_valid = true;
+  if (int st = read_scalars(P, h)) return st;
+  x_cost = h[SC_COST]; gmax = h[SC_GMAX]; x_norm = std::sqrt(h[SC_XNORM2]);
+  sum->initial_cost = x_cost;
+  record(x_cost, 0, 0, 0, 0);
+  if (!std::isfinite(x_cost)) return finish(GSFM_TERM_FAILURE);
+  if (gmax <= o.gradient_tolerance) return finish(GSFM_TERM_GRADIENT_TOLERANCE);
+  bool last_successful = false;
+  while (true) {
+    if (iteration >= o.max_num_iterations) return finish(GSFM_TERM_NO_CONVERGENCE);
+    if (last_successful && gmax <= o.gradient_tolerance) return finish(GSFM_TERM_GRADIENT_TOLERANCE);
+    if (radius <= o.min_trust_region_radius) return finish(GSFM_TERM_FAILURE);
+    ++iteration;
+    last_successful = false;
+    if (!prep_valid) launch_prep(P, o, radius, false);
+    prep_valid = false;
+    int cg = 0; double cg_rel = 0;
+    if (int st = run_pcg(P, o, &cg, &cg_rel)) return st;
+    sum->num_cg_iterations += cg;
+    launch_step(P);
+    if (int st = launch_cost(P, P->q_trial.p, SC_TRIAL)) return st;
+    sum->num_residual_sweeps++;
+    if (int st = read_scalars(P, h)) return st;
+    // model_cost_change = -eta.g - 1/2 eta^T B eta with B eta = -g - r_cg - Lambda eta
+    const double eta_g = h[SC_STEP], eta_r = h[SC_STEP + 1], eta_L = h[SC_STEP + 2];
+    const double model_cost_change = -0.5 * eta_g + 0.5 * eta_r + 0.5 * eta_L;
+    const bool valid = std::isfinite(model_cost_change) && model_cost_change > 0.0;
+    if (!valid) {  // HandleInvalidStep
+      if (++num_invalid >= 5) return finish(GSFM_TERM_FAILURE);
+      radius /= decrease_factor; decrease_factor *= 2.0;
+      sum->num_unsuccessful_steps++;
+      record(x_cost, 0, 0, 0, cg);
+      continue;
+    }
+    num_invalid = 0;
+    double cand_cost = h[SC_TRIAL];
+    if (!std::isfinite(cand_cost)) { cand_cost = std::numeric_limits<double>::max(); sum->nonfinite = 1; }
+    const double step_norm = std::sqrt(h[SC_STEP + 3]);
+    const double cost_change = x_cost - cand_cost;
+    const double rel_dec = cost_change / model_cost_change;
+    if (sum->iters_to_1e6 < 0 && std::fabs(cost_change) <= 1e-6 * x_cost) sum->iters_to_1e6 = iteration;
+    if (step_norm <= o.parameter_tolerance * (x_norm + o.parameter_tolerance)) { record(x_cost, cost_change, step_norm, rel_dec, cg); return finish(GSFM_TERM_PARAMETER_TOLERANCE); }
+    if (std::fabs(cost_change) <= o.function_tolerance * x_cost) { record(x_cost, cost_change, step_norm, rel_dec, cg); return finish(GSFM_TERM_FUNCTION_TOLERANCE); }
+    if (rel_dec > o.min_relative_decrease) {  // HandleSuccessfulStep
+      std::swap(P->x.p, P->x_trial.p);
+      std::swap(P->q.p, P->q_trial.p);
+      x_norm = std::sqrt(h[SC_STEP + 4]);
+      x_cost = cand_cost;  // Ceres re-evaluates at the accepted point: same value
+      if (int st = launch_lin(P, P->q.p)) return st;
+      sum->num_residual_sweeps++; sum->num_linearizations++;
+      radius = radius / std::fmax(1.0 / 3.0, 1.0 - std::pow(2.0 * rel_dec - 1.0, 3));
+      radius = std::fmin(o.max_trust_region_radius, radius);
+      decrease_factor = 2.0;
+      launch_prep(P, o, radius, false);
+      prep_valid = true;
+      if (int st = read_scalars(P, h)) return st;
+      gmax = h[SC_GMAX];
+      sum->num_successful_steps++;
+      last_successful = true;
+    } else {  // HandleUnsuccessfulStep
+      radius /= decrease_factor; decrease_factor *= 2.0;
+      sum->num_unsuccessful_steps++;
+    }
+    record(x_cost, cost_change, step_norm, rel_dec, cg);
+  }
+}
+
+gsfm_rot_options default_options() { gsfm_rot_options o; gsfm_rot_options_default(&o); return o; }
+
+struct DeviceGuard {
+  int prev = -1;
+  explicit DeviceGuard(int dev) { if (hipGetDevice(&prev) == hipSuccess && prev != dev) (void)hipSetDevice(dev); else prev = -1; }
+  ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+int upload_planes(gsfm_rot_problem* P, EdgePlanes& pl, const std::vector<uint32_t>& eid, const double* rel_aa) {
+  pl.n = eid.size();
+  std::vector<double2> q0(pl.n), q1(pl.n);
+  for (size_t t = 0; t < pl.n; ++t) {
+    const double* aa = rel_aa + 3 * (size_t)eid[t];
+    // ceres::AngleAxisToQuaternion (estimator.cpp:132): measured R_ij as a unit quaternion
+    const double t2 = aa[0] * aa[0] + aa[1] * aa[1] + aa[2] * aa[2];
+    double w, k;
+    if (t2 > 0.0) { const double th = std::sqrt(t2); k = std::sin(0.5 * th) / th; w = std::cos(0.5 * th); }
+    else { k = 0.5; w = 1.0; }
+    q0[t] = make_double2(aa[0] * k, aa[1] * k); q1[t] = make_double2(aa[2] * k, w);
+  }
+  if (pl.eid.upload(eid) != hipSuccess || pl.qr0.upload(q0) != hipSuccess || pl.qr1.upload(q1) != hipSuccess)
+    return fail(GSFM_ERR_HIP, "uploading edge planes failed (out of memory?)");
+  if (P->wmode == W_MATRIX) {
+    if (pl.w0.alloc(pl.n) != hipSuccess || pl.w1.alloc(pl.n) != hipSuccess || pl.w2.alloc(pl.n) != hipSuccess) return fail(GSFM_ERR_HIP, "alloc whitening planes");
+  } else if (P->wmode == W_SCALAR) {
+    if (pl.ws.alloc(pl.n) != hipSuccess) return fail(GSFM_ERR_HIP, "alloc weight plane");
+  }
+  return 0;
+}
+void run_whiten(gsfm_rot_problem* P, EdgePlanes& pl, const double* d_cov6, const double* d_inl) {
+  if (P->wmode == W_NONE || pl.n == 0) return;
+  WhitenArgs a{};
+  a.cov6 = d_cov6; a.inl = d_inl; a.eid = pl.eid.p; a.n = pl.n; a.error_type = P->error_type;
+  a.w0 = pl.w0.p; a.w1 = pl.w1.p; a.w2 = pl.w2.p; a.ws = pl.ws.p;
+  hipLaunchKernelGGL(k_whiten, dim3(grid_for(pl.n)), dim3(GSFM_BLOCK), 0, P->stream, a);
+}
+
+}  // namespace
+
+// =============================================================================================
+extern "C" {
+
+int gsfm_rot_abi_version(void) { return GSFM_ROT_ABI_VERSION; }
+const char* gsfm_last_error(void) { return g_err.c_str(); }
+
+void gsfm_rot_options_default(gsfm_rot_options* o) {
+  std::memset(o, 0, sizeof(*o));
+  o->max_num_iterations = 200; o->num_threads = 1;
+  o->function_tolerance = 1e-6; o->gradient_tolerance = 1e-10; o->parameter_tolerance = 1e-8;
+  o->initial_trust_region_radius = 1e4; o->max_trust_region_radius = 1e16; o->min_trust_region_radius = 1e-32;
+  o->min_relative_decrease = 1e-3; o->min_lm_diagonal = 1e-6; o->max_lm_diagonal = 1e32;
+  o->jacobi_scaling = 1; o->max_cg_iterations = 1000; o->cg_relative_tolerance = 1e-12; o->cg_check_interval = 8; o->verbose = 0;
+}
+
+int32_t gsfm_rot_residual_dim(int32_t t) { return t == GSFM_ROT_QUATERNION_NORM ? 4 : t == GSFM_ROT_ROTATION_MAT_FNORM ? 9 : 3; }
+
+gsfm_status gsfm_rot_problem_create(uint32_t n_cams, uint64_t n_edges, const uint32_t* edge_i, const uint32_t* edge_j,
+                                    const double* rel_aa, int32_t error_type, const double* cov6, const double* inlier_weight,
+                                    const gsfm_rot_shard* shard, gsfm_rot_problem** out) {
+  if (!out) return (gsfm_status)fail(GSFM_ERR_INVALID_ARG, "out is NULL");
+  *out = nullptr;
+  if (n_cams == 0 || n_edges == 0) return (gsfm_status)fail(GSFM_ERR_EMPTY, "no cameras or no edges");
+  if (!edge_i || !edge_j || !rel_aa) return (gsfm_status)fail(GSFM_ERR_INVALID_ARG, "NULL edge arrays");
+  if (error_type < 0 || error_type > 8) return (gsfm_status)fail(GSFM_ERR_INVALID_ARG, "unknown rotation error type");
+  if (n_cams >= 0x7fffffffu || n_edges >= 0x7fffffffull) return (gsfm_status)fail(GSFM_ERR_INVALID_ARG, "problem too large for 31-bit indices");
+  const bool need_cov = error_type == GSFM_ROT_ANGLE_AXIS_COVARIANCE || error_type == GSFM_ROT_ANGLE_AXIS_COV_INLIERS ||
+                        error_type == GSFM_ROT_ANGLE_AXIS_COVTRACE || error_type == GSFM_ROT_ANGLE_AXIS_COVNORM;
+  const bool need_inl = error_type == GSFM_ROT_ANGLE_AXIS_INLIERS || error_type == GSFM_ROT_ANGLE_AXIS_COV_INLIERS;
+  if (need_cov && !cov6) return (gsfm_status)fail(GSFM_ERR_INVALID_ARG, "this error type needs per-edge covariances (cov6)");
+  if (need_inl && !inlier_weight) return (gsfm_status)fail(GSFM_ERR_INVALID_ARG, "this error type needs per-edge inlier weights");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+    return (gsfm_status)fail(GSFM_ERR_NO_DEVICE, "no HIP device: the rotation solver has no CPU fallback");
+
+  gsfm_rot_problem* P = new gsfm_rot_problem;
+  auto bail = [&](int st) { gsfm_rot_problem_destroy(P); return (gsfm_status)st; };
+  (void)hipGetDevice(&P->device);
+  P->n_cams = n_cams; P->n_edges_in = n_edges; P->error_type = error_type;
+  P->functor = error_type == GSFM_ROT_QUATERNION_COSINE ? F_QCOS : error_type == GSFM_ROT_QUATERNION_NORM ? F_QNORM
+               : error_type == GSFM_ROT_ROTATION_MAT_FNORM ? F_RFNORM : F_AA;
+  P->res_dim = gsfm_rot_residual_dim(error_type);
+  P->param_dim = P->functor == F_AA ? 3 : 4;
+  P->wmode = (error_type == GSFM_ROT_ANGLE_AXIS_COVARIANCE || error_type == GSFM_ROT_ANGLE_AXIS_COV_INLIERS) ? W_MATRIX
+             : (error_type == GSFM_ROT_ANGLE_AXIS_INLIERS || error_type == GSFM_ROT_ANGLE_AXIS_COVTRACE || error_type == GSFM_ROT_ANGLE_AXIS_COVNORM) ? W_SCALAR
+             : W_NONE;
+  if (shard && shard->world_size > 1) {
+    if (!shard->all_gather || !shard->all_reduce_sum || shard->slice_width == 0 || shard->rank < 0 || shard->rank >= shard->world_size ||
+        (uint64_t)shard->slice_width * shard->world_size < n_cams)
+      return bail(fail(GSFM_ERR_INVALID_ARG, "bad shard descriptor"));
+    P->sharded = true; P->shard = *shard;
+    P->own_begin = std::min<uint64_t>((uint64_t)shard->rank * shard->slice_width, n_cams);
+    P->own_end = std::min<uint64_t>((uint64_t)(shard->rank + 1) * shard->slice_width, n_cams);
+    P->n_pad = shard->slice_width * shard->world_size;
+  } else { P->own_begin = 0; P->own_end = n_cams; P->n_pad = n_cams; P->shard.slice_width = n_cams; P->shard.world_size = 1; }
+  P->n_rows = P->own_end - P->own_begin;
+  if (hipStreamCreateWithFlags(&P->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(GSFM_ERR_HIP, "hipStreamCreate failed"));
+  P->own_stream = true;
+  P->timer.stream = P->stream; P->timer.init();
+
+  // ---- host-side structure: directed entries by row (counting sort), cost-owned edges ----
+  const uint32_t ob = P->own_begin, oe = P->own_end;
+  auto owned = [&](uint32_t c) { return c >= ob && c < oe; };
+  std::vector<uint32_t> rp((size_t)P->n_rows + 1, 0);
+  std::vector<uint32_t> cost_eid;
+  cost_eid.reserve(P->sharded ? n_edges / 2 + 16 : n_edges);
+  for (uint64_t e = 0; e < n_edges; ++e) {
+    const uint32_t i = edge_i[e], j = edge_j[e];
+    if (i >= n_cams || j >= n_cams || i == j) return bail(fail(GSFM_ERR_INVALID_ARG, "edge with an out-of-range or repeated camera index"));
+    if (owned(i)) rp[i - ob + 1]++;
+    if (owned(j)) rp[j - ob + 1]++;
+    // each edge is cost-owned by exactly one rank: the owner of `first` if (i + j) is even, else of `second`
+    const uint32_t c = (((i + j) & 1u) == 0u) ? i : j;
+    if (owned(c)) cost_eid.push_back((uint32_t)e);
+    else if (!owned(i) && !owned(j)) return bail(fail(GSFM_ERR_INVALID_ARG, "sharded problem: edge touches no owned camera"));
+  }
+  for (size_t r = 0; r < P->n_rows; ++r) rp[r + 1] += rp[r];
+  const size_t nd = rp[P->n_rows];
+  std::vector<uint32_t> col(nd), deid(nd), fill(rp.begin(), rp.end() - 1);
+  for (uint64_t e = 0; e < n_edges; ++e) {
+    const uint32_t i = edge_i[e], j = edge_j[e];
+    if (owned(i)) { const uint32_t d = fill[i - ob]++; col[d] = j; deid[d] = (uint32_t)e; }
+    if (owned(j)) { const uint32_t d = fill[j - ob]++; col[d] = i | 0x80000000u; deid[d] = (uint32_t)e; }
+  }
+  {
+    const double mean_deg = P->n_rows ? (double)nd / P->n_rows : 0.0;
+    P->G = mean_deg >= 96 ? 64 : mean_deg >= 48 ? 32 : mean_deg >= 24 ? 16 : mean_deg >= 12 ? 8 : 4;
+  }
+  std::vector<uint2> cidx(cost_eid.size());
+  for (size_t t = 0; t < cost_eid.size(); ++t) cidx[t] = make_uint2(edge_i[cost_eid[t]], edge_j[cost_eid[t]]);
+  P->h_cost_eid = cost_eid;
+
+  // ---- uploads ----
+  if (int st = upload_planes(P, P->cost, cost_eid, rel_aa)) return bail(st);
+  if (int st = upload_planes(P, P->dir, deid, rel_aa)) return bail(st);
+  if (P->cost_idx.upload(cidx) != hipSuccess || P->row_ptr.upload(rp) != hipSuccess || P->col.upload(col) != hipSuccess)
+    return bail(fail(GSFM_ERR_HIP, "uploading graph structure failed"));
+  if (P->h0.alloc(nd) != hipSuccess || P->h1.alloc(nd) != hipSuccess || P->h2.alloc(nd) != hipSuccess || P->h3.alloc(nd) != hipSuccess || P->h4.alloc(nd) != hipSuccess)
+    return bail(fail(GSFM_ERR_HIP, "allocating normal-equation blocks failed"));
+  {  // K0 whitening
+    DevBuf<double> d_cov, d_inl;
+    if (P->wmode != W_NONE) {
+      if (cov6 && need_cov) { std::vector<double> t(cov6, cov6 + 6 * n_edges); if (d_cov.upload(t) != hipSuccess) return bail(fail(GSFM_ERR_HIP, "upload cov6")); }
+      if (inlier_weight && need_inl) { std::vector<double> t(inlier_weight, inlier_weight + n_edges); if (d_inl.upload(t) != hipSuccess) return bail(fail(GSFM_ERR_HIP, "upload inlier weights")); }
+      run_whiten(P, P->cost, d_cov.p, d_inl.p);
+      run_whiten(P, P->dir, d_cov.p, d_inl.p);
+      if (hipStreamSynchronize(P->stream) != hipSuccess) return bail(fail(GSFM_ERR_HIP, "whitening kernel failed"));
+    }
+  }
+  // ---- camera buffers ----
+  const size_t N = n_cams, NP = P->n_pad;
+  P->nb_cam = grid_for(N);
+  if (P->nb_cam > GSFM_MAX_PARTIALS * 64) return bail(fail(GSFM_ERR_INVALID_ARG, "too many cameras"));
+  P->nb_cost = std::max(1, std::min(grid_for(P->cost.n), 2048));
+  bool ok = true;
+  ok &= P->x.alloc(4 * N, true) == hipSuccess; ok &= P->x_trial.alloc(4 * N, true) == hipSuccess; ok &= P->aa_io.alloc(3 * N, true) == hipSuccess;
+  ok &= P->active.alloc(NP, true) == hipSuccess; ok &= P->scale.alloc(3 * N, true) == hipSuccess; ok &= P->gD.alloc(9 * NP, true) == hipSuccess;
+  ok &= P->Mblk.alloc(6 * N) == hipSuccess; ok &= P->Minv.alloc(6 * N) == hipSuccess; ok &= P->Lam.alloc(6 * N) == hipSuccess;
+  ok &= P->Tinv.alloc(9 * N) == hipSuccess; ok &= P->b.alloc(3 * N) == hipSuccess; ok &= P->D6.alloc(6 * N) == hipSuccess;
+  ok &= P->q.alloc(2 * N) == hipSuccess; ok &= P->q_trial.alloc(2 * N) == hipSuccess;
+  ok &= P->xcg.alloc(3 * N) == hipSuccess; ok &= P->r.alloc(3 * N) == hipSuccess; ok &= P->z.alloc(3 * N) == hipSuccess;
+  ok &= P->p.alloc(3 * NP, true) == hipSuccess; ok &= P->Ap.alloc(3 * NP, true) == hipSuccess;
+  ok &= P->part_a.alloc(P->nb_cam) == hipSuccess; ok &= P->part_b.alloc(P->nb_cam) == hipSuccess;
+  ok &= P->part_cam.alloc((size_t)5 * P->nb_cam) == hipSuccess; ok &= P->part_cost.alloc(P->nb_cost) == hipSuccess;
+  ok &= P->scal.alloc(SC_N, true) == hipSuccess; ok &= P->cgsc.alloc(1, true) == hipSuccess;
+  if (!ok) return bail(fail(GSFM_ERR_HIP, "allocating camera buffers failed"));
+  {  // cameras touched by at least one edge (Ceres only knows parameter blocks that appear in a residual block)
+    std::vector<double> act(NP, 0.0);
+    for (uint32_t r = 0; r < P->n_rows; ++r) act[ob + r] = (rp[r + 1] > rp[r]) ? 1.0 : 0.0;
+    if (hipMemcpy(P->active.p, act.data(), 8 * NP, hipMemcpyHostToDevice) != hipSuccess) return bail(fail(GSFM_ERR_HIP, "upload active mask"));
+    if (int st = all_gather(P, P->active.p, P->shard.slice_width)) return bail(st);
+    if (P->sharded && hipStreamSynchronize(P->stream) != hipSuccess) return bail(fail(GSFM_ERR_HIP, "active mask all-gather failed"));
+  }
+  if (int st = prepare_loss(P, nullptr, 0)) return bail(st);
+  *out = P;
+  return GSFM_OK;
+}
+
+void gsfm_rot_problem_destroy(gsfm_rot_problem* P) {
+  if (!P) return;
+  DeviceGuard g(P->device);
+  P->timer.destroy();
+  if (P->own_stream && P->stream) (void)hipStreamDestroy(P->stream);
+  delete P;
+}
+
+gsfm_status gsfm_rot_set_stream(gsfm_rot_problem* P, void* s) {
+  if (!P) return (gsfm_status)fail(GSFM_ERR_INVALID_ARG, "NULL problem");
+  DeviceGuard g(P->device);
+  if (P->own_stream && P->stream) { (void)hipStreamSynchronize(P->stream); (void)hipStreamDestroy(P->stream); }
+  if (s) { P->stream = (hipStream_t)s; P->own_stream = false; }
+  else { if (hipStreamCreateWithFlags(&P->stream, hipStreamNonBlocking) != hipSuccess) return (gsfm_status)fail(GSFM_ERR_HIP, "hipStreamCreate failed"); P->own_stream = true; }
+  P->timer.stream = P->stream;
+  return GSFM_OK;
+}
+
+gsfm_status gsfm_rot_set_loss(gsfm_rot_problem* P, const gsfm_loss_node* prog, int32_t n) {
+  if (!P || (n > 0 && !prog)) return (gsfm_status)fail(GSFM_ERR_INVALID_ARG, "NULL argument");
+  DeviceGuard g(P->device);
+  P->cb = nullptr;
+  return (gsfm_status)prepare_loss(P, prog, n);
+}
+
+gsfm_status gsfm_rot_set_loss_callback(gsfm_rot_problem* P, gsfm_loss_callback fn, void* user) {
+  if (!P || !fn) return (gsfm_status)fail(GSFM_ERR_INVALID_ARG, "NULL argument");
+  if (P->sharded) return (gsfm_status)fail(GSFM_ERR_UNSUPPORTED, "host-callback losses are not supported on a sharded problem");
+  DeviceGuard g(P->device);
+  if (!P->rho_ext.p) {
+    if (P->rho_ext.alloc(3 * P->n_edges_in) != hipSuccess || P->s_ext.alloc(P->n_edges_in) != hipSuccess)
+      return (gsfm_status)fail(GSFM_ERR_HIP, "allocating callback-loss buffers failed");
+  }
+  P->cb = fn; P->cb_user = user;
+  return GSFM_OK;
+}
+
+gsfm_status gsfm_rot_set_edge_weights(gsfm_rot_problem* P, const double* w) {
+  if (!P || !w) return (gsfm_status)fail(GSFM_ERR_INVALID_ARG, "NULL argument");
+  if (P->functor != F_AA || P->wmode == W_MATRIX) return (gsfm_status)fail(GSFM_ERR_INVALID_ARG, "edge weights only apply to the scalar-weight angle-axis types");
+  DeviceGuard g(P->device);
+  if (P->wmode == W_NONE) {  // ANGLE_AXIS: promote to a scalar-weight problem
+    if (P->cost.ws.alloc(P->cost.n) != hipSuccess || P->dir.ws.alloc(P->dir.n) != hipSuccess) return (gsfm_status)fail(GSFM_ERR_HIP, "alloc weight planes");
+    P->wmode = W_SCALAR;
+  }
+  if (!P->w_orig.p && P->w_orig.alloc(P->n_edges_in) != hipSuccess) return (gsfm_status)fail(GSFM_ERR_HIP, "alloc weights");
+  if (hipMemcpyAsync(P->w_orig.p, w, 8 * P->n_edges_in, hipMemcpyHostToDevice, P->stream) != hipSuccess) return (gsfm_status)fail(GSFM_ERR_HIP, "upload weights");
+  if (P->cost.n) hipLaunchKernelGGL(k_gather_weights, dim3(grid_for(P->cost.n)), dim3(GSFM_BLOCK), 0, P->stream, P->w_orig.p, P->cost.eid.p, P->cost.n, P->cost.ws.p);
+  if (P->dir.n) hipLaunchKernelGGL(k_gather_weights, dim3(grid_for(P->dir.n)), dim3(GSFM_BLOCK), 0, P->stream, P->w_orig.p, P->dir.eid.p, P->dir.n, P->dir.ws.p);
+  return (gsfm_status)sync_check(P, "set_edge_weights");
+}
+
+gsfm_status gsfm_rot_solve(gsfm_rot_problem* P, double* rot, const gsfm_rot_options* opt, gsfm_rot_summary* summary) {
+  if (!P || !rot) return (gsfm_status)fail(GSFM_ERR_INVALID_ARG, "NULL argument");
+  DeviceGuard g(P->device);
+  const gsfm_rot_options o = opt ? *opt : default_options();
+  gsfm_rot_summary local; if (!summary) summary = &local;
+  const double t0 = now_ms();
+  if (int st = upload_state(P, rot)) return (gsfm_status)st;
+  if (int st = lm_solve(P, o, summary)) return (gsfm_status)st;
+  if (int st = download_state(P, rot)) return (gsfm_status)st;
+  summary->t_total_ms = now_ms() - t0;
+  return GSFM_OK;
+}
+
+// EstimateRotationsWithSigmaConsensus (estimator.cpp:314-457)
+gsfm_status gsfm_rot_solve_sigma_consensus(gsfm_rot_problem* P, double* rot, int32_t iters_num, double sigma_max,
+                                           const gsfm_rot_options* opt, gsfm_rot_summary* summary) {
+  if (!P || !rot) return (gsfm_status)fail(GSFM_ERR_INVALID_ARG, "NULL argument");
+  if (P->error_type != GSFM_ROT_ANGLE_AXIS) return (gsfm_status)fail(GSFM_ERR_INVALID_ARG, "sigma consensus needs an ANGLE_AXIS problem");
+  if (P->sharded) return (gsfm_status)fail(GSFM_ERR_UNSUPPORTED, "sigma consensus is single-GPU in this version");
+  DeviceGuard g(P->device);
+  const gsfm_rot_options o = opt ? *opt : default_options();
+  gsfm_rot_summary local, total; if (!summary) summary = &local;
+  std::memset(&total, 0, sizeof(total));
+  const double t0 = now_ms();
+  const MagsacConst c = magsac_const(3);
+  const std::vector<double>& table = magsac_table(3);
+  const double squared_sigma_max_2 = sigma_max * sigma_max * 2.0;
+  const double dof_minus_one_per_two = (c.nu - 1.0) / 2.0;
+  const double one_over_sigma = c.C * std::pow(2.0, dof_minus_one_per_two) / sigma_max;
+  const double weight_zero = one_over_sigma * (std::tgamma(dof_minus_one_per_two) - c.gk);
+  const size_t E = P->n_edges_in;
+  std::vector<double> ones(E, 1.0), s(E), weights(E, 0.0), last_weights(E, 0.0);
+  if (!P->s_ext.p && P->s_ext.alloc(E) != hipSuccess) return (gsfm_status)fail(GSFM_ERR_HIP, "alloc");
+  // the weights are a function of the UNWEIGHTED residual norm: evaluate with w = 1, then set w.
+  int outer = 0;
+  for (int it = 0; it < iters_num; ++it) {
+    ++outer;
+    if (gsfm_status st = gsfm_rot_set_edge_weights(P, ones.data())) return st;
+    if (int st = upload_state(P, rot)) return (gsfm_status)st;
+    {  // K6 = K1 in s-only mode: s_e = ||log(R_j R_i^T R_ij^T)||^2  (:378-398)
+      CostArgs a{};
+      a.n = P->cost.n; a.idx = P->cost_idx.p; a.qr0 = P->cost.qr0.p; a.qr1 = P->cost.qr1.p; a.ws = P->cost.ws.p;
+      a.q = P->q.p; a.loss = P->d_loss.p; a.eid = P->cost.eid.p; a.partials = P->part_cost.p; a.s_out = P->s_ext.p; a.s_only = 1;
+      if (dispatch<CostArgs, CostLauncher>(P, a, P->nb_cost)) return (gsfm_status)fail(GSFM_ERR_UNSUPPORTED, "dispatch");
+      if (hipMemcpyAsync(s.data(), P->s_ext.p, 8 * E, hipMemcpyDeviceToHost, P->stream) != hipSuccess) return (gsfm_status)fail(GSFM_ERR_HIP, "read s");
+      if (int st = sync_check(P, "sigma consensus sweep")) return (gsfm_status)st;
+    }
+    for (size_t e = 0; e < E; ++e) {
+      const double residual = std::sqrt(s[e]);
+      double weight;
+      if (residual < std::numeric_limits<double>::epsilon()) weight = weight_zero;  // :400-401
+      else {
+        const double squared_residual = residual * residual;
+        size_t x = (size_t)std::round(1000.0 * squared_residual / squared_sigma_max_2);  // :407
+        // :411-412 clamps to stored_gamma_number3, one past the table's end (an out-of-bounds read in the
+        // reference); the last stored entry is used instead.
+        if ((size_t)c.n - 1 < x) x = (size_t)c.n - 1;
+        weight = one_over_sigma * (table[x] - c.gk);
+      }
+      weights[e] = weight;
+    }
+    double avg = 0; for (size_t e = 0; e < E; ++e) avg += std::fabs(weights[e] - last_weights[e]);
+    avg /= (double)E;
+    if (gsfm_status st = gsfm_rot_set_edge_weights(P, weights.data())) return st;
+    std::swap(weights, last_weights);
+    if (gsfm_status st = gsfm_rot_solve(P, rot, &o, summary)) return st;
+    if (it == 0) total = *summary;
+    else {
+      total.num_iterations += summary->num_iterations; total.num_successful_steps += summary->num_successful_steps;
+      total.num_unsuccessful_steps += summary->num_unsuccessful_steps; total.num_residual_sweeps += summary->num_residual_sweeps;
+      total.num_linearizations += summary->num_linearizations; total.num_cg_iterations += summary->num_cg_iterations;
+      total.final_cost = summary->final_cost; total.termination = summary->termination;
+      total.final_gradient_max_norm = summary->final_gradient_max_norm; total.final_radius = summary->final_radius;
+      total.t_linearize_ms += summary->t_linearize_ms; total.t_sweep_ms += summary->t_sweep_ms; total.t_cg_ms += summary->t_cg_ms;
+    }
+    total.num_residual_sweeps += 1;  // the weight sweep
+    total.last_weight_change = avg;
+    if (avg <= 1e-7) break;  // :448
+  }
+  total.outer_iterations = outer; total.t_total_ms = now_ms() - t0;
+  *summary = total;
+  return GSFM_OK;
+}
+
+gsfm_status gsfm_rot_residuals(gsfm_rot_problem* P, const double* rot, double* s_out, double* rho_out, double* r_out, double* cost) {
+  if (!P || !rot) return (gsfm_status)fail(GSFM_ERR_INVALID_ARG, "NULL argument");
+  DeviceGuard g(P->device);
+  const size_t E = P->n_edges_in;
+  if (int st = upload_state(P, rot)) return (gsfm_status)st;
+  DevBuf<double> ds, drho, dr;
+  if (ds.alloc(E, true) != hipSuccess || drho.alloc(3 * E, true) != hipSuccess || dr.alloc((size_t)P->res_dim * E, true) != hipSuccess)
+    return (gsfm_status)fail(GSFM_ERR_HIP, "alloc outputs");
+  if (int st = launch_cost(P, P->q.p, SC_COST, ds.p, drho.p, dr.p)) return (gsfm_status)st;
+  double h[SC_N];
+  if (int st = read_scalars(P, h)) return (gsfm_status)st;
+  if (cost) *cost = h[SC_COST];
+  if (s_out && hipMemcpy(s_out, ds.p, 8 * E, hipMemcpyDeviceToHost) != hipSuccess) return (gsfm_status)fail(GSFM_ERR_HIP, "copy s");
+  if (rho_out && hipMemcpy(rho_out, drho.p, 24 * E, hipMemcpyDeviceToHost) != hipSuccess) return (gsfm_status)fail(GSFM_ERR_HIP, "copy rho");
+  if (r_out && hipMemcpy(r_out, dr.p, 8 * (size_t)P->res_dim * E, hipMemcpyDeviceToHost) != hipSuccess) return (gsfm_status)fail(GSFM_ERR_HIP, "copy r");
+  return GSFM_OK;
+}
+
+gsfm_status gsfm_rot_linearize(gsfm_rot_problem* P, const double* rot, double* gradient, double* diag_blocks, double* cost) {
+  if (!P || !rot) return (gsfm_status)fail(GSFM_ERR_INVALID_ARG, "NULL argument");
+  DeviceGuard g(P->device);
+  const size_t N = P->n_cams;
+  if (int st = upload_state(P, rot)) return (gsfm_status)st;
+  if (int st = launch_cost(P, P->q.p, SC_COST)) return (gsfm_status)st;
+  if (int st = launch_lin(P, P->q.p)) return (gsfm_status)st;
+  DevBuf<double> dg, dblk;
+  if (dg.alloc(3 * N) != hipSuccess || dblk.alloc(9 * N) != hipSuccess) return (gsfm_status)fail(GSFM_ERR_HIP, "alloc outputs");
+  hipLaunchKernelGGL(k_cam_export, dim3(grid_for(N)), dim3(GSFM_BLOCK), 0, P->stream, P->x.p, P->gD.p, P->n_cams, P->param_dim, dg.p, dblk.p, P->D6.p);
+  double h[SC_N];
+  if (int st = read_scalars(P, h)) return (gsfm_status)st;
+  if (cost) *cost = h[SC_COST];
+  if (gradient && hipMemcpy(gradient, dg.p, 24 * N, hipMemcpyDeviceToHost) != hipSuccess) return (gsfm_status)fail(GSFM_ERR_HIP, "copy gradient");
+  if (diag_blocks && hipMemcpy(diag_blocks, dblk.p, 72 * N, hipMemcpyDeviceToHost) != hipSuccess) return (gsfm_status)fail(GSFM_ERR_HIP, "copy blocks");
+  return GSFM_OK;
+}
+
+gsfm_status gsfm_rot_normal_matvec(gsfm_rot_problem* P, const double* v, double* y) {
+  if (!P || !v || !y) return (gsfm_status)fail(GSFM_ERR_INVALID_ARG, "NULL argument");
+  if (!P->have_lin) return (gsfm_status)fail(GSFM_ERR_INVALID_ARG, "call gsfm_rot_linearize first");
+  DeviceGuard g(P->device);
+  const size_t N = P->n_cams;
+  // y = T^T B_eta (T v): xcg <- v, p <- T v, Ap <- B p, xcg <- T^T Ap
+  if (hipMemcpyAsync(P->xcg.p, v, 24 * N, hipMemcpyHostToDevice, P->stream) != hipSuccess) return (gsfm_status)fail(GSFM_ERR_HIP, "upload v");
+  hipLaunchKernelGGL(k_cam_apply_T, dim3(grid_for(N)), dim3(GSFM_BLOCK), 0, P->stream, P->x.p, P->n_cams, P->param_dim, 0, P->xcg.p, P->p.p);
+  if (int st = launch_matvec(P, P->D6.p, P->p.p, P->Ap.p, nullptr)) return (gsfm_status)st;
+  hipLaunchKernelGGL(k_cam_apply_T, dim3(grid_for(N)), dim3(GSFM_BLOCK), 0, P->stream, P->x.p, P->n_cams, P->param_dim, 1, P->Ap.p, P->xcg.p);
+  if (hipMemcpyAsync(y, P->xcg.p, 24 * N, hipMemcpyDeviceToHost, P->stream) != hipSuccess) return (gsfm_status)fail(GSFM_ERR_HIP, "download y");
+  return (gsfm_status)sync_check(P, "normal_matvec");
+}
+
+int32_t gsfm_rot_get_trace(gsfm_rot_problem* P, double* out, int32_t cap_rows) {
+  if (!P) return 0;
+  const int rows = (int)(P->trace.size() / GSFM_ROT_TRACE_COLS);
+  const int m = std::min(rows, cap_rows);
+  if (out && m > 0) std::memcpy(out, P->trace.data(), sizeof(double) * GSFM_ROT_TRACE_COLS * m);
+  return rows;
+}
+
+gsfm_status gsfm_rot_time_sweep(gsfm_rot_problem* P, const double* rot, int32_t reps, double* mean_ms) {
+  if (!P || !rot || !mean_ms || reps <= 0) return (gsfm_status)fail(GSFM_ERR_INVALID_ARG, "bad argument");
+  if (P->cb) return (gsfm_status)fail(GSFM_ERR_UNSUPPORTED, "time_sweep needs a native loss");
+  DeviceGuard g(P->device);
+  if (int st = upload_state(P, rot)) return (gsfm_status)st;
+  CostArgs a{};
+  a.n = P->cost.n; a.idx = P->cost_idx.p; a.qr0 = P->cost.qr0.p; a.qr1 = P->cost.qr1.p;
+  a.w0 = P->cost.w0.p; a.w1 = P->cost.w1.p; a.w2 = P->cost.w2.p; a.ws = P->cost.ws.p;
+  a.q = P->q.p; a.loss = P->d_loss.p; a.eid = P->cost.eid.p; a.partials = P->part_cost.p;
+  for (int k = 0; k < 3; ++k) if (dispatch<CostArgs, CostLauncher>(P, a, P->nb_cost)) return (gsfm_status)fail(GSFM_ERR_UNSUPPORTED, "dispatch");
+  hipEvent_t e0, e1;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return (gsfm_status)fail(GSFM_ERR_HIP, "event create");
+  (void)hipEventRecord(e0, P->stream);
+  for (int k = 0; k < reps; ++k) dispatch<CostArgs, CostLauncher>(P, a, P->nb_cost);
+  (void)hipEventRecord(e1, P->stream);
+  int st = sync_check(P, "time_sweep");
+  float ms = 0;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  *mean_ms = ms / reps;
+  return (gsfm_status)st;
+}
+
+gsfm_status gsfm_rot_sweep_bytes(gsfm_rot_problem* P, double* algorithmic, double* layout) {
+  if (!P) return (gsfm_status)fail(GSFM_ERR_INVALID_ARG, "NULL problem");
+  // indices 8 B + measurement 24 B (32 B for the quaternion types) + whitening 48/8/0 B + weight out 8 B
+  const double w = P->wmode == W_MATRIX ? 48.0 : P->wmode == W_SCALAR ? 8.0 : 0.0;
+  if (algorithmic) *algorithmic = 8.0 + (P->functor == F_AA ? 24.0 : 32.0) + w + 8.0;
+  // as laid out: uint2 idx + 32 B quaternion + whitening planes; the weight is consumed in-kernel (no per-edge store)
+  if (layout) *layout = 8.0 + 32.0 + w;
+  return GSFM_OK;
+}
+
+int32_t gsfm_magsac_table(int32_t nu, double* out, int32_t cap) {
+  if (nu != 3 && nu != 4 && nu != 9) return -1;
+  const std::vector<double>& t = magsac_table(nu);
+  const int m = std::min((int)t.size(), cap);
+  if (out && m > 0) std::memcpy(out, t.data(), 8 * (size_t)m);
+  return (int)t.size();
+}
+gsfm_status gsfm_magsac_constants(int32_t nu, double* C, double* q, double* gk) {
+  if (nu != 3 && nu != 4 && nu != 9) return (gsfm_status)fail(GSFM_ERR_INVALID_ARG, "nu must be 3, 4 or 9");
+  const MagsacConst c = magsac_const(nu);
+  if (C) *C = c.C; if (q) *q = c.q; if (gk) *gk = c.gk;
+  return GSFM_OK;
+}
+
+}  // extern "C"

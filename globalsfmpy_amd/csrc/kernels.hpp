@@ -1,0 +1,868 @@
+// HIP kernels of the rotation-averaging hot path (gfx950, fp64, HBM-bound; no MFMA: there is
+// no dense contraction on this path).
+//
+// Data layout in HBM (all per-edge streams are planes of 16-byte chunks so that a wavefront's
+// loads are 64 x 16 B = 1 KiB contiguous):
+//   cameras        quats  q[k]  = 2 x double2 (x,y)(z,w)     gathered (L2 / Infinity-Cache resident)
+//   cost edges     idx    uint2 (i, j)                        8 B / edge
+//                  qrel   2 planes of double2                 32 B / edge
+//                  W      0 | 1 plane double | 3 planes double2 (upper-triangular Lt) 0 / 8 / 48 B
+//   directed rows  one entry per (owned camera k <- neighbour m) = the block-CSR structure of
+//                  J^T J; per entry: col (u32, bit31 = role), qrel, W (copies), H block (72 B,
+//                  4 planes double2 + 1 plane double) written by K2, read by K3.
+//
+// K1 k_cost      1 edge / lane            residual + robust reweight sweep, block-reduced cost
+// K2 k_lin       G lanes / camera row     residual, 3x3 body Jacobians, Corrector, g, D, H blocks
+// K3 k_matvec    G lanes / camera row     y = M p + sum_d H_d p[col_d]
+// K4 k_cg_*      1 camera / lane          fused PCG vector updates + dot-product partials
+// K5 k_cam_*     1 camera / lane          quaternion cache, LM diagonal / preconditioner, step
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "loss_dev.hpp"
+#include "so3_dev.hpp"
+
+namespace gsfm {
+
+enum { F_AA = 0, F_QCOS = 1, F_QNORM = 2, F_RFNORM = 3 };
+enum { W_NONE = 0, W_SCALAR = 1, W_MATRIX = 2 };
+
+template <int F> struct ResDim { static constexpr int R = (F == F_QNORM) ? 4 : (F == F_RFNORM) ? 9 : 3; };
+
+#define GSFM_BLOCK 256
+#define GSFM_MAX_PARTIALS 1024
+
+// ------------------------------------------------------------------------------------------
+// reductions (deterministic: fixed tree inside a wave, fixed order across waves)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off, 64));
+  return v;
+}
+// result valid in every thread
+__device__ __forceinline__ double block_sum_bcast(double v, double* lds /* >= 5 */) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) lds[w] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) { double t = 0; for (int k = 0; k < GSFM_BLOCK / 64; ++k) t += lds[k]; lds[4] = t; }
+  __syncthreads();
+  return lds[4];
+}
+__device__ __forceinline__ double block_max_bcast(double v, double* lds) {
+  v = wave_max(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) lds[w] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) { double t = lds[0]; for (int k = 1; k < GSFM_BLOCK / 64; ++k) t = fmax(t, lds[k]); lds[4] = t; }
+  __syncthreads();
+  return lds[4];
+}
+// every block sums the same `n` partials in the same order -> identical scalar in every block
+__device__ __forceinline__ double sum_partials_bcast(const double* __restrict__ partials, int n, double* lds) {
+  double v = 0.0;
+  for (int k = threadIdx.x; k < n; k += GSFM_BLOCK) v += partials[k];
+  return block_sum_bcast(v, lds);
+}
+
+// ------------------------------------------------------------------------------------------
+// per-edge evaluation
+// ------------------------------------------------------------------------------------------
+struct EdgeW { double l00, l01, l02, l11, l12, l22; };  // upper-triangular whitening factor / scalar in l00
+
+template <int WM>
+__device__ __forceinline__ void apply_w_vec(const EdgeW& W, const double* e, double* r) {
+  if (WM == W_NONE) { r[0] = e[0]; r[1] = e[1]; r[2] = e[2]; }
+  else if (WM == W_SCALAR) { r[0] = W.l00 * e[0]; r[1] = W.l00 * e[1]; r[2] = W.l00 * e[2]; }
+  else {
+    r[0] = W.l00 * e[0] + W.l01 * e[1] + W.l02 * e[2];
+    r[1] = W.l11 * e[1] + W.l12 * e[2];
+    r[2] = W.l22 * e[2];
+  }
+}
+template <int WM>
+__device__ __forceinline__ void apply_w_mat(const EdgeW& W, const double* M, double* O) {  // O = W M
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    if (WM == W_NONE) { O[c] = M[c]; O[3 + c] = M[3 + c]; O[6 + c] = M[6 + c]; }
+    else if (WM == W_SCALAR) { O[c] = W.l00 * M[c]; O[3 + c] = W.l00 * M[3 + c]; O[6 + c] = W.l00 * M[6 + c]; }
+    else {
+      O[c] = W.l00 * M[c] + W.l01 * M[3 + c] + W.l02 * M[6 + c];
+      O[3 + c] = W.l11 * M[3 + c] + W.l12 * M[6 + c];
+      O[6 + c] = W.l22 * M[6 + c];
+    }
+  }
+}
+
+// Residual only.  qi, qj: camera quaternions of (first, second); qr: measured R_ij.
+template <int F, int WM>
+__device__ __forceinline__ void edge_residual(const Quat& qi, const Quat& qj, const Quat& qr, const EdgeW& W, double* r) {
+  if (F == F_AA) {
+    // e = log(R_j R_i^T R_ij^T)   (Theia pairwise_rotation_error.h:80-92 / quat.hpp:231-246)
+    const Quat qe = qmul(qmul(qj, qconj(qi)), qconj(qr));
+    double e[3], s, th;
+    quat_log(qe, e, &s, &th);
+    apply_w_vec<WM>(W, e, r);
+  } else if (F == F_QCOS) {
+    // r = 2 vec(q_ij * (q_b * q_a^-1)^*)   (quat.hpp:86-103)
+    const Quat dq = qmul(qr, qconj(qmul(qj, qconj(qi))));
+    r[0] = 2.0 * dq.x; r[1] = 2.0 * dq.y; r[2] = 2.0 * dq.z;
+  } else if (F == F_QNORM) {
+    // r = canon(q_b) - canon(q_ij q_a), canon tests the y coefficient  (quat.hpp:130-147)
+    const Quat est = qmul(qr, qi);
+    const double sb = (qj.y < 0.0) ? -1.0 : 1.0, se = (est.y < 0.0) ? -1.0 : 1.0;
+    r[0] = sb * qj.x - se * est.x; r[1] = sb * qj.y - se * est.y;
+    r[2] = sb * qj.z - se * est.z; r[3] = sb * qj.w - se * est.w;
+  } else {
+    // r = vec_colmajor(R_ij R_a - R_b)   (quat.hpp:170-193)
+    double Est[9], Rb[9];
+    qmat(qmul(qr, qi), Est);
+    qmat(qj, Rb);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { const int rr = k % 3, cc = k / 3; r[k] = Est[3 * rr + cc] - Rb[3 * rr + cc]; }
+  }
+}
+
+__device__ __forceinline__ void plus_jac_half(const Quat& q, double sgn, double* P /*4x3*/) {
+  // 1/2 * d((h,1) (x) q)/dh : rows x,y,z,w  (ceres EigenQuaternionParameterization::ComputeJacobian, eta = 2 delta)
+  const double h = 0.5 * sgn;
+  P[0] = h * q.w;  P[1] = h * q.z;   P[2] = -h * q.y;
+  P[3] = -h * q.z; P[4] = h * q.w;   P[5] = h * q.x;
+  P[6] = h * q.y;  P[7] = -h * q.x;  P[8] = h * q.w;
+  P[9] = -h * q.x; P[10] = -h * q.y; P[11] = -h * q.z;
+}
+
+// Residual and body Jacobians A_i, A_j (R x 3, row-major) w.r.t. left perturbations of R_i, R_j.
+template <int F, int WM>
+__device__ __forceinline__ void edge_linearize(const Quat& qi, const Quat& qj, const Quat& qr, const EdgeW& W,
+                                               double* r, double* Ai, double* Aj) {
+  if (F == F_AA) {
+    const Quat qe = qmul(qmul(qj, qconj(qi)), qconj(qr));
+    double e[3], s, th;
+    quat_log(qe, e, &s, &th);
+    apply_w_vec<WM>(W, e, r);
+    const double c = jlinv_coeff(th, s, fabs(qe.w));
+    double B[9], Rij[9], Bt_R[9];
+    jlinv_matrix(e, c, B);            // de/d eta_j = J_l^-1(e)
+    apply_w_mat<WM>(W, B, Aj);
+    qmat(qr, Rij);
+    mat3_tmul(B, Rij, Bt_R);          // de/d eta_i = -J_r^-1(e) R_ij = -J_l^-1(e)^T R_ij
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Bt_R[k] = -Bt_R[k];
+    apply_w_mat<WM>(W, Bt_R, Ai);
+  } else if (F == F_QCOS) {
+    const Quat a = qmul(qr, qconj(qmul(qj, qconj(qi))));
+    r[0] = 2.0 * a.x; r[1] = 2.0 * a.y; r[2] = 2.0 * a.z;
+    Aj[0] = -a.w; Aj[1] = a.z;  Aj[2] = -a.y;
+    Aj[3] = -a.z; Aj[4] = -a.w; Aj[5] = a.x;
+    Aj[6] = a.y;  Aj[7] = -a.x; Aj[8] = -a.w;
+    const double K[9] = {a.w, a.z, -a.y, -a.z, a.w, a.x, a.y, -a.x, a.w};
+    double Rij[9];
+    qmat(qr, Rij);
+    mat3_mul(K, Rij, Ai);
+  } else if (F == F_QNORM) {
+    const Quat est = qmul(qr, qi);
+    const double sb = (qj.y < 0.0) ? -1.0 : 1.0, se = (est.y < 0.0) ? -1.0 : 1.0;
+    r[0] = sb * qj.x - se * est.x; r[1] = sb * qj.y - se * est.y;
+    r[2] = sb * qj.z - se * est.z; r[3] = sb * qj.w - se * est.w;
+    plus_jac_half(qj, sb, Aj);
+    double P[12], Rij[9];
+    plus_jac_half(est, -se, P);
+    qmat(qr, Rij);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) Ai[3 * k + c] = P[3 * k] * Rij[c] + P[3 * k + 1] * Rij[3 + c] + P[3 * k + 2] * Rij[6 + c];
+  } else {
+    double Est[9], Rb[9], Rij[9];
+    qmat(qmul(qr, qi), Est);
+    qmat(qj, Rb);
+    qmat(qr, Rij);
+#pragma unroll
+    for (int cc = 0; cc < 3; ++cc) {
+      const double u0 = Rb[cc], u1 = Rb[3 + cc], u2 = Rb[6 + cc];        // column cc of R_b
+      const double v0 = Est[cc], v1 = Est[3 + cc], v2 = Est[6 + cc];     // column cc of R_ij R_a
+      r[3 * cc] = v0 - u0; r[3 * cc + 1] = v1 - u1; r[3 * cc + 2] = v2 - u2;
+      // d(-R_b col)/d eta_j = [u]x
+      double* J = Aj + 9 * cc;
+      J[0] = 0.0; J[1] = -u2; J[2] = u1;
+      J[3] = u2;  J[4] = 0.0; J[5] = -u0;
+      J[6] = -u1; J[7] = u0;  J[8] = 0.0;
+      // d(Est col)/d eta_i = -[v]x R_ij
+      const double K[9] = {0.0, v2, -v1, -v2, 0.0, v0, v1, -v0, 0.0};
+      mat3_mul(K, Rij, Ai + 9 * cc);
+    }
+  }
+}
+
+// Ceres ResidualBlock::Evaluate + Corrector applied in place; returns 1/2 rho.
+template <int R>
+__device__ __forceinline__ void robustify(const Rho3& rho, double s, double* r, double* Ai, double* Aj) {
+  const Corrector c = make_corrector(s, rho);
+  if (c.alpha_sq_norm == 0.0) {
+#pragma unroll
+    for (int k = 0; k < 3 * R; ++k) { Ai[k] *= c.sqrt_rho1; Aj[k] *= c.sqrt_rho1; }
+  } else {
+#pragma unroll
+    for (int col = 0; col < 3; ++col) {
+      double ti = 0.0, tj = 0.0;
+#pragma unroll
+      for (int k = 0; k < R; ++k) { ti += Ai[3 * k + col] * r[k]; tj += Aj[3 * k + col] * r[k]; }
+#pragma unroll
+      for (int k = 0; k < R; ++k) {
+        Ai[3 * k + col] = c.sqrt_rho1 * (Ai[3 * k + col] - c.alpha_sq_norm * r[k] * ti);
+        Aj[3 * k + col] = c.sqrt_rho1 * (Aj[3 * k + col] - c.alpha_sq_norm * r[k] * tj);
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < R; ++k) r[k] *= c.residual_scaling;
+}
+
+template <int WM>
+__device__ __forceinline__ EdgeW load_w(const double2* __restrict__ w0, const double2* __restrict__ w1,
+                                        const double2* __restrict__ w2, const double* __restrict__ ws, size_t e) {
+  EdgeW W;
+  W.l00 = 1.0; W.l01 = W.l02 = W.l12 = 0.0; W.l11 = W.l22 = 1.0;
+  if (WM == W_SCALAR) { W.l00 = ws[e]; }
+  else if (WM == W_MATRIX) {
+    const double2 a = w0[e], b = w1[e], c = w2[e];
+    W.l00 = a.x; W.l01 = a.y; W.l02 = b.x; W.l11 = b.y; W.l12 = c.x; W.l22 = c.y;
+  }
+  return W;
+}
+__device__ __forceinline__ Quat load_q(const double2* __restrict__ q2, uint32_t k) {
+  const double2 a = q2[2 * (size_t)k], b = q2[2 * (size_t)k + 1];
+  return Quat{a.x, a.y, b.x, b.y};
+}
+
+// ------------------------------------------------------------------------------------------
+// K0: whitening precompute (src/GSfM_nonlinear_rotation_estimator.cpp:251-288), once per problem
+// ------------------------------------------------------------------------------------------
+struct WhitenArgs {
+  const double* cov6;      // per ORIGINAL edge, C00 C11 C22 C01 C02 C12 (may be null)
+  const double* inl;       // per original edge (may be null)
+  const uint32_t* eid;     // entry -> original edge
+  size_t n;
+  int error_type;
+  double2 *w0, *w1, *w2;   // W_MATRIX outputs
+  double* ws;              // W_SCALAR output
+};
+__global__ void __launch_bounds__(GSFM_BLOCK) k_whiten(WhitenArgs a) {
+  const size_t t = (size_t)blockIdx.x * GSFM_BLOCK + threadIdx.x;
+  if (t >= a.n) return;
+  const size_t e = a.eid[t];
+  double cov[6] = {0, 0, 0, 0, 0, 0};
+  if (a.cov6) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) cov[k] = a.cov6[6 * e + k] * 1e8;  // :252
+  }
+  const double iw = a.inl ? a.inl[e] : 1.0;
+  const double c00 = cov[0], c11 = cov[1], c22 = cov[2], c01 = cov[3], c02 = cov[4], c12 = cov[5];
+  if (a.error_type == GSFM_ROT_ANGLE_AXIS_COVARIANCE || a.error_type == GSFM_ROT_ANGLE_AXIS_COV_INLIERS) {
+    // P = cov^-1 by cofactors (Eigen's fixed-size 3x3 inverse), P = L L^T, Lt = L^T
+    const double k00 = c11 * c22 - c12 * c12;
+    const double k10 = c12 * c02 - c01 * c22;
+    const double k20 = c01 * c12 - c11 * c02;
+    const double id = 1.0 / (c00 * k00 + c01 * k10 + c02 * k20);
+    const double p00 = k00 * id, p10 = k10 * id, p20 = k20 * id;
+    const double p11 = (c00 * c22 - c02 * c02) * id;
+    const double p21 = (c02 * c01 - c00 * c12) * id;
+    const double p22 = (c00 * c11 - c01 * c01) * id;
+    const double l00 = sqrt(p00);
+    const double l10 = p10 / l00, l20 = p20 / l00;
+    const double l11 = sqrt(p11 - l10 * l10);
+    const double l21 = (p21 - l20 * l10) / l11;
+    const double l22 = sqrt(p22 - l20 * l20 - l21 * l21);
+    const double m = (a.error_type == GSFM_ROT_ANGLE_AXIS_COV_INLIERS) ? iw : 1.0;
+    a.w0[t] = make_double2(l00 * m, l10 * m);
+    a.w1[t] = make_double2(l20 * m, l11 * m);
+    a.w2[t] = make_double2(l21 * m, l22 * m);
+  } else if (a.error_type == GSFM_ROT_ANGLE_AXIS_INLIERS) {
+    a.ws[t] = iw;                                                     // :263
+  } else if (a.error_type == GSFM_ROT_ANGLE_AXIS_COVTRACE) {
+    a.ws[t] = sqrt(1.0 / (c00 + c11 + c22));                          // :276-281
+  } else if (a.error_type == GSFM_ROT_ANGLE_AXIS_COVNORM) {
+    const double f = c00 * c00 + c11 * c11 + c22 * c22 + 2.0 * (c01 * c01 + c02 * c02 + c12 * c12);
+    a.ws[t] = sqrt(1.0 / sqrt(f));                                    // :284-286
+  }
+}
+
+// scatter per-original-edge scalar weights into an entry-ordered plane (sigma consensus / set_edge_weights)
+__global__ void __launch_bounds__(GSFM_BLOCK) k_gather_weights(const double* __restrict__ w_orig,
+                                                               const uint32_t* __restrict__ eid, size_t n,
+                                                               double* __restrict__ ws) {
+  const size_t t = (size_t)blockIdx.x * GSFM_BLOCK + threadIdx.x;
+  if (t < n) ws[t] = w_orig[eid[t]];
+}
+
+// ------------------------------------------------------------------------------------------
+// K1: residual + robust reweight sweep over the cost-owned edges
+// ------------------------------------------------------------------------------------------
+struct CostArgs {
+  size_t n;                  // edges
+  const uint2* idx;          // (i, j)
+  const double2 *qr0, *qr1;  // q_rel planes (x,y) (z,w)
+  const double2 *w0, *w1, *w2;
+  const double* ws;
+  const double2* q;          // camera quaternions
+  const DevLoss* loss;
+  const double* rho_ext;     // external rho triples per ORIGINAL edge (callback path) or null
+  const uint32_t* eid;       // entry -> original edge (for outputs / rho_ext)
+  double* partials;          // [gridDim.x] sum of 1/2 rho
+  // optional per-edge outputs in ORIGINAL edge order (null in the solver loop)
+  double* s_out;
+  double* rho_out;
+  double* r_out;
+  int s_only;                // 1: write s_out only, skip the loss (callback path, phase 1)
+};
+
+template <int F, int WM>
+__global__ void __launch_bounds__(GSFM_BLOCK) k_cost(CostArgs a) {
+  constexpr int R = ResDim<F>::R;
+  __shared__ double lds[8];
+  double acc = 0.0;
+  const size_t stride = (size_t)gridDim.x * GSFM_BLOCK;
+  for (size_t e = (size_t)blockIdx.x * GSFM_BLOCK + threadIdx.x; e < a.n; e += stride) {
+    const uint2 ij = a.idx[e];
+    const double2 r0 = a.qr0[e], r1 = a.qr1[e];
+    const Quat qr{r0.x, r0.y, r1.x, r1.y};
+    const EdgeW W = load_w<WM>(a.w0, a.w1, a.w2, a.ws, e);
+    const Quat qi = load_q(a.q, ij.x), qj = load_q(a.q, ij.y);
+    double r[R];
+    edge_residual<F, WM>(qi, qj, qr, W, r);
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < R; ++k) s += r[k] * r[k];
+    if (a.s_only) { a.s_out[a.eid[e]] = s; continue; }
+    Rho3 rho;
+    if (a.rho_ext) { const size_t o = 3 * (size_t)a.eid[e]; rho.r0 = a.rho_ext[o]; rho.r1 = a.rho_ext[o + 1]; rho.r2 = a.rho_ext[o + 2]; }
+    else rho = loss_eval(a.loss, s);
+    acc += 0.5 * rho.r0;
+    if (a.s_out) {
+      const size_t o = a.eid[e];
+      a.s_out[o] = s;
+      if (a.rho_out) { a.rho_out[3 * o] = rho.r0; a.rho_out[3 * o + 1] = rho.r1; a.rho_out[3 * o + 2] = rho.r2; }
+      if (a.r_out) {
+#pragma unroll
+        for (int k = 0; k < R; ++k) a.r_out[R * o + k] = r[k];
+      }
+    }
+  }
+  const double t = block_sum_bcast(acc, lds);
+  if (threadIdx.x == 0) a.partials[blockIdx.x] = t;
+}
+
+// out[0] = sum partials (single block, fixed order)
+__global__ void __launch_bounds__(GSFM_BLOCK) k_sum_partials(const double* __restrict__ partials, int n, double* out) {
+  __shared__ double lds[8];
+  const double t = sum_partials_bcast(partials, n, lds);
+  if (threadIdx.x == 0) out[0] = t;
+}
+
+// ------------------------------------------------------------------------------------------
+// K2: linearise.  G lanes cooperate on one camera row of the block-CSR J^T J.
+// ------------------------------------------------------------------------------------------
+struct LinArgs {
+  uint32_t n_rows;           // owned rows
+  uint32_t row_base;         // global camera index of row 0
+  uint32_t G;                // lanes per row (power of two, <= 64)
+  const uint32_t* row_ptr;   // [n_rows + 1]
+  const uint32_t* col;       // neighbour camera | role << 31 (role 1: the row camera is `second`)
+  const uint32_t* eid;
+  const double2 *qr0, *qr1;
+  const double2 *w0, *w1, *w2;
+  const double* ws;
+  const double2* q;
+  const DevLoss* loss;
+  const double* rho_ext;
+  double2 *h0, *h1, *h2, *h3;  // H block planes (row-major 3x3: h0=(H00,H01) h1=(H02,H10) h2=(H11,H12) h3=(H20,H21))
+  double* h4;                  // H22
+  double* gD;                  // 9 per camera: g(3), D sym(6: d00 d01 d02 d11 d12 d22)
+};
+
+template <int F, int WM>
+__global__ void __launch_bounds__(GSFM_BLOCK) k_lin(LinArgs a) {
+  constexpr int R = ResDim<F>::R;
+  const uint32_t G = a.G;
+  const uint32_t t = blockIdx.x * GSFM_BLOCK + threadIdx.x;
+  const uint32_t row = t / G, lane = t % G;
+  const bool live = row < a.n_rows;
+  double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  if (live) {
+    const uint32_t k = a.row_base + row;
+    const Quat qk = load_q(a.q, k);
+    const uint32_t end = a.row_ptr[row + 1];
+    for (uint32_t d = a.row_ptr[row] + lane; d < end; d += G) {
+      const uint32_t cr = a.col[d];
+      const uint32_t m = cr & 0x7fffffffu;
+      const bool row_is_second = (cr >> 31) != 0;
+      const double2 r0 = a.qr0[d], r1 = a.qr1[d];
+      const Quat qr{r0.x, r0.y, r1.x, r1.y};
+      const EdgeW W = load_w<WM>(a.w0, a.w1, a.w2, a.ws, d);
+      const Quat qm = load_q(a.q, m);
+      double r[R], Ai[3 * R], Aj[3 * R];
+      if (row_is_second) edge_linearize<F, WM>(qm, qk, qr, W, r, Ai, Aj);
+      else edge_linearize<F, WM>(qk, qm, qr, W, r, Ai, Aj);
+      double s = 0.0;
+#pragma unroll
+      for (int c = 0; c < R; ++c) s += r[c] * r[c];
+      Rho3 rho;
+      if (a.rho_ext) { const size_t o = 3 * (size_t)a.eid[d]; rho.r0 = a.rho_ext[o]; rho.r1 = a.rho_ext[o + 1]; rho.r2 = a.rho_ext[o + 2]; }
+      else rho = loss_eval(a.loss, s);
+      robustify<R>(rho, s, r, Ai, Aj);
+      const double* Ar = row_is_second ? Aj : Ai;  // Jacobian of the row camera
+      const double* Ac = row_is_second ? Ai : Aj;  // Jacobian of the neighbour
+      double H[9];
+#pragma unroll
+      for (int x = 0; x < 3; ++x) {
+        double g = 0.0;
+#pragma unroll
+        for (int c = 0; c < R; ++c) g += Ar[3 * c + x] * r[c];
+        acc[x] += g;
+#pragma unroll
+        for (int y = 0; y < 3; ++y) {
+          double h = 0.0;
+#pragma unroll
+          for (int c = 0; c < R; ++c) h += Ar[3 * c + x] * Ac[3 * c + y];
+          H[3 * x + y] = h;
+        }
+      }
+      {
+        double d00 = 0, d01 = 0, d02 = 0, d11 = 0, d12 = 0, d22 = 0;
+#pragma unroll
+        for (int c = 0; c < R; ++c) {
+          const double x0 = Ar[3 * c], x1 = Ar[3 * c + 1], x2 = Ar[3 * c + 2];
+          d00 += x0 * x0; d01 += x0 * x1; d02 += x0 * x2; d11 += x1 * x1; d12 += x1 * x2; d22 += x2 * x2;
+        }
+        acc[3] += d00; acc[4] += d01; acc[5] += d02; acc[6] += d11; acc[7] += d12; acc[8] += d22;
+      }
+      a.h0[d] = make_double2(H[0], H[1]);
+      a.h1[d] = make_double2(H[2], H[3]);
+      a.h2[d] = make_double2(H[4], H[5]);
+      a.h3[d] = make_double2(H[6], H[7]);
+      a.h4[d] = H[8];
+    }
+  }
+  // segmented reduction over the G lanes of the row (rows are G-aligned inside the wavefront)
+  for (uint32_t off = G >> 1; off > 0; off >>= 1) {
+#pragma unroll
+    for (int c = 0; c < 9; ++c) acc[c] += __shfl_down(acc[c], off, G);
+  }
+  if (live && lane == 0) {
+    double* o = a.gD + 9 * (size_t)(a.row_base + row);
+#pragma unroll
+    for (int c = 0; c < 9; ++c) o[c] = acc[c];
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// K3: y_k = M_k p_k + sum_d H_d p[col_d]   (M = diagonal block incl. LM damping, sym 6)
+// ------------------------------------------------------------------------------------------
+struct MatvecArgs {
+  uint32_t n_rows, row_base, G;
+  const uint32_t* row_ptr;
+  const uint32_t* col;
+  const double2 *h0, *h1, *h2, *h3;
+  const double* h4;
+  const double* Mblk;   // 6 per camera
+  const double* p;      // 3 per camera
+  double* y;            // 3 per camera
+  const int* done;      // PCG convergence flag (may be null)
+};
+__global__ void __launch_bounds__(GSFM_BLOCK) k_matvec(MatvecArgs a) {
+  if (a.done && *a.done) return;
+  const uint32_t G = a.G;
+  const uint32_t t = blockIdx.x * GSFM_BLOCK + threadIdx.x;
+  const uint32_t row = t / G, lane = t % G;
+  const bool live = row < a.n_rows;
+  double y0 = 0.0, y1 = 0.0, y2 = 0.0;
+  if (live) {
+    const uint32_t end = a.row_ptr[row + 1];
+    for (uint32_t d = a.row_ptr[row] + lane; d < end; d += G) {
+      const uint32_t m = a.col[d] & 0x7fffffffu;
+      const double2 A = a.h0[d], B = a.h1[d], C = a.h2[d], D = a.h3[d];
+      const double E = a.h4[d];
+      const double* pm = a.p + 3 * (size_t)m;
+      const double p0 = pm[0], p1 = pm[1], p2 = pm[2];
+      y0 += A.x * p0 + A.y * p1 + B.x * p2;
+      y1 += B.y * p0 + C.x * p1 + C.y * p2;
+      y2 += D.x * p0 + D.y * p1 + E * p2;
+    }
+  }
+  for (uint32_t off = G >> 1; off > 0; off >>= 1) {
+    y0 += __shfl_down(y0, off, G); y1 += __shfl_down(y1, off, G); y2 += __shfl_down(y2, off, G);
+  }
+  if (live && lane == 0) {
+    const size_t k = a.row_base + row;
+    const double* M = a.Mblk + 6 * k;
+    const double* pk = a.p + 3 * k;
+    double mp[3];
+    sym3_mulvec(M, pk, mp);
+    a.y[3 * k] = y0 + mp[0]; a.y[3 * k + 1] = y1 + mp[1]; a.y[3 * k + 2] = y2 + mp[2];
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// K5: camera kernels
+// ------------------------------------------------------------------------------------------
+// state -> quaternion cache.  param_dim 3: x = angle-axis; 4: x is already (x,y,z,w).
+__global__ void __launch_bounds__(GSFM_BLOCK) k_cam_cache(const double* __restrict__ x, uint32_t n, int param_dim,
+                                                          double2* __restrict__ q) {
+  const uint32_t k = blockIdx.x * GSFM_BLOCK + threadIdx.x;
+  if (k >= n) return;
+  Quat qq;
+  if (param_dim == 3) qq = aa_to_quat(x[3 * (size_t)k], x[3 * (size_t)k + 1], x[3 * (size_t)k + 2]);
+  else qq = Quat{x[4 * (size_t)k], x[4 * (size_t)k + 1], x[4 * (size_t)k + 2], x[4 * (size_t)k + 3]};
+  q[2 * (size_t)k] = make_double2(qq.x, qq.y);
+  q[2 * (size_t)k + 1] = make_double2(qq.z, qq.w);
+}
+
+// quaternion state -> angle-axis (ceres::QuaternionToAngleAxis), estimator.cpp:185-194
+__global__ void __launch_bounds__(GSFM_BLOCK) k_quat_to_aa(const double* __restrict__ x, const double* __restrict__ active,
+                                                           uint32_t n, double* __restrict__ aa) {
+  const uint32_t k = blockIdx.x * GSFM_BLOCK + threadIdx.x;
+  if (k >= n) return;
+  if (active[k] == 0.0) return;  // views never touched by an edge keep their input value
+  const Quat q{x[4 * (size_t)k], x[4 * (size_t)k + 1], x[4 * (size_t)k + 2], x[4 * (size_t)k + 3]};
+  double e[3], s, th;
+  quat_log(q, e, &s, &th);
+  aa[3 * (size_t)k] = e[0]; aa[3 * (size_t)k + 1] = e[1]; aa[3 * (size_t)k + 2] = e[2];
+}
+
+__device__ __forceinline__ void cam_tangent_maps(const double* __restrict__ x, size_t k, int param_dim, double* T, double* Tinv) {
+  if (param_dim == 3) {
+    const double w[3] = {x[3 * k], x[3 * k + 1], x[3 * k + 2]};
+    jl_and_inverse(w, T, Tinv);
+  } else {
+#pragma unroll
+    for (int c = 0; c < 9; ++c) { T[c] = 0.0; Tinv[c] = 0.0; }
+    T[0] = T[4] = T[8] = 2.0; Tinv[0] = Tinv[4] = Tinv[8] = 0.5;
+  }
+}
+
+struct PrepArgs {
+  uint32_t n;
+  int param_dim;
+  const double* x;
+  const double* gD;       // 9 per camera (eta space)
+  double* scale;          // 3 per camera: Jacobi column scaling, fixed at iteration 0
+  int init_scale;         // 1 at iteration 0
+  int jacobi_scaling;
+  double radius, min_diag, max_diag;
+  double* Mblk;           // 6: D + Lambda
+  double* Minv;           // 6
+  double* Lam;            // 6: damping block in eta space
+  double* Tinv;           // 9
+  double* b;              // 3: -g_eta
+  double* gmax_partials;  // [gridDim.x]
+};
+// LM diagonal (LevenbergMarquardtStrategy::ComputeStep), block-Jacobi preconditioner and the
+// gradient max-norm ||x - Plus(x, -g)||_inf, all per camera.
+__global__ void __launch_bounds__(GSFM_BLOCK) k_cam_prep(PrepArgs a) {
+  __shared__ double lds[8];
+  double gm = 0.0;
+  const uint32_t k = blockIdx.x * GSFM_BLOCK + threadIdx.x;
+  if (k < a.n) {
+    double T[9], Ti[9];
+    cam_tangent_maps(a.x, k, a.param_dim, T, Ti);
+    const double* gd = a.gD + 9 * (size_t)k;
+    const double g[3] = {gd[0], gd[1], gd[2]};
+    const double D[6] = {gd[3], gd[4], gd[5], gd[6], gd[7], gd[8]};
+    // squared column norms in the reference's parameter space: diag(T^T D T)
+    double dd[3], gdl[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const double t0 = T[c], t1 = T[3 + c], t2 = T[6 + c];
+      double v[3];
+      const double tv[3] = {t0, t1, t2};
+      sym3_mulvec(D, tv, v);
+      dd[c] = t0 * v[0] + t1 * v[1] + t2 * v[2];
+      gdl[c] = t0 * g[0] + t1 * g[1] + t2 * g[2];   // (T^T g)_c
+    }
+    double sc[3];
+    if (a.init_scale) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { sc[c] = a.jacobi_scaling ? 1.0 / (1.0 + sqrt(dd[c])) : 1.0; a.scale[3 * (size_t)k + c] = sc[c]; }
+    } else {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) sc[c] = a.scale[3 * (size_t)k + c];
+    }
+    double lam[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const double s2 = sc[c] * sc[c];
+      lam[c] = fmin(fmax(s2 * dd[c], a.min_diag), a.max_diag) / (a.radius * s2);
+    }
+    // Lambda_eta = Tinv^T diag(lam) Tinv
+    double L[6];
+    L[0] = lam[0] * Ti[0] * Ti[0] + lam[1] * Ti[3] * Ti[3] + lam[2] * Ti[6] * Ti[6];
+    L[1] = lam[0] * Ti[0] * Ti[1] + lam[1] * Ti[3] * Ti[4] + lam[2] * Ti[6] * Ti[7];
+    L[2] = lam[0] * Ti[0] * Ti[2] + lam[1] * Ti[3] * Ti[5] + lam[2] * Ti[6] * Ti[8];
+    L[3] = lam[0] * Ti[1] * Ti[1] + lam[1] * Ti[4] * Ti[4] + lam[2] * Ti[7] * Ti[7];
+    L[4] = lam[0] * Ti[1] * Ti[2] + lam[1] * Ti[4] * Ti[5] + lam[2] * Ti[7] * Ti[8];
+    L[5] = lam[0] * Ti[2] * Ti[2] + lam[1] * Ti[5] * Ti[5] + lam[2] * Ti[8] * Ti[8];
+    double M[6], Mi[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) { M[c] = D[c] + L[c]; a.Lam[6 * (size_t)k + c] = L[c]; a.Mblk[6 * (size_t)k + c] = M[c]; }
+    sym3_inverse(M, Mi);
+#pragma unroll
+    for (int c = 0; c < 6; ++c) a.Minv[6 * (size_t)k + c] = Mi[c];
+#pragma unroll
+    for (int c = 0; c < 9; ++c) a.Tinv[9 * (size_t)k + c] = Ti[c];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) a.b[3 * (size_t)k + c] = -g[c];
+    if (a.param_dim == 3) gm = fmax(fabs(gdl[0]), fmax(fabs(gdl[1]), fabs(gdl[2])));
+    else {
+      // || x - Plus(x, -g) ||_inf with the quaternion Plus
+      const double d0 = -gdl[0], d1 = -gdl[1], d2 = -gdl[2];
+      const double nd = sqrt(d0 * d0 + d1 * d1 + d2 * d2);
+      const Quat q{a.x[4 * (size_t)k], a.x[4 * (size_t)k + 1], a.x[4 * (size_t)k + 2], a.x[4 * (size_t)k + 3]};
+      if (nd > 0.0) {
+        double sn, cs;
+        sincos(nd, &sn, &cs);
+        const double kk = sn / nd;
+        const Quat r = qmul(Quat{kk * d0, kk * d1, kk * d2, cs}, q);
+        gm = fmax(fmax(fabs(q.x - r.x), fabs(q.y - r.y)), fmax(fabs(q.z - r.z), fabs(q.w - r.w)));
+      }
+    }
+  }
+  const double t = block_max_bcast(gm, lds);
+  if (threadIdx.x == 0) a.gmax_partials[blockIdx.x] = t;
+}
+__global__ void __launch_bounds__(GSFM_BLOCK) k_max_partials(const double* __restrict__ partials, int n, double* out) {
+  __shared__ double lds[8];
+  double v = 0.0;
+  for (int k = threadIdx.x; k < n; k += GSFM_BLOCK) v = fmax(v, partials[k]);
+  const double t = block_max_bcast(v, lds);
+  if (threadIdx.x == 0) out[0] = t;
+}
+
+struct StepArgs {
+  uint32_t n;
+  int param_dim;
+  const double* x;        // current state
+  const double* active;   // 1.0 for cameras touched by an edge
+  const double* eta;      // PCG solution (left-tangent step)
+  const double* b;        // -g_eta
+  const double* rcg;      // PCG residual b - A eta
+  const double* Lam;      // 6
+  const double* Tinv;     // 9
+  double* x_trial;
+  double2* q_trial;
+  double* partials;       // 5 * gridDim.x : eta.g, eta.rcg, eta^T Lam eta, |x - x_trial|^2, |x_trial|^2
+};
+// delta = Tinv eta; x_trial = Plus(x, delta); scalars for the model cost change and the
+// parameter-tolerance test (TrustRegionMinimizer::ComputeCandidatePointAndEvaluateCost).
+__global__ void __launch_bounds__(GSFM_BLOCK) k_cam_step(StepArgs a) {
+  __shared__ double lds[8];
+  double v[5] = {0, 0, 0, 0, 0};
+  const uint32_t k = blockIdx.x * GSFM_BLOCK + threadIdx.x;
+  if (k < a.n) {
+    const size_t k3 = 3 * (size_t)k;
+    const double e[3] = {a.eta[k3], a.eta[k3 + 1], a.eta[k3 + 2]};
+    const double* Ti = a.Tinv + 9 * (size_t)k;
+    const double d[3] = {Ti[0] * e[0] + Ti[1] * e[1] + Ti[2] * e[2], Ti[3] * e[0] + Ti[4] * e[1] + Ti[5] * e[2],
+                         Ti[6] * e[0] + Ti[7] * e[1] + Ti[8] * e[2]};
+    double le[3];
+    sym3_mulvec(a.Lam + 6 * (size_t)k, e, le);
+    v[0] = -(e[0] * a.b[k3] + e[1] * a.b[k3 + 1] + e[2] * a.b[k3 + 2]);
+    v[1] = e[0] * a.rcg[k3] + e[1] * a.rcg[k3 + 1] + e[2] * a.rcg[k3 + 2];
+    v[2] = e[0] * le[0] + e[1] * le[1] + e[2] * le[2];
+    const double act = a.active[k];
+    Quat qt;
+    if (a.param_dim == 3) {
+      const double x0 = a.x[k3] + d[0], x1 = a.x[k3 + 1] + d[1], x2 = a.x[k3 + 2] + d[2];
+      a.x_trial[k3] = x0; a.x_trial[k3 + 1] = x1; a.x_trial[k3 + 2] = x2;
+      v[3] = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+      v[4] = act * (x0 * x0 + x1 * x1 + x2 * x2);
+      qt = aa_to_quat(x0, x1, x2);
+    } else {
+      const size_t k4 = 4 * (size_t)k;
+      const Quat q{a.x[k4], a.x[k4 + 1], a.x[k4 + 2], a.x[k4 + 3]};
+      const double nd = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+      qt = q;
+      if (nd > 0.0) {
+        double sn, cs;
+        sincos(nd, &sn, &cs);
+        const double kk = sn / nd;
+        qt = qmul(Quat{kk * d[0], kk * d[1], kk * d[2], cs}, q);
+      }
+      a.x_trial[k4] = qt.x; a.x_trial[k4 + 1] = qt.y; a.x_trial[k4 + 2] = qt.z; a.x_trial[k4 + 3] = qt.w;
+      const double f0 = q.x - qt.x, f1 = q.y - qt.y, f2 = q.z - qt.z, f3 = q.w - qt.w;
+      v[3] = f0 * f0 + f1 * f1 + f2 * f2 + f3 * f3;
+      v[4] = act * (qt.x * qt.x + qt.y * qt.y + qt.z * qt.z + qt.w * qt.w);
+    }
+    a.q_trial[2 * (size_t)k] = make_double2(qt.x, qt.y);
+    a.q_trial[2 * (size_t)k + 1] = make_double2(qt.z, qt.w);
+  }
+#pragma unroll
+  for (int c = 0; c < 5; ++c) {
+    const double t = block_sum_bcast(v[c], lds);
+    if (threadIdx.x == 0) a.partials[(size_t)c * gridDim.x + blockIdx.x] = t;
+  }
+}
+// out[c] = sum partials[c*n .. c*n+n)
+__global__ void __launch_bounds__(GSFM_BLOCK) k_sum_partials_multi(const double* __restrict__ partials, int n, int m, double* out) {
+  __shared__ double lds[8];
+  for (int c = 0; c < m; ++c) {
+    const double t = sum_partials_bcast(partials + (size_t)c * n, n, lds);
+    if (threadIdx.x == 0) out[c] = t;
+  }
+}
+// |x|^2 over active cameras (Init: x_norm_)
+__global__ void __launch_bounds__(GSFM_BLOCK) k_cam_norm(const double* __restrict__ x, const double* __restrict__ active,
+                                                         uint32_t n, int param_dim, double* partials) {
+  __shared__ double lds[8];
+  double v = 0.0;
+  const uint32_t k = blockIdx.x * GSFM_BLOCK + threadIdx.x;
+  if (k < n && active[k] != 0.0) {
+    for (int c = 0; c < param_dim; ++c) { const double t = x[(size_t)param_dim * k + c]; v += t * t; }
+  }
+  const double t = block_sum_bcast(v, lds);
+  if (threadIdx.x == 0) partials[blockIdx.x] = t;
+}
+
+// export gradient / diagonal blocks in the reference's parameter space: T^T g, T^T D T
+__global__ void __launch_bounds__(GSFM_BLOCK) k_cam_export(const double* __restrict__ x, const double* __restrict__ gD,
+                                                           uint32_t n, int param_dim, double* grad, double* blocks, double* D6) {
+  const uint32_t k = blockIdx.x * GSFM_BLOCK + threadIdx.x;
+  if (k >= n) return;
+  double T[9], Ti[9];
+  cam_tangent_maps(x, k, param_dim, T, Ti);
+  const double* gd = gD + 9 * (size_t)k;
+  const double D[9] = {gd[3], gd[4], gd[5], gd[4], gd[6], gd[7], gd[5], gd[7], gd[8]};
+  double DT[9], TDT[9];
+  mat3_mul(D, T, DT);
+  mat3_tmul(T, DT, TDT);
+  for (int c = 0; c < 3; ++c) grad[3 * (size_t)k + c] = T[c] * gd[0] + T[3 + c] * gd[1] + T[6 + c] * gd[2];
+  for (int c = 0; c < 9; ++c) blocks[9 * (size_t)k + c] = TDT[c];
+  for (int c = 0; c < 6; ++c) D6[6 * (size_t)k + c] = gd[3 + c];
+}
+// v_eta = T v (mode 0)  or  y = T^T y_eta (mode 1), for gsfm_rot_normal_matvec
+__global__ void __launch_bounds__(GSFM_BLOCK) k_cam_apply_T(const double* __restrict__ x, uint32_t n, int param_dim, int transpose,
+                                                            const double* __restrict__ in, double* __restrict__ out) {
+  const uint32_t k = blockIdx.x * GSFM_BLOCK + threadIdx.x;
+  if (k >= n) return;
+  double T[9], Ti[9];
+  cam_tangent_maps(x, k, param_dim, T, Ti);
+  const double v0 = in[3 * (size_t)k], v1 = in[3 * (size_t)k + 1], v2 = in[3 * (size_t)k + 2];
+  for (int c = 0; c < 3; ++c)
+    out[3 * (size_t)k + c] = transpose ? (T[c] * v0 + T[3 + c] * v1 + T[6 + c] * v2) : (T[3 * c] * v0 + T[3 * c + 1] * v1 + T[3 * c + 2] * v2);
+}
+
+// ------------------------------------------------------------------------------------------
+// K4: PCG vector kernels.  Device scalars: rz[2] (parity-indexed), rz0, done, iters.
+// ------------------------------------------------------------------------------------------
+struct CgScalars {
+  double rz[2];
+  double rz0;
+  double last_rel;  // sqrt(rz/rz0) at the last iteration
+  int done;
+  int iters;
+};
+struct CgArgs {
+  uint32_t n;        // cameras
+  int nb;            // blocks of the camera kernels (= number of partials)
+  int par;           // iteration parity
+  double tol;
+  int max_iters;
+  const double* Minv;
+  const double* b;
+  double *xcg, *r, *z, *p, *Ap;
+  double* part_a;    // [nb]
+  double* part_b;    // [nb]
+  CgScalars* sc;
+};
+
+// x = 0, r = b, z = Minv r, p = z, partial r.z
+__global__ void __launch_bounds__(GSFM_BLOCK) k_cg_init(CgArgs a) {
+  __shared__ double lds[8];
+  double v = 0.0;
+  const uint32_t k = blockIdx.x * GSFM_BLOCK + threadIdx.x;
+  if (k < a.n) {
+    const size_t k3 = 3 * (size_t)k;
+    const double r[3] = {a.b[k3], a.b[k3 + 1], a.b[k3 + 2]};
+    double z[3];
+    sym3_mulvec(a.Minv + 6 * (size_t)k, r, z);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { a.xcg[k3 + c] = 0.0; a.r[k3 + c] = r[c]; a.z[k3 + c] = z[c]; a.p[k3 + c] = z[c]; v += r[c] * z[c]; }
+  }
+  const double t = block_sum_bcast(v, lds);
+  if (threadIdx.x == 0) a.part_b[blockIdx.x] = t;
+}
+__global__ void __launch_bounds__(GSFM_BLOCK) k_cg_init_fin(CgArgs a) {
+  __shared__ double lds[8];
+  const double rz = sum_partials_bcast(a.part_b, a.nb, lds);
+  if (threadIdx.x == 0) {
+    a.sc->rz[0] = rz; a.sc->rz[1] = rz; a.sc->rz0 = rz; a.sc->last_rel = 1.0;
+    a.sc->done = !(rz > 0.0); a.sc->iters = 0;
+  }
+}
+// partial p.Ap
+__global__ void __launch_bounds__(GSFM_BLOCK) k_cg_dot(CgArgs a) {
+  if (a.sc->done) return;
+  __shared__ double lds[8];
+  double v = 0.0;
+  const uint32_t k = blockIdx.x * GSFM_BLOCK + threadIdx.x;
+  if (k < a.n) {
+    const size_t k3 = 3 * (size_t)k;
+    v = a.p[k3] * a.Ap[k3] + a.p[k3 + 1] * a.Ap[k3 + 1] + a.p[k3 + 2] * a.Ap[k3 + 2];
+  }
+  const double t = block_sum_bcast(v, lds);
+  if (threadIdx.x == 0) a.part_a[blockIdx.x] = t;
+}
+// alpha = rz / pAp; x += alpha p; r -= alpha Ap; z = Minv r; partial r.z
+__global__ void __launch_bounds__(GSFM_BLOCK) k_cg_update(CgArgs a) {
+  if (a.sc->done) return;
+  __shared__ double lds[8];
+  const double pAp = sum_partials_bcast(a.part_a, a.nb, lds);
+  const double alpha = a.sc->rz[a.par] / pAp;
+  double v = 0.0;
+  const uint32_t k = blockIdx.x * GSFM_BLOCK + threadIdx.x;
+  if (k < a.n) {
+    const size_t k3 = 3 * (size_t)k;
+    double r[3], z[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { a.xcg[k3 + c] += alpha * a.p[k3 + c]; r[c] = a.r[k3 + c] - alpha * a.Ap[k3 + c]; a.r[k3 + c] = r[c]; }
+    sym3_mulvec(a.Minv + 6 * (size_t)k, r, z);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { a.z[k3 + c] = z[c]; v += r[c] * z[c]; }
+  }
+  const double t = block_sum_bcast(v, lds);
+  if (threadIdx.x == 0) a.part_b[blockIdx.x] = t;
+}
+// beta = rz_new / rz; p = z + beta p; convergence test
+__global__ void __launch_bounds__(GSFM_BLOCK) k_cg_pupdate(CgArgs a) {
+  if (a.sc->done) return;
+  __shared__ double lds[8];
+  const double rz_new = sum_partials_bcast(a.part_b, a.nb, lds);
+  const double rz_old = a.sc->rz[a.par];
+  const double beta = rz_new / rz_old;
+  const uint32_t k = blockIdx.x * GSFM_BLOCK + threadIdx.x;
+  if (k < a.n) {
+    const size_t k3 = 3 * (size_t)k;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) a.p[k3 + c] = a.z[k3 + c] + beta * a.p[k3 + c];
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    a.sc->rz[a.par ^ 1] = rz_new;
+    const int it = a.sc->iters + 1;
+    a.sc->iters = it;
+    const double rel = sqrt(rz_new / a.sc->rz0);
+    a.sc->last_rel = rel;
+    // A block of this launch that already sees done == 1 merely skips its p update, which nobody reads
+    // any more; every later kernel observes the flag at its entry (kernel boundary).
+    if (!(rel > a.tol) || it >= a.max_iters) a.sc->done = 1;
+  }
+}
+
+}  // namespace gsfm

@@ -1,0 +1,214 @@
+"""Flat-array host API over the C-ABI (include/gsfm_rot.h).
+
+`RotationProblem` is the numpy-facing wrapper used by bench.py, the tests and the
+GlobalSfMpy-compatible estimator classes.  It owns one `gsfm_rot_problem`.
+"""
+import ctypes as C
+import numpy as np
+
+from . import _abi
+
+
+def _dp(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _u32p(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint32))
+
+
+class SolverError(RuntimeError):
+    pass
+
+
+class ProblemBase(object):
+    """Shared call sequence for anything exporting the gsfm_rot_* argument lists.
+    (The CPU oracle under oracle/ mirrors them with an orc_ prefix for the parity tests.)"""
+
+    _prefix = "gsfm_rot_"
+
+    def __init__(self, lib, handle, n_cams, n_edges, error_type, residual_dim):
+        self._lib = lib
+        self._h = handle
+        self.n_cams = int(n_cams)
+        self.n_edges = int(n_edges)
+        self.error_type = int(error_type)
+        self.residual_dim = int(residual_dim)
+        self._keep = []
+
+    def _fn(self, name):
+        return getattr(self._lib, self._prefix + name)
+
+    def _check(self, st, what):
+        if st != 0:
+            raise SolverError("%s failed with status %d: %s" % (what, st, self._last_error()))
+
+    def _last_error(self):
+        return ""
+
+    def close(self):
+        if self._h is not None:
+            self._fn("problem_destroy")(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- loss ---------------------------------------------------------------
+    def set_loss(self, loss):
+        """loss: None (Ceres NULL loss), a list of (kind, p0, p1, p2) nodes, or an object with
+        .native_program() (globalsfmpy_amd.loss_functions classes); any other object with
+        .Evaluate(s, out) is used through the host callback path."""
+        if loss is None:
+            nodes = []
+        elif isinstance(loss, (list, tuple)):
+            nodes = list(loss)
+        elif hasattr(loss, "native_program") and loss.native_program() is not None:
+            nodes = loss.native_program()
+        elif hasattr(loss, "Evaluate"):
+            return self.set_loss_callback(loss.Evaluate)
+        else:
+            raise TypeError("unsupported loss object %r" % (loss,))
+        arr, n = _abi.make_program(nodes)
+        self._check(self._fn("set_loss")(self._h, arr, n), "set_loss")
+
+    def set_loss_callback(self, evaluate):
+        def _cb(_user, s, out):
+            buf = [0.0, 0.0, 0.0]
+            evaluate(s, buf)
+            out[0], out[1], out[2] = buf[0], buf[1], buf[2]
+        cb = _abi.LOSS_CALLBACK_FN(_cb)
+        self._keep.append(cb)
+        self._check(self._fn("set_loss_callback")(self._h, cb, None), "set_loss_callback")
+
+    def set_edge_weights(self, w):
+        w = np.ascontiguousarray(w, dtype=np.float64)
+        assert w.shape == (self.n_edges,)
+        self._check(self._fn("set_edge_weights")(self._h, _dp(w)), "set_edge_weights")
+
+    # -- evaluation ---------------------------------------------------------
+    def residuals(self, rot_aa, want_residuals=False):
+        rot = np.ascontiguousarray(rot_aa, dtype=np.float64).reshape(self.n_cams, 3)
+        s = np.empty(self.n_edges)
+        rho = np.empty((self.n_edges, 3))
+        r = np.empty((self.n_edges, self.residual_dim)) if want_residuals else None
+        cost = C.c_double(0)
+        self._check(self._fn("residuals")(self._h, _dp(rot), _dp(s), _dp(rho), _dp(r), C.byref(cost)), "residuals")
+        return {"s": s, "rho": rho, "residuals": r, "cost": cost.value}
+
+    def linearize(self, rot_aa):
+        rot = np.ascontiguousarray(rot_aa, dtype=np.float64).reshape(self.n_cams, 3)
+        g = np.empty((self.n_cams, 3))
+        d = np.empty((self.n_cams, 3, 3))
+        cost = C.c_double(0)
+        self._check(self._fn("linearize")(self._h, _dp(rot), _dp(g), _dp(d), C.byref(cost)), "linearize")
+        return {"gradient": g, "diag_blocks": d, "cost": cost.value}
+
+    def normal_matvec(self, v):
+        v = np.ascontiguousarray(v, dtype=np.float64).reshape(self.n_cams, 3)
+        y = np.empty_like(v)
+        self._check(self._fn("normal_matvec")(self._h, _dp(v), _dp(y)), "normal_matvec")
+        return y
+
+    # -- solve --------------------------------------------------------------
+    def default_options(self):
+        o = _abi.Options()
+        self._options_default(o)
+        return o
+
+    def _options(self, kw):
+        o = self.default_options()
+        for k, v in kw.items():
+            if not hasattr(o, k):
+                raise TypeError("unknown solver option %r" % k)
+            setattr(o, k, v)
+        return o
+
+    def solve(self, rot_aa, **options):
+        rot = np.array(rot_aa, dtype=np.float64, order="C").reshape(self.n_cams, 3)
+        o = self._options(options)
+        s = _abi.Summary()
+        st = self._fn("solve")(self._h, _dp(rot), C.byref(o), C.byref(s))
+        self._check(st, "solve")
+        return rot, s.as_dict()
+
+    def solve_sigma_consensus(self, rot_aa, iters_num, sigma_max, **options):
+        rot = np.array(rot_aa, dtype=np.float64, order="C").reshape(self.n_cams, 3)
+        o = self._options(options)
+        s = _abi.Summary()
+        st = self._fn("solve_sigma_consensus")(self._h, _dp(rot), int(iters_num), float(sigma_max), C.byref(o), C.byref(s))
+        self._check(st, "solve_sigma_consensus")
+        return rot, s.as_dict()
+
+    def trace(self):
+        rows = self._fn("get_trace")(self._h, None, 0)
+        out = np.zeros((max(rows, 0), 8))
+        if rows > 0:
+            self._fn("get_trace")(self._h, _dp(out), rows)
+        return out
+
+
+def _prep_edges(n_cams, edge_i, edge_j, rel_aa, cov6, inlier_weight):
+    ei = np.ascontiguousarray(edge_i, dtype=np.uint32)
+    ej = np.ascontiguousarray(edge_j, dtype=np.uint32)
+    rel = np.ascontiguousarray(rel_aa, dtype=np.float64).reshape(-1, 3)
+    n_edges = ei.shape[0]
+    if ej.shape[0] != n_edges or rel.shape[0] != n_edges:
+        raise ValueError("edge arrays disagree in length")
+    c6 = None if cov6 is None else np.ascontiguousarray(cov6, dtype=np.float64).reshape(n_edges, 6)
+    iw = None if inlier_weight is None else np.ascontiguousarray(inlier_weight, dtype=np.float64).reshape(n_edges)
+    return ei, ej, rel, c6, iw, n_edges
+
+
+class RotationProblem(ProblemBase):
+    """The product: gsfm_rot_problem on the current HIP device."""
+
+    def __init__(self, n_cams, edge_i, edge_j, rel_aa, error_type=_abi.ANGLE_AXIS, cov6=None,
+                 inlier_weight=None, shard=None, stream=None):
+        lib = _abi.load_library()
+        ei, ej, rel, c6, iw, n_edges = _prep_edges(n_cams, edge_i, edge_j, rel_aa, cov6, inlier_weight)
+        h = C.c_void_p()
+        st = lib.gsfm_rot_problem_create(int(n_cams), int(n_edges), _u32p(ei), _u32p(ej), _dp(rel), int(error_type),
+                                         _dp(c6), _dp(iw), C.byref(shard) if shard is not None else None, C.byref(h))
+        if st != 0:
+            raise SolverError("gsfm_rot_problem_create failed with status %d: %s"
+                              % (st, lib.gsfm_last_error().decode("utf-8", "replace")))
+        ProblemBase.__init__(self, lib, h, n_cams, n_edges, error_type, lib.gsfm_rot_residual_dim(int(error_type)))
+        self._shard = shard
+        if stream is not None:
+            self._check(lib.gsfm_rot_set_stream(self._h, C.c_void_p(int(stream))), "set_stream")
+
+    def _last_error(self):
+        return self._lib.gsfm_last_error().decode("utf-8", "replace")
+
+    def _options_default(self, o):
+        self._lib.gsfm_rot_options_default(C.byref(o))
+
+    def time_sweep(self, rot_aa, reps=20):
+        rot = np.ascontiguousarray(rot_aa, dtype=np.float64).reshape(self.n_cams, 3)
+        ms = C.c_double(0)
+        self._check(self._lib.gsfm_rot_time_sweep(self._h, _dp(rot), int(reps), C.byref(ms)), "time_sweep")
+        return ms.value
+
+    def sweep_bytes(self):
+        a, b = C.c_double(0), C.c_double(0)
+        self._check(self._lib.gsfm_rot_sweep_bytes(self._h, C.byref(a), C.byref(b)), "sweep_bytes")
+        return a.value, b.value
+
+
+def magsac_table(nu):
+    lib = _abi.load_library()
+    n = lib.gsfm_magsac_table(int(nu), None, 0)
+    out = np.empty(n)
+    lib.gsfm_magsac_table(int(nu), _dp(out), n)
+    return out
+
+
+def magsac_constants(nu):
+    lib = _abi.load_library()
+    a, b, c = C.c_double(), C.c_double(), C.c_double()
+    lib.gsfm_magsac_constants(int(nu), C.byref(a), C.byref(b), C.byref(c))
+    return a.value, b.value, c.value

@@ -1,0 +1,278 @@
+/*
+ * gsfm_rot.h — C ABI of the MI355X-native robust rotation-averaging solver.
+ *
+ * This is the drop-in boundary for ONE path of zhangganlin/GlobalSfMpy: the
+ * robust rotation-averaging solve behind
+ *   theia::GSfMNonlinearRotationEstimator::EstimateRotations*()
+ * (reference: include/GSfM_nonlinear_rotation_estimator.hpp:22-59,
+ *  src/GSfM_nonlinear_rotation_estimator.cpp:24-457).  In the reference that
+ * path is a ceres::Problem (one AutoDiff residual block per view-graph edge)
+ * solved by Levenberg-Marquardt + SPARSE_NORMAL_CHOLESKY.  Here the whole
+ * inner loop (residuals, 3x3 Jacobians, covariance whitening, robust-loss
+ * correction, normal-equation assembly, block-Jacobi PCG, LM control) runs as
+ * hand-written fp64 HIP kernels for gfx950 behind these entry points.
+ *
+ * Conventions (all identical to the reference):
+ *   - a camera orientation is a world->camera angle-axis 3-vector;
+ *   - an edge (i, j) carries the angle-axis of R_ij ~= R_j * R_i^T
+ *     (thirdparty/TheiaSfM/src/theia/sfm/global_pose_estimation/pairwise_rotation_error.h:47-48);
+ *   - cost = sum_e 1/2 rho(||r_e||^2) (Ceres convention, scripts/loss_functions.py:16-19).
+ *
+ * Plain pointers and sizes only: no C++ types, no torch types.  All pointers are
+ * HOST pointers unless the name ends in _dev.  The caller owns every buffer; the
+ * library copies what it needs into HBM at create time.  Every function returns a
+ * gsfm_status and never aborts; gsfm_last_error() gives the message of the last
+ * failure on the calling thread.  One problem may be used by one thread at a time.
+ */
+#ifndef GSFM_ROT_H_
+#define GSFM_ROT_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GSFM_ROT_ABI_VERSION 1
+
+typedef enum {
+  GSFM_OK = 0,
+  GSFM_ERR_INVALID_ARG = 1,
+  GSFM_ERR_NO_DEVICE = 2,   /* no HIP device / HIP runtime failure at init */
+  GSFM_ERR_HIP = 3,         /* a HIP call failed */
+  GSFM_ERR_EMPTY = 4,       /* no cameras or no usable edges (reference returns false) */
+  GSFM_ERR_COMM = 5,        /* a shard communicator callback failed */
+  GSFM_ERR_UNSUPPORTED = 6
+} gsfm_status;
+
+/* Same numeric values as `enum class RotationErrorType`
+ * (reference include/pairwise_rotation_error_quat.hpp:50-61). */
+typedef enum {
+  GSFM_ROT_QUATERNION_NORM = 0,        /* 4 residuals, PairwiseRotationErrorQuatFNorm  (quat.hpp:108-150) */
+  GSFM_ROT_ROTATION_MAT_FNORM = 1,     /* 9 residuals, PairwiseRotationErrorRotFNorm   (quat.hpp:152-196) */
+  GSFM_ROT_QUATERNION_COSINE = 2,      /* 3 residuals, PairwiseRotationErrorQuat       (quat.hpp:65-106)  */
+  GSFM_ROT_ANGLE_AXIS_COVARIANCE = 3,  /* r = Lt * log(.)  Lt = chol((1e8*Sigma)^-1)^T  (estimator.cpp:251-256) */
+  GSFM_ROT_ANGLE_AXIS = 4,             /* r = log(.)                                    (estimator.cpp:257-259) */
+  GSFM_ROT_ANGLE_AXIS_INLIERS = 5,     /* r = (#common/100) * log(.)                    (estimator.cpp:260-264) */
+  GSFM_ROT_ANGLE_AXIS_COV_INLIERS = 6, /* r = (#common/100) * Lt * log(.)               (estimator.cpp:265-274) */
+  GSFM_ROT_ANGLE_AXIS_COVTRACE = 7,    /* r = sqrt(1/trace(1e8*Sigma)) * log(.)         (estimator.cpp:275-282) */
+  GSFM_ROT_ANGLE_AXIS_COVNORM = 8      /* r = sqrt(1/||1e8*Sigma||_F) * log(.)          (estimator.cpp:283-287) */
+} gsfm_rot_error_type;
+
+/* ------------------------------------------------------------------------- */
+/* Robust losses: a native descriptor of scripts/loss_functions.py            */
+/* ------------------------------------------------------------------------- */
+/* A loss is a short postfix program run by a tiny stack machine, once per edge,
+ * on the device.  Leaves push (rho, rho', rho'')(arg); combinators rewrite the
+ * stack.  arg is the top of an argument stack that starts as [s].
+ *   ScaledLoss(rho, a)    ->  prog(rho), SCALE(a)
+ *   ComposedLoss(f, g)    ->  prog(g), PUSH_ARG, prog(f), COMPOSE
+ * A NULL / empty program is the Ceres NULL loss (cost = s/2, no correction).   */
+typedef enum {
+  GSFM_LOSS_TRIVIAL = 0,       /* loss_functions.py:47   */
+  GSFM_LOSS_HUBER = 1,         /* :56   p0 = a           */
+  GSFM_LOSS_SOFT_L1 = 2,       /* :74   p0 = a           */
+  GSFM_LOSS_CAUCHY = 3,        /* :88   p0 = a           */
+  GSFM_LOSS_ARCTAN = 4,        /* :101  p0 = a           */
+  GSFM_LOSS_TOLERANT = 5,      /* :114  p0 = a, p1 = b   */
+  GSFM_LOSS_TUKEY = 6,         /* :167  p0 = a           */
+  GSFM_LOSS_LONE_HALF = 7,     /* :187  p0 = a           */
+  GSFM_LOSS_LTWO = 8,          /* :216  p0 = a (sigma2 ignored, as in the reference) */
+  GSFM_LOSS_GEMAN_MCCLURE = 9, /* :239  p0 = a, p1 = sigma2 */
+  GSFM_LOSS_MAGSAC = 10,       /* :285/:344/:402  p0 = sigma, p1 = nu (3|4|9), p2 = inverse (0|1) */
+  GSFM_LOSS_OP_SCALE = 32,     /* :267  p0 = a           */
+  GSFM_LOSS_OP_PUSH_ARG = 33,  /* push top-of-stack rho as the new argument */
+  GSFM_LOSS_OP_COMPOSE = 34    /* :250  pops f, g -> (f.rho, f'.g', f''.g'^2 + f'.g'') */
+} gsfm_loss_kind;
+
+typedef struct {
+  int32_t kind;     /* gsfm_loss_kind */
+  int32_t reserved; /* must be 0 */
+  double p[3];
+} gsfm_loss_node;
+
+#define GSFM_LOSS_MAX_NODES 16
+#define GSFM_LOSS_MAX_STACK 6
+
+/* Arbitrary user loss (a Python subclass of LossFunction without a native
+ * descriptor): evaluated on the HOST exactly like the reference's trampoline
+ * (bind_src/GlobalSfMpy.cpp:33-65), once per edge per residual evaluation; the
+ * residuals, Jacobians and the solve still run on the device. */
+typedef void (*gsfm_loss_callback)(void* user, double sq_norm, double out[3]);
+
+/* ------------------------------------------------------------------------- */
+/* Options / summary                                                           */
+/* ------------------------------------------------------------------------- */
+typedef struct {
+  int32_t max_num_iterations;          /* 200   (estimator.cpp:73,178,301,442) */
+  int32_t num_threads;                 /* accepted for signature parity; unused on the device path */
+  double function_tolerance;           /* 1e-6  Ceres 1.14 default */
+  double gradient_tolerance;           /* 1e-10 */
+  double parameter_tolerance;          /* 1e-8  */
+  double initial_trust_region_radius;  /* 1e4   */
+  double max_trust_region_radius;      /* 1e16  */
+  double min_trust_region_radius;      /* 1e-32 */
+  double min_relative_decrease;        /* 1e-3  */
+  double min_lm_diagonal;              /* 1e-6  */
+  double max_lm_diagonal;              /* 1e32  */
+  int32_t jacobi_scaling;              /* 1     */
+  int32_t max_cg_iterations;           /* PCG replaces CHOLMOD: iteration cap per LM step (default 1000) */
+  double cg_relative_tolerance;        /* stop when sqrt(r.M^-1 r / b.M^-1 b) <= tol (default 1e-12 ~ "exact") */
+  int32_t cg_check_interval;           /* CG iterations enqueued between host checks (default 8) */
+  int32_t verbose;                     /* 1: print one line per LM iteration to stderr */
+} gsfm_rot_options;
+
+typedef enum {
+  GSFM_TERM_FUNCTION_TOLERANCE = 0,
+  GSFM_TERM_GRADIENT_TOLERANCE = 1,
+  GSFM_TERM_PARAMETER_TOLERANCE = 2,
+  GSFM_TERM_NO_CONVERGENCE = 3, /* max_num_iterations reached */
+  GSFM_TERM_FAILURE = 4         /* too many invalid steps / trust region collapsed / non-finite */
+} gsfm_rot_termination;
+
+typedef struct {
+  int32_t termination;            /* gsfm_rot_termination */
+  int32_t num_iterations;         /* LM iterations (iteration 0 = initial evaluation, not counted) */
+  int32_t num_successful_steps;
+  int32_t num_unsuccessful_steps;
+  int32_t num_residual_sweeps;    /* full passes over all edges (linearisations + trial-cost evaluations) */
+  int32_t num_linearizations;
+  int32_t num_cg_iterations;      /* total PCG iterations (= normal-equation mat-vecs) */
+  int32_t iters_to_1e6;           /* first LM iteration with |dcost|/cost <= 1e-6, -1 if never */
+  int32_t nonfinite;              /* 1 if a NaN/Inf cost was seen */
+  int32_t outer_iterations;       /* sigma-consensus only: IRLS outer iterations run */
+  uint64_t num_edges_used;        /* residual blocks in the problem (this rank's cost-owned edges when sharded) */
+  double initial_cost;
+  double final_cost;
+  double final_gradient_max_norm;
+  double final_radius;
+  double last_weight_change;      /* sigma-consensus: last mean |w - w_prev| */
+  double t_total_ms;              /* host wall time of the call (uploads of the 3N rotations included) */
+  double t_linearize_ms;          /* GPU time (HIP events) in the linearise kernel */
+  double t_sweep_ms;              /* GPU time in the residual+reweight cost sweep */
+  double t_cg_ms;                 /* GPU time in PCG kernels */
+} gsfm_rot_summary;
+
+/* ------------------------------------------------------------------------- */
+/* Multi-GPU sharding (one process per GPU)                                    */
+/* ------------------------------------------------------------------------- */
+/* Cameras (rows of the normal equations) are split into world_size contiguous
+ * slices of `slice_width` rows: rank r owns [r*slice_width, min((r+1)*slice_width, n_cams)).
+ * A rank passes the edges that touch at least one owned camera.  It evaluates the
+ * directed (row) contributions of its owned cameras in full, so per-camera sums
+ * need no reduction: slices are exchanged with an in-place all-gather; scalars
+ * (cost, dot products) with a sum all-reduce.  Both callbacks receive DEVICE
+ * pointers and must enqueue on `hip_stream` (or make it wait).                 */
+typedef struct {
+  int32_t rank;
+  int32_t world_size;
+  uint32_t slice_width;
+  uint32_t reserved;
+  void* ctx;
+  /* buf holds world_size * count doubles; rank r's input already sits at buf + r*count */
+  int (*all_gather)(void* ctx, double* buf_dev, size_t count, void* hip_stream);
+  int (*all_reduce_sum)(void* ctx, double* buf_dev, size_t count, void* hip_stream);
+} gsfm_rot_shard;
+
+/* ------------------------------------------------------------------------- */
+/* Entry points                                                                */
+/* ------------------------------------------------------------------------- */
+typedef struct gsfm_rot_problem gsfm_rot_problem;
+
+int gsfm_rot_abi_version(void);
+const char* gsfm_last_error(void);
+void gsfm_rot_options_default(gsfm_rot_options* opt);
+
+/* Build the problem: replaces the edge loop that fills the ceres::Problem
+ * (estimator.cpp:47-65, 110-166, 228-295).  Cameras are dense indices
+ * 0..n_cams-1 (= rank of the ViewId among the views that HAVE an initial
+ * orientation; edges touching other views are skipped by the caller, as the
+ * reference does at :57-60).  (edge_i[e], edge_j[e]) is the ViewIdPair
+ * (first, second); rel_aa[3e..] is TwoViewInfo::rotation_2.
+ *   cov6          6 doubles per edge, order C00 C11 C22 C01 C02 C12 (the order of
+ *                 covariance_rot.txt, src/uncertainty.cpp:185-195); required for the
+ *                 *_COV* error types, ignored otherwise (may be NULL).
+ *   inlier_weight one double per edge = (#common tracks)/100 (estimator.cpp:263,268);
+ *                 required for the *_INLIERS types, ignored otherwise.
+ *   shard         NULL for a single GPU.
+ * The current HIP device of the calling thread is used.                        */
+gsfm_status gsfm_rot_problem_create(uint32_t n_cams, uint64_t n_edges,
+                                    const uint32_t* edge_i, const uint32_t* edge_j,
+                                    const double* rel_aa, int32_t error_type,
+                                    const double* cov6, const double* inlier_weight,
+                                    const gsfm_rot_shard* shard,
+                                    gsfm_rot_problem** out);
+void gsfm_rot_problem_destroy(gsfm_rot_problem* p);
+
+/* Run all work of this problem on an existing hipStream_t (e.g. torch's current
+ * stream).  NULL = a stream owned by the problem (default). */
+gsfm_status gsfm_rot_set_stream(gsfm_rot_problem* p, void* hip_stream);
+
+/* Replaces the ceres::LossFunction* argument.  n_nodes == 0 -> NULL loss. */
+gsfm_status gsfm_rot_set_loss(gsfm_rot_problem* p, const gsfm_loss_node* prog, int32_t n_nodes);
+gsfm_status gsfm_rot_set_loss_callback(gsfm_rot_problem* p, gsfm_loss_callback fn, void* user);
+
+/* Replace the per-edge scalar weights (only for the scalar-weight angle-axis
+ * types; used by the sigma-consensus outer loop and exposed for callers). */
+gsfm_status gsfm_rot_set_edge_weights(gsfm_rot_problem* p, const double* w /* n_edges */);
+
+/* ceres::Solve replacement (estimator.cpp:72-78, 176-183, 299-306): LM on the
+ * device; rot_aa_inout is the in/out global_orientations (3 doubles per camera). */
+gsfm_status gsfm_rot_solve(gsfm_rot_problem* p, double* rot_aa_inout,
+                           const gsfm_rot_options* opt, gsfm_rot_summary* summary);
+
+/* EstimateRotationsWithSigmaConsensus (estimator.cpp:314-457): outer IRLS with
+ * MAGSAC (nu = 3) weights from the residual norm, inner full LM solve.  The
+ * problem must have been created with GSFM_ROT_ANGLE_AXIS.                      */
+gsfm_status gsfm_rot_solve_sigma_consensus(gsfm_rot_problem* p, double* rot_aa_inout,
+                                           int32_t iters_num, double sigma_max,
+                                           const gsfm_rot_options* opt, gsfm_rot_summary* summary);
+
+/* One residual + reweight sweep (kernel K1) at the given rotations; any output
+ * may be NULL.  s_out[e] = ||r_e||^2, rho_out[3e..] = (rho, rho', rho''),
+ * residual_out[stride*e..] = the raw residual (3, 4 or 9 values, see
+ * gsfm_rot_residual_dim), *cost = sum 1/2 rho.  Outputs follow the edge order
+ * given at create time.                                                         */
+gsfm_status gsfm_rot_residuals(gsfm_rot_problem* p, const double* rot_aa,
+                               double* s_out, double* rho_out, double* residual_out,
+                               double* cost);
+int32_t gsfm_rot_residual_dim(int32_t error_type);
+
+/* Linearise at rot_aa (kernel K2): gradient J~^T r~ (3 per camera) and the
+ * diagonal 3x3 blocks of J~^T J~ (9 per camera, row-major), both with respect to
+ * the reference's own parameters (additive angle-axis, or the quaternion local
+ * parameterisation for the QUATERNION_ / ROTATION_MAT_ types).  Also keeps the
+ * linearisation on the device for gsfm_rot_normal_matvec.                       */
+gsfm_status gsfm_rot_linearize(gsfm_rot_problem* p, const double* rot_aa,
+                               double* gradient, double* diag_blocks, double* cost);
+/* y = (J~^T J~) v for the last linearisation (kernel K3), 3 per camera. */
+gsfm_status gsfm_rot_normal_matvec(gsfm_rot_problem* p, const double* v, double* y);
+
+/* Per-iteration trace of the last solve: rows of GSFM_ROT_TRACE_COLS doubles
+ * [iteration, cost, cost_change, gradient_max_norm, step_norm, relative_decrease,
+ *  trust_region_radius, cg_iterations].  Returns the number of rows available.   */
+#define GSFM_ROT_TRACE_COLS 8
+int32_t gsfm_rot_get_trace(gsfm_rot_problem* p, double* out, int32_t cap_rows);
+
+/* Timed loop of `reps` K1 sweeps with everything resident in HBM; returns the
+ * mean kernel time (HIP events on the problem's stream).  For bench.py.         */
+gsfm_status gsfm_rot_time_sweep(gsfm_rot_problem* p, const double* rot_aa, int32_t reps,
+                                double* mean_kernel_ms);
+
+/* Bytes moved per edge by one K1 sweep as laid out in HBM / as counted
+ * algorithmically: for roofline reporting.                          */
+gsfm_status gsfm_rot_sweep_bytes(gsfm_rot_problem* p, double* algorithmic_bytes,
+                                 double* layout_bytes);
+
+/* MAGSAC lookup table Gamma((nu-1)/2, x/1000), x = 0..n-1 (include/gamma_values.cpp);
+ * regenerated analytically.  Returns the table length; copies min(n, cap) values. */
+int32_t gsfm_magsac_table(int32_t nu, double* out, int32_t cap);
+/* C_nu, sigma_quantile_nu, upper_incomplete_gamma_of_k_nu (gamma_values.cpp:6-11,384-389,780-785) */
+gsfm_status gsfm_magsac_constants(int32_t nu, double* C, double* sigma_quantile,
+                                  double* upper_incomplete_gamma_of_k);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSFM_ROT_H_ */

@@ -1,0 +1,158 @@
+"""-m gpu: the HIP path (through the C-ABI) against the CPU oracle on the same seeded inputs.
+
+Tolerances (fp64): per-edge residual quantities 1e-12 relative to the problem scale; assembled
+gradient / blocks / mat-vec 1e-10 relative; solved rotations <= 1e-6 rad mean angular difference
+(the north-star bar; observed differences are orders of magnitude below it).
+"""
+import numpy as np
+import pytest
+
+from globalsfmpy_amd import _abi, synth
+from globalsfmpy_amd import loss_functions as LF
+
+pytestmark = pytest.mark.gpu
+
+ERROR_TYPES = list(range(9))
+
+
+def _losses():
+    return {
+        "null": None,
+        "trivial": LF.TrivialLoss(),
+        "huber": LF.HuberLoss(0.1),
+        "softl1": LF.SoftLOneLoss(0.1),
+        "cauchy": LF.CauchyLoss(0.2),
+        "arctan": LF.ArctanLoss(0.5),
+        "tolerant": LF.TolerantLoss(0.05, 0.01),
+        "tukey": LF.TukeyLoss(1.0),
+        "lonehalf": LF.LOneHalfLoss(0.5),
+        "ltwo": LF.LTwoLoss(1.0, 1.0),
+        "gm": LF.GemanMcClureLoss(0.3, 1.0),
+        "magsac3": LF.MAGSACWeightBasedLoss(0.02),
+        "magsac3inv": LF.MAGSACWeightBasedLoss(0.5, True),
+        "magsac4": LF.MAGSACWeightBasedLoss4(0.5),
+        "magsac9": LF.MAGSACWeightBasedLoss9(0.05),
+        "scaled": LF.ScaledLoss(LF.HuberLoss(0.1), 2.5),
+        "composed": LF.ComposedLoss(LF.CauchyLoss(0.3), LF.SoftLOneLoss(0.2)),
+    }
+
+
+def _pair(oracle, g, et, loss):
+    from globalsfmpy_amd.solver import RotationProblem
+    dev = RotationProblem(g["n_cams"], g["edge_i"], g["edge_j"], g["rel_aa"], et, cov6=g["cov6"], inlier_weight=g["inlier_weight"])
+    ora = oracle.OracleProblem(g["n_cams"], g["edge_i"], g["edge_j"], g["rel_aa"], et, cov6=g["cov6"], inlier_weight=g["inlier_weight"])
+    dev.set_loss(loss)
+    ora.set_loss(loss)
+    return dev, ora
+
+
+def _relerr(a, b):
+    scale = max(1.0, float(np.max(np.abs(b))))
+    return float(np.max(np.abs(np.asarray(a) - np.asarray(b)))) / scale
+
+
+@pytest.fixture(scope="module")
+def graph():
+    return synth.make_graph(n_cams=150, n_edges=1500, seed=11, outlier_frac=0.2, full_so3=True)
+
+
+@pytest.mark.parametrize("et", ERROR_TYPES)
+def test_residual_sweep_matches_oracle(oracle, graph, et):
+    dev, ora = _pair(oracle, graph, et, LF.HuberLoss(0.1))
+    a = dev.residuals(graph["init_aa"], want_residuals=True)
+    b = ora.residuals(graph["init_aa"], want_residuals=True)
+    assert _relerr(a["residuals"], b["residuals"]) < 1e-12
+    assert _relerr(a["s"], b["s"]) < 1e-12
+    assert _relerr(a["rho"], b["rho"]) < 1e-11
+    assert abs(a["cost"] - b["cost"]) <= 1e-12 * max(1.0, abs(b["cost"]))
+
+
+@pytest.mark.parametrize("name", sorted(_losses().keys()))
+def test_every_loss_on_device(oracle, graph, name):
+    loss = _losses()[name]
+    for et in (_abi.ANGLE_AXIS_COVARIANCE, _abi.ANGLE_AXIS):
+        dev, ora = _pair(oracle, graph, et, loss)
+        a = dev.residuals(graph["init_aa"])
+        b = ora.residuals(graph["init_aa"])
+        assert _relerr(a["rho"], b["rho"]) < 1e-10, (name, et)
+        assert abs(a["cost"] - b["cost"]) <= 1e-11 * max(1.0, abs(b["cost"]))
+
+
+@pytest.mark.parametrize("et", ERROR_TYPES)
+@pytest.mark.parametrize("lname", ["huber", "magsac3", "tolerant"])
+def test_linearization_matches_oracle(oracle, graph, et, lname):
+    loss = _losses()[lname]
+    dev, ora = _pair(oracle, graph, et, loss)
+    a = dev.linearize(graph["init_aa"])
+    b = ora.linearize(graph["init_aa"])
+    assert abs(a["cost"] - b["cost"]) <= 1e-11 * max(1.0, abs(b["cost"]))
+    assert _relerr(a["gradient"], b["gradient"]) < 1e-9
+    assert _relerr(a["diag_blocks"], b["diag_blocks"]) < 1e-9
+    rng = np.random.default_rng(5)
+    v = rng.standard_normal((graph["n_cams"], 3))
+    assert _relerr(dev.normal_matvec(v), ora.normal_matvec(v)) < 1e-9
+
+
+@pytest.mark.parametrize("et", ERROR_TYPES)
+def test_solve_matches_oracle(oracle, graph, et):
+    loss = LF.MAGSACWeightBasedLoss(0.02) if et in (_abi.ANGLE_AXIS_COVARIANCE, _abi.ANGLE_AXIS_COV_INLIERS) else LF.HuberLoss(0.1)
+    dev, ora = _pair(oracle, graph, et, loss)
+    rd, sd = dev.solve(graph["init_aa"])
+    ro, so = ora.solve(graph["init_aa"])
+    assert sd["num_iterations"] == so["num_iterations"], (dev.trace(), ora.trace())
+    assert sd["termination"] == so["termination"]
+    assert abs(sd["final_cost"] - so["final_cost"]) <= 1e-9 * max(1.0, abs(so["final_cost"]))
+    assert synth.angular_distance(rd, ro).mean() <= 1e-6
+
+
+def test_noise_free_graph_recovers_ground_truth(oracle):
+    # template: Theia robust_rotation_estimator_test.cc:215-241 (noise 0 -> exact up to gauge)
+    from globalsfmpy_amd.solver import RotationProblem
+    g = synth.make_graph(n_cams=100, n_edges=800, seed=56, noise=False, init_noise_deg=5.0)
+    dev = RotationProblem(g["n_cams"], g["edge_i"], g["edge_j"], g["rel_aa"], _abi.ANGLE_AXIS)
+    dev.set_loss(LF.SoftLOneLoss(0.1))
+    r, s = dev.solve(g["init_aa"])
+    aligned = synth.align_rotations(r, g["gt_aa"])
+    assert np.rad2deg(synth.angular_distance(aligned, g["gt_aa"]).max()) < 1e-6
+
+
+def test_sigma_consensus_matches_oracle(oracle):
+    from globalsfmpy_amd.solver import RotationProblem
+    g = synth.make_graph(n_cams=80, n_edges=700, seed=3, outlier_frac=0.25)
+    dev = RotationProblem(g["n_cams"], g["edge_i"], g["edge_j"], g["rel_aa"], _abi.ANGLE_AXIS)
+    ora = oracle.OracleProblem(g["n_cams"], g["edge_i"], g["edge_j"], g["rel_aa"], _abi.ANGLE_AXIS)
+    for p in (dev, ora):
+        p.set_loss(LF.TrivialLoss())
+    rd, sd = dev.solve_sigma_consensus(g["init_aa"], 10, 0.1)
+    ro, so = ora.solve_sigma_consensus(g["init_aa"], 10, 0.1)
+    assert sd["outer_iterations"] == so["outer_iterations"]
+    assert abs(sd["last_weight_change"] - so["last_weight_change"]) < 1e-9
+    assert synth.angular_distance(rd, ro).mean() <= 1e-6
+
+
+def test_python_callback_loss(oracle, graph):
+    """A user loss with only Evaluate() (no native descriptor) goes through the host callback."""
+    class MyCauchy(object):
+        def Evaluate(self, s, out):
+            t = 1.0 + s / 0.04
+            out[0] = 0.04 * np.log(t); out[1] = 1.0 / t; out[2] = -1.0 / (0.04 * t * t)
+    from globalsfmpy_amd.solver import RotationProblem
+    g = synth.make_graph(n_cams=40, n_edges=200, seed=9, outlier_frac=0.1)
+    dev = RotationProblem(g["n_cams"], g["edge_i"], g["edge_j"], g["rel_aa"], _abi.ANGLE_AXIS)
+    dev.set_loss(MyCauchy())
+    ref = RotationProblem(g["n_cams"], g["edge_i"], g["edge_j"], g["rel_aa"], _abi.ANGLE_AXIS)
+    ref.set_loss(LF.CauchyLoss(0.2))
+    r1, s1 = dev.solve(g["init_aa"])
+    r2, s2 = ref.solve(g["init_aa"])
+    assert s1["num_iterations"] == s2["num_iterations"]
+    assert synth.angular_distance(r1, r2).max() < 1e-9
+
+
+def test_error_behaviour():
+    from globalsfmpy_amd.solver import RotationProblem, SolverError
+    with pytest.raises(SolverError):
+        RotationProblem(3, [0, 1], [1, 5], np.zeros((2, 3)))            # out-of-range camera
+    with pytest.raises(SolverError):
+        RotationProblem(3, [0, 1], [1, 2], np.zeros((2, 3)), _abi.ANGLE_AXIS_COVARIANCE)  # covariance missing
+    with pytest.raises(SolverError):
+        RotationProblem(3, np.zeros(0, np.uint32), np.zeros(0, np.uint32), np.zeros((0, 3)))  # empty (reference returns false)
