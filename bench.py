@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""bench.py -- the hot path's headline metric on MI355X.
+
+Metric (BASELINE.json): edge-residuals/sec (+ IRLS iterations to 1e-6) of the robust
+rotation-averaging solve on the synthetic 100k-camera / 10M-edge pose graph with 30 % outlier
+edges, covariance-whitened residuals (ANGLE_AXIS_COVARIANCE) and the MAGSAC sigma-consensus loss
+(the reference pipeline's defaults, scripts/sfm_pipeline.py:136-141).
+
+A "step" is ONE full solve (gsfm_rot_solve) from the same initial guess with the graph already
+resident in HBM.  value = E * (full-edge residual sweeps per solve) / (time per solve), aggregated
+over all ranks.  N > 1 shards the SAME graph by camera slices (strong scaling, one process per GPU,
+RCCL all-gather of the per-camera slices), launched as
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s peak (spec)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--cams", type=int, default=100000)
+    ap.add_argument("--edges", type=int, default=10000000)
+    ap.add_argument("--outliers", type=float, default=0.3)
+    ap.add_argument("--seed", type=int, default=2023)
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
+    ap.add_argument("--sweep-reps", type=int, default=20)
+    ap.add_argument("--cpu-baseline", type=int, default=1)
+    ap.add_argument("--cpu-sample-cams", type=int, default=20000)
+    ap.add_argument("--cpu-sample-edges", type=int, default=2000000)
+    ap.add_argument("--verbose", type=int, default=0)
+    return ap.parse_args()
+
+
+def cpu_baseline(args, loss_ctor, error_type):
+    """The CPU oracle (restatement of the reference's Ceres path) timed on this host's cores on a
+    bounded sample of the same workload: same generator and mean degree, fewer cameras/edges."""
+    from globalsfmpy_amd import synth
+    from oracle import pyoracle
+    g = synth.make_graph(args.cpu_sample_cams, args.cpu_sample_edges, args.seed + 1, outlier_frac=args.outliers)
+    p = pyoracle.OracleProblem(g["n_cams"], g["edge_i"], g["edge_j"], g["rel_aa"], error_type, cov6=g["cov6"])
+    p.set_loss(loss_ctor())
+    t0 = time.perf_counter()
+    _, s = p.solve(g["init_aa"])
+    dt = time.perf_counter() - t0
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    return {
+        "value": args.cpu_sample_edges * s["num_residual_sweeps"] / dt,
+        "unit": "edge-residuals/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": "oracle/ (C++ restatement of the reference's Ceres LM path, OpenMP over edges, PCG 1e-14): "
+                  "1 full solve of a %d-camera / %d-edge graph from the same generator (same mean degree, %g outliers), "
+                  "%d sweeps, %d LM iterations, %.1f s" % (args.cpu_sample_cams, args.cpu_sample_edges, args.outliers,
+                                                           s["num_residual_sweeps"], s["num_iterations"], dt),
+    }
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+        args.gpus = world
+
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the solver has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    from globalsfmpy_amd import _abi, synth, sharding
+    from globalsfmpy_amd.loss_functions import MAGSACWeightBasedLoss
+    from globalsfmpy_amd.solver import RotationProblem
+
+    error_type = _abi.ANGLE_AXIS_COVARIANCE
+    loss_ctor = lambda: MAGSACWeightBasedLoss(0.02)  # noqa: E731
+
+    n_cams, n_edges = args.cams, args.edges
+    if args.scaling == "weak":
+        n_cams, n_edges = args.cams * world, args.edges * world
+    t_gen = time.perf_counter()
+    g = synth.make_graph(n_cams, n_edges, args.seed, outlier_frac=args.outliers)
+    t_gen = time.perf_counter() - t_gen
+
+    t_create = time.perf_counter()
+    if world > 1:
+        comm = sharding.TorchComm(n_cams)
+        prob, perm = sharding.make_sharded_problem(g, error_type, comm, loss=loss_ctor())
+        init = np.empty_like(g["init_aa"]); init[perm] = g["init_aa"]
+        gt = np.empty_like(g["gt_aa"]); gt[perm] = g["gt_aa"]
+    else:
+        prob = RotationProblem(n_cams, g["edge_i"], g["edge_j"], g["rel_aa"], error_type, cov6=g["cov6"])
+        prob.set_loss(loss_ctor())
+        init, gt = g["init_aa"], g["gt_aa"]
+    torch.cuda.synchronize()
+    t_create = time.perf_counter() - t_create
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    summ = None
+    for _ in range(args.warmup):
+        _, summ = prob.solve(init, verbose=args.verbose if rank == 0 else 0)
+    barrier()
+    t0 = time.perf_counter()
+    sweeps = 0
+    for _ in range(args.steps):
+        rot, summ = prob.solve(init)
+        sweeps += summ["num_residual_sweeps"]
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # K1 sweep kernel, timed live with HIP events on the solver's stream (this rank's cost-owned edges)
+    sweep_ms = prob.time_sweep(init, reps=args.sweep_reps)
+    alg_b, lay_b = prob.sweep_bytes()
+    e_local = summ["num_edges_used"]
+    achieved = (e_local * alg_b + 24.0 * n_cams) / (sweep_ms * 1e-3) / 1e9
+
+    if rank == 0:
+        aligned = synth.align_rotations(rot, gt)
+        err = synth.angular_distance(aligned, gt)
+        value = n_edges * sweeps / elapsed
+        out = {
+            "metric": "edge_residuals_per_sec", "value": value, "unit": "edge-residuals/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "synthetic SO(3) pose graph %d cams / %d edges, %g outlier edges, ANGLE_AXIS_COVARIANCE + "
+                                   "MAGSACWeightBasedLoss(0.02), one full LM solve per step (BASELINE.json configs[4] graph)"
+                                   % (n_cams, n_edges, args.outliers),
+                       "cams": n_cams, "edges": n_edges, "outlier_frac": args.outliers, "seed": args.seed,
+                       "parallelism": "camera-slice x%d" % world},
+            "iters_to_1e-6": summ["iters_to_1e6"], "lm_iterations": summ["num_iterations"],
+            "residual_sweeps_per_solve": summ["num_residual_sweeps"], "cg_iterations_per_solve": summ["num_cg_iterations"],
+            "termination": summ["termination_name"], "final_cost": summ["final_cost"],
+            "mean_angular_error_vs_ground_truth_deg": float(np.rad2deg(err.mean())),
+            "gpu_ms_per_solve": {"linearize": summ["t_linearize_ms"], "sweep": summ["t_sweep_ms"], "pcg": summ["t_cg_ms"]},
+            "setup_s": {"generate": t_gen, "create_problem": t_create},
+            "roofline": {"bound": "hbm", "kernel": "k_cost (K1 residual + robust reweight sweep)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                         "traffic": None, "algorithmic_bytes_per_edge": alg_b, "layout_bytes_per_edge": lay_b,
+                         "edges_per_launch": int(e_local), "kernel_ms": sweep_ms,
+                         "sweep_rate_edges_per_s": e_local / (sweep_ms * 1e-3)},
+        }
+        if args.cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args, loss_ctor, error_type)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,186 @@
+"""Multi-GPU host layer: camera-slice partition of the normal equations + the two collectives the
+C-ABI asks for (include/gsfm_rot.h, gsfm_rot_shard), implemented with torch.distributed.
+
+One process per GPU.  Rank r owns the contiguous camera slice [r*P, (r+1)*P) (P = slice_width) and
+receives every edge that touches an owned camera; per-camera sums (gradient, diagonal blocks,
+A.p) are therefore complete on the owner and are exchanged with ONE in-place all-gather (no
+reduction arithmetic, bitwise identical to the single-GPU sums); only scalars (cost) are
+all-reduced.  Backend "nccl" (= RCCL over xGMI) operates directly on the device buffers on the
+solver's stream; backend "gloo" (CPU tests, or several ranks sharing one GPU) stages through host.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _abi
+
+
+def slice_width(n_cams, world_size):
+    return (int(n_cams) + world_size - 1) // world_size
+
+
+def balance_permutation(n_cams, edge_i, edge_j, world_size):
+    """Relabel cameras so that contiguous slices carry equal numbers of directed entries
+    (greedy snake over the degree-sorted cameras).  Returns perm with new_id = perm[old_id]."""
+    deg = np.bincount(np.asarray(edge_i, dtype=np.int64), minlength=n_cams) + \
+        np.bincount(np.asarray(edge_j, dtype=np.int64), minlength=n_cams)
+    order = np.argsort(-deg, kind="stable")
+    P = slice_width(n_cams, world_size)
+    # deal the cameras out to the slices boustrophedon-wise: slice loads stay within one degree of each other
+    k = np.arange(n_cams)
+    rnd, pos = k // world_size, k % world_size
+    part = np.where(rnd % 2 == 0, pos, world_size - 1 - pos)
+    part = np.minimum(part, world_size - 1)
+    new_id = np.empty(n_cams, dtype=np.int64)
+    fill = np.zeros(world_size, dtype=np.int64)
+    # stable placement inside each slice
+    for r in range(world_size):
+        members = order[part == r]
+        cap = min(P, n_cams - r * P)
+        if members.size > cap:  # overflow: spill later (rare, only when n_cams % world_size != 0)
+            members = members[:cap]
+        new_id[members] = r * P + np.arange(members.size)
+        fill[r] = members.size
+    placed = np.zeros(n_cams, dtype=bool)
+    for r in range(world_size):
+        placed[order[part == r][:fill[r]]] = True
+    rest = np.flatnonzero(~placed)
+    if rest.size:
+        free = []
+        for r in range(world_size):
+            cap = min(P, max(0, n_cams - r * P))
+            free.extend(range(r * P + int(fill[r]), r * P + cap))
+        new_id[rest] = np.asarray(free[:rest.size], dtype=np.int64)
+    return new_id
+
+
+def local_edge_mask(n_cams, edge_i, edge_j, rank, world_size):
+    """Edges a rank must hold: those touching one of its cameras."""
+    P = slice_width(n_cams, world_size)
+    lo, hi = rank * P, min((rank + 1) * P, n_cams)
+    ei = np.asarray(edge_i, dtype=np.int64)
+    ej = np.asarray(edge_j, dtype=np.int64)
+    return ((ei >= lo) & (ei < hi)) | ((ej >= lo) & (ej < hi))
+
+
+def cost_owner(n_cams, edge_i, edge_j, world_size):
+    """The rank that counts an edge's rho in the cost (rule of gsfm_rot_problem_create)."""
+    P = slice_width(n_cams, world_size)
+    ei = np.asarray(edge_i, dtype=np.int64)
+    ej = np.asarray(edge_j, dtype=np.int64)
+    c = np.where(((ei + ej) & 1) == 0, ei, ej)
+    return c // P
+
+
+class _DevView(object):
+    """Minimal __cuda_array_interface__ carrier so torch can alias a raw device pointer."""
+
+    def __init__(self, ptr, count):
+        self.__cuda_array_interface__ = {"shape": (int(count),), "typestr": "<f8", "data": (int(ptr), False), "version": 2}
+
+
+class TorchComm(object):
+    """Owns the ctypes callbacks handed to the library through gsfm_rot_shard."""
+
+    def __init__(self, n_cams, group=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist, self.group = torch, dist, group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+        self.backend = dist.get_backend(group)
+        self.n_cams = int(n_cams)
+        self.P = slice_width(n_cams, self.world)
+        self._views = {}
+        self._host = {}
+        self.n_all_gather = 0
+        self.n_all_reduce = 0
+        self._ag = _abi.ALL_GATHER_FN(self._all_gather)
+        self._ar = _abi.ALL_REDUCE_FN(self._all_reduce)
+        self.shard = _abi.Shard(rank=self.rank, world_size=self.world, slice_width=self.P, reserved=0, ctx=None,
+                                all_gather=self._ag, all_reduce_sum=self._ar)
+
+    def stream_handle(self):
+        """Run the solver on torch's current stream so RCCL ops are ordered with its kernels."""
+        if self.backend == "nccl":
+            return self.torch.cuda.current_stream().cuda_stream
+        return None
+
+    def _view(self, ptr, count):
+        key = (ptr, count)
+        t = self._views.get(key)
+        if t is None:
+            t = self.torch.as_tensor(_DevView(ptr, count), device="cuda")
+            self._views[key] = t
+        return t
+
+    def _host_buf(self, count):
+        t = self._host.get(count)
+        if t is None:
+            t = self.torch.empty(count, dtype=self.torch.float64).pin_memory()
+            self._host[count] = t
+        return t
+
+    def _sync_stream(self, stream):
+        if stream:
+            self.torch.cuda.ExternalStream(int(stream)).synchronize()
+        else:
+            self.torch.cuda.synchronize()
+
+    def _all_gather(self, _ctx, buf, count, stream):
+        try:
+            self.n_all_gather += 1
+            total = count * self.world
+            full = self._view(buf, total)
+            mine = full[self.rank * count:(self.rank + 1) * count]
+            if self.backend == "nccl":
+                self.dist.all_gather_into_tensor(full, mine, group=self.group)
+            else:
+                self._sync_stream(stream)
+                h_in = mine.cpu()
+                h_out = self._host_buf(total)
+                self.dist.all_gather_into_tensor(h_out, h_in, group=self.group)
+                full.copy_(h_out)
+                self._sync_stream(None)
+            return 0
+        except Exception as e:  # never let an exception cross the C boundary
+            import sys
+            print("gsfm all_gather callback failed: %r" % (e,), file=sys.stderr)
+            return 1
+
+    def _all_reduce(self, _ctx, buf, count, stream):
+        try:
+            self.n_all_reduce += 1
+            t = self._view(buf, count)
+            if self.backend == "nccl":
+                self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+            else:
+                self._sync_stream(stream)
+                h = t.cpu()
+                self.dist.all_reduce(h, op=self.dist.ReduceOp.SUM, group=self.group)
+                t.copy_(h)
+                self._sync_stream(None)
+            return 0
+        except Exception as e:
+            import sys
+            print("gsfm all_reduce callback failed: %r" % (e,), file=sys.stderr)
+            return 1
+
+
+def make_sharded_problem(graph, error_type, comm, loss=None):
+    """graph: dict from synth.make_graph (global, identical on every rank).  Returns (problem, perm)
+    where perm maps original camera ids to the balanced numbering used by the problem."""
+    from .solver import RotationProblem
+    n = graph["n_cams"]
+    perm = balance_permutation(n, graph["edge_i"], graph["edge_j"], comm.world)
+    ei = perm[np.asarray(graph["edge_i"], dtype=np.int64)].astype(np.uint32)
+    ej = perm[np.asarray(graph["edge_j"], dtype=np.int64)].astype(np.uint32)
+    m = local_edge_mask(n, ei, ej, comm.rank, comm.world)
+    cov6 = graph["cov6"][m] if graph.get("cov6") is not None else None
+    inl = graph["inlier_weight"][m] if graph.get("inlier_weight") is not None else None
+    prob = RotationProblem(n, ei[m], ej[m], graph["rel_aa"][m], error_type, cov6=cov6, inlier_weight=inl,
+                           shard=comm.shard, stream=comm.stream_handle())
+    prob._comm = comm
+    if loss is not None:
+        prob.set_loss(loss)
+    return prob, perm

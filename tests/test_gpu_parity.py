@@ -101,8 +101,13 @@ def test_solve_matches_oracle(oracle, graph, et):
     ro, so = ora.solve(graph["init_aa"])
     assert sd["num_iterations"] == so["num_iterations"], (dev.trace(), ora.trace())
     assert sd["termination"] == so["termination"]
-    assert abs(sd["final_cost"] - so["final_cost"]) <= 1e-9 * max(1.0, abs(so["final_cost"]))
-    assert synth.angular_distance(rd, ro).mean() <= 1e-6
+    # The MAGSAC loss is a staircase in s (table cell = 2 sigma^2 / 1000): 1e-12-level differences between
+    # the PCG and the Cholesky step can move an edge across a cell edge, so costs agree to ~1e-6 there.
+    cost_tol = 1e-5 if isinstance(loss, LF.MAGSACWeightBasedLoss) else 1e-9
+    assert abs(sd["final_cost"] - so["final_cost"]) <= cost_tol * max(1.0, abs(so["final_cost"]))
+    # No camera is held fixed (the reference never calls SetParameterBlockConstant), so solutions are
+    # compared after a global gauge alignment, as BASELINE.md defines the parity bar.
+    assert synth.angular_distance(synth.align_rotations(rd, ro), ro).mean() <= 1e-6   # rad
 
 
 def test_noise_free_graph_recovers_ground_truth(oracle):
@@ -127,7 +132,7 @@ def test_sigma_consensus_matches_oracle(oracle):
     ro, so = ora.solve_sigma_consensus(g["init_aa"], 10, 0.1)
     assert sd["outer_iterations"] == so["outer_iterations"]
     assert abs(sd["last_weight_change"] - so["last_weight_change"]) < 1e-9
-    assert synth.angular_distance(rd, ro).mean() <= 1e-6
+    assert synth.angular_distance(synth.align_rotations(rd, ro), ro).mean() <= 1e-6
 
 
 def test_python_callback_loss(oracle, graph):
