@@ -30,6 +30,7 @@ inline MagsacConst magsac_const(int nu) {
 
 // Upper incomplete gamma Gamma(a, x), a = (nu-1)/2 in {1, 1.5, 4}: closed forms.
 inline double upper_gamma_closed_form(int nu, double x) {
+  if (x == 0.0) return std::tgamma((nu - 1.0) / 2.0);  // Gamma(a, 0) = Gamma(a): keeps rho(0) == 0 exactly
   if (nu == 3) return std::exp(-x);                                              // Gamma(1, x)
   if (nu == 4) return 0.5 * std::sqrt(M_PI) * std::erfc(std::sqrt(x)) + std::sqrt(x) * std::exp(-x);  // Gamma(3/2, x)
   return 6.0 * std::exp(-x) * (1.0 + x + x * x / 2.0 + x * x * x / 6.0);         // Gamma(4, x)

@@ -1,0 +1,65 @@
+"""The C-ABI library loads on a CPU-only box and exports every symbol include/gsfm_rot.h declares.
+No compute call is made here (the product has no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import have_gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_functions():
+    txt = open(os.path.join(ROOT, "include", "gsfm_rot.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    names = set(re.findall(r"\b(gsfm_[a-z0-9_]+)\s*\(", txt))
+    names.discard("gsfm_loss_callback")
+    return sorted(names)
+
+
+def test_library_exports_every_declared_entry_point():
+    from globalsfmpy_amd import _abi
+    lib = _abi.load_library()
+    names = _declared_functions()
+    assert len(names) >= 18
+    for n in names:
+        assert hasattr(lib, n), "libgsfm_rot.so does not export %s" % n
+    assert lib.gsfm_rot_abi_version() == 1
+
+
+def test_struct_layout_matches_header_defaults():
+    from globalsfmpy_amd import _abi
+    lib = _abi.load_library()
+    o = _abi.Options()
+    lib.gsfm_rot_options_default(C.byref(o))
+    # Ceres 1.14 defaults + the values hard-coded at reference estimator.cpp:72-74,176-179
+    assert (o.max_num_iterations, o.function_tolerance, o.gradient_tolerance, o.parameter_tolerance) == (200, 1e-6, 1e-10, 1e-8)
+    assert (o.initial_trust_region_radius, o.max_trust_region_radius, o.min_relative_decrease) == (1e4, 1e16, 1e-3)
+    assert (o.min_lm_diagonal, o.max_lm_diagonal, o.jacobi_scaling) == (1e-6, 1e32, 1)
+    assert o.cg_relative_tolerance == 1e-12 and o.verbose == 0
+    assert C.sizeof(_abi.LossNode) == 32
+    assert [lib.gsfm_rot_residual_dim(t) for t in range(9)] == [4, 9, 3, 3, 3, 3, 3, 3, 3]
+
+
+def test_oracle_and_product_share_option_defaults(oracle):
+    from globalsfmpy_amd import _abi
+    a, b = _abi.Options(), _abi.Options()
+    _abi.load_library().gsfm_rot_options_default(C.byref(a))
+    oracle.lib().orc_options_default(C.byref(b))
+    assert bytes(a) == bytes(b)
+
+
+@pytest.mark.skipif(have_gpu(), reason="CPU-only behaviour")
+def test_fails_loudly_without_a_gpu():
+    from globalsfmpy_amd.solver import RotationProblem, SolverError
+    with pytest.raises(SolverError, match="no HIP device"):
+        RotationProblem(3, [0, 1], [1, 2], np.zeros((2, 3)))
+
+
+def test_invalid_loss_programs_are_rejected_by_make_program():
+    from globalsfmpy_amd import _abi
+    with pytest.raises(ValueError):
+        _abi.make_program([(0, 0.0, 0.0, 0.0)] * 17)

@@ -1,0 +1,137 @@
+"""Solver-level checks of the CPU oracle (the reference has no test at this level; the fixture
+follows Theia's robust_rotation_estimator_test.cc:121-241: synthetic graph, known ground truth)."""
+import numpy as np
+import pytest
+
+from globalsfmpy_amd import _abi, synth
+from globalsfmpy_amd import loss_functions as LF
+
+
+def _problem(oracle, g, et, loss):
+    p = oracle.OracleProblem(g["n_cams"], g["edge_i"], g["edge_j"], g["rel_aa"], et, cov6=g["cov6"], inlier_weight=g["inlier_weight"])
+    p.set_loss(loss)
+    return p
+
+
+@pytest.mark.parametrize("et", list(range(9)))
+def test_autodiff_jacobians_against_central_differences(oracle, et):
+    g = synth.make_graph(12, 30, seed=4, outlier_frac=0.2, full_so3=True)
+    p = _problem(oracle, g, et, None)
+    x = g["init_aa"].copy()
+    h = 1e-6
+    for e in range(0, 30, 7):
+        i, j = int(g["edge_i"][e]), int(g["edge_j"][e])
+        r0, Ji, Jj = p.edge_jacobians(e, x)
+        if p.residual_dim == 3 and et >= 3:  # additive angle-axis parameters: plain finite differences
+            for cam, J in ((i, Ji), (j, Jj)):
+                for c in range(3):
+                    xp, xm = x.copy(), x.copy()
+                    xp[cam, c] += h
+                    xm[cam, c] -= h
+                    fd = (p.edge_jacobians(e, xp)[0] - p.edge_jacobians(e, xm)[0]) / (2 * h)
+                    assert np.max(np.abs(fd - J[:, c])) < 1e-6 * max(1.0, np.abs(J).max()), (et, e, cam, c)
+        else:
+            # quaternion types: perturb along ceres' Plus(x, delta) = dq(delta) * x (left, half-angle)
+            for cam, J in ((i, Ji), (j, Jj)):
+                for c in range(3):
+                    d = np.zeros(3); d[c] = h
+                    q = synth.aa_to_quat(x[cam])
+                    xp, xm = x.copy(), x.copy()
+                    xp[cam] = synth.quat_to_aa(synth.quat_mul(synth.aa_to_quat(2 * d), q))
+                    xm[cam] = synth.quat_to_aa(synth.quat_mul(synth.aa_to_quat(-2 * d), q))
+                    rp, rm = p.edge_jacobians(e, xp)[0], p.edge_jacobians(e, xm)[0]
+                    if et == _abi.QUATERNION_NORM and (np.sign(rp).tolist() != np.sign(rm).tolist()) and np.abs(rp - rm).max() > 0.1:
+                        continue  # the y-sign canonicalisation flipped between the two probes
+                    fd = (rp - rm) / (2 * h)
+                    assert np.max(np.abs(fd - J[:, c])) < 1e-5 * max(1.0, np.abs(J).max()), (et, e, cam, c)
+
+
+def test_gradient_is_derivative_of_cost(oracle):
+    g = synth.make_graph(15, 60, seed=8, outlier_frac=0.1)
+    p = _problem(oracle, g, _abi.ANGLE_AXIS_COVARIANCE, LF.CauchyLoss(0.5))
+    x = g["init_aa"].copy()
+    lin = p.linearize(x)
+    rng = np.random.default_rng(0)
+    d = rng.standard_normal(x.shape)
+    h = 1e-7
+    fd = (p.residuals(x + h * d)["cost"] - p.residuals(x - h * d)["cost"]) / (2 * h)
+    assert abs(fd - np.sum(lin["gradient"] * d)) < 1e-5 * max(1.0, abs(fd))
+
+
+def test_noise_free_graph_is_recovered_exactly(oracle):
+    g = synth.make_graph(40, 200, seed=56, noise=False, init_noise_deg=5.0)
+    p = _problem(oracle, g, _abi.ANGLE_AXIS, LF.SoftLOneLoss(0.1))
+    r, s = p.solve(g["init_aa"])
+    err = synth.angular_distance(synth.align_rotations(r, g["gt_aa"]), g["gt_aa"])
+    assert np.rad2deg(err.max()) < 1e-8
+    assert s["final_cost"] < 1e-20
+
+
+def test_noisy_graph_accuracy_bounds(oracle):
+    # robust_rotation_estimator_test.cc:229-241 style: 100 views / 800 edges, ~1 deg noise -> < 1 deg mean error
+    g = synth.make_graph(100, 800, seed=57, sigma_deg=(0.5, 1.5), init_noise_deg=5.0)
+    p = _problem(oracle, g, _abi.ANGLE_AXIS, LF.SoftLOneLoss(0.1))
+    r, s = p.solve(g["init_aa"])
+    err = synth.angular_distance(synth.align_rotations(r, g["gt_aa"]), g["gt_aa"])
+    assert np.rad2deg(err.mean()) < 1.0
+
+
+@pytest.mark.parametrize("et", [_abi.ANGLE_AXIS_COVARIANCE, _abi.QUATERNION_COSINE])
+def test_dense_cholesky_and_pcg_follow_the_same_trajectory(oracle, et):
+    g = synth.make_graph(60, 500, seed=21, outlier_frac=0.2)
+    out = []
+    for kind in ("dense", "pcg"):
+        p = _problem(oracle, g, et, LF.HuberLoss(0.1))
+        p.set_linear_solver(kind)
+        r, s = p.solve(g["init_aa"])
+        out.append((r, s, p.trace()))
+    (r1, s1, t1), (r2, s2, t2) = out
+    assert s1["num_iterations"] == s2["num_iterations"]
+    assert np.allclose(t1[:, 1], t2[:, 1], rtol=1e-9)
+    assert synth.angular_distance(r1, r2).max() < 1e-8
+
+
+def test_minimum_agrees_with_scipy_least_squares(oracle):
+    """Independent cross-check of the minimiser (NULL loss => plain nonlinear least squares)."""
+    from scipy.optimize import least_squares
+    g = synth.make_graph(12, 40, seed=5)
+    p = _problem(oracle, g, _abi.ANGLE_AXIS, None)
+    r, s = p.solve(g["init_aa"], function_tolerance=1e-14, parameter_tolerance=1e-14, gradient_tolerance=1e-14)
+
+    def fun(x):
+        return p.residuals(x.reshape(-1, 3), want_residuals=True)["residuals"].ravel()
+    sol = least_squares(fun, g["init_aa"].ravel(), xtol=1e-14, ftol=1e-14, gtol=1e-14)
+    assert abs(0.5 * np.sum(sol.fun ** 2) - s["final_cost"]) < 1e-10 * max(1.0, s["final_cost"])
+    aligned = synth.align_rotations(r, sol.x.reshape(-1, 3))
+    assert synth.angular_distance(aligned, sol.x.reshape(-1, 3)).max() < 1e-6
+
+
+def test_tolerant_and_inverse_magsac_use_the_triggs_correction(oracle):
+    # rho'' > 0 exercises Corrector's alpha branch (ceres corrector.cc)
+    g = synth.make_graph(30, 150, seed=6, outlier_frac=0.1)
+    for loss in (LF.TolerantLoss(0.05, 0.01), LF.MAGSACWeightBasedLoss4(0.5)):
+        p = _problem(oracle, g, _abi.ANGLE_AXIS, loss)
+        rho = p.residuals(g["init_aa"])["rho"]
+        assert (rho[:, 2] > 0).any()
+        r, s = p.solve(g["init_aa"])
+        assert s["final_cost"] <= s["initial_cost"]
+
+
+def test_sigma_consensus_converges(oracle):
+    g = synth.make_graph(40, 300, seed=3, outlier_frac=0.25)
+    p = _problem(oracle, g, _abi.ANGLE_AXIS, LF.TrivialLoss())
+    r, s = p.solve_sigma_consensus(g["init_aa"], 15, 0.1)
+    assert 1 <= s["outer_iterations"] <= 15
+    err = synth.angular_distance(synth.align_rotations(r, g["gt_aa"]), g["gt_aa"])
+    assert np.rad2deg(np.median(err)) < 2.0
+
+
+def test_views_without_edges_are_left_untouched(oracle):
+    g = synth.make_graph(20, 60, seed=2)
+    n = g["n_cams"] + 2
+    init = np.vstack([g["init_aa"], [[0.1, 0.2, 0.3], [-0.3, 0.2, 0.1]]])
+    for et in (_abi.ANGLE_AXIS, _abi.QUATERNION_COSINE):
+        p = oracle.OracleProblem(n, g["edge_i"], g["edge_j"], g["rel_aa"], et)
+        p.set_loss(LF.HuberLoss(0.1))
+        r, _ = p.solve(init)
+        assert np.array_equal(r[-2:], init[-2:])
