@@ -8,6 +8,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <string>
@@ -582,7 +583,8 @@ gsfm_status gsfm_rot_problem_create(uint32_t n_cams, uint64_t n_edges, const uin
   P->wmode = (error_type == GSFM_ROT_ANGLE_AXIS_COVARIANCE || error_type == GSFM_ROT_ANGLE_AXIS_COV_INLIERS) ? W_MATRIX
              : (error_type == GSFM_ROT_ANGLE_AXIS_INLIERS || error_type == GSFM_ROT_ANGLE_AXIS_COVTRACE || error_type == GSFM_ROT_ANGLE_AXIS_COVNORM) ? W_SCALAR
              : W_NONE;
-  if (shard && shard->world_size > 1) {
+  // GSFM_FORCE_SHARD=1 keeps the collective code path alive for a single rank (tests on a 1-GPU box)
+  if (shard && (shard->world_size > 1 || (shard->world_size == 1 && getenv("GSFM_FORCE_SHARD")))) {
     if (!shard->all_gather || !shard->all_reduce_sum || shard->slice_width == 0 || shard->rank < 0 || shard->rank >= shard->world_size ||
         (uint64_t)shard->slice_width * shard->world_size < n_cams)
       return bail(fail(GSFM_ERR_INVALID_ARG, "bad shard descriptor"));
