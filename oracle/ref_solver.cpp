@@ -230,7 +230,7 @@ double evaluate(orc_problem* p, const double* x, bool with_jacobian, double* gra
       }
     }
   } else {
-#pragma omp parallel for reduction(+ : cost) schedule(static)
+#pragma omp parallel for reduction(+ : cost) schedule(static) if (E > 50000)
     for (long e = 0; e < (long)E; ++e) {
       double r[9], ji[27], jj[27];
       edge_autodiff(p, p->edges[e], x, r, with_jacobian ? ji : nullptr, with_jacobian ? jj : nullptr);
@@ -278,7 +278,7 @@ void scale_columns(orc_problem* p, const double* scale) {
 // y = J v (per edge, res_dim), then optionally z = J^T y
 void J_times(const orc_problem* p, const double* v, double* y) {
   const int R = p->res_dim;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (p->edges.size() > 200000)
   for (long e = 0; e < (long)p->edges.size(); ++e) {
     const Edge& ed = p->edges[e];
     for (int k = 0; k < R; ++k) {
