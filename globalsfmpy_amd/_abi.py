@@ -151,6 +151,7 @@ def load_library():
     lib.gsfm_rot_set_stream.argtypes = [C.c_void_p, C.c_void_p]; lib.gsfm_rot_set_stream.restype = C.c_int
     lib.gsfm_rot_residual_dim.argtypes = [C.c_int32]; lib.gsfm_rot_residual_dim.restype = C.c_int32
     lib.gsfm_rot_time_sweep.argtypes = [C.c_void_p, _DP, C.c_int32, _DP]; lib.gsfm_rot_time_sweep.restype = C.c_int
+    lib.gsfm_rot_time_kernels.argtypes = [C.c_void_p, _DP, C.c_int32, _DP]; lib.gsfm_rot_time_kernels.restype = C.c_int
     lib.gsfm_rot_sweep_bytes.argtypes = [C.c_void_p, _DP, _DP]; lib.gsfm_rot_sweep_bytes.restype = C.c_int
     lib.gsfm_magsac_table.argtypes = [C.c_int32, _DP, C.c_int32]; lib.gsfm_magsac_table.restype = C.c_int32
     lib.gsfm_magsac_constants.argtypes = [C.c_int32, _DP, _DP, _DP]; lib.gsfm_magsac_constants.restype = C.c_int

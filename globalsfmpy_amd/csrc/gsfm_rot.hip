@@ -134,6 +134,7 @@ struct gsfm_rot_problem {
 
   EdgePlanes cost;            // cost-owned edges
   DevBuf<uint2> cost_idx;
+  DevBuf<CostTile> cost_tiles;
   EdgePlanes dir;             // directed entries (rows = owned cameras)
   DevBuf<uint32_t> row_ptr, col;
   uint32_t G = 16;
@@ -165,18 +166,37 @@ struct gsfm_rot_problem {
 
 namespace {
 
-// ---- kernel dispatch on (functor, whitening mode) -----------------------------------------
-template <typename ArgsT, template <int, int> class Launcher>
+// ---- kernel dispatch on (functor, whitening mode, loss shape) --------------------------------
+int loss_mode(const gsfm_rot_problem* P) {
+  if (P->cb) return LM_SIMPLE;  // rho comes from rho_ext; the in-kernel loss is never evaluated
+  const DevLoss& L = P->h_loss;
+  if (L.n == 0) return LM_SIMPLE;
+  if (L.n == 1) {
+    const int k = L.nodes[0].kind;
+    if (k == GSFM_LOSS_MAGSAC) return LM_MAGSAC;
+    if (k == GSFM_LOSS_TRIVIAL || k == GSFM_LOSS_HUBER || k == GSFM_LOSS_SOFT_L1 || k == GSFM_LOSS_TUKEY || k == GSFM_LOSS_GEMAN_MCCLURE) return LM_SIMPLE;
+  }
+  return LM_PROGRAM;
+}
+template <typename ArgsT, template <int, int, int> class Launcher>
 int dispatch(const gsfm_rot_problem* P, const ArgsT& args, int grid) {
-  const int f = P->functor, w = P->wmode;
-#define GSFM_CASE(F, W) if (f == F && w == W) { Launcher<F, W>::go(args, grid, P->stream); return 0; }
+  const int f = P->functor, w = P->wmode, l = loss_mode(P);
+#define GSFM_CASE3(F, W, L) if (f == F && w == W && l == L) { Launcher<F, W, L>::go(args, grid, P->stream); return 0; }
+#define GSFM_CASE(F, W) GSFM_CASE3(F, W, LM_PROGRAM) GSFM_CASE3(F, W, LM_SIMPLE) GSFM_CASE3(F, W, LM_MAGSAC)
   GSFM_CASE(F_AA, W_NONE) GSFM_CASE(F_AA, W_SCALAR) GSFM_CASE(F_AA, W_MATRIX)
   GSFM_CASE(F_QCOS, W_NONE) GSFM_CASE(F_QNORM, W_NONE) GSFM_CASE(F_RFNORM, W_NONE)
 #undef GSFM_CASE
+#undef GSFM_CASE3
   return 1;
 }
-template <int F, int W> struct CostLauncher { static void go(const CostArgs& a, int grid, hipStream_t s) { hipLaunchKernelGGL((k_cost<F, W>), dim3(grid), dim3(GSFM_BLOCK), 0, s, a); } };
-template <int F, int W> struct LinLauncher { static void go(const LinArgs& a, int grid, hipStream_t s) { hipLaunchKernelGGL((k_lin<F, W>), dim3(grid), dim3(GSFM_BLOCK), 0, s, a); } };
+template <int F, int W, int L> struct CostLauncher {
+  static void go(const CostArgs& a, int grid, hipStream_t s) {
+    const bool full = a.s_only || a.rho_ext || a.s_out;
+    if (full) hipLaunchKernelGGL((k_cost<F, W, L, true>), dim3(grid), dim3(GSFM_TILE_THREADS), 0, s, a);
+    else hipLaunchKernelGGL((k_cost<F, W, L, false>), dim3(grid), dim3(GSFM_TILE_THREADS), 0, s, a);
+  }
+};
+template <int F, int W, int L> struct LinLauncher { static void go(const LinArgs& a, int grid, hipStream_t s) { hipLaunchKernelGGL((k_lin<F, W, L>), dim3(grid), dim3(GSFM_BLOCK), 0, s, a); } };
 
 int sync_check(gsfm_rot_problem* P, const char* what) {
   hipError_t e = hipStreamSynchronize(P->stream);
@@ -270,7 +290,7 @@ void launch_cache(gsfm_rot_problem* P, const double* x, double2* q) {
 // host-callback loss: s per original edge -> host -> rho triples -> device
 int refresh_external_rho(gsfm_rot_problem* P, const double2* q) {
   CostArgs a{};
-  a.n = P->cost.n; a.idx = P->cost_idx.p; a.qr0 = P->cost.qr0.p; a.qr1 = P->cost.qr1.p;
+  a.tiles = P->cost_tiles.p; a.n_cams = P->n_cams; a.n = P->cost.n; a.idx = P->cost_idx.p; a.qr0 = P->cost.qr0.p; a.qr1 = P->cost.qr1.p;
   a.w0 = P->cost.w0.p; a.w1 = P->cost.w1.p; a.w2 = P->cost.w2.p; a.ws = P->cost.ws.p;
   a.q = q; a.loss = P->d_loss.p; a.eid = P->cost.eid.p; a.partials = P->part_cost.p; a.s_out = P->s_ext.p; a.s_only = 1;
   if (dispatch<CostArgs, CostLauncher>(P, a, P->nb_cost)) return fail(GSFM_ERR_UNSUPPORTED, "no kernel for this error type");
@@ -287,7 +307,7 @@ int refresh_external_rho(gsfm_rot_problem* P, const double2* q) {
 int launch_cost(gsfm_rot_problem* P, const double2* q, int slot, double* s_out = nullptr, double* rho_out = nullptr, double* r_out = nullptr) {
   if (P->cb) { if (int st = refresh_external_rho(P, q)) return st; }
   CostArgs a{};
-  a.n = P->cost.n; a.idx = P->cost_idx.p; a.qr0 = P->cost.qr0.p; a.qr1 = P->cost.qr1.p;
+  a.tiles = P->cost_tiles.p; a.n_cams = P->n_cams; a.n = P->cost.n; a.idx = P->cost_idx.p; a.qr0 = P->cost.qr0.p; a.qr1 = P->cost.qr1.p;
   a.w0 = P->cost.w0.p; a.w1 = P->cost.w1.p; a.w2 = P->cost.w2.p; a.ws = P->cost.ws.p;
   a.q = q; a.loss = P->d_loss.p; a.rho_ext = P->cb ? P->rho_ext.p : nullptr; a.eid = P->cost.eid.p;
   a.partials = P->part_cost.p; a.s_out = s_out; a.rho_out = rho_out; a.r_out = r_out; a.s_only = 0;
@@ -625,6 +645,38 @@ gsfm_status gsfm_rot_problem_create(uint32_t n_cams, uint64_t n_edges, const uin
   {
     const double mean_deg = P->n_rows ? (double)nd / P->n_rows : 0.0;
     P->G = mean_deg >= 96 ? 64 : mean_deg >= 48 ? 32 : mean_deg >= 24 ? 16 : mean_deg >= 12 ? 8 : 4;
+    if (const char* g = getenv("GSFM_ROW_LANES")) {  // tuning override: lanes per camera row (power of two <= 64)
+      const int v = atoi(g);
+      if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64) P->G = (uint32_t)v;
+    }
+  }
+  // cost edges ordered by (camera block of `second`, `first`): the block of `second` quaternions is staged in
+  // LDS by k_cost, `first` varies slowly so its gathers coalesce.  Two stable counting sorts, O(E + N).
+  std::vector<CostTile> tiles;
+  {
+    const size_t Ec = cost_eid.size();
+    std::vector<uint32_t> tmp(Ec), cnt((size_t)n_cams + 1, 0);
+    for (size_t t = 0; t < Ec; ++t) cnt[edge_i[cost_eid[t]] + 1]++;
+    for (size_t c = 0; c < n_cams; ++c) cnt[c + 1] += cnt[c];
+    for (size_t t = 0; t < Ec; ++t) tmp[cnt[edge_i[cost_eid[t]]]++] = cost_eid[t];
+    const uint32_t nblk = (n_cams + GSFM_CAMBLOCK - 1) / GSFM_CAMBLOCK;
+    std::vector<uint32_t> bstart((size_t)nblk + 1, 0);
+    for (size_t t = 0; t < Ec; ++t) bstart[edge_j[tmp[t]] / GSFM_CAMBLOCK + 1]++;
+    for (uint32_t b = 0; b < nblk; ++b) bstart[b + 1] += bstart[b];
+    std::vector<uint32_t> fillb(bstart.begin(), bstart.end() - 1);
+    for (size_t t = 0; t < Ec; ++t) cost_eid[fillb[edge_j[tmp[t]] / GSFM_CAMBLOCK]++] = tmp[t];
+    // workgroups: ~2 per CU over the whole sweep, at least 8192 edges each, never across a block boundary
+    const size_t per_wg = std::max<size_t>(8192, (Ec + 511) / 512);
+    for (uint32_t b = 0; b < nblk; ++b) {
+      const size_t lo = bstart[b], hi = bstart[b + 1];
+      if (hi == lo) continue;
+      const size_t nw = (hi - lo + per_wg - 1) / per_wg, chunk = (hi - lo + nw - 1) / nw;
+      for (size_t w = 0; w < nw; ++w) {
+        const size_t cb = lo + w * chunk, ce = std::min(hi, cb + chunk);
+        if (ce > cb) tiles.push_back(CostTile{b, (uint32_t)cb, (uint32_t)ce, 0});
+      }
+    }
+    if (tiles.empty()) tiles.push_back(CostTile{0, 0, 0, 0});
   }
   std::vector<uint2> cidx(cost_eid.size());
   for (size_t t = 0; t < cost_eid.size(); ++t) cidx[t] = make_uint2(edge_i[cost_eid[t]], edge_j[cost_eid[t]]);
@@ -633,6 +685,8 @@ gsfm_status gsfm_rot_problem_create(uint32_t n_cams, uint64_t n_edges, const uin
   // ---- uploads ----
   if (int st = upload_planes(P, P->cost, cost_eid, rel_aa)) return bail(st);
   if (int st = upload_planes(P, P->dir, deid, rel_aa)) return bail(st);
+  if (P->cost_tiles.upload(tiles) != hipSuccess) return bail(fail(GSFM_ERR_HIP, "uploading cost tiles failed"));
+  P->nb_cost = (int)tiles.size();
   if (P->cost_idx.upload(cidx) != hipSuccess || P->row_ptr.upload(rp) != hipSuccess || P->col.upload(col) != hipSuccess)
     return bail(fail(GSFM_ERR_HIP, "uploading graph structure failed"));
   if (P->h0.alloc(nd) != hipSuccess || P->h1.alloc(nd) != hipSuccess || P->h2.alloc(nd) != hipSuccess || P->h3.alloc(nd) != hipSuccess || P->h4.alloc(nd) != hipSuccess)
@@ -651,7 +705,6 @@ gsfm_status gsfm_rot_problem_create(uint32_t n_cams, uint64_t n_edges, const uin
   const size_t N = n_cams, NP = P->n_pad;
   P->nb_cam = grid_for(N);
   if (P->nb_cam > GSFM_MAX_PARTIALS * 64) return bail(fail(GSFM_ERR_INVALID_ARG, "too many cameras"));
-  P->nb_cost = std::max(1, std::min(grid_for(P->cost.n), 2048));
   bool ok = true;
   ok &= P->x.alloc(4 * N, true) == hipSuccess; ok &= P->x_trial.alloc(4 * N, true) == hipSuccess; ok &= P->aa_io.alloc(3 * N, true) == hipSuccess;
   ok &= P->active.alloc(NP, true) == hipSuccess; ok &= P->scale.alloc(3 * N, true) == hipSuccess; ok &= P->gD.alloc(9 * NP, true) == hipSuccess;
@@ -769,7 +822,7 @@ gsfm_status gsfm_rot_solve_sigma_consensus(gsfm_rot_problem* P, double* rot, int
     if (int st = upload_state(P, rot)) return (gsfm_status)st;
     {  // K6 = K1 in s-only mode: s_e = ||log(R_j R_i^T R_ij^T)||^2  (:378-398)
       CostArgs a{};
-      a.n = P->cost.n; a.idx = P->cost_idx.p; a.qr0 = P->cost.qr0.p; a.qr1 = P->cost.qr1.p; a.ws = P->cost.ws.p;
+      a.tiles = P->cost_tiles.p; a.n_cams = P->n_cams; a.n = P->cost.n; a.idx = P->cost_idx.p; a.qr0 = P->cost.qr0.p; a.qr1 = P->cost.qr1.p; a.ws = P->cost.ws.p;
       a.q = P->q.p; a.loss = P->d_loss.p; a.eid = P->cost.eid.p; a.partials = P->part_cost.p; a.s_out = P->s_ext.p; a.s_only = 1;
       if (dispatch<CostArgs, CostLauncher>(P, a, P->nb_cost)) return (gsfm_status)fail(GSFM_ERR_UNSUPPORTED, "dispatch");
       if (hipMemcpyAsync(s.data(), P->s_ext.p, 8 * E, hipMemcpyDeviceToHost, P->stream) != hipSuccess) return (gsfm_status)fail(GSFM_ERR_HIP, "read s");
@@ -876,7 +929,7 @@ gsfm_status gsfm_rot_time_sweep(gsfm_rot_problem* P, const double* rot, int32_t 
   DeviceGuard g(P->device);
   if (int st = upload_state(P, rot)) return (gsfm_status)st;
   CostArgs a{};
-  a.n = P->cost.n; a.idx = P->cost_idx.p; a.qr0 = P->cost.qr0.p; a.qr1 = P->cost.qr1.p;
+  a.tiles = P->cost_tiles.p; a.n_cams = P->n_cams; a.n = P->cost.n; a.idx = P->cost_idx.p; a.qr0 = P->cost.qr0.p; a.qr1 = P->cost.qr1.p;
   a.w0 = P->cost.w0.p; a.w1 = P->cost.w1.p; a.w2 = P->cost.w2.p; a.ws = P->cost.ws.p;
   a.q = P->q.p; a.loss = P->d_loss.p; a.eid = P->cost.eid.p; a.partials = P->part_cost.p;
   for (int k = 0; k < 3; ++k) if (dispatch<CostArgs, CostLauncher>(P, a, P->nb_cost)) return (gsfm_status)fail(GSFM_ERR_UNSUPPORTED, "dispatch");
@@ -891,6 +944,34 @@ gsfm_status gsfm_rot_time_sweep(gsfm_rot_problem* P, const double* rot, int32_t 
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   *mean_ms = ms / reps;
   return (gsfm_status)st;
+}
+
+gsfm_status gsfm_rot_time_kernels(gsfm_rot_problem* P, const double* rot, int32_t reps, double* out_ms3) {
+  if (!P || !rot || !out_ms3 || reps <= 0) return (gsfm_status)fail(GSFM_ERR_INVALID_ARG, "bad argument");
+  if (P->cb) return (gsfm_status)fail(GSFM_ERR_UNSUPPORTED, "time_kernels needs a native loss");
+  DeviceGuard g(P->device);
+  const gsfm_rot_options o = default_options();
+  if (int st = upload_state(P, rot)) return (gsfm_status)st;
+  if (int st = launch_lin(P, P->q.p)) return (gsfm_status)st;
+  launch_prep(P, o, o.initial_trust_region_radius, true);
+  if (int st = sync_check(P, "time_kernels setup")) return (gsfm_status)st;
+  hipEvent_t e0, e1;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return (gsfm_status)fail(GSFM_ERR_HIP, "event create");
+  for (int which = 0; which < 3; ++which) {
+    for (int k = -2; k < reps; ++k) {  // two warm-up launches
+      if (k == 0) (void)hipEventRecord(e0, P->stream);
+      if (which == 0) { if (int st = launch_cost(P, P->q.p, SC_COST)) return (gsfm_status)st; }
+      else if (which == 1) { if (int st = launch_lin(P, P->q.p)) return (gsfm_status)st; }
+      else { if (int st = launch_matvec(P, P->Mblk.p, P->b.p, P->Ap.p, nullptr)) return (gsfm_status)st; }
+    }
+    (void)hipEventRecord(e1, P->stream);
+    if (int st = sync_check(P, "time_kernels")) return (gsfm_status)st;
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    out_ms3[which] = ms / reps;
+  }
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  return GSFM_OK;
 }
 
 gsfm_status gsfm_rot_sweep_bytes(gsfm_rot_problem* P, double* algorithmic, double* layout) {

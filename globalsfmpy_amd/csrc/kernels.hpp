@@ -31,6 +31,10 @@ template <int F> struct ResDim { static constexpr int R = (F == F_QNORM) ? 4 : (
 
 #define GSFM_BLOCK 256
 #define GSFM_MAX_PARTIALS 1024
+// LDS-staged gathers: edges are bucketed by the 4096-camera block of the gathered endpoint; a
+// 1024-thread workgroup keeps that block's quaternions (4096 x 32 B = 128 KiB of the 160 KiB LDS) resident.
+#define GSFM_CAMBLOCK 4096
+#define GSFM_TILE_THREADS 1024
 
 // ------------------------------------------------------------------------------------------
 // reductions (deterministic: fixed tree inside a wave, fixed order across waves)
@@ -227,14 +231,20 @@ __device__ __forceinline__ void robustify(const Rho3& rho, double s, double* r, 
   for (int k = 0; k < R; ++k) r[k] *= c.residual_scaling;
 }
 
+__device__ __forceinline__ double2 nt_load2(const double2* __restrict__ p) {
+  double2 v;
+  v.x = __builtin_nontemporal_load(&p->x);
+  v.y = __builtin_nontemporal_load(&p->y);
+  return v;
+}
 template <int WM>
 __device__ __forceinline__ EdgeW load_w(const double2* __restrict__ w0, const double2* __restrict__ w1,
                                         const double2* __restrict__ w2, const double* __restrict__ ws, size_t e) {
   EdgeW W;
   W.l00 = 1.0; W.l01 = W.l02 = W.l12 = 0.0; W.l11 = W.l22 = 1.0;
-  if (WM == W_SCALAR) { W.l00 = ws[e]; }
+  if (WM == W_SCALAR) { W.l00 = __builtin_nontemporal_load(ws + e); }
   else if (WM == W_MATRIX) {
-    const double2 a = w0[e], b = w1[e], c = w2[e];
+    const double2 a = nt_load2(w0 + e), b = nt_load2(w1 + e), c = nt_load2(w2 + e);
     W.l00 = a.x; W.l01 = a.y; W.l02 = b.x; W.l11 = b.y; W.l12 = c.x; W.l22 = c.y;
   }
   return W;
@@ -307,7 +317,10 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_gather_weights(const double* __r
 // ------------------------------------------------------------------------------------------
 // K1: residual + robust reweight sweep over the cost-owned edges
 // ------------------------------------------------------------------------------------------
+struct CostTile { uint32_t block, begin, end, pad; };  // camera block of `second`, edge range
 struct CostArgs {
+  const CostTile* tiles;     // one per workgroup
+  uint32_t n_cams;
   size_t n;                  // edges
   const uint2* idx;          // (i, j)
   const double2 *qr0, *qr1;  // q_rel planes (x,y) (z,w)
@@ -325,27 +338,44 @@ struct CostArgs {
   int s_only;                // 1: write s_out only, skip the loss (callback path, phase 1)
 };
 
-template <int F, int WM>
-__global__ void __launch_bounds__(GSFM_BLOCK) k_cost(CostArgs a) {
+// FULL = false: the solver's trial-cost sweep (cost only).  FULL = true: per-edge outputs / external rho /
+// s-only modes of the C-ABI (gsfm_rot_residuals, host-callback losses, sigma consensus).
+template <int F, int WM, int LM, bool FULL>
+__global__ void __launch_bounds__(GSFM_TILE_THREADS) k_cost(CostArgs a) {
   constexpr int R = ResDim<F>::R;
-  __shared__ double lds[8];
+  __shared__ double2 q_xy[GSFM_CAMBLOCK];
+  __shared__ double2 q_zw[GSFM_CAMBLOCK];
+  __shared__ double lds[GSFM_TILE_THREADS / 64 + 1];
+  const CostTile tile = a.tiles[blockIdx.x];
+  {  // stage the camera block of the `second` endpoints (coalesced 16-B loads)
+    const uint32_t base = tile.block * GSFM_CAMBLOCK;
+    const uint32_t cnt = min((uint32_t)GSFM_CAMBLOCK, a.n_cams - base);
+    for (uint32_t c = threadIdx.x; c < cnt; c += GSFM_TILE_THREADS) {
+      q_xy[c] = a.q[2 * (size_t)(base + c)];
+      q_zw[c] = a.q[2 * (size_t)(base + c) + 1];
+    }
+  }
+  __syncthreads();
   double acc = 0.0;
-  const size_t stride = (size_t)gridDim.x * GSFM_BLOCK;
-  for (size_t e = (size_t)blockIdx.x * GSFM_BLOCK + threadIdx.x; e < a.n; e += stride) {
+  for (uint32_t e = tile.begin + threadIdx.x; e < tile.end; e += GSFM_TILE_THREADS) {
     const uint2 ij = a.idx[e];
-    const double2 r0 = a.qr0[e], r1 = a.qr1[e];
+    const double2 r0 = nt_load2(a.qr0 + e), r1 = nt_load2(a.qr1 + e);
     const Quat qr{r0.x, r0.y, r1.x, r1.y};
     const EdgeW W = load_w<WM>(a.w0, a.w1, a.w2, a.ws, e);
-    const Quat qi = load_q(a.q, ij.x), qj = load_q(a.q, ij.y);
+    const Quat qi = load_q(a.q, ij.x);                       // edges are sorted by `first`: near-broadcast
+    const uint32_t jl = ij.y - tile.block * GSFM_CAMBLOCK;   // `second` from LDS
+    const double2 jxy = q_xy[jl], jzw = q_zw[jl];
+    const Quat qj{jxy.x, jxy.y, jzw.x, jzw.y};
     double r[R];
     edge_residual<F, WM>(qi, qj, qr, W, r);
     double s = 0.0;
 #pragma unroll
     for (int k = 0; k < R; ++k) s += r[k] * r[k];
+    if (!FULL) { acc += 0.5 * loss_value<LM>(a.loss, s); continue; }
     if (a.s_only) { a.s_out[a.eid[e]] = s; continue; }
     Rho3 rho;
     if (a.rho_ext) { const size_t o = 3 * (size_t)a.eid[e]; rho.r0 = a.rho_ext[o]; rho.r1 = a.rho_ext[o + 1]; rho.r2 = a.rho_ext[o + 2]; }
-    else rho = loss_eval(a.loss, s);
+    else rho = loss_eval<LM>(a.loss, s);
     acc += 0.5 * rho.r0;
     if (a.s_out) {
       const size_t o = a.eid[e];
@@ -357,8 +387,16 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_cost(CostArgs a) {
       }
     }
   }
-  const double t = block_sum_bcast(acc, lds);
-  if (threadIdx.x == 0) a.partials[blockIdx.x] = t;
+  // deterministic block reduction (fixed tree per wave, fixed order over the 16 waves)
+  acc = wave_sum(acc);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) lds[w] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int k = 0; k < GSFM_TILE_THREADS / 64; ++k) t += lds[k];
+    a.partials[blockIdx.x] = t;
+  }
 }
 
 // out[0] = sum partials (single block, fixed order)
@@ -389,7 +427,7 @@ struct LinArgs {
   double* gD;                  // 9 per camera: g(3), D sym(6: d00 d01 d02 d11 d12 d22)
 };
 
-template <int F, int WM>
+template <int F, int WM, int LM>
 __global__ void __launch_bounds__(GSFM_BLOCK) k_lin(LinArgs a) {
   constexpr int R = ResDim<F>::R;
   const uint32_t G = a.G;
@@ -417,7 +455,7 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_lin(LinArgs a) {
       for (int c = 0; c < R; ++c) s += r[c] * r[c];
       Rho3 rho;
       if (a.rho_ext) { const size_t o = 3 * (size_t)a.eid[d]; rho.r0 = a.rho_ext[o]; rho.r1 = a.rho_ext[o + 1]; rho.r2 = a.rho_ext[o + 2]; }
-      else rho = loss_eval(a.loss, s);
+      else rho = loss_eval<LM>(a.loss, s);
       robustify<R>(rho, s, r, Ai, Aj);
       const double* Ar = row_is_second ? Aj : Ai;  // Jacobian of the row camera
       const double* Ac = row_is_second ? Ai : Aj;  // Jacobian of the neighbour
@@ -488,9 +526,10 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_matvec(MatvecArgs a) {
   if (live) {
     const uint32_t end = a.row_ptr[row + 1];
     for (uint32_t d = a.row_ptr[row] + lane; d < end; d += G) {
-      const uint32_t m = a.col[d] & 0x7fffffffu;
-      const double2 A = a.h0[d], B = a.h1[d], C = a.h2[d], D = a.h3[d];
-      const double E = a.h4[d];
+      const uint32_t m = __builtin_nontemporal_load(a.col + d) & 0x7fffffffu;
+      // H is streamed once per mat-vec: non-temporal loads keep the gathered p vector resident in L2
+      const double2 A = nt_load2(a.h0 + d), B = nt_load2(a.h1 + d), C = nt_load2(a.h2 + d), D = nt_load2(a.h3 + d);
+      const double E = __builtin_nontemporal_load(a.h4 + d);
       const double* pm = a.p + 3 * (size_t)m;
       const double p0 = pm[0], p1 = pm[1], p2 = pm[2];
       y0 += A.x * p0 + A.y * p1 + B.x * p2;

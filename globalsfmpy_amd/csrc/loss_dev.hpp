@@ -124,10 +124,55 @@ __device__ __forceinline__ Rho3 loss_leaf(const DevLossNode& n, double s) {
   return o;
 }
 
+// Cheap single leaves (no pow / cosh / atan2 / table): the kernels are specialised on the loss shape so that
+// the common configurations do not pay the registers of the general interpreter.
+__device__ __forceinline__ Rho3 loss_leaf_simple(const DevLossNode& n, double s) {
+  Rho3 o;
+  const double a = n.p[0];
+  switch (n.kind) {
+    case GSFM_LOSS_HUBER: {
+      const double b = a * a;
+      if (s > b) { const double r = sqrt(s); o.r0 = 2.0 * a * r - b; o.r1 = fmax(a / r, DBL_MIN); o.r2 = -o.r1 / (2.0 * s); }
+      else { o.r0 = s; o.r1 = 1.0; o.r2 = 0.0; }
+      break; }
+    case GSFM_LOSS_SOFT_L1: {
+      const double b = a * a, c = 1.0 / b;
+      const double sum = 1.0 + s * c, tmp = sqrt(sum);
+      o.r0 = 2.0 * b * (tmp - 1.0); o.r1 = fmax(1.0 / tmp, DBL_MIN); o.r2 = -(c * o.r1) / (2.0 * sum);
+      break; }
+    case GSFM_LOSS_TUKEY: {
+      const double a2 = a * a;
+      if (s <= a2) { const double v = 1.0 - s / a2, v2 = v * v; o.r0 = a2 / 6.0 * (1.0 - v2 * v); o.r1 = 0.5 * v2; o.r2 = -1.0 / a2 * v; }
+      else { o.r0 = a2 / 6.0; o.r1 = 0.0; o.r2 = 0.0; }
+      break; }
+    case GSFM_LOSS_GEMAN_MCCLURE: {
+      const double a2 = a * a, g2 = n.p[1];
+      const double t = s / a2 + g2;
+      o.r0 = a2 * g2 * s / (2.0 * (s + a2 * g2));
+      o.r1 = (g2 * g2) / (2.0 * (t * t));
+      o.r2 = -(g2 * g2) / (a2 * (t * t * t));
+      break; }
+    default: o.r0 = s; o.r1 = 1.0; o.r2 = 0.0;  // TRIVIAL / NULL loss
+  }
+  return o;
+}
+
+// rho only (trial-cost sweeps never need the derivatives): the MAGSAC value is one table lookup.
+__device__ __forceinline__ double loss_magsac_value(const DevLossNode& n, double sq) {
+  const double ssm2 = n.aux[1];
+  if (sq > n.aux[6]) sq = n.aux[6];
+  long x = (long)rint(1000.0 * sq / ssm2);     // same expression as the full evaluation: same table cell
+  if (x > (long)n.table_len - 1) x = (long)n.table_len - 1;
+  const double weight = n.aux[4] * (n.table[x] - n.aux[7]);
+  return n.inverse ? 1.0 / weight : n.aux[5] - weight;
+}
+
+enum { LM_PROGRAM = 0, LM_SIMPLE = 1, LM_MAGSAC = 2 };  // kernel specialisations
+
 // Evaluate the program. `loss` is a wave-uniform global pointer (scalar loads).
-__device__ __forceinline__ Rho3 loss_eval(const DevLoss* __restrict__ loss, double s) {
+__device__ __forceinline__ Rho3 loss_eval_program(const DevLoss* __restrict__ loss, double s) {
   const int n = loss->n;
-  if (n == 1) return loss_leaf(loss->nodes[0], s);  // common case: one leaf
+  if (n == 1) return loss_leaf(loss->nodes[0], s);  // one leaf of any kind
   if (n <= 0) { Rho3 t; t.r0 = s; t.r1 = 1.0; t.r2 = 0.0; return t; }
   Rho3 res[GSFM_LOSS_MAX_STACK];
   double arg[GSFM_LOSS_MAX_STACK];
@@ -151,6 +196,19 @@ __device__ __forceinline__ Rho3 loss_eval(const DevLoss* __restrict__ loss, doub
     }
   }
   return res[0];
+}
+
+template <int LM>
+__device__ __forceinline__ Rho3 loss_eval(const DevLoss* __restrict__ loss, double s) {
+  if (LM == LM_SIMPLE) return loss_leaf_simple(loss->nodes[0], s);
+  if (LM == LM_MAGSAC) return loss_magsac(loss->nodes[0], s);
+  return loss_eval_program(loss, s);
+}
+
+template <int LM>
+__device__ __forceinline__ double loss_value(const DevLoss* __restrict__ loss, double s) {
+  if (LM == LM_MAGSAC) return loss_magsac_value(loss->nodes[0], s);
+  return loss_eval<LM>(loss, s).r0;  // the unused derivatives are dead code for the simple leaves
 }
 
 // Ceres Corrector (corrector.cc 1.14): residual scaling and the alpha term.

@@ -193,6 +193,13 @@ class RotationProblem(ProblemBase):
         self._check(self._lib.gsfm_rot_time_sweep(self._h, _dp(rot), int(reps), C.byref(ms)), "time_sweep")
         return ms.value
 
+    def time_kernels(self, rot_aa, reps=10):
+        """Mean HIP-event time (ms) of k_cost, k_lin, k_matvec."""
+        rot = np.ascontiguousarray(rot_aa, dtype=np.float64).reshape(self.n_cams, 3)
+        out = np.zeros(3)
+        self._check(self._lib.gsfm_rot_time_kernels(self._h, _dp(rot), int(reps), _dp(out)), "time_kernels")
+        return {"k_cost": out[0], "k_lin": out[1], "k_matvec": out[2]}
+
     def sweep_bytes(self):
         a, b = C.c_double(0), C.c_double(0)
         self._check(self._lib.gsfm_rot_sweep_bytes(self._h, C.byref(a), C.byref(b)), "sweep_bytes")

@@ -260,6 +260,10 @@ int32_t gsfm_rot_get_trace(gsfm_rot_problem* p, double* out, int32_t cap_rows);
 gsfm_status gsfm_rot_time_sweep(gsfm_rot_problem* p, const double* rot_aa, int32_t reps,
                                 double* mean_kernel_ms);
 
+/* Same for the three hot kernels: out_ms[0] = K1 k_cost, [1] = K2 k_lin, [2] = K3 k_matvec (mean of `reps`
+ * launches each, HIP events on the problem's stream, operands resident in HBM).                      */
+gsfm_status gsfm_rot_time_kernels(gsfm_rot_problem* p, const double* rot_aa, int32_t reps, double* out_ms3);
+
 /* Bytes moved per edge by one K1 sweep as laid out in HBM / as counted
  * algorithmically: for roofline reporting.                          */
 gsfm_status gsfm_rot_sweep_bytes(gsfm_rot_problem* p, double* algorithmic_bytes,
