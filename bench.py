@@ -138,6 +138,18 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # the documented trade: PCG to 1e-8 instead of the default 1e-12 (never reported as `value`)
+    fast = None
+    if world == 1:
+        rot_fast, sf = prob.solve(init, cg_relative_tolerance=1e-8)
+        t1 = time.perf_counter()
+        rot_fast, sf = prob.solve(init, cg_relative_tolerance=1e-8)
+        dt_fast = time.perf_counter() - t1
+        dev = synth.angular_distance(synth.align_rotations(rot_fast, rot), rot)
+        fast = {"cg_relative_tolerance": 1e-8, "value": n_edges * sf["num_residual_sweeps"] / dt_fast, "ms_per_solve": 1e3 * dt_fast,
+                "lm_iterations": sf["num_iterations"], "cg_iterations": sf["num_cg_iterations"],
+                "mean_rotation_change_vs_default_rad": float(dev.mean()), "max_rotation_change_vs_default_rad": float(dev.max())}
+
     # K1 sweep kernel, timed live with HIP events on the solver's stream (this rank's cost-owned edges)
     sweep_ms = prob.time_sweep(init, reps=args.sweep_reps)
     alg_b, lay_b = prob.sweep_bytes()
@@ -169,6 +181,17 @@ def main():
                          "edges_per_launch": int(e_local), "kernel_ms": sweep_ms,
                          "sweep_rate_edges_per_s": e_local / (sweep_ms * 1e-3)},
         }
+        if fast is not None:
+            out["inexact_pcg_option"] = fast
+        kt = prob.time_kernels(init, reps=10)
+        nd = 2.0 * e_local if world == 1 else None
+        out["kernels_us"] = {k: 1e3 * v for k, v in kt.items()}
+        if nd is not None:  # algorithmic bytes of the other two hot kernels, per launch
+            out["roofline_other"] = {
+                "k_matvec": {"achieved": (nd * 76.0 + 24.0 * n_cams) / (kt["k_matvec"] * 1e-3) / 1e9, "unit": "GB/s", "peak": HBM_PEAK_GBPS,
+                             "frac": (nd * 76.0 + 24.0 * n_cams) / (kt["k_matvec"] * 1e-3) / 1e9 / HBM_PEAK_GBPS},
+                "k_lin": {"achieved": (nd * (84.0 + 72.0) + 72.0 * n_cams) / (kt["k_lin"] * 1e-3) / 1e9, "unit": "GB/s", "peak": HBM_PEAK_GBPS,
+                          "frac": (nd * (84.0 + 72.0) + 72.0 * n_cams) / (kt["k_lin"] * 1e-3) / 1e9 / HBM_PEAK_GBPS}}
         if args.cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args, loss_ctor, error_type)
         print(json.dumps(out), flush=True)

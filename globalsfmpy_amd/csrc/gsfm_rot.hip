@@ -134,7 +134,6 @@ struct gsfm_rot_problem {
 
   EdgePlanes cost;            // cost-owned edges
   DevBuf<uint2> cost_idx;
-  DevBuf<CostTile> cost_tiles;
   EdgePlanes dir;             // directed entries (rows = owned cameras)
   DevBuf<uint32_t> row_ptr, col;
   uint32_t G = 16;
@@ -192,8 +191,8 @@ int dispatch(const gsfm_rot_problem* P, const ArgsT& args, int grid) {
 template <int F, int W, int L> struct CostLauncher {
   static void go(const CostArgs& a, int grid, hipStream_t s) {
     const bool full = a.s_only || a.rho_ext || a.s_out;
-    if (full) hipLaunchKernelGGL((k_cost<F, W, L, true>), dim3(grid), dim3(GSFM_TILE_THREADS), 0, s, a);
-    else hipLaunchKernelGGL((k_cost<F, W, L, false>), dim3(grid), dim3(GSFM_TILE_THREADS), 0, s, a);
+    if (full) hipLaunchKernelGGL((k_cost<F, W, L, true>), dim3(grid), dim3(GSFM_BLOCK), 0, s, a);
+    else hipLaunchKernelGGL((k_cost<F, W, L, false>), dim3(grid), dim3(GSFM_BLOCK), 0, s, a);
   }
 };
 template <int F, int W, int L> struct LinLauncher { static void go(const LinArgs& a, int grid, hipStream_t s) { hipLaunchKernelGGL((k_lin<F, W, L>), dim3(grid), dim3(GSFM_BLOCK), 0, s, a); } };
@@ -290,7 +289,7 @@ void launch_cache(gsfm_rot_problem* P, const double* x, double2* q) {
 // host-callback loss: s per original edge -> host -> rho triples -> device
 int refresh_external_rho(gsfm_rot_problem* P, const double2* q) {
   CostArgs a{};
-  a.tiles = P->cost_tiles.p; a.n_cams = P->n_cams; a.n = P->cost.n; a.idx = P->cost_idx.p; a.qr0 = P->cost.qr0.p; a.qr1 = P->cost.qr1.p;
+  a.n = P->cost.n; a.idx = P->cost_idx.p; a.qr0 = P->cost.qr0.p; a.qr1 = P->cost.qr1.p;
   a.w0 = P->cost.w0.p; a.w1 = P->cost.w1.p; a.w2 = P->cost.w2.p; a.ws = P->cost.ws.p;
   a.q = q; a.loss = P->d_loss.p; a.eid = P->cost.eid.p; a.partials = P->part_cost.p; a.s_out = P->s_ext.p; a.s_only = 1;
   if (dispatch<CostArgs, CostLauncher>(P, a, P->nb_cost)) return fail(GSFM_ERR_UNSUPPORTED, "no kernel for this error type");
@@ -307,7 +306,7 @@ int refresh_external_rho(gsfm_rot_problem* P, const double2* q) {
 int launch_cost(gsfm_rot_problem* P, const double2* q, int slot, double* s_out = nullptr, double* rho_out = nullptr, double* r_out = nullptr) {
   if (P->cb) { if (int st = refresh_external_rho(P, q)) return st; }
   CostArgs a{};
-  a.tiles = P->cost_tiles.p; a.n_cams = P->n_cams; a.n = P->cost.n; a.idx = P->cost_idx.p; a.qr0 = P->cost.qr0.p; a.qr1 = P->cost.qr1.p;
+  a.n = P->cost.n; a.idx = P->cost_idx.p; a.qr0 = P->cost.qr0.p; a.qr1 = P->cost.qr1.p;
   a.w0 = P->cost.w0.p; a.w1 = P->cost.w1.p; a.w2 = P->cost.w2.p; a.ws = P->cost.ws.p;
   a.q = q; a.loss = P->d_loss.p; a.rho_ext = P->cb ? P->rho_ext.p : nullptr; a.eid = P->cost.eid.p;
   a.partials = P->part_cost.p; a.s_out = s_out; a.rho_out = rho_out; a.r_out = r_out; a.s_only = 0;
@@ -650,33 +649,15 @@ gsfm_status gsfm_rot_problem_create(uint32_t n_cams, uint64_t n_edges, const uin
       if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64) P->G = (uint32_t)v;
     }
   }
-  // cost edges ordered by (camera block of `second`, `first`): the block of `second` quaternions is staged in
-  // LDS by k_cost, `first` varies slowly so its gathers coalesce.  Two stable counting sorts, O(E + N).
-  std::vector<CostTile> tiles;
+  // cost edges sorted by `first` (stable counting sort, O(E + N)): consecutive lanes then share the first
+  // camera's quaternion (a broadcast load); only the `second` gather is random.
   {
     const size_t Ec = cost_eid.size();
     std::vector<uint32_t> tmp(Ec), cnt((size_t)n_cams + 1, 0);
     for (size_t t = 0; t < Ec; ++t) cnt[edge_i[cost_eid[t]] + 1]++;
     for (size_t c = 0; c < n_cams; ++c) cnt[c + 1] += cnt[c];
     for (size_t t = 0; t < Ec; ++t) tmp[cnt[edge_i[cost_eid[t]]]++] = cost_eid[t];
-    const uint32_t nblk = (n_cams + GSFM_CAMBLOCK - 1) / GSFM_CAMBLOCK;
-    std::vector<uint32_t> bstart((size_t)nblk + 1, 0);
-    for (size_t t = 0; t < Ec; ++t) bstart[edge_j[tmp[t]] / GSFM_CAMBLOCK + 1]++;
-    for (uint32_t b = 0; b < nblk; ++b) bstart[b + 1] += bstart[b];
-    std::vector<uint32_t> fillb(bstart.begin(), bstart.end() - 1);
-    for (size_t t = 0; t < Ec; ++t) cost_eid[fillb[edge_j[tmp[t]] / GSFM_CAMBLOCK]++] = tmp[t];
-    // workgroups: ~2 per CU over the whole sweep, at least 8192 edges each, never across a block boundary
-    const size_t per_wg = std::max<size_t>(8192, (Ec + 511) / 512);
-    for (uint32_t b = 0; b < nblk; ++b) {
-      const size_t lo = bstart[b], hi = bstart[b + 1];
-      if (hi == lo) continue;
-      const size_t nw = (hi - lo + per_wg - 1) / per_wg, chunk = (hi - lo + nw - 1) / nw;
-      for (size_t w = 0; w < nw; ++w) {
-        const size_t cb = lo + w * chunk, ce = std::min(hi, cb + chunk);
-        if (ce > cb) tiles.push_back(CostTile{b, (uint32_t)cb, (uint32_t)ce, 0});
-      }
-    }
-    if (tiles.empty()) tiles.push_back(CostTile{0, 0, 0, 0});
+    cost_eid.swap(tmp);
   }
   std::vector<uint2> cidx(cost_eid.size());
   for (size_t t = 0; t < cost_eid.size(); ++t) cidx[t] = make_uint2(edge_i[cost_eid[t]], edge_j[cost_eid[t]]);
@@ -685,8 +666,7 @@ gsfm_status gsfm_rot_problem_create(uint32_t n_cams, uint64_t n_edges, const uin
   // ---- uploads ----
   if (int st = upload_planes(P, P->cost, cost_eid, rel_aa)) return bail(st);
   if (int st = upload_planes(P, P->dir, deid, rel_aa)) return bail(st);
-  if (P->cost_tiles.upload(tiles) != hipSuccess) return bail(fail(GSFM_ERR_HIP, "uploading cost tiles failed"));
-  P->nb_cost = (int)tiles.size();
+  P->nb_cost = std::max(1, std::min(grid_for(P->cost.n), GSFM_COST_BLOCKS));
   if (P->cost_idx.upload(cidx) != hipSuccess || P->row_ptr.upload(rp) != hipSuccess || P->col.upload(col) != hipSuccess)
     return bail(fail(GSFM_ERR_HIP, "uploading graph structure failed"));
   if (P->h0.alloc(nd) != hipSuccess || P->h1.alloc(nd) != hipSuccess || P->h2.alloc(nd) != hipSuccess || P->h3.alloc(nd) != hipSuccess || P->h4.alloc(nd) != hipSuccess)
@@ -822,7 +802,7 @@ gsfm_status gsfm_rot_solve_sigma_consensus(gsfm_rot_problem* P, double* rot, int
     if (int st = upload_state(P, rot)) return (gsfm_status)st;
     {  // K6 = K1 in s-only mode: s_e = ||log(R_j R_i^T R_ij^T)||^2  (:378-398)
       CostArgs a{};
-      a.tiles = P->cost_tiles.p; a.n_cams = P->n_cams; a.n = P->cost.n; a.idx = P->cost_idx.p; a.qr0 = P->cost.qr0.p; a.qr1 = P->cost.qr1.p; a.ws = P->cost.ws.p;
+      a.n = P->cost.n; a.idx = P->cost_idx.p; a.qr0 = P->cost.qr0.p; a.qr1 = P->cost.qr1.p; a.ws = P->cost.ws.p;
       a.q = P->q.p; a.loss = P->d_loss.p; a.eid = P->cost.eid.p; a.partials = P->part_cost.p; a.s_out = P->s_ext.p; a.s_only = 1;
       if (dispatch<CostArgs, CostLauncher>(P, a, P->nb_cost)) return (gsfm_status)fail(GSFM_ERR_UNSUPPORTED, "dispatch");
       if (hipMemcpyAsync(s.data(), P->s_ext.p, 8 * E, hipMemcpyDeviceToHost, P->stream) != hipSuccess) return (gsfm_status)fail(GSFM_ERR_HIP, "read s");
@@ -929,7 +909,7 @@ gsfm_status gsfm_rot_time_sweep(gsfm_rot_problem* P, const double* rot, int32_t 
   DeviceGuard g(P->device);
   if (int st = upload_state(P, rot)) return (gsfm_status)st;
   CostArgs a{};
-  a.tiles = P->cost_tiles.p; a.n_cams = P->n_cams; a.n = P->cost.n; a.idx = P->cost_idx.p; a.qr0 = P->cost.qr0.p; a.qr1 = P->cost.qr1.p;
+  a.n = P->cost.n; a.idx = P->cost_idx.p; a.qr0 = P->cost.qr0.p; a.qr1 = P->cost.qr1.p;
   a.w0 = P->cost.w0.p; a.w1 = P->cost.w1.p; a.w2 = P->cost.w2.p; a.ws = P->cost.ws.p;
   a.q = P->q.p; a.loss = P->d_loss.p; a.eid = P->cost.eid.p; a.partials = P->part_cost.p;
   for (int k = 0; k < 3; ++k) if (dispatch<CostArgs, CostLauncher>(P, a, P->nb_cost)) return (gsfm_status)fail(GSFM_ERR_UNSUPPORTED, "dispatch");

@@ -31,10 +31,7 @@ template <int F> struct ResDim { static constexpr int R = (F == F_QNORM) ? 4 : (
 
 #define GSFM_BLOCK 256
 #define GSFM_MAX_PARTIALS 1024
-// LDS-staged gathers: edges are bucketed by the 4096-camera block of the gathered endpoint; a
-// 1024-thread workgroup keeps that block's quaternions (4096 x 32 B = 128 KiB of the 160 KiB LDS) resident.
-#define GSFM_CAMBLOCK 4096
-#define GSFM_TILE_THREADS 1024
+#define GSFM_COST_BLOCKS 4096  // grid of the K1 sweep (grid-stride; 16 blocks per CU)
 
 // ------------------------------------------------------------------------------------------
 // reductions (deterministic: fixed tree inside a wave, fixed order across waves)
@@ -317,11 +314,8 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_gather_weights(const double* __r
 // ------------------------------------------------------------------------------------------
 // K1: residual + robust reweight sweep over the cost-owned edges
 // ------------------------------------------------------------------------------------------
-struct CostTile { uint32_t block, begin, end, pad; };  // camera block of `second`, edge range
 struct CostArgs {
-  const CostTile* tiles;     // one per workgroup
-  uint32_t n_cams;
-  size_t n;                  // edges
+  size_t n;                  // edges (sorted by `first`, so its quaternion gather is a near-broadcast)
   const uint2* idx;          // (i, j)
   const double2 *qr0, *qr1;  // q_rel planes (x,y) (z,w)
   const double2 *w0, *w1, *w2;
@@ -338,34 +332,23 @@ struct CostArgs {
   int s_only;                // 1: write s_out only, skip the loss (callback path, phase 1)
 };
 
-// FULL = false: the solver's trial-cost sweep (cost only).  FULL = true: per-edge outputs / external rho /
-// s-only modes of the C-ABI (gsfm_rot_residuals, host-callback losses, sigma consensus).
+// K1.  FULL = false: the solver's trial-cost sweep (cost only: for MAGSAC the value is one table lookup, no exp).
+// FULL = true: per-edge outputs / external rho / s-only modes of the C-ABI (gsfm_rot_residuals, host-callback
+// losses, sigma consensus).  One edge per lane, grid-stride; all seven streamed planes are 16-byte coalesced and
+// non-temporal, the camera quaternions are gathered (L2-resident).  Measured ablation (tools/bench_cost.hip,
+// C5): streams only 137 us, + all arithmetic 138-152 us (hidden), + the random q_second gather 181 us.
 template <int F, int WM, int LM, bool FULL>
-__global__ void __launch_bounds__(GSFM_TILE_THREADS) k_cost(CostArgs a) {
+__global__ void __launch_bounds__(GSFM_BLOCK) k_cost(CostArgs a) {
   constexpr int R = ResDim<F>::R;
-  __shared__ double2 q_xy[GSFM_CAMBLOCK];
-  __shared__ double2 q_zw[GSFM_CAMBLOCK];
-  __shared__ double lds[GSFM_TILE_THREADS / 64 + 1];
-  const CostTile tile = a.tiles[blockIdx.x];
-  {  // stage the camera block of the `second` endpoints (coalesced 16-B loads)
-    const uint32_t base = tile.block * GSFM_CAMBLOCK;
-    const uint32_t cnt = min((uint32_t)GSFM_CAMBLOCK, a.n_cams - base);
-    for (uint32_t c = threadIdx.x; c < cnt; c += GSFM_TILE_THREADS) {
-      q_xy[c] = a.q[2 * (size_t)(base + c)];
-      q_zw[c] = a.q[2 * (size_t)(base + c) + 1];
-    }
-  }
-  __syncthreads();
+  __shared__ double lds[8];
   double acc = 0.0;
-  for (uint32_t e = tile.begin + threadIdx.x; e < tile.end; e += GSFM_TILE_THREADS) {
+  const size_t stride = (size_t)gridDim.x * GSFM_BLOCK;
+  for (size_t e = (size_t)blockIdx.x * GSFM_BLOCK + threadIdx.x; e < a.n; e += stride) {
     const uint2 ij = a.idx[e];
     const double2 r0 = nt_load2(a.qr0 + e), r1 = nt_load2(a.qr1 + e);
     const Quat qr{r0.x, r0.y, r1.x, r1.y};
     const EdgeW W = load_w<WM>(a.w0, a.w1, a.w2, a.ws, e);
-    const Quat qi = load_q(a.q, ij.x);                       // edges are sorted by `first`: near-broadcast
-    const uint32_t jl = ij.y - tile.block * GSFM_CAMBLOCK;   // `second` from LDS
-    const double2 jxy = q_xy[jl], jzw = q_zw[jl];
-    const Quat qj{jxy.x, jxy.y, jzw.x, jzw.y};
+    const Quat qi = load_q(a.q, ij.x), qj = load_q(a.q, ij.y);
     double r[R];
     edge_residual<F, WM>(qi, qj, qr, W, r);
     double s = 0.0;
@@ -387,16 +370,8 @@ __global__ void __launch_bounds__(GSFM_TILE_THREADS) k_cost(CostArgs a) {
       }
     }
   }
-  // deterministic block reduction (fixed tree per wave, fixed order over the 16 waves)
-  acc = wave_sum(acc);
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  if (lane == 0) lds[w] = acc;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double t = 0.0;
-    for (int k = 0; k < GSFM_TILE_THREADS / 64; ++k) t += lds[k];
-    a.partials[blockIdx.x] = t;
-  }
+  const double t = block_sum_bcast(acc, lds);
+  if (threadIdx.x == 0) a.partials[blockIdx.x] = t;
 }
 
 // out[0] = sum partials (single block, fixed order)

