@@ -82,12 +82,17 @@ def main():
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the solver has no CPU fallback")
+    local_rank %= torch.cuda.device_count()   # (dev smoke test: several gloo ranks may share one GPU)
     torch.cuda.set_device(local_rank)
     dist = None
+    backend = os.environ.get("GSFM_BENCH_BACKEND", "nccl")  # "nccl" = RCCL over xGMI; "gloo" only for smoke tests
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
 
     from globalsfmpy_amd import _abi, synth, sharding
     from globalsfmpy_amd.loss_functions import MAGSACWeightBasedLoss
@@ -105,7 +110,7 @@ def main():
 
     t_create = time.perf_counter()
     if world > 1:
-        comm = sharding.TorchComm(n_cams)
+        comm = sharding.make_comm(n_cams)
         prob, perm = sharding.make_sharded_problem(g, error_type, comm, loss=loss_ctor())
         init = np.empty_like(g["init_aa"]); init[perm] = g["init_aa"]
         gt = np.empty_like(g["gt_aa"]); gt[perm] = g["gt_aa"]
@@ -134,7 +139,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -155,6 +160,7 @@ def main():
     alg_b, lay_b = prob.sweep_bytes()
     e_local = summ["num_edges_used"]
     achieved = (e_local * alg_b + 24.0 * n_cams) / (sweep_ms * 1e-3) / 1e9
+    kt = prob.time_kernels(init, reps=10)   # contains collectives when sharded: every rank must call it
 
     if rank == 0:
         aligned = synth.align_rotations(rot, gt)
@@ -168,7 +174,8 @@ def main():
                                    "MAGSACWeightBasedLoss(0.02), one full LM solve per step (BASELINE.json configs[4] graph)"
                                    % (n_cams, n_edges, args.outliers),
                        "cams": n_cams, "edges": n_edges, "outlier_frac": args.outliers, "seed": args.seed,
-                       "parallelism": "camera-slice x%d" % world},
+                       "parallelism": "camera-slice x%d" % world,
+                       "collectives": (comm.backend if world > 1 else "none")},
             "iters_to_1e-6": summ["iters_to_1e6"], "lm_iterations": summ["num_iterations"],
             "residual_sweeps_per_solve": summ["num_residual_sweeps"], "cg_iterations_per_solve": summ["num_cg_iterations"],
             "termination": summ["termination_name"], "final_cost": summ["final_cost"],
@@ -183,7 +190,6 @@ def main():
         }
         if fast is not None:
             out["inexact_pcg_option"] = fast
-        kt = prob.time_kernels(init, reps=10)
         nd = 2.0 * e_local if world == 1 else None
         out["kernels_us"] = {k: 1e3 * v for k, v in kt.items()}
         if nd is not None:  # algorithmic bytes of the other two hot kernels, per launch

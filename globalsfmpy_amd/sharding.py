@@ -9,6 +9,7 @@ all-reduced.  Backend "nccl" (= RCCL over xGMI) operates directly on the device 
 solver's stream; backend "gloo" (CPU tests, or several ranks sharing one GPU) stages through host.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -165,6 +166,68 @@ class TorchComm(object):
             import sys
             print("gsfm all_reduce callback failed: %r" % (e,), file=sys.stderr)
             return 1
+
+
+class NativeComm(object):
+    """The same two collectives issued by C++ (globalsfmpy_amd/csrc/gsfm_rccl.cpp) straight into RCCL on the
+    solver's own stream.  torch.distributed is used once, to hand the ncclUniqueId to every rank."""
+
+    def __init__(self, n_cams, group=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+        self.n_cams = int(n_cams)
+        self.P = slice_width(n_cams, self.world)
+        here = os.path.dirname(os.path.abspath(__file__))
+        lib = C.CDLL(os.path.join(here, "libgsfm_rccl.so"))
+        lib.gsfm_rccl_last_error.restype = C.c_char_p
+        lib.gsfm_rccl_create.restype = C.c_void_p
+        lib.gsfm_rccl_create.argtypes = [C.c_char_p, C.c_int, C.c_int]
+        lib.gsfm_rccl_destroy.argtypes = [C.c_void_p]
+        lib.gsfm_rccl_init.argtypes = [C.c_char_p]
+        bundled = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        if lib.gsfm_rccl_init(bundled.encode() if os.path.exists(bundled) else None) != 0:
+            raise RuntimeError("RCCL not available: %s" % lib.gsfm_rccl_last_error().decode())
+        ident = [None]
+        if self.rank == 0:
+            buf = C.create_string_buffer(128)
+            if lib.gsfm_rccl_unique_id(buf) != 0:
+                raise RuntimeError("ncclGetUniqueId failed: %s" % lib.gsfm_rccl_last_error().decode())
+            ident[0] = buf.raw
+        dist.broadcast_object_list(ident, src=0, group=group)
+        torch.cuda.synchronize()
+        self._ctx = lib.gsfm_rccl_create(ident[0], self.rank, self.world)
+        if not self._ctx:
+            raise RuntimeError("ncclCommInitRank failed: %s" % lib.gsfm_rccl_last_error().decode())
+        self._lib = lib
+        self.backend = "rccl-native"
+        self.n_all_gather = self.n_all_reduce = -1  # not counted on this path
+        ag = C.cast(lib.gsfm_rccl_all_gather, C.c_void_p).value
+        ar = C.cast(lib.gsfm_rccl_all_reduce_sum, C.c_void_p).value
+        self.shard = _abi.Shard(rank=self.rank, world_size=self.world, slice_width=self.P, reserved=0, ctx=self._ctx,
+                                all_gather=_abi.ALL_GATHER_FN(ag), all_reduce_sum=_abi.ALL_REDUCE_FN(ar))
+
+    def stream_handle(self):
+        return None  # the problem's own non-blocking stream
+
+    def close(self):
+        if self._ctx:
+            self._lib.gsfm_rccl_destroy(self._ctx)
+            self._ctx = None
+
+
+def make_comm(n_cams, prefer_native=True, group=None):
+    """NativeComm when RCCL can be driven from C++ (backend nccl), else the torch.distributed callbacks."""
+    import torch.distributed as dist
+    if prefer_native and dist.get_backend(group) == "nccl" and os.environ.get("GSFM_NO_NATIVE_RCCL") is None:
+        try:
+            return NativeComm(n_cams, group)
+        except Exception as e:  # noqa: BLE001
+            import sys
+            print("gsfm: native RCCL unavailable (%r); falling back to torch.distributed collectives" % (e,), file=sys.stderr)
+    return TorchComm(n_cams, group)
 
 
 def make_sharded_problem(graph, error_type, comm, loss=None):

@@ -21,14 +21,14 @@ def main():
     from globalsfmpy_amd import _abi, sharding, synth
     from globalsfmpy_amd.loss_functions import MAGSACWeightBasedLoss
     g = synth.make_graph(1203, 40000, seed=23, outlier_frac=0.3)
-    comm = sharding.TorchComm(g["n_cams"])
+    comm = sharding.make_comm(g["n_cams"], prefer_native=(len(sys.argv) > 3 and sys.argv[3] == "native"))
     prob, perm = sharding.make_sharded_problem(g, _abi.ANGLE_AXIS_COVARIANCE, comm, loss=MAGSACWeightBasedLoss(0.02))
     init = np.empty_like(g["init_aa"]); init[perm] = g["init_aa"]
     rot, summ = prob.solve(init)
     sweep_ms = prob.time_sweep(init, reps=3)
     if dist.get_rank() == 0:
         np.savez(out, rot=rot[perm], cost=summ["final_cost"], iters=summ["num_iterations"], cg=summ["num_cg_iterations"],
-                 term=summ["termination"], n_ag=comm.n_all_gather, n_ar=comm.n_all_reduce, sweep_ms=sweep_ms,
+                 term=summ["termination"], backend=comm.backend, n_ag=comm.n_all_gather, n_ar=comm.n_all_reduce, sweep_ms=sweep_ms,
                  trace=prob.trace())
     dist.barrier()
     dist.destroy_process_group()

@@ -26,13 +26,13 @@ def _reference():
     return rot, s, p.trace()
 
 
-def _launch(nproc, backend, out, extra_env=None):
+def _launch(nproc, backend, out, extra_env=None, mode="torch"):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.update(extra_env or {})
     port = 29600 + (os.getpid() % 300) + (0 if backend == "gloo" else 1)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "sharded_worker.py"), backend, out]
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "sharded_worker.py"), backend, out, mode]
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     return np.load(out)
@@ -57,3 +57,10 @@ def test_forced_single_rank_shard_over_rccl(tmp_path):
     res = _launch(1, "nccl", str(tmp_path / "nccl1.npz"), {"GSFM_FORCE_SHARD": "1"})
     _compare(res, _reference())
     assert int(res["n_ag"]) > 0
+
+
+def test_forced_single_rank_shard_over_native_rccl(tmp_path):
+    """The C++ RCCL communicator (libgsfm_rccl.so): ncclCommInitRank + all-gather / all-reduce on the solver's stream."""
+    res = _launch(1, "nccl", str(tmp_path / "native1.npz"), {"GSFM_FORCE_SHARD": "1"}, mode="native")
+    assert str(res["backend"]) == "rccl-native"
+    _compare(res, _reference())
