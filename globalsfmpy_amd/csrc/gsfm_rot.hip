@@ -144,7 +144,9 @@ struct gsfm_rot_problem {
   // cameras
   DevBuf<double> x, x_trial, aa_io, active, scale, gD, Mblk, Minv, Lam, Tinv, b, D6;
   DevBuf<double2> q, q_trial;
-  DevBuf<double> xcg, r, z, p, Ap;
+  DevBuf<double> xcg, r, z, p, Ap, s_dir, part_g2, part_d2;
+  DevBuf<Cg2Scalars> cg2sc;
+  int nb_mv = 1;
   DevBuf<double> part_a, part_b, part_cost, part_cam, scal;
   DevBuf<CgScalars> cgsc;
   int nb_cam = 1, nb_cost = 1;
@@ -382,6 +384,45 @@ int run_pcg(gsfm_rot_problem* P, const gsfm_rot_options& o, int* iters_out, doub
   return 0;
 }
 
+// single-reduction PCG: 2 kernels per iteration (3 + one all-gather when sharded)
+int run_pcg2(gsfm_rot_problem* P, const gsfm_rot_options& o, int* iters_out, double* rel_out) {
+  Cg2Args c{};
+  c.n = P->n_cams; c.nb_cam = P->nb_cam; c.n_part_d = P->sharded ? P->nb_cam : P->nb_mv; c.par = 0; c.first = 1; c.tol = o.cg_relative_tolerance;
+  c.Minv = P->Minv.p; c.b = P->b.p; c.x = P->xcg.p; c.r = P->r.p; c.u = P->z.p; c.w = P->Ap.p; c.p = P->p.p; c.s = P->s_dir.p;
+  c.part_g = P->part_g2.p; c.part_d = P->part_d2.p; c.sc = P->cg2sc.p;
+  MatvecCgArgs m{};
+  m.mv.n_rows = P->n_rows; m.mv.row_base = P->own_begin; m.mv.G = P->G; m.mv.row_ptr = P->row_ptr.p; m.mv.col = P->col.p;
+  m.mv.h0 = P->h0.p; m.mv.h1 = P->h1.p; m.mv.h2 = P->h2.p; m.mv.h3 = P->h3.p; m.mv.h4 = P->h4.p; m.mv.Mblk = P->Mblk.p;
+  m.mv.p = P->z.p; m.mv.y = P->Ap.p; m.mv.done = nullptr; m.with_dots = P->sharded ? 0 : 1;
+  const dim3 gcam(P->nb_cam), gmv(P->nb_mv), blk(GSFM_BLOCK);
+  const int tk0 = P->timer.begin(T_CG);
+  hipLaunchKernelGGL(k_cg2_init, gcam, blk, 0, P->stream, c);
+  P->timer.end(tk0);
+  Cg2Scalars h{};
+  const int chunk = std::max(1, o.cg_check_interval);
+  int launched = 0;
+  while (true) {
+    const int tk = P->timer.begin(T_CG);
+    for (int k = 0; k < chunk; ++k) {
+      m.cg = c;
+      hipLaunchKernelGGL(k_matvec_cg, gmv, blk, 0, P->stream, m);
+      if (P->sharded) {
+        if (int st = all_gather(P, P->Ap.p, (size_t)P->shard.slice_width * 3)) return st;
+        hipLaunchKernelGGL(k_cg2_dots, gcam, blk, 0, P->stream, c);
+      }
+      hipLaunchKernelGGL(k_cg2_step, gcam, blk, 0, P->stream, c);
+      c.par ^= 1; c.first = 0;
+      ++launched;
+    }
+    P->timer.end(tk);
+    HIPCHK(hipMemcpyAsync(&h, P->cg2sc.p, sizeof(h), hipMemcpyDeviceToHost, P->stream));
+    if (int st = sync_check(P, "pcg")) return st;
+    if (h.done || launched >= o.max_cg_iterations) break;
+  }
+  *iters_out = h.iters; *rel_out = h.last_rel;
+  return 0;
+}
+
 int launch_step(gsfm_rot_problem* P) {
   StepArgs a{};
   a.n = P->n_cams; a.param_dim = P->param_dim; a.x = P->x.p; a.active = P->active.p; a.eta = P->xcg.p; a.b = P->b.p; a.rcg = P->r.p;
@@ -467,7 +508,7 @@ int lm_solve(gsfm_rot_problem* P, const gsfm_rot_options& o, gsfm_rot_summary* s
     if (!prep_valid) launch_prep(P, o, radius, false);
     prep_valid = false;
     int cg = 0; double cg_rel = 0;
-    if (int st = run_pcg(P, o, &cg, &cg_rel)) return st;
+    if (int st = (o.pcg_single_reduction ? run_pcg2(P, o, &cg, &cg_rel) : run_pcg(P, o, &cg, &cg_rel))) return st;
     sum->num_cg_iterations += cg;
     launch_step(P);
     if (int st = launch_cost(P, P->q_trial.p, SC_TRIAL)) return st;
@@ -568,7 +609,7 @@ void gsfm_rot_options_default(gsfm_rot_options* o) {
   o->function_tolerance = 1e-6; o->gradient_tolerance = 1e-10; o->parameter_tolerance = 1e-8;
   o->initial_trust_region_radius = 1e4; o->max_trust_region_radius = 1e16; o->min_trust_region_radius = 1e-32;
   o->min_relative_decrease = 1e-3; o->min_lm_diagonal = 1e-6; o->max_lm_diagonal = 1e32;
-  o->jacobi_scaling = 1; o->max_cg_iterations = 1000; o->cg_relative_tolerance = 1e-12; o->cg_check_interval = 8; o->verbose = 0;
+  o->jacobi_scaling = 1; o->max_cg_iterations = 1000; o->cg_relative_tolerance = 1e-12; o->cg_check_interval = 8; o->verbose = 0; o->pcg_single_reduction = 0; o->reserved0 = 0;
 }
 
 int32_t gsfm_rot_residual_dim(int32_t t) { return t == GSFM_ROT_QUATERNION_NORM ? 4 : t == GSFM_ROT_ROTATION_MAT_FNORM ? 9 : 3; }
@@ -696,6 +737,9 @@ gsfm_status gsfm_rot_problem_create(uint32_t n_cams, uint64_t n_edges, const uin
   ok &= P->part_a.alloc(P->nb_cam) == hipSuccess; ok &= P->part_b.alloc(P->nb_cam) == hipSuccess;
   ok &= P->part_cam.alloc((size_t)5 * P->nb_cam) == hipSuccess; ok &= P->part_cost.alloc(P->nb_cost) == hipSuccess;
   ok &= P->scal.alloc(SC_N, true) == hipSuccess; ok &= P->cgsc.alloc(1, true) == hipSuccess;
+  P->nb_mv = std::max(1, std::min<int>(GSFM_MV_BLOCKS, (int)(((size_t)P->n_rows * P->G + GSFM_BLOCK - 1) / GSFM_BLOCK)));
+  ok &= P->s_dir.alloc(3 * N, true) == hipSuccess; ok &= P->part_g2.alloc((size_t)2 * P->nb_cam, true) == hipSuccess;
+  ok &= P->part_d2.alloc(std::max(P->nb_mv, P->nb_cam), true) == hipSuccess; ok &= P->cg2sc.alloc(1, true) == hipSuccess;
   if (!ok) return bail(fail(GSFM_ERR_HIP, "allocating camera buffers failed"));
   {  // cameras touched by at least one edge (Ceres only knows parameter blocks that appear in a residual block)
     std::vector<double> act(NP, 0.0);

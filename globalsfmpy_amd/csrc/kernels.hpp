@@ -234,6 +234,10 @@ __device__ __forceinline__ double2 nt_load2(const double2* __restrict__ p) {
   v.y = __builtin_nontemporal_load(&p->y);
   return v;
 }
+__device__ __forceinline__ void nt_store2(double2* __restrict__ p, double x, double y) {
+  __builtin_nontemporal_store(x, &p->x);
+  __builtin_nontemporal_store(y, &p->y);
+}
 template <int WM>
 __device__ __forceinline__ EdgeW load_w(const double2* __restrict__ w0, const double2* __restrict__ w1,
                                         const double2* __restrict__ w2, const double* __restrict__ ws, size_t e) {
@@ -415,10 +419,10 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_lin(LinArgs a) {
     const Quat qk = load_q(a.q, k);
     const uint32_t end = a.row_ptr[row + 1];
     for (uint32_t d = a.row_ptr[row] + lane; d < end; d += G) {
-      const uint32_t cr = a.col[d];
+      const uint32_t cr = __builtin_nontemporal_load(a.col + d);
       const uint32_t m = cr & 0x7fffffffu;
       const bool row_is_second = (cr >> 31) != 0;
-      const double2 r0 = a.qr0[d], r1 = a.qr1[d];
+      const double2 r0 = nt_load2(a.qr0 + d), r1 = nt_load2(a.qr1 + d);
       const Quat qr{r0.x, r0.y, r1.x, r1.y};
       const EdgeW W = load_w<WM>(a.w0, a.w1, a.w2, a.ws, d);
       const Quat qm = load_q(a.q, m);
@@ -458,11 +462,13 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_lin(LinArgs a) {
         }
         acc[3] += d00; acc[4] += d01; acc[5] += d02; acc[6] += d11; acc[7] += d12; acc[8] += d22;
       }
-      a.h0[d] = make_double2(H[0], H[1]);
-      a.h1[d] = make_double2(H[2], H[3]);
-      a.h2[d] = make_double2(H[4], H[5]);
-      a.h3[d] = make_double2(H[6], H[7]);
-      a.h4[d] = H[8];
+      // streamed out once, read back by K3: non-temporal stores avoid the write-allocate fetch that PMC showed
+      // (FETCH_SIZE of this kernel was 1.8x its algorithmic reads, profiles/r01_c_pmc_hbm_traffic.txt)
+      nt_store2(a.h0 + d, H[0], H[1]);
+      nt_store2(a.h1 + d, H[2], H[3]);
+      nt_store2(a.h2 + d, H[4], H[5]);
+      nt_store2(a.h3 + d, H[6], H[7]);
+      __builtin_nontemporal_store(H[8], a.h4 + d);
     }
   }
   // segmented reduction over the G lanes of the row (rows are G-aligned inside the wavefront)
@@ -877,6 +883,167 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_cg_pupdate(CgArgs a) {
     // any more; every later kernel observes the flag at its entry (kernel boundary).
     if (!(rel > a.tol) || it >= a.max_iters) a.sc->done = 1;
   }
+}
+
+// ------------------------------------------------------------------------------------------
+// Single-reduction PCG (Chronopoulos & Gear): one mat-vec kernel + one vector kernel per iteration.
+//   u = M^-1 r, w = A u, gamma = r.u, delta = w.u
+//   beta = gamma/gamma_prev, alpha = gamma / (delta - beta gamma / alpha_prev)
+//   p = u + beta p, s = w + beta s, x += alpha p, r -= alpha s, u = M^-1 r
+// gamma partials are produced by the vector kernel (for the NEXT iteration), delta partials by the
+// mat-vec; every block re-sums the partials in the same order, so all blocks (and all ranks) see
+// bit-identical scalars and no finalize launch or atomics are needed.
+// ------------------------------------------------------------------------------------------
+#define GSFM_MV_BLOCKS 4096  // persistent grid of the fused mat-vec
+struct Cg2Scalars {
+  double gamma[2];   // parity-indexed gamma_i
+  double alpha[2];
+  double gamma0;
+  double last_rel;
+  int done;
+  int iters;
+};
+struct Cg2Args {
+  uint32_t n;            // cameras
+  int nb_cam;            // blocks of the camera kernels
+  int n_part_d;          // number of delta partials (mat-vec blocks, or nb_cam when sharded)
+  int par;               // iteration parity
+  int first;             // 1 on iteration 0
+  double tol;
+  const double* Minv;
+  const double* b;
+  double *x, *r, *u, *w, *p, *s;
+  double* part_g;        // [2][nb_cam]  (parity-indexed)
+  double* part_d;        // [n_part_d]
+  Cg2Scalars* sc;
+};
+
+// x = 0, r = b, u = M^-1 r, p = s = 0, gamma_0 partials
+__global__ void __launch_bounds__(GSFM_BLOCK) k_cg2_init(Cg2Args a) {
+  __shared__ double lds[8];
+  double v = 0.0;
+  const uint32_t k = blockIdx.x * GSFM_BLOCK + threadIdx.x;
+  if (k < a.n) {
+    const size_t k3 = 3 * (size_t)k;
+    const double r[3] = {a.b[k3], a.b[k3 + 1], a.b[k3 + 2]};
+    double u[3];
+    sym3_mulvec(a.Minv + 6 * (size_t)k, r, u);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { a.x[k3 + c] = 0.0; a.r[k3 + c] = r[c]; a.u[k3 + c] = u[c]; a.p[k3 + c] = 0.0; a.s[k3 + c] = 0.0; v += r[c] * u[c]; }
+  }
+  const double t = block_sum_bcast(v, lds);
+  if (threadIdx.x == 0) a.part_g[blockIdx.x] = t;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { a.sc->done = 0; a.sc->iters = 0; a.sc->last_rel = 1.0; a.sc->gamma0 = 0.0; }
+}
+
+// Convergence test shared by the mat-vec and the dots kernel: gamma_i from the partials of parity `par`.
+__device__ __forceinline__ bool cg2_converged(const Cg2Args& a, double* lds, double* gamma_out) {
+  const double gamma = sum_partials_bcast(a.part_g + (size_t)a.par * a.nb_cam, a.nb_cam, lds);
+  *gamma_out = gamma;
+  if (a.first) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) { a.sc->gamma0 = gamma; if (!(gamma > 0.0)) a.sc->done = 1; }
+    return !(gamma > 0.0);
+  }
+  const double rel = sqrt(gamma / a.sc->gamma0);
+  const bool conv = !(rel > a.tol);
+  if (blockIdx.x == 0 && threadIdx.x == 0) { a.sc->last_rel = rel; if (conv) a.sc->done = 1; }
+  return conv;
+}
+
+// w = A u on the owned rows (persistent grid, G lanes per row) + delta partials (unsharded only)
+struct MatvecCgArgs { MatvecArgs mv; Cg2Args cg; int with_dots; };
+__global__ void __launch_bounds__(GSFM_BLOCK) k_matvec_cg(MatvecCgArgs aa) {
+  __shared__ double lds[8];
+  const MatvecArgs& a = aa.mv;
+  if (aa.cg.sc->done) return;
+  double gamma;
+  if (cg2_converged(aa.cg, lds, &gamma)) return;
+  const uint32_t G = a.G, rows_per_block = GSFM_BLOCK / G;
+  const uint32_t lane = threadIdx.x % G, sub = threadIdx.x / G;
+  double dpart = 0.0;
+  for (uint32_t row0 = blockIdx.x * rows_per_block; row0 < a.n_rows; row0 += gridDim.x * rows_per_block) {
+    const uint32_t row = row0 + sub;
+    const bool live = row < a.n_rows;
+    double y0 = 0.0, y1 = 0.0, y2 = 0.0;
+    if (live) {
+      const uint32_t end = a.row_ptr[row + 1];
+      for (uint32_t d = a.row_ptr[row] + lane; d < end; d += G) {
+        const uint32_t m = __builtin_nontemporal_load(a.col + d) & 0x7fffffffu;
+        const double2 A = nt_load2(a.h0 + d), B = nt_load2(a.h1 + d), C = nt_load2(a.h2 + d), D = nt_load2(a.h3 + d);
+        const double E = __builtin_nontemporal_load(a.h4 + d);
+        const double* pm = a.p + 3 * (size_t)m;
+        const double p0 = pm[0], p1 = pm[1], p2 = pm[2];
+        y0 += A.x * p0 + A.y * p1 + B.x * p2;
+        y1 += B.y * p0 + C.x * p1 + C.y * p2;
+        y2 += D.x * p0 + D.y * p1 + E * p2;
+      }
+    }
+    for (uint32_t off = G >> 1; off > 0; off >>= 1) {
+      y0 += __shfl_down(y0, off, G); y1 += __shfl_down(y1, off, G); y2 += __shfl_down(y2, off, G);
+    }
+    if (live && lane == 0) {
+      const size_t k = a.row_base + row;
+      const double* pk = a.p + 3 * k;
+      double mp[3];
+      sym3_mulvec(a.Mblk + 6 * k, pk, mp);
+      const double w0 = y0 + mp[0], w1 = y1 + mp[1], w2 = y2 + mp[2];
+      a.y[3 * k] = w0; a.y[3 * k + 1] = w1; a.y[3 * k + 2] = w2;
+      dpart += w0 * pk[0] + w1 * pk[1] + w2 * pk[2];
+    }
+  }
+  if (aa.with_dots) {
+    const double t = block_sum_bcast(dpart, lds);
+    if (threadIdx.x == 0) aa.cg.part_d[blockIdx.x] = t;
+  }
+}
+
+// sharded path: delta partials over ALL cameras after the all-gather of w (identical on every rank)
+__global__ void __launch_bounds__(GSFM_BLOCK) k_cg2_dots(Cg2Args a) {
+  if (a.sc->done) return;
+  __shared__ double lds[8];
+  double v = 0.0;
+  const uint32_t k = blockIdx.x * GSFM_BLOCK + threadIdx.x;
+  if (k < a.n) {
+    const size_t k3 = 3 * (size_t)k;
+    v = a.w[k3] * a.u[k3] + a.w[k3 + 1] * a.u[k3 + 1] + a.w[k3 + 2] * a.u[k3 + 2];
+  }
+  const double t = block_sum_bcast(v, lds);
+  if (threadIdx.x == 0) a.part_d[blockIdx.x] = t;
+}
+
+// alpha, beta and all five vector updates; gamma partials of the next iteration
+__global__ void __launch_bounds__(GSFM_BLOCK) k_cg2_step(Cg2Args a) {
+  if (a.sc->done) return;
+  __shared__ double lds[8];
+  const double gamma = sum_partials_bcast(a.part_g + (size_t)a.par * a.nb_cam, a.nb_cam, lds);
+  const double delta = sum_partials_bcast(a.part_d, a.n_part_d, lds);
+  double beta, alpha;
+  if (a.first) { beta = 0.0; alpha = gamma / delta; }
+  else {
+    beta = gamma / a.sc->gamma[a.par ^ 1];
+    alpha = gamma / (delta - beta * gamma / a.sc->alpha[a.par ^ 1]);
+  }
+  double v = 0.0;
+  const uint32_t k = blockIdx.x * GSFM_BLOCK + threadIdx.x;
+  if (k < a.n) {
+    const size_t k3 = 3 * (size_t)k;
+    double r[3], u[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const double p = a.u[k3 + c] + beta * a.p[k3 + c];
+      const double s = a.w[k3 + c] + beta * a.s[k3 + c];
+      a.p[k3 + c] = p; a.s[k3 + c] = s;
+      a.x[k3 + c] += alpha * p;
+      r[c] = a.r[k3 + c] - alpha * s;
+      a.r[k3 + c] = r[c];
+    }
+    sym3_mulvec(a.Minv + 6 * (size_t)k, r, u);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { a.u[k3 + c] = u[c]; v += r[c] * u[c]; }
+  }
+  const double t = block_sum_bcast(v, lds);
+  if (threadIdx.x == 0) a.part_g[(size_t)(a.par ^ 1) * a.nb_cam + blockIdx.x] = t;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { a.sc->gamma[a.par] = gamma; a.sc->alpha[a.par] = alpha; a.sc->iters = a.sc->iters + 1; }
 }
 
 }  // namespace gsfm

@@ -125,6 +125,10 @@ typedef struct {
                                           ill-conditioned real Madrid graph 1e-10 already costs 1e-6 rad mid-trajectory. */
   int32_t cg_check_interval;           /* CG iterations enqueued between host checks (default 8) */
   int32_t verbose;                     /* 1: print one line per LM iteration to stderr */
+  int32_t pcg_single_reduction;        /* 0 (default): textbook PCG, 4 kernels per iteration; 1: Chronopoulos-Gear single-reduction
+                                          PCG, 2 kernels per iteration (same iterates to rounding; measured 13% slower on one GPU
+                                          at C5 because its persistent mat-vec streams less well) */
+  int32_t reserved0;
 } gsfm_rot_options;
 
 typedef enum {

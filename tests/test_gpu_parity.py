@@ -161,3 +161,15 @@ def test_error_behaviour():
         RotationProblem(3, [0, 1], [1, 2], np.zeros((2, 3)), _abi.ANGLE_AXIS_COVARIANCE)  # covariance missing
     with pytest.raises(SolverError):
         RotationProblem(3, np.zeros(0, np.uint32), np.zeros(0, np.uint32), np.zeros((0, 3)))  # empty (reference returns false)
+
+
+def test_single_reduction_pcg_matches_textbook_pcg(graph):
+    """Chronopoulos-Gear PCG (2 kernels per iteration) produces the same iterates as the default PCG."""
+    from globalsfmpy_amd.solver import RotationProblem
+    p = RotationProblem(graph["n_cams"], graph["edge_i"], graph["edge_j"], graph["rel_aa"], _abi.ANGLE_AXIS_COVARIANCE, cov6=graph["cov6"])
+    p.set_loss(LF.MAGSACWeightBasedLoss(0.02))
+    r0, s0 = p.solve(graph["init_aa"], pcg_single_reduction=0)
+    r1, s1 = p.solve(graph["init_aa"], pcg_single_reduction=1)
+    assert s0["num_iterations"] == s1["num_iterations"] and s0["num_cg_iterations"] == s1["num_cg_iterations"]
+    assert abs(s0["final_cost"] - s1["final_cost"]) <= 1e-9 * s0["final_cost"]
+    assert synth.angular_distance(r0, r1).max() < 1e-9
