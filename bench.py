@@ -162,6 +162,15 @@ def main():
     achieved = (e_local * alg_b + 24.0 * n_cams) / (sweep_ms * 1e-3) / 1e9
     kt = prob.time_kernels(init, reps=10)   # contains collectives when sharded: every rank must call it
 
+    traffic, traffic_src = None, None
+    try:  # committed PMC measurement of the same kernel on the same workload (bench.py cannot run rocprofv3 on itself)
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+        if world == 1 and pm["workload"] == {"cams": n_cams, "edges": n_edges}:
+            traffic = pm["k_cost"]["fetch_bytes"] + pm["k_cost"]["write_bytes"]
+            traffic_src = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2 gfx950 correction)"
+    except Exception:
+        pass
+
     if rank == 0:
         aligned = synth.align_rotations(rot, gt)
         err = synth.angular_distance(aligned, gt)
@@ -184,7 +193,9 @@ def main():
             "setup_s": {"generate": t_gen, "create_problem": t_create},
             "roofline": {"bound": "hbm", "kernel": "k_cost (K1 residual + robust reweight sweep)",
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                         "traffic": None, "algorithmic_bytes_per_edge": alg_b, "layout_bytes_per_edge": lay_b,
+                         "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": e_local * alg_b + 24.0 * n_cams,
+                         "algorithmic_bytes_per_edge": alg_b, "layout_bytes_per_edge": lay_b,
                          "edges_per_launch": int(e_local), "kernel_ms": sweep_ms,
                          "sweep_rate_edges_per_s": e_local / (sweep_ms * 1e-3)},
         }
