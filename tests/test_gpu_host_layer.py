@@ -177,3 +177,15 @@ def test_madrid_graph_through_the_reference_pipeline_call_sequence(tmp_path, gol
     assert abs(s["num_iterations"] - so["num_iterations"]) <= 2
     assert abs(s["final_cost"] - so["final_cost"]) <= 3e-6 * so["final_cost"]
     assert diff.mean() <= 1e-3
+
+
+def test_cpp_plugin_surface_without_python(tmp_path):
+    """Compiles and runs tests/cpp/rotation_estimator_test.cpp against libgsfm_estimator.so / libgsfm_rot.so."""
+    import subprocess
+    pkg = os.path.join(ROOT, "globalsfmpy_amd")
+    exe = str(tmp_path / "rotation_estimator_test")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", os.path.join(ROOT, "tests", "cpp", "rotation_estimator_test.cpp"), "-o", exe,
+                           "-L" + pkg, "-lgsfm_estimator", "-lgsfm_rot", "-Wl,-rpath," + pkg])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    print(r.stdout)
+    assert r.returncode == 0 and "PASSED" in r.stdout, r.stdout + r.stderr
