@@ -134,6 +134,7 @@ struct gsfm_rot_problem {
 
   EdgePlanes cost;            // cost-owned edges
   DevBuf<uint2> cost_idx;
+  DevBuf<CostTile> cost_tiles;
   EdgePlanes dir;             // directed entries (rows = owned cameras)
   DevBuf<uint32_t> row_ptr, col;
   uint32_t G = 16;
@@ -193,8 +194,8 @@ int dispatch(const gsfm_rot_problem* P, const ArgsT& args, int grid) {
 template <int F, int W, int L> struct CostLauncher {
   static void go(const CostArgs& a, int grid, hipStream_t s) {
     const bool full = a.s_only || a.rho_ext || a.s_out;
-    if (full) hipLaunchKernelGGL((k_cost<F, W, L, true>), dim3(grid), dim3(GSFM_BLOCK), 0, s, a);
-    else hipLaunchKernelGGL((k_cost<F, W, L, false>), dim3(grid), dim3(GSFM_BLOCK), 0, s, a);
+    if (full) hipLaunchKernelGGL((k_cost<F, W, L, true>), dim3(grid), dim3(GSFM_TILE_THREADS), 0, s, a);
+    else hipLaunchKernelGGL((k_cost<F, W, L, false>), dim3(grid), dim3(GSFM_TILE_THREADS), 0, s, a);
   }
 };
 template <int F, int W, int L> struct LinLauncher { static void go(const LinArgs& a, int grid, hipStream_t s) { hipLaunchKernelGGL((k_lin<F, W, L>), dim3(grid), dim3(GSFM_BLOCK), 0, s, a); } };
@@ -291,7 +292,7 @@ void launch_cache(gsfm_rot_problem* P, const double* x, double2* q) {
 // host-callback loss: s per original edge -> host -> rho triples -> device
 int refresh_external_rho(gsfm_rot_problem* P, const double2* q) {
   CostArgs a{};
-  a.n = P->cost.n; a.idx = P->cost_idx.p; a.qr0 = P->cost.qr0.p; a.qr1 = P->cost.qr1.p;
+  a.tiles = P->cost_tiles.p; a.n_cams = P->n_cams; a.n = P->cost.n; a.idx = P->cost_idx.p; a.qr0 = P->cost.qr0.p; a.qr1 = P->cost.qr1.p;
   a.w0 = P->cost.w0.p; a.w1 = P->cost.w1.p; a.w2 = P->cost.w2.p; a.ws = P->cost.ws.p;
   a.q = q; a.loss = P->d_loss.p; a.eid = P->cost.eid.p; a.partials = P->part_cost.p; a.s_out = P->s_ext.p; a.s_only = 1;
   if (dispatch<CostArgs, CostLauncher>(P, a, P->nb_cost)) return fail(GSFM_ERR_UNSUPPORTED, "no kernel for this error type");
@@ -308,7 +309,7 @@ int refresh_external_rho(gsfm_rot_problem* P, const double2* q) {
 int launch_cost(gsfm_rot_problem* P, const double2* q, int slot, double* s_out = nullptr, double* rho_out = nullptr, double* r_out = nullptr) {
   if (P->cb) { if (int st = refresh_external_rho(P, q)) return st; }
   CostArgs a{};
-  a.n = P->cost.n; a.idx = P->cost_idx.p; a.qr0 = P->cost.qr0.p; a.qr1 = P->cost.qr1.p;
+  a.tiles = P->cost_tiles.p; a.n_cams = P->n_cams; a.n = P->cost.n; a.idx = P->cost_idx.p; a.qr0 = P->cost.qr0.p; a.qr1 = P->cost.qr1.p;
   a.w0 = P->cost.w0.p; a.w1 = P->cost.w1.p; a.w2 = P->cost.w2.p; a.ws = P->cost.ws.p;
   a.q = q; a.loss = P->d_loss.p; a.rho_ext = P->cb ? P->rho_ext.p : nullptr; a.eid = P->cost.eid.p;
   a.partials = P->part_cost.p; a.s_out = s_out; a.rho_out = rho_out; a.r_out = r_out; a.s_only = 0;
@@ -690,24 +691,46 @@ gsfm_status gsfm_rot_problem_create(uint32_t n_cams, uint64_t n_edges, const uin
       if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64) P->G = (uint32_t)v;
     }
   }
-  // cost edges sorted by `first` (stable counting sort, O(E + N)): consecutive lanes then share the first
-  // camera's quaternion (a broadcast load); only the `second` gather is random.
+  // cost edges ordered by the tile (camera block of `first`, camera block of `second`), and by `first` inside a
+  // tile: two stable counting sorts, O(E + N + #tiles).  k_cost stages both blocks of a tile in LDS.
+  std::vector<CostTile> tiles;
   {
     const size_t Ec = cost_eid.size();
     std::vector<uint32_t> tmp(Ec), cnt((size_t)n_cams + 1, 0);
     for (size_t t = 0; t < Ec; ++t) cnt[edge_i[cost_eid[t]] + 1]++;
     for (size_t c = 0; c < n_cams; ++c) cnt[c + 1] += cnt[c];
     for (size_t t = 0; t < Ec; ++t) tmp[cnt[edge_i[cost_eid[t]]]++] = cost_eid[t];
-    cost_eid.swap(tmp);
+    const uint64_t nblk = ((uint64_t)n_cams + GSFM_CAMBLOCK - 1) / GSFM_CAMBLOCK;
+    auto tile_of = [&](uint32_t e) { return (uint64_t)(edge_i[e] / GSFM_CAMBLOCK) * nblk + edge_j[e] / GSFM_CAMBLOCK; };
+    std::vector<size_t> tstart(nblk * nblk + 1, 0);
+    for (size_t t = 0; t < Ec; ++t) tstart[tile_of(tmp[t]) + 1]++;
+    for (uint64_t b = 0; b < nblk * nblk; ++b) tstart[b + 1] += tstart[b];
+    {
+      std::vector<size_t> fillt(tstart.begin(), tstart.end() - 1);
+      for (size_t t = 0; t < Ec; ++t) cost_eid[fillt[tile_of(tmp[t])]++] = tmp[t];
+    }
+    // one workgroup per <= max_tile edges of a tile: ~2 workgroups per CU for big sweeps, >= 1 pass of 1024 lanes for small ones
+    const size_t max_tile = std::min<size_t>(16384, std::max<size_t>(GSFM_TILE_THREADS, (Ec + 511) / 512));
+    for (uint64_t b = 0; b < nblk * nblk; ++b) {
+      size_t lo = tstart[b];
+      const size_t hi = tstart[b + 1];
+      while (lo < hi) {
+        const size_t ce = std::min(hi, lo + max_tile);
+        tiles.push_back(CostTile{(uint32_t)(b / nblk), (uint32_t)(b % nblk), (uint32_t)lo, (uint32_t)ce});
+        lo = ce;
+      }
+    }
+    if (tiles.empty()) tiles.push_back(CostTile{0, 0, 0, 0});
   }
   std::vector<uint2> cidx(cost_eid.size());
-  for (size_t t = 0; t < cost_eid.size(); ++t) cidx[t] = make_uint2(edge_i[cost_eid[t]], edge_j[cost_eid[t]]);
+  for (size_t t = 0; t < cost_eid.size(); ++t) cidx[t] = make_uint2(edge_i[cost_eid[t]] % GSFM_CAMBLOCK, edge_j[cost_eid[t]] % GSFM_CAMBLOCK);
   P->h_cost_eid = cost_eid;
 
   // ---- uploads ----
   if (int st = upload_planes(P, P->cost, cost_eid, rel_aa)) return bail(st);
   if (int st = upload_planes(P, P->dir, deid, rel_aa)) return bail(st);
-  P->nb_cost = std::max(1, std::min(grid_for(P->cost.n), GSFM_COST_BLOCKS));
+  if (P->cost_tiles.upload(tiles) != hipSuccess) return bail(fail(GSFM_ERR_HIP, "uploading cost tiles failed"));
+  P->nb_cost = (int)tiles.size();
   if (P->cost_idx.upload(cidx) != hipSuccess || P->row_ptr.upload(rp) != hipSuccess || P->col.upload(col) != hipSuccess)
     return bail(fail(GSFM_ERR_HIP, "uploading graph structure failed"));
   if (P->h0.alloc(nd) != hipSuccess || P->h1.alloc(nd) != hipSuccess || P->h2.alloc(nd) != hipSuccess || P->h3.alloc(nd) != hipSuccess || P->h4.alloc(nd) != hipSuccess)
@@ -846,7 +869,7 @@ gsfm_status gsfm_rot_solve_sigma_consensus(gsfm_rot_problem* P, double* rot, int
     if (int st = upload_state(P, rot)) return (gsfm_status)st;
     {  // K6 = K1 in s-only mode: s_e = ||log(R_j R_i^T R_ij^T)||^2  (:378-398)
       CostArgs a{};
-      a.n = P->cost.n; a.idx = P->cost_idx.p; a.qr0 = P->cost.qr0.p; a.qr1 = P->cost.qr1.p; a.ws = P->cost.ws.p;
+      a.tiles = P->cost_tiles.p; a.n_cams = P->n_cams; a.n = P->cost.n; a.idx = P->cost_idx.p; a.qr0 = P->cost.qr0.p; a.qr1 = P->cost.qr1.p; a.ws = P->cost.ws.p;
       a.q = P->q.p; a.loss = P->d_loss.p; a.eid = P->cost.eid.p; a.partials = P->part_cost.p; a.s_out = P->s_ext.p; a.s_only = 1;
       if (dispatch<CostArgs, CostLauncher>(P, a, P->nb_cost)) return (gsfm_status)fail(GSFM_ERR_UNSUPPORTED, "dispatch");
       if (hipMemcpyAsync(s.data(), P->s_ext.p, 8 * E, hipMemcpyDeviceToHost, P->stream) != hipSuccess) return (gsfm_status)fail(GSFM_ERR_HIP, "read s");
@@ -953,7 +976,7 @@ gsfm_status gsfm_rot_time_sweep(gsfm_rot_problem* P, const double* rot, int32_t 
   DeviceGuard g(P->device);
   if (int st = upload_state(P, rot)) return (gsfm_status)st;
   CostArgs a{};
-  a.n = P->cost.n; a.idx = P->cost_idx.p; a.qr0 = P->cost.qr0.p; a.qr1 = P->cost.qr1.p;
+  a.tiles = P->cost_tiles.p; a.n_cams = P->n_cams; a.n = P->cost.n; a.idx = P->cost_idx.p; a.qr0 = P->cost.qr0.p; a.qr1 = P->cost.qr1.p;
   a.w0 = P->cost.w0.p; a.w1 = P->cost.w1.p; a.w2 = P->cost.w2.p; a.ws = P->cost.ws.p;
   a.q = P->q.p; a.loss = P->d_loss.p; a.eid = P->cost.eid.p; a.partials = P->part_cost.p;
   for (int k = 0; k < 3; ++k) if (dispatch<CostArgs, CostLauncher>(P, a, P->nb_cost)) return (gsfm_status)fail(GSFM_ERR_UNSUPPORTED, "dispatch");

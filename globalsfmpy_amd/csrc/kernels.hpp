@@ -31,7 +31,11 @@ template <int F> struct ResDim { static constexpr int R = (F == F_QNORM) ? 4 : (
 
 #define GSFM_BLOCK 256
 #define GSFM_MAX_PARTIALS 1024
-#define GSFM_COST_BLOCKS 4096  // grid of the K1 sweep (grid-stride; 16 blocks per CU)
+// K1 tiles: cost edges are bucketed by (camera block of `first`, camera block of `second`), 2048 cameras per block;
+// a 1024-thread workgroup stages BOTH quaternion blocks in LDS (2 x 2048 x 32 B = 128 KiB of the 160 KiB), so the
+// sweep performs no global gather at all.
+#define GSFM_CAMBLOCK 2048
+#define GSFM_TILE_THREADS 1024
 
 // ------------------------------------------------------------------------------------------
 // reductions (deterministic: fixed tree inside a wave, fixed order across waves)
@@ -318,8 +322,11 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_gather_weights(const double* __r
 // ------------------------------------------------------------------------------------------
 // K1: residual + robust reweight sweep over the cost-owned edges
 // ------------------------------------------------------------------------------------------
+struct CostTile { uint32_t ib, jb, begin, end; };  // camera blocks of (first, second), edge range
 struct CostArgs {
-  size_t n;                  // edges (sorted by `first`, so its quaternion gather is a near-broadcast)
+  const CostTile* tiles;     // one per workgroup
+  uint32_t n_cams;
+  size_t n;                  // edges, ordered by tile; idx holds BLOCK-LOCAL camera indices
   const uint2* idx;          // (i, j)
   const double2 *qr0, *qr1;  // q_rel planes (x,y) (z,w)
   const double2 *w0, *w1, *w2;
@@ -336,23 +343,32 @@ struct CostArgs {
   int s_only;                // 1: write s_out only, skip the loss (callback path, phase 1)
 };
 
-// K1.  FULL = false: the solver's trial-cost sweep (cost only: for MAGSAC the value is one table lookup, no exp).
-// FULL = true: per-edge outputs / external rho / s-only modes of the C-ABI (gsfm_rot_residuals, host-callback
-// losses, sigma consensus).  One edge per lane, grid-stride; all seven streamed planes are 16-byte coalesced and
-// non-temporal, the camera quaternions are gathered (L2-resident).  Measured ablation (tools/bench_cost.hip,
-// C5): streams only 137 us, + all arithmetic 138-152 us (hidden), + the random q_second gather 181 us.
+// K1.  FULL = false: the solver's trial-cost sweep (cost only: for MAGSAC the value needs no exp and no division
+// by constants).  FULL = true: per-edge outputs / external rho / s-only modes of the C-ABI (gsfm_rot_residuals,
+// host-callback losses, sigma consensus).  One edge per lane; the seven streamed planes are 16-byte coalesced,
+// non-temporal loads; both camera quaternions come from LDS.  Measured (tools/bench_cost*.hip, C5): streams only
+// 137 us; + all arithmetic 138-152 us (hidden); direct global gathers 181 us; these 2-D LDS tiles 160 us.
 template <int F, int WM, int LM, bool FULL>
-__global__ void __launch_bounds__(GSFM_BLOCK) k_cost(CostArgs a) {
+__global__ void __launch_bounds__(GSFM_TILE_THREADS) k_cost(CostArgs a) {
   constexpr int R = ResDim<F>::R;
-  __shared__ double lds[8];
+  __shared__ double2 qi_xy[GSFM_CAMBLOCK], qi_zw[GSFM_CAMBLOCK], qj_xy[GSFM_CAMBLOCK], qj_zw[GSFM_CAMBLOCK];
+  __shared__ double lds[GSFM_TILE_THREADS / 64 + 1];
+  const CostTile tile = a.tiles[blockIdx.x];
+  {
+    const uint32_t bi = tile.ib * GSFM_CAMBLOCK, bj = tile.jb * GSFM_CAMBLOCK;
+    const uint32_t ci = min((uint32_t)GSFM_CAMBLOCK, a.n_cams - bi), cj = min((uint32_t)GSFM_CAMBLOCK, a.n_cams - bj);
+    for (uint32_t c = threadIdx.x; c < ci; c += GSFM_TILE_THREADS) { qi_xy[c] = a.q[2 * (size_t)(bi + c)]; qi_zw[c] = a.q[2 * (size_t)(bi + c) + 1]; }
+    for (uint32_t c = threadIdx.x; c < cj; c += GSFM_TILE_THREADS) { qj_xy[c] = a.q[2 * (size_t)(bj + c)]; qj_zw[c] = a.q[2 * (size_t)(bj + c) + 1]; }
+  }
+  __syncthreads();
   double acc = 0.0;
-  const size_t stride = (size_t)gridDim.x * GSFM_BLOCK;
-  for (size_t e = (size_t)blockIdx.x * GSFM_BLOCK + threadIdx.x; e < a.n; e += stride) {
+  for (uint32_t e = tile.begin + threadIdx.x; e < tile.end; e += GSFM_TILE_THREADS) {
     const uint2 ij = a.idx[e];
     const double2 r0 = nt_load2(a.qr0 + e), r1 = nt_load2(a.qr1 + e);
     const Quat qr{r0.x, r0.y, r1.x, r1.y};
     const EdgeW W = load_w<WM>(a.w0, a.w1, a.w2, a.ws, e);
-    const Quat qi = load_q(a.q, ij.x), qj = load_q(a.q, ij.y);
+    const double2 i0 = qi_xy[ij.x], i1 = qi_zw[ij.x], j0 = qj_xy[ij.y], j1 = qj_zw[ij.y];
+    const Quat qi{i0.x, i0.y, i1.x, i1.y}, qj{j0.x, j0.y, j1.x, j1.y};
     double r[R];
     edge_residual<F, WM>(qi, qj, qr, W, r);
     double s = 0.0;
@@ -374,8 +390,15 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_cost(CostArgs a) {
       }
     }
   }
-  const double t = block_sum_bcast(acc, lds);
-  if (threadIdx.x == 0) a.partials[blockIdx.x] = t;
+  // deterministic block reduction (fixed tree per wave, fixed order over the 16 waves)
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int k = 0; k < GSFM_TILE_THREADS / 64; ++k) t += lds[k];
+    a.partials[blockIdx.x] = t;
+  }
 }
 
 // out[0] = sum partials (single block, fixed order)

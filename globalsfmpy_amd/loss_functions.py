@@ -13,10 +13,33 @@ Usage is the reference's:  ``from loss_functions import *``;  ``MAGSACWeightBase
 import math
 import sys
 
-try:  # the compiled drop-in module, when it is on the path (as in scripts/sfm_pipeline.py:5-6)
-    import GlobalSfMpy as sfm  # noqa: F401
+import os
+
+
+def _compiled_module():
+    """The compiled drop-in module `GlobalSfMpy` (top-level name, as scripts/sfm_pipeline.py:5-6 imports it).  It is
+    looked up on sys.path first and then next to this file, so that the loss classes derive from its LossFunction no
+    matter which module was imported first."""
+    try:
+        import GlobalSfMpy
+        return GlobalSfMpy
+    except ImportError:
+        pass
+    here = os.path.dirname(os.path.abspath(__file__))
+    if any(f.startswith("GlobalSfMpy") and f.endswith(".so") for f in os.listdir(here)):
+        sys.path.append(here)
+        try:
+            import GlobalSfMpy
+            return GlobalSfMpy
+        except ImportError:
+            pass
+    return None
+
+
+sfm = _compiled_module()
+if sfm is not None:
     _Base = sfm.LossFunction
-except Exception:  # pure-Python use (tests, bench): same protocol, no compiled base needed
+else:  # pure-Python use (module not built): same protocol, no compiled base needed
     class _Base(object):
         def __init__(self):
             pass
