@@ -46,7 +46,7 @@ class Options(C.Structure):
         ("max_lm_diagonal", C.c_double), ("jacobi_scaling", C.c_int32),
         ("max_cg_iterations", C.c_int32), ("cg_relative_tolerance", C.c_double),
         ("cg_check_interval", C.c_int32), ("verbose", C.c_int32),
-        ("pcg_single_reduction", C.c_int32), ("reserved0", C.c_int32),
+        ("pcg_single_reduction", C.c_int32), ("cg_stall_iterations", C.c_int32),
     ]
 
 

@@ -809,8 +809,11 @@ struct CgScalars {
   double rz[2];
   double rz0;
   double last_rel;  // sqrt(rz/rz0) at the last iteration
+  double best_rel;  // smallest relative residual seen so far (stagnation detection)
   int done;
   int iters;
+  int stall;        // iterations since best_rel last halved
+  int stalled;      // 1 if the solve ended by stagnation
 };
 struct CgArgs {
   uint32_t n;        // cameras
@@ -818,6 +821,7 @@ struct CgArgs {
   int par;           // iteration parity
   double tol;
   int max_iters;
+  int stall_limit;   // 0 = off
   const double* Minv;
   const double* b;
   double *xcg, *r, *z, *p, *Ap;
@@ -846,8 +850,8 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_cg_init_fin(CgArgs a) {
   __shared__ double lds[8];
   const double rz = sum_partials_bcast(a.part_b, a.nb, lds);
   if (threadIdx.x == 0) {
-    a.sc->rz[0] = rz; a.sc->rz[1] = rz; a.sc->rz0 = rz; a.sc->last_rel = 1.0;
-    a.sc->done = !(rz > 0.0); a.sc->iters = 0;
+    a.sc->rz[0] = rz; a.sc->rz[1] = rz; a.sc->rz0 = rz; a.sc->last_rel = 1.0; a.sc->best_rel = 1.0;
+    a.sc->done = !(rz > 0.0); a.sc->iters = 0; a.sc->stall = 0; a.sc->stalled = 0;
   }
 }
 // partial p.Ap
@@ -905,6 +909,10 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_cg_pupdate(CgArgs a) {
     // A block of this launch that already sees done == 1 merely skips its p update, which nobody reads
     // any more; every later kernel observes the flag at its entry (kernel boundary).
     if (!(rel > a.tol) || it >= a.max_iters) a.sc->done = 1;
+    if (a.stall_limit > 0) {  // numerically singular system: the residual plateaus at rounding level
+      if (rel < 0.5 * a.sc->best_rel) { a.sc->best_rel = rel; a.sc->stall = 0; }
+      else if (++a.sc->stall >= a.stall_limit) { a.sc->done = 1; a.sc->stalled = 1; }
+    }
   }
 }
 
