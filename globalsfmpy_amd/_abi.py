@@ -47,6 +47,7 @@ class Options(C.Structure):
         ("max_cg_iterations", C.c_int32), ("cg_relative_tolerance", C.c_double),
         ("cg_check_interval", C.c_int32), ("verbose", C.c_int32),
         ("pcg_single_reduction", C.c_int32), ("cg_stall_iterations", C.c_int32),
+        ("dense_cholesky_max_cams", C.c_int32), ("reserved1", C.c_int32),
     ]
 
 
@@ -63,6 +64,7 @@ class Summary(C.Structure):
         ("last_weight_change", C.c_double),
         ("t_total_ms", C.c_double), ("t_linearize_ms", C.c_double),
         ("t_sweep_ms", C.c_double), ("t_cg_ms", C.c_double),
+        ("num_dense_solves", C.c_int32), ("reserved2", C.c_int32),
     ]
 
     def as_dict(self):

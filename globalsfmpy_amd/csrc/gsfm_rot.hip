@@ -2,6 +2,7 @@
 // Ceres 1.14 trust-region semantics, block-Jacobi PCG orchestration.  All arithmetic on the edges
 // and cameras runs in the kernels of kernels.hpp; the host only sequences launches and reads a
 // handful of scalars per LM iteration.  Built with hipcc --offload-arch=gfx950 into libgsfm_rot.so.
+#include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -119,6 +120,36 @@ struct EventTimer {  // GPU time per phase, resolved at host syncs
   }
 };
 
+// ---- rocSOLVER, resolved on first use (only small graphs ever touch it) ----
+struct DenseBackend {
+  bool tried = false, ok = false;
+  void* handle = nullptr;  // rocblas_handle
+  int (*create_handle)(void**) = nullptr;
+  int (*destroy_handle)(void*) = nullptr;
+  int (*set_stream)(void*, hipStream_t) = nullptr;
+  int (*dpotrf)(void*, int, int, double*, int, int*) = nullptr;
+  int (*dpotrs)(void*, int, int, int, double*, int, double*, int) = nullptr;
+  bool init() {
+    if (tried) return ok;
+    tried = true;
+    void* blas = dlopen("librocblas.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!blas) blas = dlopen("/opt/rocm/lib/librocblas.so", RTLD_NOW | RTLD_GLOBAL);
+    void* sol = dlopen("librocsolver.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!sol) sol = dlopen("/opt/rocm/lib/librocsolver.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!blas || !sol) return false;
+    create_handle = (int (*)(void**))dlsym(blas, "rocblas_create_handle");
+    destroy_handle = (int (*)(void*))dlsym(blas, "rocblas_destroy_handle");
+    set_stream = (int (*)(void*, hipStream_t))dlsym(blas, "rocblas_set_stream");
+    dpotrf = (int (*)(void*, int, int, double*, int, int*))dlsym(sol, "rocsolver_dpotrf");
+    dpotrs = (int (*)(void*, int, int, int, double*, int, double*, int))dlsym(sol, "rocsolver_dpotrs");
+    if (!create_handle || !set_stream || !dpotrf || !dpotrs) return false;
+    if (create_handle(&handle) != 0) return false;
+    ok = true;
+    return true;
+  }
+};
+DenseBackend g_dense;
+
 }  // namespace
 
 struct gsfm_rot_problem {
@@ -147,6 +178,8 @@ struct gsfm_rot_problem {
   DevBuf<double2> q, q_trial;
   DevBuf<double> xcg, r, z, p, Ap, s_dir, part_g2, part_d2;
   DevBuf<Cg2Scalars> cg2sc;
+  DevBuf<double> denseA;
+  DevBuf<int> dense_info;
   int nb_mv = 1;
   DevBuf<double> part_a, part_b, part_cost, part_cam, scal;
   DevBuf<CgScalars> cgsc;
@@ -424,6 +457,39 @@ int run_pcg2(gsfm_rot_problem* P, const gsfm_rot_options& o, int* iters_out, dou
   return 0;
 }
 
+// Exact step for small graphs: dense Cholesky of (J^T J + Lambda) in the left-tangent space. Returns 1 if the
+// factorisation could not be used (caller falls back to PCG), < 0 never, 0 on success, or a gsfm_status > 1.
+int run_dense(gsfm_rot_problem* P, bool* used) {
+  *used = false;
+  if (!g_dense.init()) return 0;
+  const uint32_t n = 3 * P->n_cams;
+  if (!P->denseA.p) {
+    if (P->denseA.alloc((size_t)n * n) != hipSuccess || P->dense_info.alloc(1) != hipSuccess) return 0;
+  }
+  const int tk = P->timer.begin(T_CG);
+  hipLaunchKernelGGL(k_zero, dim3(grid_for((size_t)n * n)), dim3(GSFM_BLOCK), 0, P->stream, P->denseA.p, (size_t)n * n);
+  DenseArgs a{};
+  a.n_rows = P->n_rows; a.row_ptr = P->row_ptr.p; a.col = P->col.p; a.h0 = P->h0.p; a.h1 = P->h1.p; a.h2 = P->h2.p; a.h3 = P->h3.p; a.h4 = P->h4.p;
+  a.Mblk = P->Mblk.p; a.A = P->denseA.p; a.n = n;
+  hipLaunchKernelGGL(k_dense_assemble, dim3(P->n_rows), dim3(GSFM_BLOCK), 0, P->stream, a);
+  HIPCHK(hipMemcpyAsync(P->xcg.p, P->b.p, 8 * (size_t)n, hipMemcpyDeviceToDevice, P->stream));
+  g_dense.set_stream(g_dense.handle, P->stream);
+  const int rocblas_fill_lower = 122;
+  int st = g_dense.dpotrf(g_dense.handle, rocblas_fill_lower, (int)n, P->denseA.p, (int)n, P->dense_info.p);
+  P->timer.end(tk);
+  int info = -1;
+  HIPCHK(hipMemcpyAsync(&info, P->dense_info.p, sizeof(int), hipMemcpyDeviceToHost, P->stream));
+  if (int e = sync_check(P, "dense potrf")) return e;
+  if (st != 0 || info != 0) return 0;  // not positive definite to working precision: PCG instead
+  const int tk2 = P->timer.begin(T_CG);
+  st = g_dense.dpotrs(g_dense.handle, rocblas_fill_lower, (int)n, 1, P->denseA.p, (int)n, P->xcg.p, (int)n);
+  P->timer.end(tk2);
+  if (st != 0) return 0;
+  HIPCHK(hipMemsetAsync(P->r.p, 0, 8 * (size_t)n, P->stream));  // exact solve: the PCG residual term of the model decrease is zero
+  *used = true;
+  return 0;
+}
+
 int launch_step(gsfm_rot_problem* P) {
   StepArgs a{};
   a.n = P->n_cams; a.param_dim = P->param_dim; a.x = P->x.p; a.active = P->active.p; a.eta = P->xcg.p; a.b = P->b.p; a.rcg = P->r.p;
@@ -509,7 +575,12 @@ int lm_solve(gsfm_rot_problem* P, const gsfm_rot_options& o, gsfm_rot_summary* s
     if (!prep_valid) launch_prep(P, o, radius, false);
     prep_valid = false;
     int cg = 0; double cg_rel = 0;
-    if (int st = (o.pcg_single_reduction ? run_pcg2(P, o, &cg, &cg_rel) : run_pcg(P, o, &cg, &cg_rel))) return st;
+    bool dense_used = false;
+    if (!P->sharded && o.dense_cholesky_max_cams > 0 && (int64_t)P->n_cams <= o.dense_cholesky_max_cams) {
+      if (int st = run_dense(P, &dense_used)) return st;
+    }
+    if (dense_used) sum->num_dense_solves++;
+    else if (int st = (o.pcg_single_reduction ? run_pcg2(P, o, &cg, &cg_rel) : run_pcg(P, o, &cg, &cg_rel))) return st;
     sum->num_cg_iterations += cg;
     launch_step(P);
     if (int st = launch_cost(P, P->q_trial.p, SC_TRIAL)) return st;
@@ -610,7 +681,7 @@ void gsfm_rot_options_default(gsfm_rot_options* o) {
   o->function_tolerance = 1e-6; o->gradient_tolerance = 1e-10; o->parameter_tolerance = 1e-8;
   o->initial_trust_region_radius = 1e4; o->max_trust_region_radius = 1e16; o->min_trust_region_radius = 1e-32;
   o->min_relative_decrease = 1e-3; o->min_lm_diagonal = 1e-6; o->max_lm_diagonal = 1e32;
-  o->jacobi_scaling = 1; o->max_cg_iterations = 1000; o->cg_relative_tolerance = 1e-12; o->cg_check_interval = 8; o->verbose = 0; o->pcg_single_reduction = 0; o->cg_stall_iterations = 0;
+  o->jacobi_scaling = 1; o->max_cg_iterations = 1000; o->cg_relative_tolerance = 1e-12; o->cg_check_interval = 8; o->verbose = 0; o->pcg_single_reduction = 0; o->cg_stall_iterations = 0; o->dense_cholesky_max_cams = 0; o->reserved1 = 0;
 }
 
 int32_t gsfm_rot_residual_dim(int32_t t) { return t == GSFM_ROT_QUATERNION_NORM ? 4 : t == GSFM_ROT_ROTATION_MAT_FNORM ? 9 : 3; }
@@ -901,6 +972,7 @@ gsfm_status gsfm_rot_solve_sigma_consensus(gsfm_rot_problem* P, double* rot, int
       total.num_linearizations += summary->num_linearizations; total.num_cg_iterations += summary->num_cg_iterations;
       total.final_cost = summary->final_cost; total.termination = summary->termination;
       total.final_gradient_max_norm = summary->final_gradient_max_norm; total.final_radius = summary->final_radius;
+      total.num_dense_solves += summary->num_dense_solves;
       total.t_linearize_ms += summary->t_linearize_ms; total.t_sweep_ms += summary->t_sweep_ms; total.t_cg_ms += summary->t_cg_ms;
     }
     total.num_residual_sweeps += 1;  // the weight sweep

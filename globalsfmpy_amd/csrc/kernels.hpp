@@ -1077,4 +1077,39 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_cg2_step(Cg2Args a) {
   if (blockIdx.x == 0 && threadIdx.x == 0) { a.sc->gamma[a.par] = gamma; a.sc->alpha[a.par] = alpha; a.sc->iters = a.sc->iters + 1; }
 }
 
+// ------------------------------------------------------------------------------------------
+// Small graphs: assemble the damped normal matrix densely (column-major n x n, n = 3 * cameras) for an exact
+// Cholesky.  The block-CSR holds both directions of every edge, so every off-diagonal block is written by its
+// own entry; atomicAdd only matters for repeated camera pairs (two contributions commute).
+// ------------------------------------------------------------------------------------------
+struct DenseArgs {
+  uint32_t n_rows;
+  const uint32_t* row_ptr;
+  const uint32_t* col;
+  const double2 *h0, *h1, *h2, *h3;
+  const double* h4;
+  const double* Mblk;  // 6 per camera
+  double* A;           // n x n, zero-filled before the launch
+  uint32_t n;
+};
+__global__ void __launch_bounds__(GSFM_BLOCK) k_dense_assemble(DenseArgs a) {
+  const uint32_t row = blockIdx.x;
+  if (row >= a.n_rows) return;
+  if (threadIdx.x == 0) {
+    const double* M = a.Mblk + 6 * (size_t)row;
+    const double m[9] = {M[0], M[1], M[2], M[1], M[3], M[4], M[2], M[4], M[5]};
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) a.A[(size_t)(3 * row + c) * a.n + 3 * row + r] = m[3 * r + c];
+  }
+  for (uint32_t d = a.row_ptr[row] + threadIdx.x; d < a.row_ptr[row + 1]; d += GSFM_BLOCK) {
+    const uint32_t m = a.col[d] & 0x7fffffffu;
+    const double2 A0 = a.h0[d], B0 = a.h1[d], C0 = a.h2[d], D0 = a.h3[d];
+    const double H[9] = {A0.x, A0.y, B0.x, B0.y, C0.x, C0.y, D0.x, D0.y, a.h4[d]};
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) atomicAdd(&a.A[(size_t)(3 * m + c) * a.n + 3 * row + r], H[3 * r + c]);
+  }
+}
+__global__ void __launch_bounds__(GSFM_BLOCK) k_zero(double* p, size_t n) {
+  const size_t i = (size_t)blockIdx.x * GSFM_BLOCK + threadIdx.x;
+  if (i < n) p[i] = 0.0;
+}
+
 }  // namespace gsfm

@@ -132,6 +132,13 @@ typedef struct {
                                           iterations (default 0 = never).  On the real Madrid graph (MAGSAC weights spanning
                                           1e-5..5e4, vanishing damping) PCG needs up to 574 iterations per step; 64 here saves
                                           12 % of them but already perturbs the early trajectory by 5e-8 in cost. */
+  int32_t dense_cholesky_max_cams;     /* opt-in (default 0 = never): graphs with at most this many cameras solve each LM step by
+                                          an exact dense Cholesky of the damped normal matrix on the device (rocSOLVER
+                                          potrf/potrs, dlopen'ed on first use) -- literally the reference's 'normal equations +
+                                          Cholesky'.  Measured on Madrid (394 cams): reproduces the oracle-Cholesky run (63 LM
+                                          iterations) but costs ~3.7 ms per step, so it only pays when PCG needs > 150
+                                          iterations per step; PCG remains the fallback if the factorisation fails. */
+  int32_t reserved1;
 } gsfm_rot_options;
 
 typedef enum {
@@ -162,7 +169,9 @@ typedef struct {
   double t_total_ms;              /* host wall time of the call (uploads of the 3N rotations included) */
   double t_linearize_ms;          /* GPU time (HIP events) in the linearise kernel */
   double t_sweep_ms;              /* GPU time in the residual+reweight cost sweep */
-  double t_cg_ms;                 /* GPU time in PCG kernels */
+  double t_cg_ms;                 /* GPU time in PCG kernels (and dense solves) */
+  int32_t num_dense_solves;       /* LM steps solved by the dense Cholesky path */
+  int32_t reserved2;
 } gsfm_rot_summary;
 
 /* ------------------------------------------------------------------------- */
