@@ -17,6 +17,7 @@
 
 #include "../../include/gsfm_rot.h"
 #include "kernels.hpp"
+#include "cov_kernels.hpp"
 
 using namespace gsfm;
 
@@ -30,6 +31,14 @@ int fail(gsfm_status st, const std::string& msg) { g_err = msg; return st; }
     hipError_t _e = (expr);                                                                       \
     if (_e != hipSuccess) {                                                                       \
       return fail(GSFM_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));               \
+    }                                                                                             \
+  } while (0)
+
+#define HIPCHK_S(expr)                                                                            \
+  do {                                                                                            \
+    hipError_t _e = (expr);                                                                       \
+    if (_e != hipSuccess) {                                                                       \
+      return (gsfm_status)fail(GSFM_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));  \
     }                                                                                             \
   } while (0)
 
@@ -1100,6 +1109,49 @@ gsfm_status gsfm_rot_sweep_bytes(gsfm_rot_problem* P, double* algorithmic, doubl
   if (algorithmic) *algorithmic = 8.0 + (P->functor == F_AA ? 24.0 : 32.0) + w + 8.0;
   // as laid out: uint2 idx + 32 B quaternion + whitening planes; the weight is consumed in-kernel (no per-edge store)
   if (layout) *layout = 8.0 + 32.0 + w;
+  return GSFM_OK;
+}
+
+gsfm_status gsfm_cov_estimate(uint64_t n_edges, const uint64_t* match_ptr, const double* matches, const double* intrinsics,
+                              const double* rot_in, const double* trans_in, int32_t max_iterations, double* cov9_out,
+                              double* rot_out, double* trans_out, int32_t* status_out, int32_t* iters_out, double* kernel_ms) {
+  if (!match_ptr || !matches || !intrinsics || !rot_in || !trans_in || !cov9_out || !rot_out || !trans_out || !status_out)
+    return (gsfm_status)fail(GSFM_ERR_INVALID_ARG, "NULL argument");
+  if (n_edges == 0) return GSFM_OK;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return (gsfm_status)fail(GSFM_ERR_NO_DEVICE, "no HIP device: the covariance estimator has no CPU fallback");
+  const uint64_t n_matches = match_ptr[n_edges];
+  for (uint64_t e = 0; e < n_edges; ++e) if (match_ptr[e + 1] < match_ptr[e]) return (gsfm_status)fail(GSFM_ERR_INVALID_ARG, "match_ptr must be non-decreasing");
+  DevBuf<uint64_t> d_ptr; DevBuf<double4> d_m; DevBuf<double> d_K, d_r, d_t, d_cov, d_ro, d_to; DevBuf<int> d_st, d_it;
+  bool ok = d_ptr.alloc(n_edges + 1) == hipSuccess && d_m.alloc(std::max<uint64_t>(n_matches, 1)) == hipSuccess && d_K.alloc(6 * n_edges) == hipSuccess &&
+            d_r.alloc(3 * n_edges) == hipSuccess && d_t.alloc(3 * n_edges) == hipSuccess && d_cov.alloc(9 * n_edges) == hipSuccess &&
+            d_ro.alloc(3 * n_edges) == hipSuccess && d_to.alloc(3 * n_edges) == hipSuccess && d_st.alloc(n_edges) == hipSuccess && d_it.alloc(n_edges) == hipSuccess;
+  if (!ok) return (gsfm_status)fail(GSFM_ERR_HIP, "allocating covariance buffers failed");
+  HIPCHK_S(hipMemcpy(d_ptr.p, match_ptr, 8 * (n_edges + 1), hipMemcpyHostToDevice));
+  if (n_matches) HIPCHK_S(hipMemcpy(d_m.p, matches, 32 * n_matches, hipMemcpyHostToDevice));
+  HIPCHK_S(hipMemcpy(d_K.p, intrinsics, 48 * n_edges, hipMemcpyHostToDevice));
+  HIPCHK_S(hipMemcpy(d_r.p, rot_in, 24 * n_edges, hipMemcpyHostToDevice));
+  HIPCHK_S(hipMemcpy(d_t.p, trans_in, 24 * n_edges, hipMemcpyHostToDevice));
+  CovArgs a{};
+  a.n_edges = n_edges; a.match_ptr = d_ptr.p; a.matches = d_m.p; a.intr = d_K.p; a.rot_in = d_r.p; a.trans_in = d_t.p;
+  a.max_iterations = max_iterations; a.cov9 = d_cov.p; a.rot_out = d_ro.p; a.trans_out = d_to.p; a.status = d_st.p; a.iters = d_it.p;
+  hipEvent_t e0, e1;
+  HIPCHK_S(hipEventCreate(&e0)); HIPCHK_S(hipEventCreate(&e1));
+  const int grid = (int)((n_edges + (GSFM_BLOCK / 64) - 1) / (GSFM_BLOCK / 64));
+  HIPCHK_S(hipEventRecord(e0, 0));
+  hipLaunchKernelGGL(k_cov_estimate, dim3(grid), dim3(GSFM_BLOCK), 0, 0, a);
+  HIPCHK_S(hipEventRecord(e1, 0));
+  HIPCHK_S(hipDeviceSynchronize());
+  HIPCHK_S(hipGetLastError());
+  float ms = 0;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  if (kernel_ms) *kernel_ms = ms;
+  HIPCHK_S(hipMemcpy(cov9_out, d_cov.p, 72 * n_edges, hipMemcpyDeviceToHost));
+  HIPCHK_S(hipMemcpy(rot_out, d_ro.p, 24 * n_edges, hipMemcpyDeviceToHost));
+  HIPCHK_S(hipMemcpy(trans_out, d_to.p, 24 * n_edges, hipMemcpyDeviceToHost));
+  HIPCHK_S(hipMemcpy(status_out, d_st.p, 4 * n_edges, hipMemcpyDeviceToHost));
+  if (iters_out) HIPCHK_S(hipMemcpy(iters_out, d_it.p, 4 * n_edges, hipMemcpyDeviceToHost));
   return GSFM_OK;
 }
 

@@ -289,6 +289,25 @@ gsfm_status gsfm_rot_time_kernels(gsfm_rot_problem* p, const double* rot_aa, int
 gsfm_status gsfm_rot_sweep_bytes(gsfm_rot_problem* p, double* algorithmic_bytes,
                                  double* layout_bytes);
 
+/* ------------------------------------------------------------------------- */
+/* Per-edge rotation covariance ("next" row of the scope: src/uncertainty.cpp)  */
+/* ------------------------------------------------------------------------- */
+/* Batched get_covariance_rot (reference src/uncertainty.cpp:82-162, driver loop :164-198): for every view pair, refine
+ * (rotation, translation) on the Sampson distance of its matched features -- translation on the sphere, TrivialLoss,
+ * Ceres LM defaults, at most max_iterations (reference: 500) -- then the 3x3 covariance of the rotation with the
+ * translation held fixed, (J_R^T J_R)^-1.  One wavefront per edge on the device.
+ *   match_ptr        n_edges + 1 offsets into `matches`
+ *   matches          4 doubles per match: x1 y1 x2 y2 (pixels)
+ *   intrinsics       6 doubles per edge: f1 u1 v1 f2 u2 v2 (CameraIntrinsicsPrior focal length / principal point, :99-104)
+ *   rot_in/trans_in  TwoViewInfo::rotation_2 / position_2 (3 doubles each)
+ *   cov9_out         row-major 3x3 per edge (what ceres::Covariance::GetCovarianceBlock returns)
+ *   status_out       0 ok, 1 skipped (zero translation, :123, or no matches), 2 singular information matrix
+ *   iters_out        LM iterations used (may be NULL)                                                                */
+gsfm_status gsfm_cov_estimate(uint64_t n_edges, const uint64_t* match_ptr, const double* matches, const double* intrinsics,
+                              const double* rot_in, const double* trans_in, int32_t max_iterations, double* cov9_out,
+                              double* rot_out, double* trans_out, int32_t* status_out, int32_t* iters_out,
+                              double* kernel_ms /* may be NULL: HIP-event time of the kernel */);
+
 /* MAGSAC lookup table Gamma((nu-1)/2, x/1000), x = 0..n-1 (include/gamma_values.cpp);
  * regenerated analytically.  Returns the table length; copies min(n, cap) values. */
 int32_t gsfm_magsac_table(int32_t nu, double* out, int32_t cap);

@@ -46,6 +46,14 @@ void orc_pairwise_rotation_error(const double* aa1, const double* aa2, const dou
                                  double* out3);
 int orc_edge_jacobians(orc_problem* p, uint64_t e, const double* rot_aa, double* r, double* Ji, double* Jj);
 
+/* ---- per-edge rotation covariance (reference src/uncertainty.cpp:36-198) ---- */
+int orc_cov_estimate(uint64_t n_edges, const uint64_t* match_ptr, const double* matches_x1y1x2y2, const double* intrinsics6,
+                     const double* rot_in, const double* trans_in, int32_t max_iterations, double* cov9_out,
+                     double* rot_out, double* trans_out, int32_t* status_out, int32_t* iters_out);
+double orc_sampson_residual(const double* match4, const double* intr6, const double* rot, const double* t, double* jac6);
+void orc_homogeneous_plus(const double* x3, const double* d2, double* out3);
+void orc_homogeneous_jacobian(const double* x3, double* J32);
+
 #ifdef __cplusplus
 }
 #endif

@@ -42,6 +42,11 @@ def lib():
             getattr(L, name).argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.orc_pairwise_rotation_error.argtypes = [C.POINTER(C.c_double)] * 3 + [C.c_double, C.POINTER(C.c_double)]
         L.orc_edge_jacobians.argtypes = [C.c_void_p, C.c_uint64] + [C.POINTER(C.c_double)] * 4
+        L.orc_cov_estimate.argtypes = [C.c_uint64, C.POINTER(C.c_uint64)] + [C.POINTER(C.c_double)] * 4 + [C.c_int32] + [C.POINTER(C.c_double)] * 3 + [C.POINTER(C.c_int32)] * 2
+        L.orc_sampson_residual.argtypes = [C.POINTER(C.c_double)] * 5
+        L.orc_sampson_residual.restype = C.c_double
+        L.orc_homogeneous_plus.argtypes = [C.POINTER(C.c_double)] * 3
+        L.orc_homogeneous_jacobian.argtypes = [C.POINTER(C.c_double)] * 2
         _lib = L
     return _lib
 
@@ -126,4 +131,31 @@ def pairwise_rotation_error(aa1, aa2, rel_aa, weight=1.0):
     a, b, c = [np.ascontiguousarray(v, dtype=np.float64) for v in (aa1, aa2, rel_aa)]
     out = np.empty(3)
     lib().orc_pairwise_rotation_error(_dp(a), _dp(b), _dp(c), float(weight), _dp(out))
+    return out
+
+
+def estimate_rotation_covariances(match_ptr, matches, intrinsics, rot, trans, max_iterations=500):
+    """CPU oracle of globalsfmpy_amd.covariance.estimate_rotation_covariances (same outputs)."""
+    from globalsfmpy_amd.covariance import _call
+    code, out = _call(lib().orc_cov_estimate, match_ptr, matches, intrinsics, rot, trans, max_iterations, False)
+    assert code == 0
+    return out
+
+
+def sampson_residual(match4, intr6, rot, t, want_jacobian=False):
+    a = [np.ascontiguousarray(v, dtype=np.float64) for v in (match4, intr6, rot, t)]
+    jac = np.zeros(6)
+    r = lib().orc_sampson_residual(_dp(a[0]), _dp(a[1]), _dp(a[2]), _dp(a[3]), _dp(jac) if want_jacobian else None)
+    return (r, jac) if want_jacobian else r
+
+
+def homogeneous_plus(x3, d2):
+    x, d, out = np.ascontiguousarray(x3, dtype=np.float64), np.ascontiguousarray(d2, dtype=np.float64), np.zeros(3)
+    lib().orc_homogeneous_plus(_dp(x), _dp(d), _dp(out))
+    return out
+
+
+def homogeneous_jacobian(x3):
+    x, out = np.ascontiguousarray(x3, dtype=np.float64), np.zeros((3, 2))
+    lib().orc_homogeneous_jacobian(_dp(x), _dp(out))
     return out

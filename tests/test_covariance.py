@@ -1,0 +1,111 @@
+"""Per-edge rotation covariance (reference src/uncertainty.cpp:36-198).
+CPU: the oracle's pieces against finite differences / scipy; GPU (-m gpu): device kernel against the oracle."""
+import numpy as np
+import pytest
+
+from conftest import have_gpu
+from globalsfmpy_amd import covariance as cv
+
+
+def test_sampson_residual_and_its_autodiff_jacobian(oracle):
+    b = cv.make_two_view_batch(1, seed=5)
+    m, K, rot, t = b["matches"][3], b["intrinsics"][0], b["rot"][0], b["trans"][0]
+    r, jac = oracle.sampson_residual(m, K, rot, t, want_jacobian=True)
+    # independent evaluation with numpy: r = |x2^T F x1| / sqrt((F x1)_0^2 + (F x1)_1^2 + (F^T x2)_0^2 + (F^T x2)_1^2)
+    from scipy.spatial.transform import Rotation as R
+    K1 = np.array([[K[0], 0, K[1]], [0, K[0], K[2]], [0, 0, 1]]); K2 = np.array([[K[3], 0, K[4]], [0, K[3], K[5]], [0, 0, 1]])
+    tx = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]])
+    F = np.linalg.inv(K2).T @ R.from_rotvec(rot).as_matrix() @ tx @ np.linalg.inv(K1)
+    x1, x2 = np.array([m[0], m[1], 1.0]), np.array([m[2], m[3], 1.0])
+    Fx, Ftx = F @ x1, F.T @ x2
+    want = abs(x2 @ Fx) / np.sqrt(Fx[0] ** 2 + Fx[1] ** 2 + Ftx[0] ** 2 + Ftx[1] ** 2)
+    assert abs(r - want) < 1e-12 * max(1.0, want)
+    h = 1e-7
+    for c in range(6):
+        d = np.zeros(6); d[c] = h
+        fd = (oracle.sampson_residual(m, K, rot + d[:3], t + d[3:]) - oracle.sampson_residual(m, K, rot - d[:3], t - d[3:])) / (2 * h)
+        assert abs(fd - jac[c]) < 1e-5 * max(1.0, abs(jac[c]))
+
+
+def test_homogeneous_parameterization_properties(oracle):
+    rng = np.random.default_rng(0)
+    for _ in range(50):
+        x = rng.standard_normal(3) * rng.choice([0.5, 1.0, 3.0])
+        d = rng.standard_normal(2) * 0.3
+        y = oracle.homogeneous_plus(x, d)
+        assert abs(np.linalg.norm(y) - np.linalg.norm(x)) < 1e-12           # stays on the sphere of radius |x|
+        assert np.allclose(oracle.homogeneous_plus(x, [0.0, 0.0]), x)
+        J = oracle.homogeneous_jacobian(x)
+        h = 1e-7
+        for c in range(2):
+            e = np.zeros(2); e[c] = h
+            fd = (oracle.homogeneous_plus(x, e) - oracle.homogeneous_plus(x, -e)) / (2 * h)
+            assert np.abs(fd - J[:, c]).max() < 1e-7
+        assert np.abs(J.T @ x).max() < 1e-12 * np.linalg.norm(x) ** 2 + 1e-12   # tangent to the sphere
+
+
+def test_oracle_refinement_matches_scipy_and_covariance_is_the_inverse_information(oracle):
+    from scipy.optimize import least_squares
+    b = cv.make_two_view_batch(3, seed=11, matches_per_edge=(150, 200))
+    out = oracle.estimate_rotation_covariances(b["match_ptr"], b["matches"], b["intrinsics"], b["rot"], b["trans"])
+    assert (out["status"] == 0).all()
+    for e in range(3):
+        lo, hi = int(b["match_ptr"][e]), int(b["match_ptr"][e + 1])
+        K = b["intrinsics"][e]
+        t0 = b["trans"][e]
+
+        def fun(p):  # minimal parameters: rotation (3) + homogeneous delta (2) around the initial translation
+            t = oracle.homogeneous_plus(t0, p[3:])
+            return np.array([oracle.sampson_residual(b["matches"][k], K, p[:3], t) for k in range(lo, hi)])
+        sol = least_squares(fun, np.r_[b["rot"][e], 0.0, 0.0], xtol=1e-15, ftol=1e-15, gtol=1e-15)
+        cost_ref = 0.5 * np.sum(sol.fun ** 2)
+        t_fin = out["translation"][e]
+        cost = 0.5 * sum(oracle.sampson_residual(b["matches"][k], K, out["rotation"][e], t_fin) ** 2 for k in range(lo, hi))
+        assert abs(cost - cost_ref) <= 2e-6 * cost_ref                          # both stop at function_tolerance-level
+        assert np.abs(out["rotation"][e] - sol.x[:3]).max() < 5e-5
+        JR = np.array([oracle.sampson_residual(b["matches"][k], K, out["rotation"][e], t_fin, want_jacobian=True)[1][:3] for k in range(lo, hi)])
+        assert np.allclose(out["cov"][e] @ (JR.T @ JR), np.eye(3), atol=1e-8)
+        assert np.abs(out["rotation"][e] - b["gt_rot"][e]).max() < 5e-3           # recovers the pose it was generated from
+        assert abs(np.linalg.norm(t_fin) - np.linalg.norm(t0)) < 1e-12
+
+
+def test_skip_rules(oracle):
+    b = cv.make_two_view_batch(2, seed=2)
+    b["trans"][1] = 0.0                                                        # uncertainty.cpp:123
+    out = oracle.estimate_rotation_covariances(b["match_ptr"], b["matches"], b["intrinsics"], b["rot"], b["trans"])
+    assert out["status"].tolist() == [0, 1]
+    assert np.array_equal(out["cov"][1], np.zeros((3, 3))) and np.array_equal(out["rotation"][1], b["rot"][1])
+
+
+@pytest.mark.gpu
+def test_device_kernel_matches_oracle(oracle):
+    b = cv.make_two_view_batch(500, seed=21)
+    b["trans"][17] = 0.0
+    dev = cv.estimate_rotation_covariances(b["match_ptr"], b["matches"], b["intrinsics"], b["rot"], b["trans"])
+    ora = oracle.estimate_rotation_covariances(b["match_ptr"], b["matches"], b["intrinsics"], b["rot"], b["trans"])
+    assert np.array_equal(dev["status"], ora["status"]) and dev["status"][17] == 1
+    assert np.array_equal(dev["iterations"], ora["iterations"])
+    ok = ora["status"] == 0
+    assert np.abs(dev["rotation"] - ora["rotation"]).max() < 1e-10
+    assert np.abs(dev["translation"] - ora["translation"]).max() < 1e-10
+    rel = np.abs(dev["cov"][ok] - ora["cov"][ok]).max(axis=(1, 2)) / np.abs(ora["cov"][ok]).max(axis=(1, 2))
+    assert rel.max() < 1e-8
+    # covariances are symmetric positive definite and usable by the rotation solver
+    assert (np.linalg.eigvalsh(dev["cov"][ok]) > 0).all()
+    assert cv.cov_to_cov6(dev["cov"]).shape == (500, 6)
+
+
+@pytest.mark.gpu
+def test_device_kernel_throughput_sanity():
+    b = cv.make_two_view_batch(4000, seed=22, matches_per_edge=(100, 300))
+    dev = cv.estimate_rotation_covariances(b["match_ptr"], b["matches"], b["intrinsics"], b["rot"], b["trans"])
+    assert (dev["status"] == 0).all() and dev["kernel_ms"] > 0
+    print("covariance kernel: %d edges, %d matches, %.2f ms -> %.3e edges/s" % (4000, int(b["match_ptr"][-1]), dev["kernel_ms"], 4000 / (dev["kernel_ms"] * 1e-3)))
+
+
+@pytest.mark.skipif(have_gpu(), reason="CPU-only behaviour")
+def test_device_entry_point_fails_loudly_without_a_gpu():
+    from globalsfmpy_amd.solver import SolverError
+    b = cv.make_two_view_batch(1, seed=1)
+    with pytest.raises(SolverError, match="no HIP device"):
+        cv.estimate_rotation_covariances(b["match_ptr"], b["matches"], b["intrinsics"], b["rot"], b["trans"])
