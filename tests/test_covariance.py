@@ -103,6 +103,22 @@ def test_device_kernel_throughput_sanity():
     print("covariance kernel: %d edges, %d matches, %.2f ms -> %.3e edges/s" % (4000, int(b["match_ptr"][-1]), dev["kernel_ms"], 4000 / (dev["kernel_ms"] * 1e-3)))
 
 
+@pytest.mark.gpu
+def test_covariances_feed_the_rotation_solver_end_to_end():
+    """matches -> gsfm_cov_estimate -> ANGLE_AXIS_COVARIANCE + MAGSAC solve, on a scene whose edges differ widely in
+    quality: the uncertainty-whitened robust solve must be at least as accurate as the unit-weight one."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
+    import uncertainty_pipeline as up
+    out = up.run(n_cams=150, n_edges=2000, seed=4, verbose=False)
+    w, u = out["covariance-whitened MAGSAC"], out["unit-weight SoftL1"]
+    print(out)
+    assert out["edges_with_covariance"] >= 1990
+    assert w["median_deg"] < 0.6
+    assert w["mean_deg"] <= 0.9 * u["mean_deg"]      # measured: 0.41 deg vs 0.63 deg
+
+
 @pytest.mark.skipif(have_gpu(), reason="CPU-only behaviour")
 def test_device_entry_point_fails_loudly_without_a_gpu():
     from globalsfmpy_amd.solver import SolverError
