@@ -36,6 +36,45 @@ __global__ void __launch_bounds__(256) k_mv(Args a) {
   if (live && lane == 0) { a.y[3 * (size_t)row] = y0; a.y[3 * (size_t)row + 1] = y1; a.y[3 * (size_t)row + 2] = y2; }
 }
 
+
+// unrolled by two: both trips' column indices and blocks are requested before either gather is consumed
+__global__ void __launch_bounds__(256) k_mv_u2(Args a) {
+  const unsigned G = a.G, t = blockIdx.x * 256 + threadIdx.x, row = t / G, lane = t % G;
+  const bool live = row < a.n_rows;
+  double y0 = 0, y1 = 0, y2 = 0;
+  if (live) {
+    const unsigned end = a.row_ptr[row + 1];
+    unsigned d = a.row_ptr[row] + lane;
+    for (; d + G < end; d += 2 * G) {
+      const unsigned d2 = d + G;
+      const unsigned m1 = __builtin_nontemporal_load(&a.col[d]), m2 = __builtin_nontemporal_load(&a.col[d2]);
+      double2 A1, B1, C1, D1, A2, B2, C2, D2;
+      A1.x = __builtin_nontemporal_load(&a.h0[d].x); A1.y = __builtin_nontemporal_load(&a.h0[d].y);
+      B1.x = __builtin_nontemporal_load(&a.h1[d].x); B1.y = __builtin_nontemporal_load(&a.h1[d].y);
+      C1.x = __builtin_nontemporal_load(&a.h2[d].x); C1.y = __builtin_nontemporal_load(&a.h2[d].y);
+      D1.x = __builtin_nontemporal_load(&a.h3[d].x); D1.y = __builtin_nontemporal_load(&a.h3[d].y);
+      A2.x = __builtin_nontemporal_load(&a.h0[d2].x); A2.y = __builtin_nontemporal_load(&a.h0[d2].y);
+      B2.x = __builtin_nontemporal_load(&a.h1[d2].x); B2.y = __builtin_nontemporal_load(&a.h1[d2].y);
+      C2.x = __builtin_nontemporal_load(&a.h2[d2].x); C2.y = __builtin_nontemporal_load(&a.h2[d2].y);
+      D2.x = __builtin_nontemporal_load(&a.h3[d2].x); D2.y = __builtin_nontemporal_load(&a.h3[d2].y);
+      const double E1 = __builtin_nontemporal_load(&a.h4[d]), E2 = __builtin_nontemporal_load(&a.h4[d2]);
+      const double* p1 = a.p + 3 * (size_t)m1; const double* p2 = a.p + 3 * (size_t)m2;
+      const double a0 = p1[0], a1 = p1[1], a2 = p1[2], b0 = p2[0], b1 = p2[1], b2 = p2[2];
+      y0 += A1.x * a0 + A1.y * a1 + B1.x * a2 + A2.x * b0 + A2.y * b1 + B2.x * b2;
+      y1 += B1.y * a0 + C1.x * a1 + C1.y * a2 + B2.y * b0 + C2.x * b1 + C2.y * b2;
+      y2 += D1.x * a0 + D1.y * a1 + E1 * a2 + D2.x * b0 + D2.y * b1 + E2 * b2;
+    }
+    if (d < end) {
+      const unsigned m = __builtin_nontemporal_load(&a.col[d]);
+      const double2 A = a.h0[d], B = a.h1[d], C = a.h2[d], D = a.h3[d]; const double E = a.h4[d];
+      const double* pm = a.p + 3 * (size_t)m;
+      y0 += A.x * pm[0] + A.y * pm[1] + B.x * pm[2]; y1 += B.y * pm[0] + C.x * pm[1] + C.y * pm[2]; y2 += D.x * pm[0] + D.y * pm[1] + E * pm[2];
+    }
+  }
+  for (unsigned off = G >> 1; off > 0; off >>= 1) { y0 += __shfl_down(y0, off, G); y1 += __shfl_down(y1, off, G); y2 += __shfl_down(y2, off, G); }
+  if (live && lane == 0) { a.y[3 * (size_t)row] = y0; a.y[3 * (size_t)row + 1] = y1; a.y[3 * (size_t)row + 2] = y2; }
+}
+
 // AoS variant: one 80-byte record per entry (9 doubles + col + pad) read as 5 x 16 B
 struct Rec { double h[9]; unsigned col, pad; };
 __global__ void __launch_bounds__(256) k_mv_aos(unsigned n_rows, unsigned G, const unsigned* row_ptr, const Rec* rec, const double4* p4, double* y) {
@@ -89,7 +128,7 @@ int main(int argc, char** argv) {
     CHK(hipMemcpy(rec, hr.data(), sizeof(Rec) * nd, hipMemcpyHostToDevice)); }
   double2* big; CHK(hipMalloc(&big, 64 * nd)); CHK(hipMemset(big, 0, 64 * nd));
   const double bytes = 76.0 * nd;
-  for (unsigned G : {64u, 16u}) {
+  for (unsigned G : {64u, 32u}) {
     Args a{N, G, d_rp, d_col, h0, h1, h2, h3, h4, p, p4, y};
     const int grid = (int)(((size_t)N * G + 255) / 256);
     const char* names[5] = {"planes+3x8B gather", "planes, no gather", "planes+double4 gather", "nontemporal+3x8B", "nontemporal+double4"};
@@ -99,6 +138,7 @@ int main(int argc, char** argv) {
     t = timeit([&] { hipLaunchKernelGGL(k_mv<2>, dim3(grid), dim3(256), 0, 0, a); }); printf("G=%2u %-24s %8.1f us  %6.2f TB/s\n", G, names[2], t, bytes / t * 1e-6);
     t = timeit([&] { hipLaunchKernelGGL(k_mv<3>, dim3(grid), dim3(256), 0, 0, a); }); printf("G=%2u %-24s %8.1f us  %6.2f TB/s\n", G, names[3], t, bytes / t * 1e-6);
     t = timeit([&] { hipLaunchKernelGGL(k_mv<4>, dim3(grid), dim3(256), 0, 0, a); }); printf("G=%2u %-24s %8.1f us  %6.2f TB/s\n", G, names[4], t, bytes / t * 1e-6);
+    t = timeit([&] { hipLaunchKernelGGL(k_mv_u2, dim3(grid), dim3(256), 0, 0, a); }); printf("G=%2u %-24s %8.1f us  %6.2f TB/s\n", G, "nt + 3x8B, unroll 2", t, bytes / t * 1e-6);
     t = timeit([&] { hipLaunchKernelGGL(k_mv_aos, dim3(grid), dim3(256), 0, 0, N, G, d_rp, rec, p4, y); }); printf("G=%2u %-24s %8.1f us  %6.2f TB/s (80 B/entry)\n", G, "AoS 80B + double4", t, 80.0 * nd / t * 1e-6);
   }
   for (int blocks : {2048, 8192, 32768}) {
