@@ -133,11 +133,40 @@ def declare_solver_signatures(lib, prefix, problem_ptr=C.c_void_p):
 _lib = None
 
 
+def preload_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so (soname libamdhip64.so.7) next to libtorch.  If the system
+    runtime under /opt/rocm is mapped first (by libgsfm_rot.so) and torch is imported afterwards, torch maps its own copy
+    as well, and the runtime that initialises second finds no device (measured on the MI355X box: `hipGetDeviceCount`
+    fails in libgsfm_rot.so after `torch.cuda.is_available()`).  The other order is fine because the loader matches
+    libgsfm_rot.so's NEEDED libamdhip64.so.7 against the soname of torch's copy.  So: when torch is installed and no HIP
+    runtime is mapped yet, map torch's copy first.  torch itself is not imported.  Processes without torch (the C++
+    consumers, scripts/sfm_pipeline.py) just get the system runtime."""
+    try:
+        with open("/proc/self/maps") as f:
+            if "libamdhip64" in f.read():
+                return None
+    except OSError:
+        pass
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return None
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if not os.path.exists(cand):
+        return None
+    C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    return cand
+
+
 def load_library():
     """Load libgsfm_rot.so (built by __graft_entry__.build()). Fails loudly."""
     global _lib
     if _lib is not None:
         return _lib
+    preload_hip_runtime()
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             "globalsfmpy_amd: %s not found. The HIP extension is the product and has no CPU fallback; "

@@ -26,6 +26,18 @@ namespace {
 thread_local std::string g_err;
 int fail(gsfm_status st, const std::string& msg) { g_err = msg; return st; }
 
+// NULL when a device is usable, else the message for GSFM_ERR_NO_DEVICE (kept in a thread-local buffer).
+const char* no_device_reason(const char* who) {
+  int ndev = 0;
+  const hipError_t e = hipGetDeviceCount(&ndev);
+  if (e == hipSuccess && ndev > 0) return nullptr;
+  static thread_local std::string msg;
+  msg = std::string("no HIP device: ") + who + " has no CPU fallback (hipGetDeviceCount: " + hipGetErrorString(e) + ", " + std::to_string(ndev) +
+        " devices; if another HIP runtime copy, e.g. PyTorch's bundled one, initialised first in this process, load it before this library)";
+  (void)hipGetLastError();
+  return msg.c_str();
+}
+
 #define HIPCHK(expr)                                                                              \
   do {                                                                                            \
     hipError_t _e = (expr);                                                                       \
@@ -709,9 +721,7 @@ gsfm_status gsfm_rot_problem_create(uint32_t n_cams, uint64_t n_edges, const uin
   const bool need_inl = error_type == GSFM_ROT_ANGLE_AXIS_INLIERS || error_type == GSFM_ROT_ANGLE_AXIS_COV_INLIERS;
   if (need_cov && !cov6) return (gsfm_status)fail(GSFM_ERR_INVALID_ARG, "this error type needs per-edge covariances (cov6)");
   if (need_inl && !inlier_weight) return (gsfm_status)fail(GSFM_ERR_INVALID_ARG, "this error type needs per-edge inlier weights");
-  int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
-    return (gsfm_status)fail(GSFM_ERR_NO_DEVICE, "no HIP device: the rotation solver has no CPU fallback");
+  if (const char* why = no_device_reason("the rotation solver")) return (gsfm_status)fail(GSFM_ERR_NO_DEVICE, why);
 
   gsfm_rot_problem* P = new gsfm_rot_problem;
   auto bail = [&](int st) { gsfm_rot_problem_destroy(P); return (gsfm_status)st; };
@@ -1118,8 +1128,7 @@ gsfm_status gsfm_cov_estimate(uint64_t n_edges, const uint64_t* match_ptr, const
   if (!match_ptr || !matches || !intrinsics || !rot_in || !trans_in || !cov9_out || !rot_out || !trans_out || !status_out)
     return (gsfm_status)fail(GSFM_ERR_INVALID_ARG, "NULL argument");
   if (n_edges == 0) return GSFM_OK;
-  int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return (gsfm_status)fail(GSFM_ERR_NO_DEVICE, "no HIP device: the covariance estimator has no CPU fallback");
+  if (const char* why = no_device_reason("the covariance estimator")) return (gsfm_status)fail(GSFM_ERR_NO_DEVICE, why);
   const uint64_t n_matches = match_ptr[n_edges];
   for (uint64_t e = 0; e < n_edges; ++e) if (match_ptr[e + 1] < match_ptr[e]) return (gsfm_status)fail(GSFM_ERR_INVALID_ARG, "match_ptr must be non-decreasing");
   DevBuf<uint64_t> d_ptr; DevBuf<double4> d_m; DevBuf<double> d_K, d_r, d_t, d_cov, d_ro, d_to; DevBuf<int> d_st, d_it;

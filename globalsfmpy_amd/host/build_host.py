@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Builds the C++ host layer in-tree:
   globalsfmpy_amd/libgsfm_estimator.so  theia::GSfMNonlinearRotationEstimator + view-graph helpers
-  globalsfmpy_amd/GlobalSfMpy<ext>      the pybind11 module (importable as `GlobalSfMpy`)
+  globalsfmpy_amd/_GlobalSfMpy<ext>     the pybind11 module, imported as `GlobalSfMpy` through the GlobalSfMpy.py shim beside it
 Both link libgsfm_rot.so (the HIP C-ABI library) through an $ORIGIN rpath."""
 import os
 import subprocess
@@ -28,11 +28,14 @@ def main():
     common = [cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function", "-fvisibility=default"]
     link = ["-L" + PKG, "-lgsfm_rot", "-Wl,-rpath,$ORIGIN"]
     est = os.path.join(PKG, "libgsfm_estimator.so")
-    est_src = [os.path.join(HERE, "rotation_estimator.cpp"), os.path.join(HERE, "view_graph.cpp")]
+    est_src = [os.path.join(HERE, "rotation_estimator.cpp"), os.path.join(HERE, "view_graph.cpp"), os.path.join(HERE, "dataset_1dsfm.cpp")]
     if force or newer(est, est_src + inc + [os.path.join(PKG, "libgsfm_rot.so")]):
         subprocess.check_call(common + ["-o", est] + est_src + link)
     ext = sysconfig.get_config_var("EXT_SUFFIX")
-    mod = os.path.join(PKG, "GlobalSfMpy" + ext)
+    mod = os.path.join(PKG, "_GlobalSfMpy" + ext)
+    stale = os.path.join(PKG, "GlobalSfMpy" + ext)  # pre-shim builds: an extension would shadow GlobalSfMpy.py
+    if os.path.exists(stale):
+        os.remove(stale)
     mod_src = [os.path.join(HERE, "module.cpp")]
     if force or newer(mod, mod_src + inc + [est]):
         subprocess.check_call(common + ["-fvisibility=hidden", "-I" + pybind11.get_include(), "-I" + sysconfig.get_paths()["include"],

@@ -196,7 +196,7 @@ void load_1dsfm_config(const std::string& flagfile, ReconstructionBuilderOptions
 
 }  // namespace
 
-PYBIND11_MODULE(GlobalSfMpy, m) {
+PYBIND11_MODULE(_GlobalSfMpy, m) {  // imported through the GlobalSfMpy.py shim beside it (HIP runtime pre-load)
   m.doc() = "MI355X-native drop-in for the rotation-averaging surface of zhangganlin/GlobalSfMpy";
 
   py::bind_map<OrientationMap>(m, "MapViewIdVector3d");
@@ -268,6 +268,7 @@ PYBIND11_MODULE(GlobalSfMpy, m) {
       .def("ViewIds", &ViewGraph::ViewIds)
       .def("AddEdge", &ViewGraph::AddEdge)
       .def("RemoveEdge", &ViewGraph::RemoveEdge)
+      .def("GetEdge", &ViewGraph::GetEdge, py::return_value_policy::reference_internal)
       .def("GetAllEdges", &ViewGraph::GetAllEdges, py::return_value_policy::reference);
 
   py::class_<TwoViewInfo>(m, "TwoViewInfo")
@@ -316,6 +317,43 @@ PYBIND11_MODULE(GlobalSfMpy, m) {
   });
   m.def("ReadCovariance", [](const std::string& dir, CovarianceMap& cov) { gsfm::ReadCovariance(dir, &cov); });
   m.def("WriteCovariance", [](const std::string& dir, const CovarianceMap& cov) { return gsfm::WriteCovariance(dir, cov); });
+  // The flattened inputs CalcCovariance hands to gsfm_cov_estimate, for inspection and for globalsfmpy_amd.covariance.
+  m.def("Read1DSFMEdgeMatches", [](const std::string& dir) {
+    gsfm::Tracks1DSfM tracks;
+    theia::ViewGraph vg;
+    std::string err;
+    if (!gsfm::Read1DSFMTracks(dir, &tracks, &err) || !gsfm::Read1DSFMViewGraph(dir, &vg, &err)) throw std::runtime_error(err);
+    gsfm::EdgeMatches em;
+    gsfm::CollectEdgeMatches(tracks, vg, &em);
+    const py::ssize_t E = (py::ssize_t)em.edges.size();
+    py::array_t<uint32_t> edges({E, (py::ssize_t)2});
+    for (py::ssize_t e = 0; e < E; ++e) { edges.mutable_at(e, 0) = em.edges[e].first; edges.mutable_at(e, 1) = em.edges[e].second; }
+    auto vec = [](const std::vector<double>& v, py::ssize_t cols) {
+      py::array_t<double> a({(py::ssize_t)(v.size() / cols), cols});
+      if (!v.empty()) std::memcpy(a.mutable_data(), v.data(), v.size() * sizeof(double));
+      return a;
+    };
+    py::array_t<uint64_t> ptr((py::ssize_t)em.match_ptr.size());
+    std::memcpy(ptr.mutable_data(), em.match_ptr.data(), em.match_ptr.size() * sizeof(uint64_t));
+    py::dict d;
+    d["edges"] = edges; d["match_ptr"] = ptr; d["matches"] = vec(em.matches, 4); d["intrinsics"] = vec(em.intrinsics, 6);
+    d["rot"] = vec(em.rotation, 3); d["trans"] = vec(em.position, 3);
+    return d;
+  });
+  // bind :623-628: estimates every edge's rotation covariance on the device and writes <dir>/covariance_rot.txt;
+  // returns the counters (the reference returns None).
+  m.def("CalcCovariance", [](const std::string& dir) {
+    gsfm::CalcCovarianceStats st;
+    std::string err;
+    {
+      py::gil_scoped_release release;
+      if (!gsfm::CalcCovariance(dir, nullptr, &st, &err)) { py::gil_scoped_acquire a; throw std::runtime_error(err); }
+    }
+    py::dict d;
+    d["num_edges"] = st.num_edges; d["num_matches"] = st.num_matches; d["num_written"] = st.num_written;
+    d["num_skipped"] = st.num_skipped; d["num_singular"] = st.num_singular; d["kernel_ms"] = st.kernel_ms;
+    return d;
+  });
   m.def("OrientationsFromMaximumSpanningTree", [](const ViewGraph& vg, OrientationMap* o) { return OrientationsFromMaximumSpanningTree(vg, o); });
   m.def("FilterViewPairsFromOrientation", &FilterViewPairsFromOrientation);
   m.def("residuals_of_relative_rot", &gsfm::ResidualsOfRelativeRotations);

@@ -229,7 +229,26 @@ bool Read1DSFMViewGraph(const std::string& dir, theia::ViewGraph* view_graph, st
     for (int k = 0; k < 3; ++k) info.position_2[k] = S[k] * t[k];
     view_graph->AddEdge(a, b, info);
   }
+  AnnotateViewGraphFromTracks(dir, view_graph);
   return true;
+}
+
+// read_1dsfm.cc:341-368: focal lengths from the EXIF prior (else 1.2 * principal point x) and
+// num_verified_matches = visibility_score = number of common tracks -- when the dataset carries tracks at all.
+void AnnotateViewGraphFromTracks(const std::string& dir, theia::ViewGraph* view_graph) {
+  for (const char* name : {"/list.txt", "/coords.txt", "/tracks.txt"})
+    if (!std::ifstream(dir + name).is_open()) return;
+  Tracks1DSfM tracks;
+  if (!Read1DSFMTracks(dir, &tracks, nullptr)) return;
+  EdgeMatches em;
+  CollectEdgeMatches(tracks, *view_graph, &em);
+  for (size_t e = 0; e < em.edges.size(); ++e) {
+    theia::TwoViewInfo info = *view_graph->GetEdge(em.edges[e].first, em.edges[e].second);
+    info.focal_length_1 = em.intrinsics[6 * e];
+    info.focal_length_2 = em.intrinsics[6 * e + 3];
+    info.num_verified_matches = info.visibility_score = (int)(em.match_ptr[e + 1] - em.match_ptr[e]);
+    view_graph->AddEdge(em.edges[e].first, em.edges[e].second, info);
+  }
 }
 
 bool ReadCovariance(const std::string& dir, CovarianceMap* covariances) {

@@ -26,7 +26,7 @@ def _compiled_module():
     except ImportError:
         pass
     here = os.path.dirname(os.path.abspath(__file__))
-    if any(f.startswith("GlobalSfMpy") and f.endswith(".so") for f in os.listdir(here)):
+    if any(f.startswith("_GlobalSfMpy") and f.endswith(".so") for f in os.listdir(here)):
         sys.path.append(here)
         try:
             import GlobalSfMpy

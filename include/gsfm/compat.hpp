@@ -37,6 +37,15 @@ struct Vector3d {
   double y() const { return v[1]; }
   double z() const { return v[2]; }
 };
+struct Vector2d {
+  double v[2];
+  Vector2d() : v{0, 0} {}
+  Vector2d(double x, double y) : v{x, y} {}
+  double& operator[](int k) { return v[k]; }
+  const double& operator[](int k) const { return v[k]; }
+  double x() const { return v[0]; }
+  double y() const { return v[1]; }
+};
 struct Matrix3d {  // column-major storage like Eigen's default
   double m[9];
   Matrix3d() : m{0, 0, 0, 0, 0, 0, 0, 0, 0} {}

@@ -62,12 +62,47 @@ std::unordered_set<ViewId> RemoveDisconnectedViewPairs(ViewGraph* view_graph);
 
 namespace gsfm {
 // 1DSfM: EGs.txt (+ cc.txt restriction) -> view graph. Convention of io/read_1dsfm.cc:299-372:
-// R' = S R^T S with S = diag(1,-1,-1), no re-orthonormalisation, t' = S t.  tracks.txt/coords.txt are not
-// read (camera priors and tracks are out of scope); num_verified_matches stays 0 unless `matches` is given.
+// R' = S R^T S with S = diag(1,-1,-1), no re-orthonormalisation, t' = S t.  When tracks.txt / coords.txt / list.txt are
+// present, num_verified_matches = number of common tracks and the focal lengths follow read_1dsfm.cc:341-362.
 bool Read1DSFMViewGraph(const std::string& dataset_directory, theia::ViewGraph* view_graph, std::string* error);
+void AnnotateViewGraphFromTracks(const std::string& dataset_directory, theia::ViewGraph* view_graph);
 // covariance_rot.txt codec (src/uncertainty.cpp:164-230): doubles stored as the decimal of their bit pattern.
 bool ReadCovariance(const std::string& dataset_directory, CovarianceMap* covariances);
 bool WriteCovariance(const std::string& dataset_directory, const CovarianceMap& covariances);
+
+// ---- 1DSfM keypoints and tracks + the CalcCovariance driver ----
+// What thirdparty/TheiaSfM/src/theia/io/read_1dsfm.cc:114-292 reads besides the epipolar geometries: list.txt (view id =
+// line index, optional EXIF focal), coords.txt (per view: principal point, keypoints) and tracks.txt.
+struct Tracks1DSfM {
+  std::unordered_map<theia::ViewId, double> focal;  // list.txt; 0 = no EXIF focal (read_1dsfm.cc:136-142)
+  std::unordered_map<theia::ViewId, Eigen::Vector2d> principal_point;  // coords.txt header (parsed as float, :176-193)
+  std::unordered_map<theia::ViewId, std::vector<Eigen::Vector2d>> keypoints;
+  std::vector<std::vector<std::pair<theia::ViewId, int>>> tracks;  // (view, keypoint index)
+};
+bool Read1DSFMTracks(const std::string& dataset_directory, Tracks1DSfM* out, std::string* error);
+
+// The matched features of every view-graph edge, flattened for gsfm_cov_estimate: the common tracks of the two views
+// (get_matched_features, src/uncertainty.cpp:3-33), the intrinsics of :99-104 and TwoViewInfo::rotation_2/position_2.
+struct EdgeMatches {
+  std::vector<theia::ViewIdPair> edges;  // sorted by key
+  std::vector<uint64_t> match_ptr;       // edges.size() + 1
+  std::vector<double> matches;           // x1 y1 x2 y2
+  std::vector<double> intrinsics;        // f1 u1 v1 f2 u2 v2
+  std::vector<double> rotation, position;
+};
+void CollectEdgeMatches(const Tracks1DSfM& tracks, const theia::ViewGraph& view_graph, EdgeMatches* out);
+
+struct CalcCovarianceStats {
+  size_t num_edges = 0, num_matches = 0, num_written = 0, num_skipped = 0, num_singular = 0;
+  double kernel_ms = 0.0;
+};
+// bind_src/GlobalSfMpy.cpp:623-628 + store_covariance_rot (src/uncertainty.cpp:164-198): read the dataset, estimate the
+// rotation covariance of every edge on the device (one wavefront per edge, gsfm_cov_estimate) and write
+// covariance_rot.txt with the refined relative rotation beside it.  Edges the reference skips (zero translation, no
+// common track, singular information matrix) are not written.
+bool CalcCovariance(const std::string& dataset_directory, CovarianceMap* covariances_or_null, CalcCovarianceStats* stats,
+                    std::string* error);
+
 // Per-edge angular residual || log(R_ij^T R_j R_i^T) || in degrees (src/compare_reconstructions.cpp:617-647).
 std::vector<double> ResidualsOfRelativeRotations(const theia::ViewGraph& view_graph,
                                                  const std::unordered_map<theia::ViewId, Eigen::Vector3d>& orientations);
