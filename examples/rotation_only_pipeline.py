@@ -36,6 +36,8 @@ if __name__ == "__main__":
     dataset = sys.argv[1]
     flags = sys.argv[2] if len(sys.argv) > 2 else None
     sfm.InitGlog(0, True, "./log")
+    if not os.path.exists(os.path.join(dataset, "covariance_rot.txt")):  # sfm_pipeline.py:136-137
+        print("covariance_rot.txt missing: estimating per-edge covariances on the device:", sfm.CalcCovariance(dataset))
     rec, est = sfm_pipeline(flags, dataset, MAGSACWeightBasedLoss(0.02), sfm.RotationErrorType.ANGLE_AXIS_COVARIANCE)  # noqa: F405
     print("estimated %d orientations; solver summary: %s" % (len(rec.EstimatedOrientations()), est.LastSummary()))
     sfm.WriteReconstruction(rec, os.path.join(dataset, "rotations_out.txt"))
