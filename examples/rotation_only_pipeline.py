@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Counterpart of the reference's scripts/sfm_pipeline.py run with onlyRotationAvg=True (:23-70, :114-148):
 the same module calls in the same order with the same argument kinds, on a 1DSfM-style dataset directory
-(EGs.txt, cc.txt, covariance_rot.txt).  usage: rotation_only_pipeline.py <dataset_dir> [flags.yaml]"""
+(EGs.txt, cc.txt, covariance_rot.txt) or, with use1DSfM=False, on a COLMAP export (two_views.txt, images/).
+usage: rotation_only_pipeline.py <dataset_dir> [flags.yaml]"""
 import os
 import sys
 
@@ -13,15 +14,25 @@ import GlobalSfMpy as sfm  # noqa: E402
 from globalsfmpy_amd.loss_functions import *  # noqa: E402,F401,F403
 
 
-def sfm_pipeline(flagfile, dataset_path, loss_func, rotation_error_type):
-    options = sfm.ReconstructionBuilderOptions()
-    if flagfile:
-        sfm.load_1DSFM_config(flagfile, options)
-    reconstruction = sfm.Reconstruction()
-    view_graph = sfm.ViewGraph()
-    rot_covariances = sfm.MapEdgesCovariance()
-    sfm.Read1DSFM(dataset_path, reconstruction, view_graph, rot_covariances)
-    reconstruction_builder = sfm.ReconstructionBuilder(options, reconstruction, view_graph)
+def sfm_pipeline(flagfile, dataset_path, loss_func, rotation_error_type, use1DSfM=True):
+    if use1DSfM:
+        options = sfm.ReconstructionBuilderOptions()
+        if flagfile:
+            sfm.load_1DSFM_config(flagfile, options)
+        reconstruction = sfm.Reconstruction()
+        view_graph = sfm.ViewGraph()
+        rot_covariances = sfm.MapEdgesCovariance()
+        sfm.Read1DSFM(dataset_path, reconstruction, view_graph, rot_covariances)
+        reconstruction_builder = sfm.ReconstructionBuilder(options, reconstruction, view_graph)
+    else:  # COLMAP export: two_views.txt + images/ + covariance_rot.txt (sfm_pipeline.py:38-47)
+        database = sfm.FeaturesAndMatchesDatabase(dataset_path + "/database")
+        options = sfm.ReconstructionBuilderOptions()
+        if flagfile:
+            sfm.load_1DSFM_config(flagfile, options)
+        rot_covariances = sfm.MapEdgesCovariance()
+        sfm.ReadCovariance(dataset_path, rot_covariances)
+        reconstruction_builder = sfm.ReconstructionBuilder(options, database)
+        sfm.AddColmapMatchesToReconstructionBuilder(dataset_path + "/two_views.txt", dataset_path + "/images/*.JPG", reconstruction_builder)
     reconstruction_builder.CheckView()
     view_graph = reconstruction_builder.get_view_graph()
     reconstruction = reconstruction_builder.get_reconstruction()

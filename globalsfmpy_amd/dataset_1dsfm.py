@@ -22,13 +22,8 @@ def _look_at(center, target, rng, jitter):
     return dq @ R
 
 
-def write_synthetic_dataset(path, n_cams=12, n_points=600, seed=0, p_visible=0.6, noise_px=0.5, min_common=15, exif_every=2,
-                            rel_rot_noise=0.01, rel_pos_noise=0.02, outside_cc=1):
-    """Cameras on an arc looking at a point cloud; every point seen by a random subset of the cameras.  Returns the ground
-    truth.  `outside_cc` extra views are listed in list.txt/coords.txt but left out of cc.txt (the reader must drop them)."""
-    rng = np.random.Generator(np.random.PCG64(seed))
-    os.makedirs(path, exist_ok=True)
-    total = n_cams + outside_cc
+def _synthetic_scene(rng, total, n_points, p_visible, noise_px):
+    """Cameras on an arc looking at a point cloud; every point seen by a random subset of the cameras."""
     ang = np.linspace(-0.9, 0.9, total) + 0.03 * rng.standard_normal(total)
     centers = np.c_[9.0 * np.sin(ang), 0.8 * rng.standard_normal(total), -9.0 * np.cos(ang)]
     R = np.stack([_look_at(centers[k], 0.3 * rng.standard_normal(3), rng, 0.05) for k in range(total)])
@@ -49,6 +44,17 @@ def write_synthetic_dataset(path, n_cams=12, n_points=600, seed=0, p_visible=0.6
             keypoints[k].append(uv)
         if len(obs) >= 2:
             tracks.append(obs)
+    return centers, R, focal, pp, keypoints, tracks
+
+
+def write_synthetic_dataset(path, n_cams=12, n_points=600, seed=0, p_visible=0.6, noise_px=0.5, min_common=15, exif_every=2,
+                            rel_rot_noise=0.01, rel_pos_noise=0.02, outside_cc=1):
+    """A synthetic scene in 1DSfM format.  Returns the ground truth.  `outside_cc` extra views are listed in
+    list.txt/coords.txt but left out of cc.txt (the reader must drop them)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    os.makedirs(path, exist_ok=True)
+    total = n_cams + outside_cc
+    centers, R, focal, pp, keypoints, tracks = _synthetic_scene(rng, total, n_points, p_visible, noise_px)
     in_cc = np.arange(total) < n_cams
     with open(os.path.join(path, "cc.txt"), "w") as f:
         f.write("\n".join(str(k) for k in range(total) if in_cc[k]) + "\n")
@@ -144,3 +150,108 @@ def read_edge_matches(path):
     rot = synth.quat_to_aa(synth.matrix_to_quat(np.array([edges[k][0] for k in keys]).reshape(-1, 3, 3)))
     trans = np.array([edges[k][1] for k in keys]).reshape(-1, 3)
     return {"edges": keys, "match_ptr": ptr, "matches": np.ascontiguousarray(matches), "intrinsics": intr, "rot": rot, "trans": trans}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# COLMAP export: two_views.txt (scripts/read_colmap_database.py:52-133, read by src/read_colmap_posegraph.cpp:55-164)
+# ---------------------------------------------------------------------------------------------------------------------
+def _fake_jpeg(path, width, height):
+    """The marker segments of a baseline JPEG up to the frame header: enough for a size probe, not a decodable image."""
+    app0 = b"\xff\xe0" + (16).to_bytes(2, "big") + b"JFIF\x00\x01\x01\x00\x00\x01\x00\x01\x00\x00"
+    sof0 = b"\xff\xc0" + (17).to_bytes(2, "big") + b"\x08" + int(height).to_bytes(2, "big") + int(width).to_bytes(2, "big") + \
+        b"\x03\x01\x22\x00\x02\x11\x01\x03\x11\x01"
+    with open(path, "wb") as f:
+        f.write(b"\xff\xd8" + app0 + sof0 + b"\xff\xd9")
+
+
+def _fake_png(path, width, height):
+    import struct
+    import zlib
+    ihdr = struct.pack(">IIBBBBB", int(width), int(height), 8, 2, 0, 0, 0)
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n" + struct.pack(">I", 13) + b"IHDR" + ihdr + struct.pack(">I", zlib.crc32(b"IHDR" + ihdr)))
+
+
+def write_synthetic_colmap_export(path, n_cams=10, n_points=500, seed=0, p_visible=0.6, noise_px=0.5, min_common=15,
+                                  rel_rot_noise=0.01, rel_pos_noise=0.02, reversed_every=4):
+    """A synthetic scene as the COLMAP branch stores it: <path>/two_views.txt and <path>/images/*.JPG (header-only files
+    whose size gives the principal point).  The translation column holds TwoViewInfo::position_2 in the convention of the
+    Sampson functor of src/uncertainty.cpp:51-81 (x2^T K2^-T R [t]x K1^-1 x1 = 0), which is how the reference consumes it.
+    Every `reversed_every`-th pair is listed larger-view-first to exercise SwapCameras."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    os.makedirs(os.path.join(path, "images"), exist_ok=True)
+    centers, R, focal, pp, keypoints, tracks = _synthetic_scene(rng, n_cams, n_points, p_visible, noise_px)
+    names = ["DSC_%04d.JPG" % k for k in range(n_cams)]
+    for k in range(n_cams):
+        _fake_jpeg(os.path.join(path, "images", names[k]), 2 * pp[k, 0], 2 * pp[k, 1])
+    pairs = {}
+    for t in tracks:
+        for a in range(len(t)):
+            for b in range(a + 1, len(t)):
+                pairs.setdefault((t[a][0], t[b][0]), []).append((t[a][1], t[b][1]))
+    rows = []
+    first_seen = []
+    for n, ((i, j), m) in enumerate(sorted(pairs.items())):
+        if len(m) < min_common:
+            continue
+        noise = synth.quat_to_matrix(synth.aa_to_quat(rel_rot_noise * rng.standard_normal((1, 3))))[0]
+        Rij = noise @ R[j] @ R[i].T
+        pos = R[i] @ (centers[j] - centers[i])
+        pos = pos / np.linalg.norm(pos) + rel_pos_noise * rng.standard_normal(3)
+        xi = np.array([keypoints[i][a] for a, _ in m]); xj = np.array([keypoints[j][b] for _, b in m])
+        a, b, fa, fb, Rab, pab, xa, xb = i, j, focal[i], focal[j], Rij, pos, xi, xj
+        if reversed_every and n % reversed_every == reversed_every - 1 and i in first_seen and j in first_seen:
+            a, b, fa, fb, Rab, pab, xa, xb = j, i, focal[j], focal[i], Rij.T, -(Rij @ pos), xj, xi
+        for v in (a, b):
+            if v not in first_seen:
+                first_seen.append(v)
+        rot = synth.quat_to_aa(synth.matrix_to_quat(Rab[None]))[0]
+        rows.append((a, b, fa, fb, rot, pab, xa, xb))
+    with open(os.path.join(path, "two_views.txt"), "w") as f:
+        f.write("# img_name1 image_name2 f1 f2 num_inlier rot[0] rot[1] rot[2] trans[0] trans[1] trans[2]\n# features1 [p0x p0y p1x p1y ...]\n# features2 [p0x p0y p1x p1y ...]\n")
+        for a, b, fa, fb, rot, pab, xa, xb in rows:
+            f.write("%s %s %.17g %.17g %d %s %s\n" % (names[a], names[b], fa, fb, len(xa), " ".join("%.17g" % v for v in rot), " ".join("%.17g" % v for v in pab)))
+            f.write(" ".join("%.17g %.17g" % (p[0], p[1]) for p in xa) + " \n")
+            f.write(" ".join("%.17g %.17g" % (p[0], p[1]) for p in xb) + " \n")
+    # ground truth indexed by the view ids the reader will assign (first appearance)
+    order = first_seen
+    gt_aa = synth.quat_to_aa(synth.matrix_to_quat(R[order]))
+    return {"n_cams": len(order), "rotations_aa": gt_aa, "names": [names[k] for k in order], "focal": focal[order],
+            "principal_point": pp[order], "num_pairs": len(rows)}
+
+
+def read_colmap_two_views(path, image_sizes):
+    """numpy restatement of the host's ReadColmapTwoViews.  image_sizes: {file name: (width, height)}."""
+    toks = iter(open(path).read().split("\n", 3)[3].split())
+    ids, edges = {}, {}
+    pp = {}
+
+    def vid(name):
+        if name not in ids:
+            ids[name] = len(ids)
+            w, h = image_sizes.get(name, (0, 0))
+            pp[ids[name]] = (float(int(w) // 2), float(int(h) // 2))
+        return ids[name]
+
+    while True:
+        try:
+            n1 = next(toks)
+        except StopIteration:
+            break
+        n2 = next(toks)
+        f1, f2 = float(next(toks)), float(next(toks))
+        num = int(next(toks))
+        r = np.array([float(next(toks)) for _ in range(3)]); t = np.array([float(next(toks)) for _ in range(3)])
+        a = np.array([float(next(toks)) for _ in range(2 * num)]).reshape(-1, 2)
+        b = np.array([float(next(toks)) for _ in range(2 * num)]).reshape(-1, 2)
+        i, j = vid(n1), vid(n2)
+        if i > j:
+            Rm = synth.quat_to_matrix(synth.aa_to_quat(r[None]))[0]
+            i, j, f1, f2, r, t, a, b = j, i, f2, f1, -r, -(Rm @ t), b, a
+        edges[(i, j)] = (f1, f2, r, t, np.c_[a, b])
+    keys = sorted(edges)
+    ptr = np.zeros(len(keys) + 1, dtype=np.uint64)
+    ptr[1:] = np.cumsum([len(edges[k][4]) for k in keys])
+    intr = np.array([[edges[k][0], pp[k[0]][0], pp[k[0]][1], edges[k][1], pp[k[1]][0], pp[k[1]][1]] for k in keys]).reshape(-1, 6)
+    return {"edges": keys, "names": sorted(ids, key=ids.get), "match_ptr": ptr, "matches": np.ascontiguousarray(np.vstack([edges[k][4] for k in keys])),
+            "intrinsics": intr, "rot": np.array([edges[k][2] for k in keys]), "trans": np.array([edges[k][3] for k in keys])}

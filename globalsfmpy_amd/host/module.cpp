@@ -9,6 +9,7 @@
 #include <pybind11/stl_bind.h>
 
 #include <cmath>
+#include <cstring>
 #include <fstream>
 #include <memory>
 
@@ -110,11 +111,35 @@ struct ReconstructionBuilderOptions {
   int num_threads = 1;
   ReconstructionEstimatorOptions reconstruction_estimator_options;
 };
+struct FeaturesAndMatchesDatabase {  // bind :166-170 wraps a RocksDB store; only its path matters to the rotation stage
+  std::string path;
+};
 struct ReconstructionBuilder {
   ReconstructionBuilderOptions options;
   Reconstruction* reconstruction;
   ViewGraph* view_graph;
+  // the (options, database) form owns what the COLMAP ingestion fills
+  std::shared_ptr<Reconstruction> owned_reconstruction;
+  std::shared_ptr<ViewGraph> owned_view_graph;
 };
+
+// The flattened inputs of gsfm_cov_estimate as numpy arrays, for inspection and for globalsfmpy_amd.covariance.
+py::dict edge_matches_dict(const gsfm::EdgeMatches& em) {
+  const py::ssize_t E = (py::ssize_t)em.edges.size();
+  py::array_t<uint32_t> edges({E, (py::ssize_t)2});
+  for (py::ssize_t e = 0; e < E; ++e) { edges.mutable_at(e, 0) = em.edges[e].first; edges.mutable_at(e, 1) = em.edges[e].second; }
+  auto vec = [](const std::vector<double>& v, py::ssize_t cols) {
+    py::array_t<double> a({(py::ssize_t)(v.size() / cols), cols});
+    if (!v.empty()) std::memcpy(a.mutable_data(), v.data(), v.size() * sizeof(double));
+    return a;
+  };
+  py::array_t<uint64_t> ptr((py::ssize_t)em.match_ptr.size());
+  std::memcpy(ptr.mutable_data(), em.match_ptr.data(), em.match_ptr.size() * sizeof(uint64_t));
+  py::dict d;
+  d["edges"] = edges; d["match_ptr"] = ptr; d["matches"] = vec(em.matches, 4); d["intrinsics"] = vec(em.intrinsics, 6);
+  d["rot"] = vec(em.rotation, 3); d["trans"] = vec(em.position, 3);
+  return d;
+}
 
 py::dict summary_dict(const gsfm_rot_summary& s) {
   py::dict d;
@@ -257,7 +282,10 @@ PYBIND11_MODULE(_GlobalSfMpy, m) {  // imported through the GlobalSfMpy.py shim 
       .def(py::init<>())
       .def("NumTracks", &Reconstruction::NumTracks)
       .def("NumViews", &Reconstruction::NumViews)
-      .def("EstimatedOrientations", [](const Reconstruction& r) { return r.orientation; });
+      .def("EstimatedOrientations", [](const Reconstruction& r) { return r.orientation; })
+      .def("ViewNames", [](const Reconstruction& r) { return r.view_names; })
+      .def("MatchedFeatures", [](const Reconstruction& r) { return r.matches ? py::object(edge_matches_dict(*r.matches)) : py::object(py::none()); })
+      .def("NumMatchedPairs", [](const Reconstruction& r) { return r.matches ? (int)r.matches->edges.size() : 0; });
 
   py::class_<ViewGraph>(m, "ViewGraph")
       .def(py::init<>())
@@ -284,11 +312,18 @@ PYBIND11_MODULE(_GlobalSfMpy, m) {  // imported through the GlobalSfMpy.py shim 
   py::class_<ReconstructionBuilder>(m, "ReconstructionBuilder")
       .def(py::init([](ReconstructionBuilderOptions& o, Reconstruction* r, ViewGraph* g) { return new ReconstructionBuilder{o, r, g}; }),
            py::keep_alive<1, 3>(), py::keep_alive<1, 4>())
+      .def(py::init([](ReconstructionBuilderOptions& o, FeaturesAndMatchesDatabase*) {  // sfm_pipeline.py:46
+        auto* b = new ReconstructionBuilder{o, nullptr, nullptr, std::make_shared<Reconstruction>(), std::make_shared<ViewGraph>()};
+        b->reconstruction = b->owned_reconstruction.get();
+        b->view_graph = b->owned_view_graph.get();
+        return b;
+      }))
       .def("CheckView", [](ReconstructionBuilder& b) {  // views of the graph become views of the reconstruction
         for (ViewId v : b.view_graph->ViewIds()) b.reconstruction->views.insert(v);
       })
-      .def("get_view_graph", [](ReconstructionBuilder& b) { return b.view_graph; }, py::return_value_policy::reference)
-      .def("get_reconstruction", [](ReconstructionBuilder& b) { return b.reconstruction; }, py::return_value_policy::reference);
+      // reference_internal: the (options, database) form owns both objects, so they must keep the builder alive
+      .def("get_view_graph", [](ReconstructionBuilder& b) { return b.view_graph; }, py::return_value_policy::reference_internal)
+      .def("get_reconstruction", [](ReconstructionBuilder& b) { return b.reconstruction; }, py::return_value_policy::reference_internal);
 
   py::class_<GlobalReconstructionEstimator>(m, "GlobalReconstructionEstimator")
       .def(py::init<const ReconstructionEstimatorOptions&>())
@@ -313,7 +348,37 @@ PYBIND11_MODULE(_GlobalSfMpy, m) {  // imported through the GlobalSfMpy.py shim 
     std::string err;
     if (!gsfm::Read1DSFMViewGraph(dir, vg, &err)) throw std::runtime_error(err);
     for (ViewId v : vg->ViewIds()) rec->views.insert(v);
+    gsfm::Tracks1DSfM tracks;
+    if (gsfm::Read1DSFMTracks(dir, &tracks, nullptr)) {  // keypoints + tracks, when the dataset has them
+      auto em = std::make_shared<gsfm::EdgeMatches>();
+      gsfm::CollectEdgeMatches(tracks, *vg, em.get());
+      rec->matches = em;
+    }
     gsfm::ReadCovariance(dir, &cov);
+  });
+  py::class_<FeaturesAndMatchesDatabase>(m, "FeaturesAndMatchesDatabase").def(py::init([](const std::string& p) { return new FeaturesAndMatchesDatabase{p}; }));
+  // src/read_colmap_posegraph.cpp:55-164
+  m.def("AddColmapMatchesToReconstructionBuilder", [](const std::string& two_views, const std::string& images_wildcard, ReconstructionBuilder* b) {
+    gsfm::ColmapPoseGraph g;
+    std::string err;
+    if (!gsfm::ReadColmapTwoViews(two_views, gsfm::ExpandWildcard(images_wildcard), &g, &err)) throw std::runtime_error(err);
+    for (const auto& e : g.view_graph.GetAllEdges()) b->view_graph->AddEdge(e.first.first, e.first.second, e.second);
+    for (size_t v = 0; v < g.view_names.size(); ++v) { b->reconstruction->views.insert((ViewId)v); b->reconstruction->view_names[(ViewId)v] = g.view_names[v]; }
+    b->reconstruction->matches = std::make_shared<gsfm::EdgeMatches>(std::move(g.matches));
+  });
+  // bind :286-287 -> src/uncertainty.cpp:164-198; returns the counters (the reference returns None)
+  m.def("store_covariance_rot", [](const std::string& dir, Reconstruction* rec, ViewGraph* vg) {
+    if (!rec->matches) throw std::runtime_error("store_covariance_rot: the reconstruction carries no matched features (dataset without tracks)");
+    gsfm::CalcCovarianceStats st;
+    std::string err;
+    {
+      py::gil_scoped_release release;
+      if (!gsfm::StoreCovarianceRot(dir, *rec->matches, *vg, nullptr, &st, &err)) { py::gil_scoped_acquire a; throw std::runtime_error(err); }
+    }
+    py::dict d;
+    d["num_edges"] = st.num_edges; d["num_matches"] = st.num_matches; d["num_written"] = st.num_written;
+    d["num_skipped"] = st.num_skipped; d["num_singular"] = st.num_singular; d["kernel_ms"] = st.kernel_ms;
+    return d;
   });
   m.def("ReadCovariance", [](const std::string& dir, CovarianceMap& cov) { gsfm::ReadCovariance(dir, &cov); });
   m.def("WriteCovariance", [](const std::string& dir, const CovarianceMap& cov) { return gsfm::WriteCovariance(dir, cov); });
@@ -325,20 +390,7 @@ PYBIND11_MODULE(_GlobalSfMpy, m) {  // imported through the GlobalSfMpy.py shim 
     if (!gsfm::Read1DSFMTracks(dir, &tracks, &err) || !gsfm::Read1DSFMViewGraph(dir, &vg, &err)) throw std::runtime_error(err);
     gsfm::EdgeMatches em;
     gsfm::CollectEdgeMatches(tracks, vg, &em);
-    const py::ssize_t E = (py::ssize_t)em.edges.size();
-    py::array_t<uint32_t> edges({E, (py::ssize_t)2});
-    for (py::ssize_t e = 0; e < E; ++e) { edges.mutable_at(e, 0) = em.edges[e].first; edges.mutable_at(e, 1) = em.edges[e].second; }
-    auto vec = [](const std::vector<double>& v, py::ssize_t cols) {
-      py::array_t<double> a({(py::ssize_t)(v.size() / cols), cols});
-      if (!v.empty()) std::memcpy(a.mutable_data(), v.data(), v.size() * sizeof(double));
-      return a;
-    };
-    py::array_t<uint64_t> ptr((py::ssize_t)em.match_ptr.size());
-    std::memcpy(ptr.mutable_data(), em.match_ptr.data(), em.match_ptr.size() * sizeof(uint64_t));
-    py::dict d;
-    d["edges"] = edges; d["match_ptr"] = ptr; d["matches"] = vec(em.matches, 4); d["intrinsics"] = vec(em.intrinsics, 6);
-    d["rot"] = vec(em.rotation, 3); d["trans"] = vec(em.position, 3);
-    return d;
+    return edge_matches_dict(em);
   });
   // bind :623-628: estimates every edge's rotation covariance on the device and writes <dir>/covariance_rot.txt;
   // returns the counters (the reference returns None).
@@ -368,6 +420,11 @@ PYBIND11_MODULE(_GlobalSfMpy, m) {  // imported through the GlobalSfMpy.py shim 
     f << "# view_id angle_axis(3)  -- rotation-only reconstruction written by the MI355X build\n";
     for (const auto& kv : rec.orientation) f << kv.first << " " << kv.second[0] << " " << kv.second[1] << " " << kv.second[2] << "\n";
     return (bool)f;
+  });
+  m.def("ReadImageSize", [](const std::string& path) {
+    int w = 0, h = 0;
+    if (!gsfm::ReadImageSize(path, &w, &h)) throw std::runtime_error("cannot read the size of image " + path);
+    return py::make_tuple(w, h);
   });
   m.def("tgamma", [](double x) { return std::tgamma(x); });
 

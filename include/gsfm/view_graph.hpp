@@ -7,7 +7,11 @@
 #include <unordered_set>
 #include <vector>
 
+#include <memory>
+
 #include "compat.hpp"
+
+namespace gsfm { struct EdgeMatches; }
 
 namespace theia {
 
@@ -43,6 +47,11 @@ class Reconstruction {
  public:
   std::unordered_map<ViewId, Eigen::Vector3d> orientation;
   std::unordered_set<ViewId> views;
+  std::unordered_map<ViewId, std::string> view_names;  // COLMAP ingestion: image file name per view
+  // The matched features of the view pairs, in place of theia's tracks: all that store_covariance_rot reads of them
+  // (get_matched_features, src/uncertainty.cpp:3-33).  Set by Read1DSFM (when tracks.txt exists) and by
+  // AddColmapMatchesToReconstructionBuilder.
+  std::shared_ptr<const gsfm::EdgeMatches> matches;
   int NumTracks() const { return 0; }
   int NumViews() const { return (int)views.size(); }
 };
@@ -92,6 +101,24 @@ struct EdgeMatches {
 };
 void CollectEdgeMatches(const Tracks1DSfM& tracks, const theia::ViewGraph& view_graph, EdgeMatches* out);
 
+// two_views.txt of scripts/read_colmap_database.py:52-133 as AddColmapMatchesToReconstructionBuilder reads it
+// (src/read_colmap_posegraph.cpp:55-164): three header lines, then per pair
+//   "<image1> <image2> f1 f2 num_inliers rot[3] trans[3]" / num_inliers "x y" of image 1 / num_inliers "x y" of image 2.
+// View ids follow first appearance (the builder's AddImage order); a pair listed larger-id-first is swapped to
+// smaller->larger like GSfMReconstructionBuilder::AddMatchToViewGraph does (SwapCameras, twoview_info.cc:44-62).
+// The principal point is half the image size (:77-85); sizes are read from the JPEG/PNG headers of `image_paths`.
+// Deviation: the reference pushes the correspondences through theia's TrackBuilder and later recovers an edge's matches
+// from the common tracks; here an edge keeps exactly the inlier correspondences listed for it.
+struct ColmapPoseGraph {
+  std::vector<std::string> view_names;  // index = view id
+  std::unordered_map<theia::ViewId, Eigen::Vector2d> principal_point;
+  theia::ViewGraph view_graph;
+  EdgeMatches matches;
+};
+bool ReadColmapTwoViews(const std::string& two_views_path, const std::vector<std::string>& image_paths, ColmapPoseGraph* out, std::string* error);
+bool ReadImageSize(const std::string& path, int* width, int* height);  // JPEG (SOFn) and PNG (IHDR) headers
+std::vector<std::string> ExpandWildcard(const std::string& pattern);
+
 struct CalcCovarianceStats {
   size_t num_edges = 0, num_matches = 0, num_written = 0, num_skipped = 0, num_singular = 0;
   double kernel_ms = 0.0;
@@ -102,6 +129,10 @@ struct CalcCovarianceStats {
 // common track, singular information matrix) are not written.
 bool CalcCovariance(const std::string& dataset_directory, CovarianceMap* covariances_or_null, CalcCovarianceStats* stats,
                     std::string* error);
+// store_covariance_rot (src/uncertainty.cpp:164-198) on already-flattened matches: the edges of `view_graph` that have
+// matches are estimated in one device launch and written to <dir>/covariance_rot.txt.
+bool StoreCovarianceRot(const std::string& dataset_directory, const EdgeMatches& matches, const theia::ViewGraph& view_graph,
+                        CovarianceMap* covariances_or_null, CalcCovarianceStats* stats, std::string* error);
 
 // Per-edge angular residual || log(R_ij^T R_j R_i^T) || in degrees (src/compare_reconstructions.cpp:617-647).
 std::vector<double> ResidualsOfRelativeRotations(const theia::ViewGraph& view_graph,

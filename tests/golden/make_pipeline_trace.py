@@ -33,19 +33,28 @@ def main():
     loss = ref.MAGSACWeightBasedLoss(0.02)
     ref.sfm_with_1dsfm_dataset("flags.yaml", "/data/scene", loss, ref.HuberLoss(0.1),
                                stub.RotationErrorType.ANGLE_AXIS_COVARIANCE, stub.PositionErrorType.BASELINE, onlyRotationAvg=True)
+    calls_1dsfm = list(log)
+    del log[:]
+    ref.sfm_pipeline("flags.yaml", "/data/scene", loss, ref.HuberLoss(0.1), stub.RotationErrorType.ANGLE_AXIS_COVARIANCE,
+                     stub.PositionErrorType.BASELINE, onlyRotationAvg=True, use1DSfM=False)
+    calls_colmap = list(log)
+    # scripts/get_covariance_from_colmap.py is a flat script (argparse + exit()): its module calls, in textual order
+    cov_src = open(os.path.join(REF, "scripts", "get_covariance_from_colmap.py")).read()
+    cov_calls = re.findall(r"(?:sfm|reconstruction_builder)\.(\w+)\(", cov_src)
     src = open(os.path.join(REF, "scripts", "sfm_pipeline.py")).read()
     main_block = src[src.index("if __name__ == '__main__':"):]
     yaml_keys = re.findall(r"config\['([^']+)'\]", main_block)
     main_calls = re.findall(r"sfm\.(\w+)\(", main_block)
     out = {"source": "scripts/sfm_pipeline.py: sfm_with_1dsfm_dataset(flagfile, path, MAGSACWeightBasedLoss(0.02), HuberLoss(0.1), "
                      "ANGLE_AXIS_COVARIANCE, BASELINE, onlyRotationAvg=True)",
-           "calls": log, "main_yaml_keys": yaml_keys, "main_module_calls": main_calls,
+           "calls": calls_1dsfm, "calls_colmap": calls_colmap, "get_covariance_from_colmap_calls": cov_calls, "main_yaml_keys": yaml_keys, "main_module_calls": main_calls,
            "main_defaults": {"rotation_loss": "MAGSACWeightBasedLoss(0.02)", "position_loss": "HuberLoss(0.1)",
                              "rotation_error_type": "ANGLE_AXIS_COVARIANCE", "position_error_type": "BASELINE"}}
     with open(os.path.join(HERE, "pipeline_trace.json"), "w") as f:
         json.dump(out, f, indent=1)
-    for c in log:
+    for c in calls_colmap:
         print(c)
+    print(cov_calls)
     print(yaml_keys, main_calls)
 
 

@@ -70,6 +70,88 @@ def test_spanning_tree_initialisation_prefers_edges_with_more_common_tracks(data
     assert synth.angular_distance(aligned, gt["rotations_aa"]).max() < 0.08
 
 
+@pytest.fixture(scope="module")
+def colmap_export(tmp_path_factory):
+    path = str(tmp_path_factory.mktemp("synthetic_colmap"))
+    gt = ds.write_synthetic_colmap_export(path, n_cams=10, n_points=500, seed=2)
+    return path, gt
+
+
+def _colmap_builder(path):
+    b = sfm.ReconstructionBuilder(sfm.ReconstructionBuilderOptions(), sfm.FeaturesAndMatchesDatabase(path + "/database"))
+    sfm.AddColmapMatchesToReconstructionBuilder(path + "/two_views.txt", path + "/images/*.JPG", b)
+    b.CheckView()
+    return b
+
+
+def test_image_size_probe_reads_jpeg_and_png_headers(tmp_path):
+    ds._fake_jpeg(str(tmp_path / "a.JPG"), 6048, 4032)
+    ds._fake_png(str(tmp_path / "b.png"), 1234, 567)
+    assert sfm.ReadImageSize(str(tmp_path / "a.JPG")) == (6048, 4032)
+    assert sfm.ReadImageSize(str(tmp_path / "b.png")) == (1234, 567)
+    (tmp_path / "c.JPG").write_bytes(b"not an image")
+    with pytest.raises(RuntimeError):
+        sfm.ReadImageSize(str(tmp_path / "c.JPG"))
+
+
+def test_colmap_two_views_reader_matches_the_numpy_restatement(colmap_export):
+    path, gt = colmap_export
+    b = _colmap_builder(path)
+    vg, rec = b.get_view_graph(), b.get_reconstruction()
+    sizes = {n: sfm.ReadImageSize(os.path.join(path, "images", n)) for n in gt["names"]}
+    want = ds.read_colmap_two_views(os.path.join(path, "two_views.txt"), sizes)
+    got = rec.MatchedFeatures()
+    assert want["names"] == gt["names"] == [rec.ViewNames()[k] for k in range(gt["n_cams"])]   # ids by first appearance
+    assert [tuple(e) for e in got["edges"]] == want["edges"] and vg.NumEdges() == len(want["edges"]) == gt["num_pairs"]
+    for k in ("match_ptr", "matches", "intrinsics"):
+        assert np.array_equal(got[k], want[k]), k
+    assert np.abs(got["rot"] - want["rot"]).max() < 1e-15 and np.abs(got["trans"] - want["trans"]).max() < 1e-14
+    # principal point = half the image size (read_colmap_posegraph.cpp:77-85)
+    assert np.array_equal(got["intrinsics"][0, 1:3], gt["principal_point"][want["edges"][0][0]])
+    # pairs listed larger-view-first were swapped to smaller->larger (SwapCameras): consistent with the ground truth
+    R = synth.quat_to_matrix(synth.aa_to_quat(gt["rotations_aa"]))
+    rel = synth.quat_to_aa(synth.matrix_to_quat(np.array([R[j] @ R[i].T for i, j in want["edges"]])))
+    assert synth.angular_distance(rel, got["rot"]).max() < 0.06
+    for e, (i, j) in enumerate(want["edges"]):
+        info = vg.GetEdge(i, j)
+        assert info.focal_length_1 == gt["focal"][i] and info.focal_length_2 == gt["focal"][j]
+        assert info.num_verified_matches == info.num_homography_inliers == int(want["match_ptr"][e + 1] - want["match_ptr"][e])
+
+
+def test_store_covariance_rot_needs_matches():
+    with pytest.raises(RuntimeError, match="no matched features"):
+        sfm.store_covariance_rot("/tmp", sfm.Reconstruction(), sfm.ViewGraph())
+
+
+@pytest.mark.gpu
+def test_colmap_branch_covariances_and_pipeline(colmap_export, oracle):
+    path, gt = colmap_export
+    # scripts/get_covariance_from_colmap.py, same calls
+    b = _colmap_builder(path)
+    vg, rec = b.get_view_graph(), b.get_reconstruction()
+    stats = sfm.store_covariance_rot(path, rec, vg)
+    em = rec.MatchedFeatures()
+    E = len(em["edges"])
+    assert stats["num_written"] == E == gt["num_pairs"]
+    cov = sfm.MapEdgesCovariance()
+    sfm.ReadCovariance(path, cov)
+    want = oracle.estimate_rotation_covariances(em["match_ptr"], em["matches"], em["intrinsics"], em["rot"], em["trans"])
+    for e, key in enumerate(map(tuple, em["edges"])):
+        C, r = np.array(cov[key][0]), np.array(cov[key][1])
+        assert np.abs(r - want["rotation"][e]).max() < 1e-8
+        assert np.abs(C - want["cov"][e]).max() < 1e-5 * np.abs(want["cov"][e]).max()
+    # then the use1DSfM=False branch of the pipeline on the completed export
+    spec = importlib.util.spec_from_file_location("rotation_only_pipeline", os.path.join(ROOT, "examples", "rotation_only_pipeline.py"))
+    pipe = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(pipe)
+    from globalsfmpy_amd.loss_functions import MAGSACWeightBasedLoss
+    rec2, est = pipe.sfm_pipeline(None, path, MAGSACWeightBasedLoss(0.02), sfm.RotationErrorType.ANGLE_AXIS_COVARIANCE, use1DSfM=False)
+    o = rec2.EstimatedOrientations()
+    got = np.array([o[k] for k in range(gt["n_cams"])])
+    err = synth.angular_distance(synth.align_rotations(got, gt["rotations_aa"]), gt["rotations_aa"])
+    assert err.max() < 0.05, err
+
+
 @pytest.mark.skipif(have_gpu(), reason="loud-failure check is for boxes without a device")
 def test_calc_covariance_fails_loudly_without_a_device(dataset):
     with pytest.raises(RuntimeError):

@@ -24,6 +24,9 @@ drv = importlib.util.module_from_spec(spec); spec.loader.exec_module(drv)
 del log[:]
 drv.sfm_pipeline("flags.yaml", "/data/scene", drv.MAGSACWeightBasedLoss(0.02), stub.RotationErrorType.ANGLE_AXIS_COVARIANCE)
 print("TRACE " + json.dumps(log))
+del log[:]
+drv.sfm_pipeline("flags.yaml", "/data/scene", drv.MAGSACWeightBasedLoss(0.02), stub.RotationErrorType.ANGLE_AXIS_COVARIANCE, use1DSfM=False)
+print("COLMAP " + json.dumps(log))
 """
 
 
@@ -40,6 +43,8 @@ def test_driver_issues_the_reference_call_sequence(reference_trace):
     ref = reference_trace["calls"]
     assert [c[0] for c in ours] == [c[0] for c in ref]
     assert ours == ref  # argument kinds too: objects are named after the call that produced them
+    colmap = json.loads(next(l for l in out.stdout.splitlines() if l.startswith("COLMAP "))[7:])
+    assert colmap == reference_trace["calls_colmap"]  # the use1DSfM=False branch (sfm_pipeline.py:38-47)
 
 
 def test_compiled_module_answers_every_call_of_the_trace(reference_trace):
@@ -55,6 +60,12 @@ def test_compiled_module_answers_every_call_of_the_trace(reference_trace):
         else:
             assert hasattr(sfm, name), name
     assert hasattr(objs["GlobalReconstructionEstimator()"], "orientations")
+    for name, _, _ in reference_trace["calls_colmap"]:
+        if "()." not in name:
+            assert hasattr(sfm, name), name
+    # scripts/get_covariance_from_colmap.py: module functions and builder methods it calls
+    for name in reference_trace["get_covariance_from_colmap_calls"]:
+        assert hasattr(sfm, name) or hasattr(objs["ReconstructionBuilder()"], name), name
     # the __main__ block (:114-148): everything but the PLY export, which needs camera positions and points (out of scope)
     missing = [n for n in reference_trace["main_module_calls"] if not hasattr(sfm, n)]
     assert missing == ["WritePlyFile"]
