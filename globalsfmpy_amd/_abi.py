@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgsfm_rot.so")
+LIB_PATH = os.environ.get("GSFM_ROT_LIB") or os.path.join(_HERE, "libgsfm_rot.so")  # override: A/B builds of the kernels (tools/)
 
 # gsfm_status
 OK, ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_EMPTY, ERR_COMM, ERR_UNSUPPORTED = range(7)

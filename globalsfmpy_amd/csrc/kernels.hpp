@@ -35,7 +35,12 @@ template <int F> struct ResDim { static constexpr int R = (F == F_QNORM) ? 4 : (
 // a 1024-thread workgroup stages BOTH quaternion blocks in LDS (2 x 2048 x 32 B = 128 KiB of the 160 KiB), so the
 // sweep performs no global gather at all.
 #define GSFM_CAMBLOCK 2048
+#ifndef GSFM_TILE_THREADS
 #define GSFM_TILE_THREADS 1024
+#endif
+#ifndef GSFM_K1_UNROLL
+#define GSFM_K1_UNROLL 1   // edges per lane whose streams are requested before any of them is evaluated
+#endif
 
 // ------------------------------------------------------------------------------------------
 // reductions (deterministic: fixed tree inside a wave, fixed order across waves)
@@ -362,31 +367,47 @@ __global__ void __launch_bounds__(GSFM_TILE_THREADS) k_cost(CostArgs a) {
   }
   __syncthreads();
   double acc = 0.0;
-  for (uint32_t e = tile.begin + threadIdx.x; e < tile.end; e += GSFM_TILE_THREADS) {
-    const uint2 ij = a.idx[e];
-    const double2 r0 = nt_load2(a.qr0 + e), r1 = nt_load2(a.qr1 + e);
-    const Quat qr{r0.x, r0.y, r1.x, r1.y};
-    const EdgeW W = load_w<WM>(a.w0, a.w1, a.w2, a.ws, e);
-    const double2 i0 = qi_xy[ij.x], i1 = qi_zw[ij.x], j0 = qj_xy[ij.y], j1 = qj_zw[ij.y];
-    const Quat qi{i0.x, i0.y, i1.x, i1.y}, qj{j0.x, j0.y, j1.x, j1.y};
-    double r[R];
-    edge_residual<F, WM>(qi, qj, qr, W, r);
-    double s = 0.0;
+  constexpr int U = GSFM_K1_UNROLL;
+  for (uint32_t e0 = tile.begin + threadIdx.x; e0 < tile.end; e0 += U * GSFM_TILE_THREADS) {
+    // request phase: the streams of U edges are in flight before the first residual is evaluated
+    uint2 ij[U];
+    double2 r0[U], r1[U];
+    EdgeW Wm[U];
 #pragma unroll
-    for (int k = 0; k < R; ++k) s += r[k] * r[k];
-    if (!FULL) { acc += 0.5 * loss_value<LM>(a.loss, s); continue; }
-    if (a.s_only) { a.s_out[a.eid[e]] = s; continue; }
-    Rho3 rho;
-    if (a.rho_ext) { const size_t o = 3 * (size_t)a.eid[e]; rho.r0 = a.rho_ext[o]; rho.r1 = a.rho_ext[o + 1]; rho.r2 = a.rho_ext[o + 2]; }
-    else rho = loss_eval<LM>(a.loss, s);
-    acc += 0.5 * rho.r0;
-    if (a.s_out) {
-      const size_t o = a.eid[e];
-      a.s_out[o] = s;
-      if (a.rho_out) { a.rho_out[3 * o] = rho.r0; a.rho_out[3 * o + 1] = rho.r1; a.rho_out[3 * o + 2] = rho.r2; }
-      if (a.r_out) {
+    for (int u = 0; u < U; ++u) {
+      const uint32_t eu = e0 + u * GSFM_TILE_THREADS;
+      const uint32_t e = eu < tile.end ? eu : e0;   // lanes past the end re-read their first edge and discard it
+      ij[u] = a.idx[e];
+      r0[u] = nt_load2(a.qr0 + e); r1[u] = nt_load2(a.qr1 + e);
+      Wm[u] = load_w<WM>(a.w0, a.w1, a.w2, a.ws, e);
+    }
 #pragma unroll
-        for (int k = 0; k < R; ++k) a.r_out[R * o + k] = r[k];
+    for (int u = 0; u < U; ++u) {
+      const uint32_t e = e0 + u * GSFM_TILE_THREADS;
+      if (e >= tile.end) continue;
+      const Quat qr{r0[u].x, r0[u].y, r1[u].x, r1[u].y};
+      const EdgeW& W = Wm[u];
+      const double2 i0 = qi_xy[ij[u].x], i1 = qi_zw[ij[u].x], j0 = qj_xy[ij[u].y], j1 = qj_zw[ij[u].y];
+      const Quat qi{i0.x, i0.y, i1.x, i1.y}, qj{j0.x, j0.y, j1.x, j1.y};
+      double r[R];
+      edge_residual<F, WM>(qi, qj, qr, W, r);
+      double s = 0.0;
+#pragma unroll
+      for (int k = 0; k < R; ++k) s += r[k] * r[k];
+      if (!FULL) { acc += 0.5 * loss_value<LM>(a.loss, s); continue; }
+      if (a.s_only) { a.s_out[a.eid[e]] = s; continue; }
+      Rho3 rho;
+      if (a.rho_ext) { const size_t o = 3 * (size_t)a.eid[e]; rho.r0 = a.rho_ext[o]; rho.r1 = a.rho_ext[o + 1]; rho.r2 = a.rho_ext[o + 2]; }
+      else rho = loss_eval<LM>(a.loss, s);
+      acc += 0.5 * rho.r0;
+      if (a.s_out) {
+        const size_t o = a.eid[e];
+        a.s_out[o] = s;
+        if (a.rho_out) { a.rho_out[3 * o] = rho.r0; a.rho_out[3 * o + 1] = rho.r1; a.rho_out[3 * o + 2] = rho.r2; }
+        if (a.r_out) {
+#pragma unroll
+          for (int k = 0; k < R; ++k) a.r_out[R * o + k] = r[k];
+        }
       }
     }
   }

@@ -75,6 +75,32 @@ __global__ void __launch_bounds__(256) k_mv_u2(Args a) {
   if (live && lane == 0) { a.y[3 * (size_t)row] = y0; a.y[3 * (size_t)row + 1] = y1; a.y[3 * (size_t)row + 2] = y2; }
 }
 
+
+// fp32 copy of the blocks (two float4 planes + one float plane, 36 B + 4 B col per entry); p and y stay fp64
+struct Args32 { unsigned n_rows, G; const unsigned* row_ptr; const unsigned* col; const float4 *g0, *g1; const float* g2; const double* p; double* y; };
+__global__ void __launch_bounds__(256) k_mv_f32(Args32 a) {
+  const unsigned G = a.G, t = blockIdx.x * 256 + threadIdx.x, row = t / G, lane = t % G;
+  const bool live = row < a.n_rows;
+  double y0 = 0, y1 = 0, y2 = 0;
+  if (live) {
+    const unsigned end = a.row_ptr[row + 1];
+    for (unsigned d = a.row_ptr[row] + lane; d < end; d += G) {
+      const unsigned m = __builtin_nontemporal_load(&a.col[d]);
+      float4 A, B;
+      A.x = __builtin_nontemporal_load(&a.g0[d].x); A.y = __builtin_nontemporal_load(&a.g0[d].y); A.z = __builtin_nontemporal_load(&a.g0[d].z); A.w = __builtin_nontemporal_load(&a.g0[d].w);
+      B.x = __builtin_nontemporal_load(&a.g1[d].x); B.y = __builtin_nontemporal_load(&a.g1[d].y); B.z = __builtin_nontemporal_load(&a.g1[d].z); B.w = __builtin_nontemporal_load(&a.g1[d].w);
+      const float E = __builtin_nontemporal_load(&a.g2[d]);
+      const double* pm = a.p + 3 * (size_t)m;
+      const double p0 = pm[0], p1 = pm[1], p2 = pm[2];
+      y0 += (double)A.x * p0 + (double)A.y * p1 + (double)A.z * p2;
+      y1 += (double)A.w * p0 + (double)B.x * p1 + (double)B.y * p2;
+      y2 += (double)B.z * p0 + (double)B.w * p1 + (double)E * p2;
+    }
+  }
+  for (unsigned off = G >> 1; off > 0; off >>= 1) { y0 += __shfl_down(y0, off, G); y1 += __shfl_down(y1, off, G); y2 += __shfl_down(y2, off, G); }
+  if (live && lane == 0) { a.y[3 * (size_t)row] = y0; a.y[3 * (size_t)row + 1] = y1; a.y[3 * (size_t)row + 2] = y2; }
+}
+
 // AoS variant: one 80-byte record per entry (9 doubles + col + pad) read as 5 x 16 B
 struct Rec { double h[9]; unsigned col, pad; };
 __global__ void __launch_bounds__(256) k_mv_aos(unsigned n_rows, unsigned G, const unsigned* row_ptr, const Rec* rec, const double4* p4, double* y) {
@@ -138,6 +164,8 @@ int main(int argc, char** argv) {
     t = timeit([&] { hipLaunchKernelGGL(k_mv<2>, dim3(grid), dim3(256), 0, 0, a); }); printf("G=%2u %-24s %8.1f us  %6.2f TB/s\n", G, names[2], t, bytes / t * 1e-6);
     t = timeit([&] { hipLaunchKernelGGL(k_mv<3>, dim3(grid), dim3(256), 0, 0, a); }); printf("G=%2u %-24s %8.1f us  %6.2f TB/s\n", G, names[3], t, bytes / t * 1e-6);
     t = timeit([&] { hipLaunchKernelGGL(k_mv<4>, dim3(grid), dim3(256), 0, 0, a); }); printf("G=%2u %-24s %8.1f us  %6.2f TB/s\n", G, names[4], t, bytes / t * 1e-6);
+    { Args32 b{N, G, d_rp, d_col, (const float4*)h0, (const float4*)h1, (const float*)h2, p, y};
+      t = timeit([&] { hipLaunchKernelGGL(k_mv_f32, dim3(grid), dim3(256), 0, 0, b); }); printf("G=%2u %-24s %8.1f us  %6.2f TB/s (40 B/entry)\n", G, "fp32 blocks, fp64 p/y", t, 40.0 * nd / t * 1e-6); }
     t = timeit([&] { hipLaunchKernelGGL(k_mv_u2, dim3(grid), dim3(256), 0, 0, a); }); printf("G=%2u %-24s %8.1f us  %6.2f TB/s\n", G, "nt + 3x8B, unroll 2", t, bytes / t * 1e-6);
     t = timeit([&] { hipLaunchKernelGGL(k_mv_aos, dim3(grid), dim3(256), 0, 0, N, G, d_rp, rec, p4, y); }); printf("G=%2u %-24s %8.1f us  %6.2f TB/s (80 B/entry)\n", G, "AoS 80B + double4", t, 80.0 * nd / t * 1e-6);
   }
