@@ -173,3 +173,39 @@ def test_single_reduction_pcg_matches_textbook_pcg(graph):
     assert s0["num_iterations"] == s1["num_iterations"] and s0["num_cg_iterations"] == s1["num_cg_iterations"]
     assert abs(s0["final_cost"] - s1["final_cost"]) <= 1e-9 * s0["final_cost"]
     assert synth.angular_distance(r0, r1).max() < 1e-9
+
+
+def test_ragged_graph_hub_isolated_cameras_duplicates_and_reversed_pairs(oracle):
+    """Shapes the synthetic generators never produce: one hub camera of degree N-1 (a CSR row two hundred times the mean),
+    cameras without any edge, the same pair measured twice, and pairs handed over larger-index-first."""
+    from globalsfmpy_amd.solver import RotationProblem
+    rng = np.random.Generator(np.random.PCG64(99))
+    n = 600
+    gt = synth.aa_to_quat(0.4 * rng.uniform(-1, 1, (n, 3)))
+    ei = np.r_[np.zeros(n - 41, dtype=np.int64), np.arange(1, n - 41)]           # hub 0 -> 1..n-41, chain 1-2-...-(n-41)
+    ej = np.r_[np.arange(1, n - 40), np.arange(2, n - 40)]
+    extra = rng.integers(1, n - 40, (1500, 2))
+    extra = extra[extra[:, 0] != extra[:, 1]]
+    ei, ej = np.r_[ei, extra[:, 0]], np.r_[ej, extra[:, 1]]                      # random pairs, either order, duplicates likely
+    ei, ej = np.r_[ei, ei[:50]], np.r_[ej, ej[:50]]                              # 50 pairs measured twice
+    assert (ei > ej).any() and len(set(zip(ei.tolist(), ej.tolist()))) < len(ei)
+    # measurement of the pair as handed over: R_ij = R_j R_i^T whatever the index order
+    rel = synth.quat_mul(synth.quat_mul(synth.aa_to_quat(0.02 * rng.standard_normal((len(ei), 3))), gt[ej]), synth.quat_conj(gt[ei]))
+    rel_aa = synth.quat_to_aa(rel)
+    init = synth.quat_to_aa(synth.quat_mul(synth.aa_to_quat(0.05 * rng.standard_normal((n, 3))), gt))
+    ei32, ej32 = ei.astype(np.uint32), ej.astype(np.uint32)
+    for et, loss in ((_abi.ANGLE_AXIS, LF.SoftLOneLoss(0.1)), (_abi.QUATERNION_COSINE, LF.HuberLoss(0.1))):
+        dev = RotationProblem(n, ei32, ej32, rel_aa, et); dev.set_loss(loss)
+        ref = oracle.OracleProblem(n, ei32, ej32, rel_aa, et); ref.set_loss(loss)
+        d, o = dev.residuals(init), ref.residuals(init)
+        assert np.abs(d["s"] - o["s"]).max() < 1e-12 * max(1.0, np.abs(o["s"]).max()) and abs(d["cost"] - o["cost"]) < 1e-11 * abs(o["cost"])
+        r1, s1 = dev.solve(init)
+        r2, s2 = ref.solve(init)
+        assert s1["num_iterations"] == s2["num_iterations"]
+        assert abs(s1["final_cost"] - s2["final_cost"]) < 1e-9 * abs(s2["final_cost"])
+        active = np.arange(n) < n - 40
+        assert synth.angular_distance(r1[active], r2[active]).max() < 1e-8
+        # the 40 cameras without an edge have a zero gradient and stay where they started, on both sides
+        assert np.abs(r1[~active] - init[~active]).max() < 1e-12 and np.abs(r2[~active] - init[~active]).max() < 1e-12
+        err = synth.angular_distance(synth.align_rotations(r1[active], synth.quat_to_aa(gt[active])), synth.quat_to_aa(gt[active]))
+        assert err.mean() < 0.02   # 0.02 rad measurement noise, mean degree ~8
