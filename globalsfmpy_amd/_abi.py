@@ -47,7 +47,7 @@ class Options(C.Structure):
         ("max_cg_iterations", C.c_int32), ("cg_relative_tolerance", C.c_double),
         ("cg_check_interval", C.c_int32), ("verbose", C.c_int32),
         ("pcg_single_reduction", C.c_int32), ("cg_stall_iterations", C.c_int32),
-        ("dense_cholesky_max_cams", C.c_int32), ("reserved1", C.c_int32),
+        ("dense_cholesky_max_cams", C.c_int32), ("pcg_hip_graph", C.c_int32),
     ]
 
 

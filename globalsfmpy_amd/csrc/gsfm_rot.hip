@@ -183,6 +183,13 @@ struct gsfm_rot_problem {
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
+  // replayable chunk of PCG iterations (hipGraph), keyed on the by-value kernel arguments it froze
+  struct PcgGraph {
+    hipGraphExec_t exec = nullptr;
+    double tol = 0; int max_iters = 0, stall = 0, chunk = 0;
+    bool unusable = false;
+    void reset() { if (exec) (void)hipGraphExecDestroy(exec); exec = nullptr; }
+  } pcg_graph;
 
   EdgePlanes cost;            // cost-owned edges
   DevBuf<uint2> cost_idx;
@@ -419,17 +426,38 @@ int run_pcg(gsfm_rot_problem* P, const gsfm_rot_options& o, int* iters_out, doub
   P->timer.end(tk0);
   CgScalars h{};
   const int chunk = std::max(1, o.cg_check_interval);
-  int launched = 0;
-  while (true) {
-    const int tk = P->timer.begin(T_CG);
+  auto enqueue_chunk = [&]() -> int {  // `chunk` iterations; leaves a.par where it found it when chunk is even
     for (int c = 0; c < chunk; ++c) {
       if (int st = launch_matvec(P, P->Mblk.p, P->p.p, P->Ap.p, &P->cgsc.p->done)) return st;
       hipLaunchKernelGGL(k_cg_dot, g, blk, 0, P->stream, a);
       hipLaunchKernelGGL(k_cg_update, g, blk, 0, P->stream, a);
       hipLaunchKernelGGL(k_cg_pupdate, g, blk, 0, P->stream, a);
       a.par ^= 1;
-      ++launched;
     }
+    return 0;
+  };
+  // The chunk between two host checks as one hipGraph launch: 4 * chunk dependent kernels whose arguments never change.
+  auto& G = P->pcg_graph;
+  bool graph = o.pcg_hip_graph && !P->sharded && chunk % 2 == 0 && !G.unusable;
+  if (graph && (!G.exec || G.tol != a.tol || G.max_iters != a.max_iters || G.stall != a.stall_limit || G.chunk != chunk)) {
+    G.reset();
+    hipGraph_t captured = nullptr;
+    if (hipStreamBeginCapture(P->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+      const int st = enqueue_chunk();
+      const hipError_t e = hipStreamEndCapture(P->stream, &captured);
+      if (st == 0 && e == hipSuccess && captured && hipGraphInstantiate(&G.exec, captured, nullptr, nullptr, 0) == hipSuccess) {
+        G.tol = a.tol; G.max_iters = a.max_iters; G.stall = a.stall_limit; G.chunk = chunk;
+      } else { G.exec = nullptr; }
+      if (captured) (void)hipGraphDestroy(captured);
+    }
+    if (!G.exec) { (void)hipGetLastError(); G.unusable = true; graph = false; }  // e.g. a stream that cannot be captured: plain launches
+  }
+  int launched = 0;
+  while (true) {
+    const int tk = P->timer.begin(T_CG);
+    if (graph) { HIPCHK(hipGraphLaunch(G.exec, P->stream)); }
+    else if (int st = enqueue_chunk()) return st;
+    launched += chunk;
     P->timer.end(tk);
     HIPCHK(hipMemcpyAsync(&h, P->cgsc.p, sizeof(h), hipMemcpyDeviceToHost, P->stream));
     if (int st = sync_check(P, "pcg")) return st;
@@ -702,7 +730,7 @@ void gsfm_rot_options_default(gsfm_rot_options* o) {
   o->function_tolerance = 1e-6; o->gradient_tolerance = 1e-10; o->parameter_tolerance = 1e-8;
   o->initial_trust_region_radius = 1e4; o->max_trust_region_radius = 1e16; o->min_trust_region_radius = 1e-32;
   o->min_relative_decrease = 1e-3; o->min_lm_diagonal = 1e-6; o->max_lm_diagonal = 1e32;
-  o->jacobi_scaling = 1; o->max_cg_iterations = 1000; o->cg_relative_tolerance = 1e-12; o->cg_check_interval = 8; o->verbose = 0; o->pcg_single_reduction = 0; o->cg_stall_iterations = 0; o->dense_cholesky_max_cams = 0; o->reserved1 = 0;
+  o->jacobi_scaling = 1; o->max_cg_iterations = 1000; o->cg_relative_tolerance = 1e-12; o->cg_check_interval = 8; o->verbose = 0; o->pcg_single_reduction = 0; o->cg_stall_iterations = 0; o->dense_cholesky_max_cams = 0; o->pcg_hip_graph = 1;
 }
 
 int32_t gsfm_rot_residual_dim(int32_t t) { return t == GSFM_ROT_QUATERNION_NORM ? 4 : t == GSFM_ROT_ROTATION_MAT_FNORM ? 9 : 3; }
@@ -870,6 +898,7 @@ void gsfm_rot_problem_destroy(gsfm_rot_problem* P) {
   if (!P) return;
   DeviceGuard g(P->device);
   P->timer.destroy();
+  P->pcg_graph.reset();
   if (P->own_stream && P->stream) (void)hipStreamDestroy(P->stream);
   delete P;
 }
@@ -878,6 +907,7 @@ gsfm_status gsfm_rot_set_stream(gsfm_rot_problem* P, void* s) {
   if (!P) return (gsfm_status)fail(GSFM_ERR_INVALID_ARG, "NULL problem");
   DeviceGuard g(P->device);
   if (P->own_stream && P->stream) { (void)hipStreamSynchronize(P->stream); (void)hipStreamDestroy(P->stream); }
+  P->pcg_graph.reset(); P->pcg_graph.unusable = false;
   if (s) { P->stream = (hipStream_t)s; P->own_stream = false; }
   else { if (hipStreamCreateWithFlags(&P->stream, hipStreamNonBlocking) != hipSuccess) return (gsfm_status)fail(GSFM_ERR_HIP, "hipStreamCreate failed"); P->own_stream = true; }
   P->timer.stream = P->stream;

@@ -138,7 +138,11 @@ typedef struct {
                                           Cholesky'.  Measured on Madrid (394 cams): reproduces the oracle-Cholesky run (63 LM
                                           iterations) but costs ~3.7 ms per step, so it only pays when PCG needs > 150
                                           iterations per step; PCG remains the fallback if the factorisation fails. */
-  int32_t reserved1;
+  int32_t pcg_hip_graph;               /* default 1: the chunk of cg_check_interval PCG iterations between two host checks
+                                          (4 dependent kernels each) is captured once into a hipGraph and replayed -- the loop is
+                                          launch-latency-bound on small graphs.  Same kernels, same order, same iterates.
+                                          Ignored when sharded (the collective callbacks are not captured) or when the
+                                          problem runs on a stream that cannot be captured (the legacy default stream). */
 } gsfm_rot_options;
 
 typedef enum {

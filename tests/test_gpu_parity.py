@@ -209,3 +209,16 @@ def test_ragged_graph_hub_isolated_cameras_duplicates_and_reversed_pairs(oracle)
         assert np.abs(r1[~active] - init[~active]).max() < 1e-12 and np.abs(r2[~active] - init[~active]).max() < 1e-12
         err = synth.angular_distance(synth.align_rotations(r1[active], synth.quat_to_aa(gt[active])), synth.quat_to_aa(gt[active]))
         assert err.mean() < 0.02   # 0.02 rad measurement noise, mean degree ~8
+
+
+def test_pcg_hip_graph_replay_is_bitwise_identical(graph):
+    """The captured chunk of PCG iterations replays the same kernels in the same order: identical bits, fewer launches."""
+    from globalsfmpy_amd.solver import RotationProblem
+    p = RotationProblem(graph["n_cams"], graph["edge_i"], graph["edge_j"], graph["rel_aa"], _abi.ANGLE_AXIS_COVARIANCE, cov6=graph["cov6"])
+    p.set_loss(LF.MAGSACWeightBasedLoss(0.02))
+    r0, s0 = p.solve(graph["init_aa"], pcg_hip_graph=0)
+    r1, s1 = p.solve(graph["init_aa"], pcg_hip_graph=1)
+    r2, s2 = p.solve(graph["init_aa"], pcg_hip_graph=1, cg_check_interval=4)   # re-captured for the new chunk length
+    r3, s3 = p.solve(graph["init_aa"], pcg_hip_graph=1, cg_check_interval=3)   # odd chunk: plain launches
+    for r, s in ((r1, s1), (r2, s2), (r3, s3)):
+        assert np.array_equal(r, r0) and s["final_cost"] == s0["final_cost"] and s["num_cg_iterations"] == s0["num_cg_iterations"]

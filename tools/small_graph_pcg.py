@@ -9,13 +9,14 @@ from globalsfmpy_amd.solver import RotationProblem
 def run(name, g, et, loss, **kw):
     p = RotationProblem(g["n_cams"], g["edge_i"], g["edge_j"], g["rel_aa"], et, **kw); p.set_loss(loss)
     out = {}
-    for sr in (0, 1):
-        p.solve(g["init_aa"], pcg_single_reduction=sr)
-        t = time.perf_counter(); r, s = p.solve(g["init_aa"], pcg_single_reduction=sr); dt = time.perf_counter() - t
-        out[sr] = r
-        print("%-34s single_reduction=%d %8.2f ms  %3d LM it %6d cg it  cost %.12e" % (name, sr, dt * 1e3, s["num_iterations"], s["num_cg_iterations"], s["final_cost"]))
-    d = synth.angular_distance(synth.align_rotations(out[1], out[0]), out[0])
-    print("   mean/max rotation difference between the two: %.2e / %.2e rad" % (d.mean(), d.max()))
+    for sr, gr in ((0, 0), (0, 1), (1, 0)):
+        p.solve(g["init_aa"], pcg_single_reduction=sr, pcg_hip_graph=gr)
+        ts = []
+        for _ in range(3):
+            t = time.perf_counter(); r, s = p.solve(g["init_aa"], pcg_single_reduction=sr, pcg_hip_graph=gr); ts.append(time.perf_counter() - t)
+        out[(sr, gr)] = r
+        print("%-34s single_reduction=%d graph=%d %8.2f ms  %3d LM it %6d cg it  cost %.12e  (gpu pcg %.2f ms)" % (name, sr, gr, min(ts) * 1e3, s["num_iterations"], s["num_cg_iterations"], s["final_cost"], s["t_cg_ms"]))
+    print("   graph vs plain launches: max rotation difference %.1e rad (same kernels, same order)" % np.abs(out[(0, 1)] - out[(0, 0)]).max())
 
 for n, e in ((400, 24000), (2000, 40000), (10000, 200000), (30000, 1000000)):
     g = synth.make_graph(n, e, 11, outlier_frac=0.1)
