@@ -452,16 +452,27 @@ int run_pcg(gsfm_rot_problem* P, const gsfm_rot_options& o, int* iters_out, doub
     }
     if (!G.exec) { (void)hipGetLastError(); G.unusable = true; graph = false; }  // e.g. a stream that cannot be captured: plain launches
   }
-  int launched = 0;
+  int launched = 0, chunks = 1;
   while (true) {
     const int tk = P->timer.begin(T_CG);
-    if (graph) { HIPCHK(hipGraphLaunch(G.exec, P->stream)); }
-    else if (int st = enqueue_chunk()) return st;
-    launched += chunk;
+    for (int c = 0; c < chunks; ++c) {
+      if (graph) { HIPCHK(hipGraphLaunch(G.exec, P->stream)); }
+      else if (int st = enqueue_chunk()) return st;
+      launched += chunk;
+    }
     P->timer.end(tk);
     HIPCHK(hipMemcpyAsync(&h, P->cgsc.p, sizeof(h), hipMemcpyDeviceToHost, P->stream));
     if (int st = sync_check(P, "pcg")) return st;
     if (h.done || launched >= o.max_cg_iterations + chunk) break;
+    // Fewer host round trips: extrapolate the average convergence factor so far to the tolerance and enqueue that many
+    // chunks before looking again (kernels past convergence return at their first instruction, so overshoot is cheap).
+    chunks = 1;
+    if (h.iters > 0 && h.last_rel > 0.0 && h.last_rel < 1.0 && a.tol > 0.0 && a.tol < h.last_rel) {
+      const double per_iter = std::log(h.last_rel) / h.iters;
+      const double remaining = std::log(a.tol / h.last_rel) / per_iter;
+      chunks = (int)std::min(8.0, std::max(1.0, std::ceil(remaining / chunk)));
+    }
+    chunks = std::min(chunks, std::max(1, (o.max_cg_iterations + chunk - launched + chunk - 1) / chunk));
   }
   *iters_out = h.iters; *rel_out = h.last_rel;
   return 0;
