@@ -15,6 +15,7 @@ extern "C" {
 typedef struct orc_problem orc_problem;
 
 void orc_options_default(gsfm_rot_options* o);
+int orc_set_num_threads(int n); /* OpenMP threads for the parallel loops; returns the previous maximum */
 int32_t orc_residual_dim(int32_t error_type);
 orc_problem* orc_problem_create(uint32_t n_cams, uint64_t n_edges, const uint32_t* edge_i, const uint32_t* edge_j,
                                 const double* rel_aa, int32_t error_type, const double* cov6,

@@ -27,6 +27,9 @@
 #include <vector>
 
 #include "oracle_api.h"
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include "ref_loss.hpp"
 #include "ref_residuals.hpp"
 
@@ -521,6 +524,16 @@ gsfm_rot_options defaults() { gsfm_rot_options o; orc_options_default(&o); retur
 }  // namespace
 
 extern "C" {
+
+int orc_set_num_threads(int n) {  // for the 1-thread / all-cores CPU baselines; returns the previous maximum
+#ifdef _OPENMP
+  const int prev = omp_get_max_threads();
+  if (n > 0) omp_set_num_threads(n);
+  return prev;
+#else
+  (void)n; return 1;
+#endif
+}
 
 void orc_options_default(gsfm_rot_options* o) {
   std::memset(o, 0, sizeof(*o));
