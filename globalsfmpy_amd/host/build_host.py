@@ -28,7 +28,7 @@ def main():
     common = [cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function", "-fvisibility=default"]
     link = ["-L" + PKG, "-lgsfm_rot", "-Wl,-rpath,$ORIGIN"]
     est = os.path.join(PKG, "libgsfm_estimator.so")
-    est_src = [os.path.join(HERE, "rotation_estimator.cpp"), os.path.join(HERE, "view_graph.cpp"), os.path.join(HERE, "dataset_1dsfm.cpp")]
+    est_src = [os.path.join(HERE, "rotation_estimator.cpp"), os.path.join(HERE, "view_graph.cpp"), os.path.join(HERE, "dataset_1dsfm.cpp"), os.path.join(HERE, "evaluation.cpp")]
     if force or newer(est, est_src + inc + [os.path.join(PKG, "libgsfm_rot.so")]):
         subprocess.check_call(common + ["-o", est] + est_src + link)
     ext = sysconfig.get_config_var("EXT_SUFFIX")

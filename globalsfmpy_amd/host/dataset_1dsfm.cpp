@@ -50,7 +50,11 @@ bool Read1DSFMTracks(const std::string& dir, Tracks1DSfM* out, std::string* erro
       int flag = 0;
       double focal = 0.0;
       if (!(ss >> flag >> focal)) focal = 0.0;
-      if (cc.empty() || cc.count(id)) out->focal[id] = focal;
+      if (cc.empty() || cc.count(id)) {
+        out->focal[id] = focal;
+        const size_t slash = name.find_last_of('/');
+        out->names[id] = slash == std::string::npos ? name : name.substr(slash + 1);
+      }
       ++id;
     }
   }

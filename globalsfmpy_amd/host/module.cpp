@@ -14,6 +14,7 @@
 #include <memory>
 
 #include "../../include/gsfm/GSfM_nonlinear_rotation_estimator.hpp"
+#include "../../include/gsfm/evaluation.hpp"
 #include "../../include/gsfm/view_graph.hpp"
 
 namespace py = pybind11;
@@ -284,6 +285,8 @@ PYBIND11_MODULE(_GlobalSfMpy, m) {  // imported through the GlobalSfMpy.py shim 
       .def("NumViews", &Reconstruction::NumViews)
       .def("EstimatedOrientations", [](const Reconstruction& r) { return r.orientation; })
       .def("ViewNames", [](const Reconstruction& r) { return r.view_names; })
+      .def("SetViewName", [](Reconstruction& r, ViewId v, const std::string& name) { r.views.insert(v); r.view_names[v] = name; })
+      .def("SetOrientation", [](Reconstruction& r, ViewId v, const Eigen::Vector3d& aa) { r.views.insert(v); r.orientation[v] = aa; })
       .def("MatchedFeatures", [](const Reconstruction& r) { return r.matches ? py::object(edge_matches_dict(*r.matches)) : py::object(py::none()); })
       .def("NumMatchedPairs", [](const Reconstruction& r) { return r.matches ? (int)r.matches->edges.size() : 0; });
 
@@ -353,7 +356,9 @@ PYBIND11_MODULE(_GlobalSfMpy, m) {  // imported through the GlobalSfMpy.py shim 
       auto em = std::make_shared<gsfm::EdgeMatches>();
       gsfm::CollectEdgeMatches(tracks, *vg, em.get());
       rec->matches = em;
+      for (const auto& kv : tracks.names) if (rec->views.count(kv.first)) rec->view_names[kv.first] = kv.second;
     }
+    for (ViewId v : rec->views) if (!rec->view_names.count(v)) rec->view_names[v] = std::to_string(v);  // no list.txt: the id is the name
     gsfm::ReadCovariance(dir, &cov);
   });
   py::class_<FeaturesAndMatchesDatabase>(m, "FeaturesAndMatchesDatabase").def(py::init([](const std::string& p) { return new FeaturesAndMatchesDatabase{p}; }));
@@ -421,6 +426,33 @@ PYBIND11_MODULE(_GlobalSfMpy, m) {  // imported through the GlobalSfMpy.py shim 
     for (const auto& kv : rec.orientation) f << kv.first << " " << kv.second[0] << " " << kv.second[1] << " " << kv.second[2] << "\n";
     return (bool)f;
   });
+  // ---- evaluation (bind :387-394, :396-403, :651-664; orientations only) ----
+  py::class_<gsfm::CompareInfo>(m, "CompareInfo")
+      .def(py::init<>())
+      .def_readwrite("rotation_diff_when_align", &gsfm::CompareInfo::rotation_diff_when_align)
+      .def_readwrite("position_errors", &gsfm::CompareInfo::position_errors)
+      .def_readwrite("num_3d_points", &gsfm::CompareInfo::num_3d_points)
+      .def_readwrite("common_camera", &gsfm::CompareInfo::common_camera)
+      .def_readwrite("num_reconstructed_view", &gsfm::CompareInfo::num_reconstructed_view);
+  py::class_<gsfm::ColmapViewGraph>(m, "ColmapViewGraph")
+      .def(py::init<>())
+      .def("read_poses", &gsfm::ColmapViewGraph::read_poses)
+      .def_readwrite("num_view", &gsfm::ColmapViewGraph::num_view)
+      .def_readwrite("image_ids", &gsfm::ColmapViewGraph::image_ids)
+      .def_readwrite("image_names", &gsfm::ColmapViewGraph::image_names)
+      .def_readwrite("poses", &gsfm::ColmapViewGraph::poses);
+  m.def("AngularDifference", &gsfm::AngularDifference);
+  m.def("AlignRotations", [](const std::vector<Eigen::Vector3d>& gt, std::vector<Eigen::Vector3d> rot) {
+    const gsfm::AlignmentSummary s = gsfm::AlignRotations(gt, &rot);
+    py::dict d;
+    d["alignment"] = s.alignment; d["initial_cost"] = s.initial_cost; d["final_cost"] = s.final_cost;
+    d["iterations"] = s.iterations; d["converged"] = s.converged; d["message"] = s.message;
+    return py::make_tuple(rot, d);
+  }, "Returns (aligned rotations, summary); the reference aligns in place.");
+  m.def("FindCommonViewsByName", &gsfm::FindCommonEstimatedViewsByName);
+  m.def("FindCommonViewsByNameColmap", &gsfm::FindCommonEstimatedViewsByNameColmap);
+  m.def("compare_orientations", &gsfm::compare_orientations);
+  m.def("compare_orientations_colmap", &gsfm::compare_orientations_colmap);
   m.def("ReadImageSize", [](const std::string& path) {
     int w = 0, h = 0;
     if (!gsfm::ReadImageSize(path, &w, &h)) throw std::runtime_error("cannot read the size of image " + path);

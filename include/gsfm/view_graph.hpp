@@ -84,6 +84,7 @@ bool WriteCovariance(const std::string& dataset_directory, const CovarianceMap& 
 // line index, optional EXIF focal), coords.txt (per view: principal point, keypoints) and tracks.txt.
 struct Tracks1DSfM {
   std::unordered_map<theia::ViewId, double> focal;  // list.txt; 0 = no EXIF focal (read_1dsfm.cc:136-142)
+  std::unordered_map<theia::ViewId, std::string> names;  // list.txt: file name without its directory (:128-130)
   std::unordered_map<theia::ViewId, Eigen::Vector2d> principal_point;  // coords.txt header (parsed as float, :176-193)
   std::unordered_map<theia::ViewId, std::vector<Eigen::Vector2d>> keypoints;
   std::vector<std::vector<std::pair<theia::ViewId, int>>> tracks;  // (view, keypoint index)
