@@ -222,3 +222,18 @@ def test_pcg_hip_graph_replay_is_bitwise_identical(graph):
     r3, s3 = p.solve(graph["init_aa"], pcg_hip_graph=1, cg_check_interval=3)   # odd chunk: plain launches
     for r, s in ((r1, s1), (r2, s2), (r3, s3)):
         assert np.array_equal(r, r0) and s["final_cost"] == s0["final_cost"] and s["num_cg_iterations"] == s0["num_cg_iterations"]
+
+
+def test_non_finite_inputs_fail_like_ceres_without_touching_the_rotations(oracle):
+    """Ceres reports FAILURE when the initial cost is not finite and leaves the parameters alone; so do both sides here."""
+    from globalsfmpy_amd.solver import RotationProblem
+    g = synth.make_graph(300, 3000, 5, outlier_frac=0.1)
+    rel = g["rel_aa"].copy(); rel[17] = np.nan
+    init = g["init_aa"].copy(); init[5] = np.inf
+    for measurements, start in ((rel, g["init_aa"]), (g["rel_aa"], init)):
+        for cls in (RotationProblem, oracle.OracleProblem):
+            p = cls(g["n_cams"], g["edge_i"], g["edge_j"], measurements, _abi.ANGLE_AXIS); p.set_loss(LF.HuberLoss(0.1))
+            r, s = p.solve(start)
+            assert s["termination_name"] == "FAILURE" and s["num_iterations"] == 0
+            finite = np.isfinite(start)
+            assert np.array_equal(r[finite], start[finite])
