@@ -194,6 +194,7 @@ struct gsfm_rot_problem {
   EdgePlanes cost;            // cost-owned edges
   DevBuf<uint2> cost_idx;
   DevBuf<CostTile> cost_tiles;
+  int cost_direct = 0;        // 1: K1 gathers the quaternions directly (thin tiles), 0: 2-D LDS tiles
   EdgePlanes dir;             // directed entries (rows = owned cameras)
   DevBuf<uint32_t> row_ptr, col;
   uint32_t G = 16;
@@ -255,6 +256,11 @@ int dispatch(const gsfm_rot_problem* P, const ArgsT& args, int grid) {
 template <int F, int W, int L> struct CostLauncher {
   static void go(const CostArgs& a, int grid, hipStream_t s) {
     const bool full = a.s_only || a.rho_ext || a.s_out;
+    if (a.direct) {
+      if (full) hipLaunchKernelGGL((k_cost_direct<F, W, L, true>), dim3(grid), dim3(GSFM_BLOCK), 0, s, a);
+      else hipLaunchKernelGGL((k_cost_direct<F, W, L, false>), dim3(grid), dim3(GSFM_BLOCK), 0, s, a);
+      return;
+    }
     if (full) hipLaunchKernelGGL((k_cost<F, W, L, true>), dim3(grid), dim3(GSFM_TILE_THREADS), 0, s, a);
     else hipLaunchKernelGGL((k_cost<F, W, L, false>), dim3(grid), dim3(GSFM_TILE_THREADS), 0, s, a);
   }
@@ -353,7 +359,7 @@ void launch_cache(gsfm_rot_problem* P, const double* x, double2* q) {
 // host-callback loss: s per original edge -> host -> rho triples -> device
 int refresh_external_rho(gsfm_rot_problem* P, const double2* q) {
   CostArgs a{};
-  a.tiles = P->cost_tiles.p; a.n_cams = P->n_cams; a.n = P->cost.n; a.idx = P->cost_idx.p; a.qr0 = P->cost.qr0.p; a.qr1 = P->cost.qr1.p;
+  a.tiles = P->cost_tiles.p; a.direct = P->cost_direct; a.n_cams = P->n_cams; a.n = P->cost.n; a.idx = P->cost_idx.p; a.qr0 = P->cost.qr0.p; a.qr1 = P->cost.qr1.p;
   a.w0 = P->cost.w0.p; a.w1 = P->cost.w1.p; a.w2 = P->cost.w2.p; a.ws = P->cost.ws.p;
   a.q = q; a.loss = P->d_loss.p; a.eid = P->cost.eid.p; a.partials = P->part_cost.p; a.s_out = P->s_ext.p; a.s_only = 1;
   if (dispatch<CostArgs, CostLauncher>(P, a, P->nb_cost)) return fail(GSFM_ERR_UNSUPPORTED, "no kernel for this error type");
@@ -370,7 +376,7 @@ int refresh_external_rho(gsfm_rot_problem* P, const double2* q) {
 int launch_cost(gsfm_rot_problem* P, const double2* q, int slot, double* s_out = nullptr, double* rho_out = nullptr, double* r_out = nullptr) {
   if (P->cb) { if (int st = refresh_external_rho(P, q)) return st; }
   CostArgs a{};
-  a.tiles = P->cost_tiles.p; a.n_cams = P->n_cams; a.n = P->cost.n; a.idx = P->cost_idx.p; a.qr0 = P->cost.qr0.p; a.qr1 = P->cost.qr1.p;
+  a.tiles = P->cost_tiles.p; a.direct = P->cost_direct; a.n_cams = P->n_cams; a.n = P->cost.n; a.idx = P->cost_idx.p; a.qr0 = P->cost.qr0.p; a.qr1 = P->cost.qr1.p;
   a.w0 = P->cost.w0.p; a.w1 = P->cost.w1.p; a.w2 = P->cost.w2.p; a.ws = P->cost.ws.p;
   a.q = q; a.loss = P->d_loss.p; a.rho_ext = P->cb ? P->rho_ext.p : nullptr; a.eid = P->cost.eid.p;
   a.partials = P->part_cost.p; a.s_out = s_out; a.rho_out = rho_out; a.r_out = r_out; a.s_only = 0;
@@ -831,28 +837,46 @@ gsfm_status gsfm_rot_problem_create(uint32_t n_cams, uint64_t n_edges, const uin
     for (size_t t = 0; t < Ec; ++t) tmp[cnt[edge_i[cost_eid[t]]]++] = cost_eid[t];
     const uint64_t nblk = ((uint64_t)n_cams + GSFM_CAMBLOCK - 1) / GSFM_CAMBLOCK;
     auto tile_of = [&](uint32_t e) { return (uint64_t)(edge_i[e] / GSFM_CAMBLOCK) * nblk + edge_j[e] / GSFM_CAMBLOCK; };
-    std::vector<size_t> tstart(nblk * nblk + 1, 0);
-    for (size_t t = 0; t < Ec; ++t) tstart[tile_of(tmp[t]) + 1]++;
-    for (uint64_t b = 0; b < nblk * nblk; ++b) tstart[b + 1] += tstart[b];
-    {
+    // The bucket table has nblk^2 entries: beyond 4096 camera blocks (8.4M cameras) the edges simply stay ordered by
+    // `first` (such a sweep is far too thin for LDS tiles anyway).
+    const bool bucketed = nblk <= 4096;
+    std::vector<size_t> tstart(bucketed ? nblk * nblk + 1 : 1, 0);
+    size_t populated = 0;
+    if (bucketed) {
+      for (size_t t = 0; t < Ec; ++t) tstart[tile_of(tmp[t]) + 1]++;
+      for (uint64_t b = 0; b < nblk * nblk; ++b) tstart[b + 1] += tstart[b];
       std::vector<size_t> fillt(tstart.begin(), tstart.end() - 1);
       for (size_t t = 0; t < Ec; ++t) cost_eid[fillt[tile_of(tmp[t])]++] = tmp[t];
+      for (uint64_t b = 0; b < nblk * nblk; ++b) populated += tstart[b + 1] > tstart[b];
+    } else {
+      cost_eid = tmp;
     }
-    // one workgroup per <= max_tile edges of a tile: ~2 workgroups per CU for big sweeps, >= 1 pass of 1024 lanes for small ones
-    const size_t max_tile = std::min<size_t>(16384, std::max<size_t>(GSFM_TILE_THREADS, (Ec + 511) / 512));
-    for (uint64_t b = 0; b < nblk * nblk; ++b) {
-      size_t lo = tstart[b];
-      const size_t hi = tstart[b + 1];
-      while (lo < hi) {
-        const size_t ce = std::min(hi, lo + max_tile);
-        tiles.push_back(CostTile{(uint32_t)(b / nblk), (uint32_t)(b % nblk), (uint32_t)lo, (uint32_t)ce});
-        lo = ce;
+    // Thin tiles cannot amortise the 128 KiB LDS fill (88 B streamed per edge): below ~4096 edges per populated tile the
+    // sweep gathers the quaternions directly instead (k_cost_direct).  GSFM_K1_DIRECT=0/1 overrides (A/B measurements).
+    P->cost_direct = !bucketed || (populated > 0 && Ec / populated < 4096);
+    if (const char* v = getenv("GSFM_K1_DIRECT")) P->cost_direct = !bucketed || atoi(v) != 0;
+    if (P->cost_direct) {
+      const size_t chunk = std::min<size_t>(8192, std::max<size_t>(GSFM_BLOCK, (Ec + 2047) / 2048));
+      for (size_t lo = 0; lo < Ec; lo += chunk) tiles.push_back(CostTile{0, 0, (uint32_t)lo, (uint32_t)std::min(Ec, lo + chunk)});
+    } else {
+      // one workgroup per <= max_tile edges of a tile: ~2 workgroups per CU for big sweeps, >= 1 pass of 1024 lanes for small ones
+      const size_t max_tile = std::min<size_t>(16384, std::max<size_t>(GSFM_TILE_THREADS, (Ec + 511) / 512));
+      for (uint64_t b = 0; b < nblk * nblk; ++b) {
+        size_t lo = tstart[b];
+        const size_t hi = tstart[b + 1];
+        while (lo < hi) {
+          const size_t ce = std::min(hi, lo + max_tile);
+          tiles.push_back(CostTile{(uint32_t)(b / nblk), (uint32_t)(b % nblk), (uint32_t)lo, (uint32_t)ce});
+          lo = ce;
+        }
       }
     }
     if (tiles.empty()) tiles.push_back(CostTile{0, 0, 0, 0});
   }
   std::vector<uint2> cidx(cost_eid.size());
-  for (size_t t = 0; t < cost_eid.size(); ++t) cidx[t] = make_uint2(edge_i[cost_eid[t]] % GSFM_CAMBLOCK, edge_j[cost_eid[t]] % GSFM_CAMBLOCK);
+  const uint32_t idx_mod = P->cost_direct ? 0xffffffffu : (uint32_t)GSFM_CAMBLOCK;   // global or block-local camera indices
+  for (size_t t = 0; t < cost_eid.size(); ++t)
+    cidx[t] = P->cost_direct ? make_uint2(edge_i[cost_eid[t]], edge_j[cost_eid[t]]) : make_uint2(edge_i[cost_eid[t]] % idx_mod, edge_j[cost_eid[t]] % idx_mod);
   P->h_cost_eid = cost_eid;
 
   // ---- uploads ----
@@ -1000,7 +1024,7 @@ gsfm_status gsfm_rot_solve_sigma_consensus(gsfm_rot_problem* P, double* rot, int
     if (int st = upload_state(P, rot)) return (gsfm_status)st;
     {  // K6 = K1 in s-only mode: s_e = ||log(R_j R_i^T R_ij^T)||^2  (:378-398)
       CostArgs a{};
-      a.tiles = P->cost_tiles.p; a.n_cams = P->n_cams; a.n = P->cost.n; a.idx = P->cost_idx.p; a.qr0 = P->cost.qr0.p; a.qr1 = P->cost.qr1.p; a.ws = P->cost.ws.p;
+      a.tiles = P->cost_tiles.p; a.direct = P->cost_direct; a.n_cams = P->n_cams; a.n = P->cost.n; a.idx = P->cost_idx.p; a.qr0 = P->cost.qr0.p; a.qr1 = P->cost.qr1.p; a.ws = P->cost.ws.p;
       a.q = P->q.p; a.loss = P->d_loss.p; a.eid = P->cost.eid.p; a.partials = P->part_cost.p; a.s_out = P->s_ext.p; a.s_only = 1;
       if (dispatch<CostArgs, CostLauncher>(P, a, P->nb_cost)) return (gsfm_status)fail(GSFM_ERR_UNSUPPORTED, "dispatch");
       if (hipMemcpyAsync(s.data(), P->s_ext.p, 8 * E, hipMemcpyDeviceToHost, P->stream) != hipSuccess) return (gsfm_status)fail(GSFM_ERR_HIP, "read s");
@@ -1108,7 +1132,7 @@ gsfm_status gsfm_rot_time_sweep(gsfm_rot_problem* P, const double* rot, int32_t 
   DeviceGuard g(P->device);
   if (int st = upload_state(P, rot)) return (gsfm_status)st;
   CostArgs a{};
-  a.tiles = P->cost_tiles.p; a.n_cams = P->n_cams; a.n = P->cost.n; a.idx = P->cost_idx.p; a.qr0 = P->cost.qr0.p; a.qr1 = P->cost.qr1.p;
+  a.tiles = P->cost_tiles.p; a.direct = P->cost_direct; a.n_cams = P->n_cams; a.n = P->cost.n; a.idx = P->cost_idx.p; a.qr0 = P->cost.qr0.p; a.qr1 = P->cost.qr1.p;
   a.w0 = P->cost.w0.p; a.w1 = P->cost.w1.p; a.w2 = P->cost.w2.p; a.ws = P->cost.ws.p;
   a.q = P->q.p; a.loss = P->d_loss.p; a.eid = P->cost.eid.p; a.partials = P->part_cost.p;
   for (int k = 0; k < 3; ++k) if (dispatch<CostArgs, CostLauncher>(P, a, P->nb_cost)) return (gsfm_status)fail(GSFM_ERR_UNSUPPORTED, "dispatch");

@@ -346,6 +346,7 @@ struct CostArgs {
   double* rho_out;
   double* r_out;
   int s_only;                // 1: write s_out only, skip the loss (callback path, phase 1)
+  int direct;                // 1: k_cost_direct (idx = global camera indices, tiles = plain chunks)
 };
 
 // K1.  FULL = false: the solver's trial-cost sweep (cost only: for MAGSAC the value needs no exp and no division
@@ -353,9 +354,34 @@ struct CostArgs {
 // host-callback losses, sigma consensus).  One edge per lane; the seven streamed planes are 16-byte coalesced,
 // non-temporal loads; both camera quaternions come from LDS.  Measured (tools/bench_cost*.hip, C5): streams only
 // 137 us; + all arithmetic 138-152 us (hidden); direct global gathers 181 us; these 2-D LDS tiles 160 us.
+// One edge of K1: residual, s, loss, optional per-edge outputs; returns the edge's 1/2 rho (0 in s_only mode).
+template <int F, int WM, int LM, bool FULL>
+__device__ __forceinline__ double cost_edge(const CostArgs& a, uint32_t e, const Quat& qi, const Quat& qj, const Quat& qr, const EdgeW& W) {
+  constexpr int R = ResDim<F>::R;
+  double r[R];
+  edge_residual<F, WM>(qi, qj, qr, W, r);
+  double s = 0.0;
+#pragma unroll
+  for (int k = 0; k < R; ++k) s += r[k] * r[k];
+  if (!FULL) return 0.5 * loss_value<LM>(a.loss, s);
+  if (a.s_only) { a.s_out[a.eid[e]] = s; return 0.0; }
+  Rho3 rho;
+  if (a.rho_ext) { const size_t o = 3 * (size_t)a.eid[e]; rho.r0 = a.rho_ext[o]; rho.r1 = a.rho_ext[o + 1]; rho.r2 = a.rho_ext[o + 2]; }
+  else rho = loss_eval<LM>(a.loss, s);
+  if (a.s_out) {
+    const size_t o = a.eid[e];
+    a.s_out[o] = s;
+    if (a.rho_out) { a.rho_out[3 * o] = rho.r0; a.rho_out[3 * o + 1] = rho.r1; a.rho_out[3 * o + 2] = rho.r2; }
+    if (a.r_out) {
+#pragma unroll
+      for (int k = 0; k < R; ++k) a.r_out[R * o + k] = r[k];
+    }
+  }
+  return 0.5 * rho.r0;
+}
+
 template <int F, int WM, int LM, bool FULL>
 __global__ void __launch_bounds__(GSFM_TILE_THREADS) k_cost(CostArgs a) {
-  constexpr int R = ResDim<F>::R;
   __shared__ double2 qi_xy[GSFM_CAMBLOCK], qi_zw[GSFM_CAMBLOCK], qj_xy[GSFM_CAMBLOCK], qj_zw[GSFM_CAMBLOCK];
   __shared__ double lds[GSFM_TILE_THREADS / 64 + 1];
   const CostTile tile = a.tiles[blockIdx.x];
@@ -386,29 +412,9 @@ __global__ void __launch_bounds__(GSFM_TILE_THREADS) k_cost(CostArgs a) {
       const uint32_t e = e0 + u * GSFM_TILE_THREADS;
       if (e >= tile.end) continue;
       const Quat qr{r0[u].x, r0[u].y, r1[u].x, r1[u].y};
-      const EdgeW& W = Wm[u];
       const double2 i0 = qi_xy[ij[u].x], i1 = qi_zw[ij[u].x], j0 = qj_xy[ij[u].y], j1 = qj_zw[ij[u].y];
       const Quat qi{i0.x, i0.y, i1.x, i1.y}, qj{j0.x, j0.y, j1.x, j1.y};
-      double r[R];
-      edge_residual<F, WM>(qi, qj, qr, W, r);
-      double s = 0.0;
-#pragma unroll
-      for (int k = 0; k < R; ++k) s += r[k] * r[k];
-      if (!FULL) { acc += 0.5 * loss_value<LM>(a.loss, s); continue; }
-      if (a.s_only) { a.s_out[a.eid[e]] = s; continue; }
-      Rho3 rho;
-      if (a.rho_ext) { const size_t o = 3 * (size_t)a.eid[e]; rho.r0 = a.rho_ext[o]; rho.r1 = a.rho_ext[o + 1]; rho.r2 = a.rho_ext[o + 2]; }
-      else rho = loss_eval<LM>(a.loss, s);
-      acc += 0.5 * rho.r0;
-      if (a.s_out) {
-        const size_t o = a.eid[e];
-        a.s_out[o] = s;
-        if (a.rho_out) { a.rho_out[3 * o] = rho.r0; a.rho_out[3 * o + 1] = rho.r1; a.rho_out[3 * o + 2] = rho.r2; }
-        if (a.r_out) {
-#pragma unroll
-          for (int k = 0; k < R; ++k) a.r_out[R * o + k] = r[k];
-        }
-      }
+      acc += cost_edge<F, WM, LM, FULL>(a, e, qi, qj, qr, Wm[u]);
     }
   }
   // deterministic block reduction (fixed tree per wave, fixed order over the 16 waves)
@@ -418,6 +424,32 @@ __global__ void __launch_bounds__(GSFM_TILE_THREADS) k_cost(CostArgs a) {
   if (threadIdx.x == 0) {
     double t = 0.0;
     for (int k = 0; k < GSFM_TILE_THREADS / 64; ++k) t += lds[k];
+    a.partials[blockIdx.x] = t;
+  }
+}
+
+// K1 without LDS staging, for sweeps whose (first block, second block) tiles are too thinly populated to amortise the
+// 128 KiB fill -- many cameras at a fixed degree (edges per tile = degree * 2048^2 / cameras), or one rank's share of a
+// sharded problem.  Same edge order (so a chunk's gathers fall into few 64 KiB windows of q), `idx` holds GLOBAL camera
+// indices, the quaternions are gathered through L1/L2; 256 lanes per workgroup, no LDS, so the occupancy is VGPR-bound.
+template <int F, int WM, int LM, bool FULL>
+__global__ void __launch_bounds__(GSFM_BLOCK) k_cost_direct(CostArgs a) {
+  __shared__ double lds[GSFM_BLOCK / 64 + 1];
+  const CostTile tile = a.tiles[blockIdx.x];
+  double acc = 0.0;
+  for (uint32_t e = tile.begin + threadIdx.x; e < tile.end; e += GSFM_BLOCK) {
+    const uint2 ij = a.idx[e];
+    const double2 r0 = nt_load2(a.qr0 + e), r1 = nt_load2(a.qr1 + e);
+    const EdgeW W = load_w<WM>(a.w0, a.w1, a.w2, a.ws, e);
+    const Quat qi = load_q(a.q, ij.x), qj = load_q(a.q, ij.y);
+    acc += cost_edge<F, WM, LM, FULL>(a, e, qi, qj, Quat{r0.x, r0.y, r1.x, r1.y}, W);
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int k = 0; k < GSFM_BLOCK / 64; ++k) t += lds[k];
     a.partials[blockIdx.x] = t;
   }
 }

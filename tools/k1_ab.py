@@ -7,4 +7,4 @@ from globalsfmpy_amd.solver import RotationProblem
 g = synth.make_graph(100000, 10000000, 2023, outlier_frac=0.3)
 p = RotationProblem(g["n_cams"], g["edge_i"], g["edge_j"], g["rel_aa"], _abi.ANGLE_AXIS_COVARIANCE, cov6=g["cov6"])
 p.set_loss(MAGSACWeightBasedLoss(0.02))
-print("K1 %s: %.1f us" % (os.environ.get("GSFM_K1_DIRECT", "lds"), 1e3 * p.time_sweep(g["init_aa"], reps=20)))
+print("K1 %s: %.1f us" % (os.environ.get("GSFM_K1_DIRECT", "auto"), 1e3 * p.time_sweep(g["init_aa"], reps=20)))
