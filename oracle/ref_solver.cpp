@@ -222,7 +222,7 @@ double evaluate(orc_problem* p, const double* x, bool with_jacobian, double* gra
   const size_t E = p->edges.size();
   if (with_jacobian) { p->rt.assign(E * R, 0.0); p->Ji.assign(E * R * 3, 0.0); p->Jj.assign(E * R * 3, 0.0); }
   // 80-bit accumulator: at 1e8 edges a plain double running sum per thread is only good to ~1e-9 relative, which made the
-  // CHECKER the less accurate side (the device's fixed-tree sums equal math.fsum of the per-edge values; tools/cost_sum_probe.py)
+  // CHECKER the less accurate side (the device's fixed-tree sums equal math.fsum of the per-edge values; tests/manual/cost_sum_probe.py)
   long double cost = 0.0L;
   const bool serial = (p->cb != nullptr);
   if (serial) {

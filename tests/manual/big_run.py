@@ -3,7 +3,7 @@
 oracle over ALL edges, checks the normal-matrix symmetry, then solves.  usage: big_run.py [n_cams] [n_edges]"""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from globalsfmpy_amd import _abi, synth
 from globalsfmpy_amd import loss_functions as LF
 from globalsfmpy_amd.solver import RotationProblem

@@ -1,6 +1,6 @@
 import os, sys, math
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from globalsfmpy_amd import _abi, synth
 from globalsfmpy_amd import loss_functions as LF
 from globalsfmpy_amd.solver import RotationProblem
