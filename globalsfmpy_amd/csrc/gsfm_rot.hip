@@ -265,7 +265,12 @@ template <int F, int W, int L> struct CostLauncher {
     else hipLaunchKernelGGL((k_cost<F, W, L, false>), dim3(grid), dim3(GSFM_TILE_THREADS), 0, s, a);
   }
 };
-template <int F, int W, int L> struct LinLauncher { static void go(const LinArgs& a, int grid, hipStream_t s) { hipLaunchKernelGGL((k_lin<F, W, L>), dim3(grid), dim3(GSFM_BLOCK), 0, s, a); } };
+template <int F, int W, int L> struct LinLauncher {
+  static void go(const LinArgs& a, int grid, hipStream_t s) {
+    if constexpr (L != LM_PROGRAM && F != F_RFNORM) hipLaunchKernelGGL((k_lin3<F, W, L>), dim3(grid), dim3(GSFM_BLOCK), 0, s, a);
+    else hipLaunchKernelGGL((k_lin<F, W, L>), dim3(grid), dim3(GSFM_BLOCK), 0, s, a);
+  }
+};
 
 int sync_check(gsfm_rot_problem* P, const char* what) {
   hipError_t e = hipStreamSynchronize(P->stream);

@@ -38,6 +38,11 @@ template <int F> struct ResDim { static constexpr int R = (F == F_QNORM) ? 4 : (
 #ifndef GSFM_TILE_THREADS
 #define GSFM_TILE_THREADS 1024
 #endif
+#ifndef GSFM_K2_ATTR
+// K2 is latency-bound (profiles/r01_e_pmc_sq_valu.txt): at the compiler's free choice of 184 VGPRs only two waves fit a
+// SIMD; asking for at least three costs no spill (168 VGPRs) and 7.5 % less time on C5.  Four would spill 37 VGPRs (2x slower).
+#define GSFM_K2_ATTR __attribute__((amdgpu_waves_per_eu(3)))
+#endif
 #ifndef GSFM_K1_UNROLL
 #define GSFM_K1_UNROLL 1   // edges per lane whose streams are requested before any of them is evaluated
 #endif
@@ -483,7 +488,7 @@ struct LinArgs {
 };
 
 template <int F, int WM, int LM>
-__global__ void __launch_bounds__(GSFM_BLOCK) k_lin(LinArgs a) {
+__device__ __forceinline__ void lin_rows(const LinArgs& a) {
   constexpr int R = ResDim<F>::R;
   const uint32_t G = a.G;
   const uint32_t t = blockIdx.x * GSFM_BLOCK + threadIdx.x;
@@ -558,6 +563,12 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_lin(LinArgs a) {
     for (int c = 0; c < 9; ++c) o[c] = acc[c];
   }
 }
+// Two entry points over the same body: `k_lin3` asks for at least three waves per SIMD, which is free (no spill) for the
+// instantiations that matter and would spill for the general loss program and the 9-residual functor; the launcher picks.
+template <int F, int WM, int LM>
+__global__ void __launch_bounds__(GSFM_BLOCK) k_lin(LinArgs a) { lin_rows<F, WM, LM>(a); }
+template <int F, int WM, int LM>
+__global__ void __launch_bounds__(GSFM_BLOCK) GSFM_K2_ATTR k_lin3(LinArgs a) { lin_rows<F, WM, LM>(a); }
 
 // ------------------------------------------------------------------------------------------
 // K3: y_k = M_k p_k + sum_d H_d p[col_d]   (M = diagonal block incl. LM damping, sym 6)
