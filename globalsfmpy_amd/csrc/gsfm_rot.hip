@@ -194,6 +194,9 @@ struct gsfm_rot_problem {
   EdgePlanes cost;            // cost-owned edges
   DevBuf<uint2> cost_idx;
   DevBuf<CostTile> cost_tiles;
+  // locality relabelling adopted at create (empty = identity): internal id = perm[external id]
+  std::vector<uint32_t> perm;
+  std::vector<double> h_cam;   // staging for permuted per-camera transfers
   int cost_direct = 0;        // 1: K1 gathers the quaternions directly (thin tiles), 0: 2-D LDS tiles
   EdgePlanes dir;             // directed entries (rows = owned cameras)
   DevBuf<uint32_t> row_ptr, col;
@@ -575,9 +578,68 @@ int read_scalars(gsfm_rot_problem* P, double* h) {
   return sync_check(P, "read scalars");
 }
 
+// Reverse Cuthill-McKee style relabelling (plain BFS from a minimum-degree camera of every component, reversed).  The p[col]
+// and q[col] gathers of K3/K2 are bound by uncoalesced lane requests; when the neighbours of a camera sit within a few
+// hundred indices of each other the lanes of a row share 128-byte lines and the gather becomes free (tools/bench_matvec.hip:
+// 346 us -> 235 us at a window of 400, 284 us at 2000, no gain at 20000).  View graphs of real scenes are spatially
+// coherent but their ids are arbitrary; a uniformly random graph (the C5 benchmark) has nothing to recover.  The
+// relabelling is therefore adopted only if it shrinks the mean |i - j| over the edges by more than half AND brings it
+// under 1024 (neighbours within about +-2000); small problems (< 2048 cameras: everything is cache-resident) are left alone.
+// GSFM_REORDER=0 disables it, =1 forces adoption.  Returns true when `perm` (external -> internal) must be applied.
+bool reorder_for_locality(uint32_t n_cams, uint64_t n_edges, const uint32_t* ei, const uint32_t* ej, std::vector<uint32_t>* perm) {
+  perm->clear();
+  const char* env = getenv("GSFM_REORDER");
+  const int mode = env ? atoi(env) : -1;  // -1 auto, 0 off, 1 force
+  if (mode == 0 || (mode < 0 && n_cams < 2048)) return false;
+  double before = 0.0;
+  for (uint64_t e = 0; e < n_edges; ++e) before += std::fabs((double)ei[e] - (double)ej[e]);
+  before /= (double)n_edges;
+  if (mode < 0 && before < 256.0) return false;  // already local (a mean index distance of 256 ~ neighbours within +-500)
+  std::vector<uint32_t> ptr((size_t)n_cams + 1, 0);
+  for (uint64_t e = 0; e < n_edges; ++e) { ptr[ei[e] + 1]++; ptr[ej[e] + 1]++; }
+  for (size_t c = 0; c < n_cams; ++c) ptr[c + 1] += ptr[c];
+  std::vector<uint32_t> adj(ptr[n_cams]), fill(ptr.begin(), ptr.end() - 1);
+  for (uint64_t e = 0; e < n_edges; ++e) { adj[fill[ei[e]]++] = ej[e]; adj[fill[ej[e]]++] = ei[e]; }
+  std::vector<uint32_t> by_degree(n_cams);
+  for (uint32_t c = 0; c < n_cams; ++c) by_degree[c] = c;
+  std::stable_sort(by_degree.begin(), by_degree.end(), [&](uint32_t a, uint32_t b) { return ptr[a + 1] - ptr[a] < ptr[b + 1] - ptr[b]; });
+  std::vector<uint32_t> order;
+  order.reserve(n_cams);
+  std::vector<uint8_t> seen(n_cams, 0);
+  for (uint32_t s0 : by_degree) {
+    if (seen[s0]) continue;
+    seen[s0] = 1;
+    size_t head = order.size();
+    order.push_back(s0);
+    while (head < order.size()) {
+      const uint32_t c = order[head++];
+      for (uint32_t d = ptr[c]; d < ptr[c + 1]; ++d) if (!seen[adj[d]]) { seen[adj[d]] = 1; order.push_back(adj[d]); }
+    }
+  }
+  std::vector<uint32_t> p(n_cams);
+  for (uint32_t k = 0; k < n_cams; ++k) p[order[k]] = n_cams - 1 - k;
+  double after = 0.0;
+  for (uint64_t e = 0; e < n_edges; ++e) after += std::fabs((double)p[ei[e]] - (double)p[ej[e]]);
+  after /= (double)n_edges;
+  if (mode < 0 && !(after < 0.5 * before && after < 1024.0)) return false;
+  perm->swap(p);
+  return true;
+}
+
+// Per-camera host arrays (rotations, gradient, mat-vec operands) enter and leave in the caller's numbering.
+const double* to_internal(gsfm_rot_problem* P, const double* ext, int width) {
+  if (P->perm.empty()) return ext;
+  P->h_cam.resize((size_t)P->n_cams * width);
+  for (size_t k = 0; k < P->n_cams; ++k) std::memcpy(&P->h_cam[(size_t)P->perm[k] * width], ext + k * width, 8 * (size_t)width);
+  return P->h_cam.data();
+}
+void to_external(gsfm_rot_problem* P, const double* internal, double* ext, int width) {
+  for (size_t k = 0; k < P->n_cams; ++k) std::memcpy(ext + k * width, internal + (size_t)P->perm[k] * width, 8 * (size_t)width);
+}
+
 int upload_state(gsfm_rot_problem* P, const double* rot_aa) {
   const size_t N = P->n_cams;
-  HIPCHK(hipMemcpyAsync(P->aa_io.p, rot_aa, 24 * N, hipMemcpyHostToDevice, P->stream));
+  HIPCHK(hipMemcpyAsync(P->aa_io.p, to_internal(P, rot_aa, 3), 24 * N, hipMemcpyHostToDevice, P->stream));
   if (P->param_dim == 3) { HIPCHK(hipMemcpyAsync(P->x.p, P->aa_io.p, 24 * N, hipMemcpyDeviceToDevice, P->stream)); }
   else {  // estimator.cpp:130-136: angle-axis -> quaternion state
     hipLaunchKernelGGL(k_cam_cache, dim3(grid_for(N)), dim3(GSFM_BLOCK), 0, P->stream, P->aa_io.p, P->n_cams, 3, (double2*)P->x.p);
@@ -587,12 +649,16 @@ int upload_state(gsfm_rot_problem* P, const double* rot_aa) {
 }
 int download_state(gsfm_rot_problem* P, double* rot_aa) {
   const size_t N = P->n_cams;
-  if (P->param_dim == 3) { HIPCHK(hipMemcpyAsync(rot_aa, P->x.p, 24 * N, hipMemcpyDeviceToHost, P->stream)); }
+  double* dst = rot_aa;
+  if (!P->perm.empty()) { P->h_cam.resize(3 * N); dst = P->h_cam.data(); }
+  if (P->param_dim == 3) { HIPCHK(hipMemcpyAsync(dst, P->x.p, 24 * N, hipMemcpyDeviceToHost, P->stream)); }
   else {
     hipLaunchKernelGGL(k_quat_to_aa, dim3(grid_for(N)), dim3(GSFM_BLOCK), 0, P->stream, P->x.p, P->active.p, P->n_cams, P->aa_io.p);
-    HIPCHK(hipMemcpyAsync(rot_aa, P->aa_io.p, 24 * N, hipMemcpyDeviceToHost, P->stream));
+    HIPCHK(hipMemcpyAsync(dst, P->aa_io.p, 24 * N, hipMemcpyDeviceToHost, P->stream));
   }
-  return sync_check(P, "download rotations");
+  if (int st = sync_check(P, "download rotations")) return st;
+  if (!P->perm.empty()) to_external(P, dst, rot_aa, 3);
+  return 0;
 }
 
 // ---- TrustRegionMinimizer::Minimize + LevenbergMarquardtStrategy (ceres 1.14 semantics) ----
@@ -757,13 +823,13 @@ void gsfm_rot_options_default(gsfm_rot_options* o) {
 
 int32_t gsfm_rot_residual_dim(int32_t t) { return t == GSFM_ROT_QUATERNION_NORM ? 4 : t == GSFM_ROT_ROTATION_MAT_FNORM ? 9 : 3; }
 
-gsfm_status gsfm_rot_problem_create(uint32_t n_cams, uint64_t n_edges, const uint32_t* edge_i, const uint32_t* edge_j,
+gsfm_status gsfm_rot_problem_create(uint32_t n_cams, uint64_t n_edges, const uint32_t* edge_i_in, const uint32_t* edge_j_in,
                                     const double* rel_aa, int32_t error_type, const double* cov6, const double* inlier_weight,
                                     const gsfm_rot_shard* shard, gsfm_rot_problem** out) {
   if (!out) return (gsfm_status)fail(GSFM_ERR_INVALID_ARG, "out is NULL");
   *out = nullptr;
   if (n_cams == 0 || n_edges == 0) return (gsfm_status)fail(GSFM_ERR_EMPTY, "no cameras or no edges");
-  if (!edge_i || !edge_j || !rel_aa) return (gsfm_status)fail(GSFM_ERR_INVALID_ARG, "NULL edge arrays");
+  if (!edge_i_in || !edge_j_in || !rel_aa) return (gsfm_status)fail(GSFM_ERR_INVALID_ARG, "NULL edge arrays");
   if (error_type < 0 || error_type > 8) return (gsfm_status)fail(GSFM_ERR_INVALID_ARG, "unknown rotation error type");
   if (n_cams >= 0x7fffffffu || n_edges >= 0x7fffffffull) return (gsfm_status)fail(GSFM_ERR_INVALID_ARG, "problem too large for 31-bit indices");
   const bool need_cov = error_type == GSFM_ROT_ANGLE_AXIS_COVARIANCE || error_type == GSFM_ROT_ANGLE_AXIS_COV_INLIERS ||
@@ -799,6 +865,17 @@ gsfm_status gsfm_rot_problem_create(uint32_t n_cams, uint64_t n_edges, const uin
   P->own_stream = true;
   P->timer.stream = P->stream; P->timer.init();
 
+  // ---- optional locality relabelling of the cameras (unsharded problems; see reorder_for_locality) ----
+  const uint32_t *edge_i = edge_i_in, *edge_j = edge_j_in;
+  std::vector<uint32_t> ei_perm, ej_perm;
+  for (uint64_t e = 0; e < n_edges; ++e)
+    if (edge_i[e] >= n_cams || edge_j[e] >= n_cams || edge_i[e] == edge_j[e]) return bail(fail(GSFM_ERR_INVALID_ARG, "edge with an out-of-range or repeated camera index"));
+  if (!P->sharded && reorder_for_locality(n_cams, n_edges, edge_i, edge_j, &P->perm)) {
+    ei_perm.resize(n_edges); ej_perm.resize(n_edges);
+    for (uint64_t e = 0; e < n_edges; ++e) { ei_perm[e] = P->perm[edge_i[e]]; ej_perm[e] = P->perm[edge_j[e]]; }
+    edge_i = ei_perm.data(); edge_j = ej_perm.data();
+  }
+
   // ---- host-side structure: directed entries by row (counting sort), cost-owned edges ----
   const uint32_t ob = P->own_begin, oe = P->own_end;
   auto owned = [&](uint32_t c) { return c >= ob && c < oe; };
@@ -822,6 +899,18 @@ gsfm_status gsfm_rot_problem_create(uint32_t n_cams, uint64_t n_edges, const uin
     const uint32_t i = edge_i[e], j = edge_j[e];
     if (owned(i)) { const uint32_t d = fill[i - ob]++; col[d] = j; deid[d] = (uint32_t)e; }
     if (owned(j)) { const uint32_t d = fill[j - ob]++; col[d] = i | 0x80000000u; deid[d] = (uint32_t)e; }
+  }
+  if (!P->perm.empty()) {  // relabelled for locality: order every row by neighbour so that adjacent lanes gather adjacent cameras
+    std::vector<std::pair<uint32_t, uint32_t>> row;
+    for (size_t r = 0; r < P->n_rows; ++r) {
+      row.clear();
+      for (uint32_t d = rp[r]; d < rp[r + 1]; ++d) row.emplace_back(col[d], deid[d]);
+      std::sort(row.begin(), row.end(), [](const std::pair<uint32_t, uint32_t>& a, const std::pair<uint32_t, uint32_t>& b) {
+        const uint32_t ca = a.first & 0x7fffffffu, cb = b.first & 0x7fffffffu;
+        return ca != cb ? ca < cb : a.second < b.second;
+      });
+      for (uint32_t d = rp[r]; d < rp[r + 1]; ++d) { col[d] = row[d - rp[r]].first; deid[d] = row[d - rp[r]].second; }
+    }
   }
   {
     const double mean_deg = P->n_rows ? (double)nd / P->n_rows : 0.0;
@@ -1104,8 +1193,16 @@ gsfm_status gsfm_rot_linearize(gsfm_rot_problem* P, const double* rot, double* g
   double h[SC_N];
   if (int st = read_scalars(P, h)) return (gsfm_status)st;
   if (cost) *cost = h[SC_COST];
-  if (gradient && hipMemcpy(gradient, dg.p, 24 * N, hipMemcpyDeviceToHost) != hipSuccess) return (gsfm_status)fail(GSFM_ERR_HIP, "copy gradient");
-  if (diag_blocks && hipMemcpy(diag_blocks, dblk.p, 72 * N, hipMemcpyDeviceToHost) != hipSuccess) return (gsfm_status)fail(GSFM_ERR_HIP, "copy blocks");
+  std::vector<double> stage;
+  if (!P->perm.empty()) stage.resize(9 * N);
+  if (gradient) {
+    if (hipMemcpy(P->perm.empty() ? gradient : stage.data(), dg.p, 24 * N, hipMemcpyDeviceToHost) != hipSuccess) return (gsfm_status)fail(GSFM_ERR_HIP, "copy gradient");
+    if (!P->perm.empty()) to_external(P, stage.data(), gradient, 3);
+  }
+  if (diag_blocks) {
+    if (hipMemcpy(P->perm.empty() ? diag_blocks : stage.data(), dblk.p, 72 * N, hipMemcpyDeviceToHost) != hipSuccess) return (gsfm_status)fail(GSFM_ERR_HIP, "copy blocks");
+    if (!P->perm.empty()) to_external(P, stage.data(), diag_blocks, 9);
+  }
   return GSFM_OK;
 }
 
@@ -1115,12 +1212,16 @@ gsfm_status gsfm_rot_normal_matvec(gsfm_rot_problem* P, const double* v, double*
   DeviceGuard g(P->device);
   const size_t N = P->n_cams;
   // y = T^T B_eta (T v): xcg <- v, p <- T v, Ap <- B p, xcg <- T^T Ap
-  if (hipMemcpyAsync(P->xcg.p, v, 24 * N, hipMemcpyHostToDevice, P->stream) != hipSuccess) return (gsfm_status)fail(GSFM_ERR_HIP, "upload v");
+  if (hipMemcpyAsync(P->xcg.p, to_internal(P, v, 3), 24 * N, hipMemcpyHostToDevice, P->stream) != hipSuccess) return (gsfm_status)fail(GSFM_ERR_HIP, "upload v");
   hipLaunchKernelGGL(k_cam_apply_T, dim3(grid_for(N)), dim3(GSFM_BLOCK), 0, P->stream, P->x.p, P->n_cams, P->param_dim, 0, P->xcg.p, P->p.p);
   if (int st = launch_matvec(P, P->D6.p, P->p.p, P->Ap.p, nullptr)) return (gsfm_status)st;
   hipLaunchKernelGGL(k_cam_apply_T, dim3(grid_for(N)), dim3(GSFM_BLOCK), 0, P->stream, P->x.p, P->n_cams, P->param_dim, 1, P->Ap.p, P->xcg.p);
-  if (hipMemcpyAsync(y, P->xcg.p, 24 * N, hipMemcpyDeviceToHost, P->stream) != hipSuccess) return (gsfm_status)fail(GSFM_ERR_HIP, "download y");
-  return (gsfm_status)sync_check(P, "normal_matvec");
+  double* dst = y;
+  if (!P->perm.empty()) { P->h_cam.resize(3 * N); dst = P->h_cam.data(); }
+  if (hipMemcpyAsync(dst, P->xcg.p, 24 * N, hipMemcpyDeviceToHost, P->stream) != hipSuccess) return (gsfm_status)fail(GSFM_ERR_HIP, "download y");
+  if (int st = sync_check(P, "normal_matvec")) return (gsfm_status)st;
+  if (!P->perm.empty()) to_external(P, dst, y, 3);
+  return GSFM_OK;
 }
 
 int32_t gsfm_rot_get_trace(gsfm_rot_problem* P, double* out, int32_t cap_rows) {

@@ -77,8 +77,31 @@ def make_edges(rng, n_cams, n_edges):
     return (keys // n_cams).astype(np.uint32), (keys % n_cams).astype(np.uint32)
 
 
+def make_local_edges(rng, n_cams, n_edges, window, shuffle=True):
+    """A spatially coherent view graph with arbitrary ids: in a hidden ordering every camera is linked to its successor
+    and to random cameras at most window/2 places away; the ids are then shuffled (shuffle=True), which is how real
+    datasets arrive.  Returns (edge_i, edge_j) with edge_i < edge_j."""
+    chain_i = np.arange(0, n_cams - 1, dtype=np.int64)
+    need = n_edges - (n_cams - 1)
+    keys = np.empty(0, dtype=np.int64)
+    while keys.size < need:
+        m = int((need - keys.size) * 1.3) + 16
+        a = rng.integers(0, n_cams, m)
+        b = a + rng.integers(2, max(3, window // 2 + 1), m)
+        ok = b < n_cams
+        keys = np.unique(np.concatenate([keys, a[ok] * n_cams + b[ok]]))
+        if keys.size > need:
+            keys = rng.permutation(keys)[:need]
+    keys = np.concatenate([chain_i * n_cams + chain_i + 1, np.sort(keys)])
+    i, j = keys // n_cams, keys % n_cams
+    if shuffle:
+        sigma = rng.permutation(n_cams)
+        i, j = sigma[i], sigma[j]
+    return np.minimum(i, j).astype(np.uint32), np.maximum(i, j).astype(np.uint32)
+
+
 def make_graph(n_cams, n_edges, seed, outlier_frac=0.0, scale=0.2, full_so3=False,
-               sigma_deg=(0.2, 2.0), kappa=3e-4, init_noise_deg=2.0, noise=True):
+               sigma_deg=(0.2, 2.0), kappa=3e-4, init_noise_deg=2.0, noise=True, local_window=0):
     """Returns dict(n_cams, edge_i, edge_j, rel_aa, cov6, inlier_weight, gt_aa, init_aa, is_outlier).
 
     Inlier measurement R_ij = Exp(n) R_j R_i^T with n ~ N(0, Sigma_ij), Sigma_ij = A diag(s^2) A^T,
@@ -94,7 +117,7 @@ def make_graph(n_cams, n_edges, seed, outlier_frac=0.0, scale=0.2, full_so3=Fals
     else:
         gt_aa = scale * rng.uniform(-1.0, 1.0, (n_cams, 3))
     q_gt = aa_to_quat(gt_aa)
-    ei, ej = make_edges(rng, n_cams, n_edges)
+    ei, ej = make_local_edges(rng, n_cams, n_edges, local_window) if local_window else make_edges(rng, n_cams, n_edges)
     E = ei.shape[0]
     q_rel = quat_mul(q_gt[ej], quat_conj(q_gt[ei]))
     lo, hi = np.log(np.deg2rad(sigma_deg[0])), np.log(np.deg2rad(sigma_deg[1]))
@@ -106,7 +129,7 @@ def make_graph(n_cams, n_edges, seed, outlier_frac=0.0, scale=0.2, full_so3=Fals
         q_rel = quat_mul(aa_to_quat(n), q_rel)
     is_out = np.zeros(E, dtype=bool)
     if outlier_frac > 0:
-        cand = np.arange(n_cams - 1, E)
+        cand = np.arange(n_cams - 1, E)   # (with local_window the chain is not a prefix of the shuffled list: any edge may be hit)
         k = int(round(outlier_frac * E))
         pick = rng.choice(cand, size=min(k, cand.size), replace=False)
         is_out[pick] = True

@@ -237,3 +237,47 @@ def test_non_finite_inputs_fail_like_ceres_without_touching_the_rotations(oracle
             assert s["termination_name"] == "FAILURE" and s["num_iterations"] == 0
             finite = np.isfinite(start)
             assert np.array_equal(r[finite], start[finite])
+
+
+def test_locality_relabelling_is_invisible_at_the_boundary(oracle, monkeypatch):
+    """GSFM_REORDER=1 forces the reverse Cuthill-McKee relabelling of the cameras at create; every per-camera array crossing the
+    C-ABI (rotations in/out, gradient, diagonal blocks, mat-vec operands) must still be in the caller's numbering."""
+    from globalsfmpy_amd.solver import RotationProblem
+    g = synth.make_graph(3000, 60000, 41, outlier_frac=0.2, local_window=300)        # coherent graph, shuffled ids
+    loss = LF.MAGSACWeightBasedLoss(0.02)
+    ora = oracle.OracleProblem(g["n_cams"], g["edge_i"], g["edge_j"], g["rel_aa"], _abi.ANGLE_AXIS_COVARIANCE, cov6=g["cov6"]); ora.set_loss(loss)
+    monkeypatch.setenv("GSFM_REORDER", "0")
+    plain = RotationProblem(g["n_cams"], g["edge_i"], g["edge_j"], g["rel_aa"], _abi.ANGLE_AXIS_COVARIANCE, cov6=g["cov6"]); plain.set_loss(loss)
+    monkeypatch.setenv("GSFM_REORDER", "1")
+    dev = RotationProblem(g["n_cams"], g["edge_i"], g["edge_j"], g["rel_aa"], _abi.ANGLE_AXIS_COVARIANCE, cov6=g["cov6"]); dev.set_loss(loss)
+    x = g["init_aa"]
+    d, o = dev.residuals(x), ora.residuals(x)
+    assert np.abs(d["s"] - o["s"]).max() < 1e-11 * max(1.0, np.abs(o["s"]).max())
+    ld, lo = dev.linearize(x), ora.linearize(x)
+    assert np.abs(ld["gradient"] - lo["gradient"]).max() < 1e-9 * np.abs(lo["gradient"]).max()
+    assert np.abs(ld["diag_blocks"] - lo["diag_blocks"]).max() < 1e-9 * np.abs(lo["diag_blocks"]).max()
+    v = np.random.default_rng(0).standard_normal((g["n_cams"], 3))
+    plain.linearize(x)
+    assert np.abs(dev.normal_matvec(v) - plain.normal_matvec(v)).max() < 1e-9 * np.abs(plain.normal_matvec(v)).max()
+    r1, s1 = dev.solve(x)
+    r0, s0 = plain.solve(x)
+    assert s1["num_iterations"] == s0["num_iterations"] and abs(s1["final_cost"] - s0["final_cost"]) < 1e-9 * s0["final_cost"]
+    assert synth.angular_distance(r1, r0).max() < 1e-9          # same numbering, same solution
+
+
+def test_locality_relabelling_is_adopted_only_when_it_helps(monkeypatch):
+    from globalsfmpy_amd.solver import RotationProblem
+    monkeypatch.delenv("GSFM_REORDER", raising=False)
+    out = {}
+    for name, win in (("local", 300), ("random", 0)):
+        g = synth.make_graph(6000, 120000, 43, outlier_frac=0.2, local_window=win)
+        p = RotationProblem(g["n_cams"], g["edge_i"], g["edge_j"], g["rel_aa"], _abi.ANGLE_AXIS); p.set_loss(LF.HuberLoss(0.1))
+        monkeypatch.setenv("GSFM_REORDER", "0")
+        q = RotationProblem(g["n_cams"], g["edge_i"], g["edge_j"], g["rel_aa"], _abi.ANGLE_AXIS); q.set_loss(LF.HuberLoss(0.1))
+        monkeypatch.delenv("GSFM_REORDER")
+        (ra, sa), (rb, sb) = p.solve(g["init_aa"]), q.solve(g["init_aa"])
+        out[name] = bool(np.array_equal(ra, rb))
+        assert synth.angular_distance(ra, rb).max() < 1e-9
+    # a uniformly random graph has nothing to recover: the auto mode leaves it alone (bit-identical to GSFM_REORDER=0);
+    # the coherent graph is relabelled, which reorders the row sums (same solution, different last bits)
+    assert out["random"] and not out["local"]

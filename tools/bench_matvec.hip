@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <vector>
 #include <random>
 #define CHK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
@@ -142,7 +143,13 @@ int main(int argc, char** argv) {
   std::vector<unsigned> rp(N + 1), col(nd);
   std::mt19937 rng(1);
   for (unsigned r = 0; r <= N; ++r) rp[r] = r * DEG;
-  for (size_t d = 0; d < nd; ++d) col[d] = rng() % N;
+  // argv[3] = locality window W (0 = uniform random columns): neighbours of row r drawn from [r - W/2, r + W/2], sorted
+  const unsigned WIN = argc > 3 ? atoi(argv[3]) : 0;
+  for (unsigned r = 0; r < N; ++r) {
+    for (unsigned k = 0; k < DEG; ++k) col[(size_t)r * DEG + k] = WIN ? (unsigned)((r + N + (rng() % WIN) - WIN / 2) % N) : rng() % N;
+    if (WIN) std::sort(col.begin() + (size_t)r * DEG, col.begin() + (size_t)(r + 1) * DEG);
+  }
+  printf("columns: %s (window %u)\n", WIN ? "local" : "uniform random", WIN);
   unsigned *d_rp, *d_col; double2 *h0, *h1, *h2, *h3; double *h4, *p, *y; double4* p4; Rec* rec;
   CHK(hipMalloc(&d_rp, 4 * (N + 1))); CHK(hipMalloc(&d_col, 4 * nd));
   CHK(hipMalloc(&h0, 16 * nd)); CHK(hipMalloc(&h1, 16 * nd)); CHK(hipMalloc(&h2, 16 * nd)); CHK(hipMalloc(&h3, 16 * nd)); CHK(hipMalloc(&h4, 8 * nd));
