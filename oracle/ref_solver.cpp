@@ -66,9 +66,14 @@ struct orc_problem {
   std::vector<double> rt;      // corrected residuals, res_dim per edge
   std::vector<double> Ji, Jj;  // corrected local jacobians, res_dim x 3 per edge (row-major)
   std::vector<double> trace;   // rows of ORC_TRACE_COLS
+  // camera -> incident edges (edge id | role << 31, role 1 = the camera is `second`), in increasing edge order: the
+  // per-camera sums below visit the same terms in the same order as a serial loop over the edges, but in parallel
+  std::vector<uint32_t> inc_ptr, inc;
 };
 
 namespace {
+
+void ensure_incidence(const orc_problem* cp);
 
 // ---- whitening, src/GSfM_nonlinear_rotation_estimator.cpp:251-288 ----
 void inverse3_cofactor(const double* m, double* inv) {  // Eigen fixed-size 3x3 inverse: cofactors / det
@@ -246,33 +251,55 @@ double evaluate(orc_problem* p, const double* x, bool with_jacobian, double* gra
     }
   }
   if (with_jacobian && gradient) {
-    std::fill(gradient, gradient + 3 * (size_t)p->n_cams, 0.0);
-    for (size_t e = 0; e < E; ++e) {
-      const Edge& ed = p->edges[e];
-      for (int c = 0; c < 3; ++c) {
-        double gi = 0, gj = 0;
-        for (int k = 0; k < R; ++k) { gi += p->Ji[(e * R + k) * 3 + c] * p->rt[e * R + k]; gj += p->Jj[(e * R + k) * 3 + c] * p->rt[e * R + k]; }
-        gradient[3 * ed.i + c] += gi; gradient[3 * ed.j + c] += gj;
+    ensure_incidence(p);
+#pragma omp parallel for schedule(dynamic, 64) if (E > 50000)
+    for (long cam = 0; cam < (long)p->n_cams; ++cam) {
+      double g[3] = {0, 0, 0};
+      for (uint32_t d = p->inc_ptr[cam]; d < p->inc_ptr[cam + 1]; ++d) {
+        const size_t e = p->inc[d] & 0x7fffffffu;
+        const double* J = (p->inc[d] >> 31) ? &p->Jj[e * R * 3] : &p->Ji[e * R * 3];
+        for (int c = 0; c < 3; ++c) {
+          double a = 0;
+          for (int k = 0; k < R; ++k) a += J[3 * k + c] * p->rt[e * R + k];
+          g[c] += a;
+        }
       }
+      gradient[3 * cam] = g[0]; gradient[3 * cam + 1] = g[1]; gradient[3 * cam + 2] = g[2];
     }
   }
   return (double)cost;
 }
 
+void ensure_incidence(const orc_problem* cp) {
+  orc_problem* p = const_cast<orc_problem*>(cp);
+  if (!p->inc_ptr.empty()) return;
+  const size_t N = p->n_cams, E = p->edges.size();
+  p->inc_ptr.assign(N + 1, 0);
+  for (size_t e = 0; e < E; ++e) { p->inc_ptr[p->edges[e].i + 1]++; p->inc_ptr[p->edges[e].j + 1]++; }
+  for (size_t c = 0; c < N; ++c) p->inc_ptr[c + 1] += p->inc_ptr[c];
+  p->inc.resize(2 * E);
+  std::vector<uint32_t> fill(p->inc_ptr.begin(), p->inc_ptr.end() - 1);
+  for (size_t e = 0; e < E; ++e) { p->inc[fill[p->edges[e].i]++] = (uint32_t)e; p->inc[fill[p->edges[e].j]++] = (uint32_t)e | 0x80000000u; }
+}
+
 void squared_column_norm(const orc_problem* p, double* d) {
   const int R = p->res_dim;
-  std::fill(d, d + 3 * (size_t)p->n_cams, 0.0);
-  for (size_t e = 0; e < p->edges.size(); ++e) {
-    const Edge& ed = p->edges[e];
-    for (int k = 0; k < R; ++k) for (int c = 0; c < 3; ++c) {
-      const double a = p->Ji[(e * R + k) * 3 + c], b = p->Jj[(e * R + k) * 3 + c];
-      d[3 * ed.i + c] += a * a; d[3 * ed.j + c] += b * b;
+  ensure_incidence(p);
+#pragma omp parallel for schedule(dynamic, 64) if (p->edges.size() > 50000)
+  for (long cam = 0; cam < (long)p->n_cams; ++cam) {
+    double acc[3] = {0, 0, 0};
+    for (uint32_t q = p->inc_ptr[cam]; q < p->inc_ptr[cam + 1]; ++q) {
+      const size_t e = p->inc[q] & 0x7fffffffu;
+      const double* J = (p->inc[q] >> 31) ? &p->Jj[e * R * 3] : &p->Ji[e * R * 3];
+      for (int k = 0; k < R; ++k) for (int c = 0; c < 3; ++c) acc[c] += J[3 * k + c] * J[3 * k + c];
     }
+    d[3 * cam] = acc[0]; d[3 * cam + 1] = acc[1]; d[3 * cam + 2] = acc[2];
   }
 }
 void scale_columns(orc_problem* p, const double* scale) {
   const int R = p->res_dim;
-  for (size_t e = 0; e < p->edges.size(); ++e) {
+#pragma omp parallel for schedule(static) if (p->edges.size() > 50000)
+  for (long e = 0; e < (long)p->edges.size(); ++e) {
     const Edge& ed = p->edges[e];
     for (int k = 0; k < R; ++k) for (int c = 0; c < 3; ++c) {
       p->Ji[(e * R + k) * 3 + c] *= scale[3 * ed.i + c];
@@ -283,7 +310,7 @@ void scale_columns(orc_problem* p, const double* scale) {
 // y = J v (per edge, res_dim), then optionally z = J^T y
 void J_times(const orc_problem* p, const double* v, double* y) {
   const int R = p->res_dim;
-#pragma omp parallel for schedule(static) if (p->edges.size() > 200000)
+#pragma omp parallel for schedule(static) if (p->edges.size() > 50000)
   for (long e = 0; e < (long)p->edges.size(); ++e) {
     const Edge& ed = p->edges[e];
     for (int k = 0; k < R; ++k) {
@@ -295,14 +322,20 @@ void J_times(const orc_problem* p, const double* v, double* y) {
 }
 void Jt_times(const orc_problem* p, const double* y, double* z) {
   const int R = p->res_dim;
-  std::fill(z, z + 3 * (size_t)p->n_cams, 0.0);
-  for (size_t e = 0; e < p->edges.size(); ++e) {
-    const Edge& ed = p->edges[e];
-    for (int c = 0; c < 3; ++c) {
-      double a = 0, b = 0;
-      for (int k = 0; k < R; ++k) { a += p->Ji[(e * R + k) * 3 + c] * y[e * R + k]; b += p->Jj[(e * R + k) * 3 + c] * y[e * R + k]; }
-      z[3 * ed.i + c] += a; z[3 * ed.j + c] += b;
+  ensure_incidence(p);
+#pragma omp parallel for schedule(dynamic, 64) if (p->edges.size() > 50000)
+  for (long cam = 0; cam < (long)p->n_cams; ++cam) {
+    double acc[3] = {0, 0, 0};
+    for (uint32_t q = p->inc_ptr[cam]; q < p->inc_ptr[cam + 1]; ++q) {
+      const size_t e = p->inc[q] & 0x7fffffffu;
+      const double* J = (p->inc[q] >> 31) ? &p->Jj[e * R * 3] : &p->Ji[e * R * 3];
+      for (int c = 0; c < 3; ++c) {
+        double a = 0;
+        for (int k = 0; k < R; ++k) a += J[3 * k + c] * y[e * R + k];
+        acc[c] += a;
+      }
     }
+    z[3 * cam] = acc[0]; z[3 * cam + 1] = acc[1]; z[3 * cam + 2] = acc[2];
   }
 }
 
@@ -344,13 +377,17 @@ bool solve_pcg(const orc_problem* p, const double* D, const double* rhs, double*
   const int R = p->res_dim;
   const size_t N = p->n_cams, n = 3 * N, E = p->edges.size();
   std::vector<double> M(9 * N, 0.0), Minv(9 * N), r(rhs, rhs + n), z(n), pv(n), Ap(n), tmp(E * R);
-  for (size_t e = 0; e < E; ++e) {
-    const Edge& ed = p->edges[e];
-    const double* Ji = &p->Ji[e * R * 3]; const double* Jj = &p->Jj[e * R * 3];
-    for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) {
-      double ii = 0, jj = 0;
-      for (int k = 0; k < R; ++k) { ii += Ji[3 * k + a] * Ji[3 * k + b]; jj += Jj[3 * k + a] * Jj[3 * k + b]; }
-      M[9 * ed.i + 3 * a + b] += ii; M[9 * ed.j + 3 * a + b] += jj;
+  ensure_incidence(p);
+#pragma omp parallel for schedule(dynamic, 64) if (E > 50000)
+  for (long cam = 0; cam < (long)N; ++cam) {
+    for (uint32_t q = p->inc_ptr[cam]; q < p->inc_ptr[cam + 1]; ++q) {
+      const size_t e = p->inc[q] & 0x7fffffffu;
+      const double* J = (p->inc[q] >> 31) ? &p->Jj[e * R * 3] : &p->Ji[e * R * 3];
+      for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) {
+        double t = 0;
+        for (int k = 0; k < R; ++k) t += J[3 * k + a] * J[3 * k + b];
+        M[9 * cam + 3 * a + b] += t;
+      }
     }
   }
   for (size_t c = 0; c < N; ++c) {
