@@ -67,13 +67,14 @@ def cpu_baseline(args, loss_ctor, error_type):
             pyoracle.lib().orc_set_num_threads(prev)
         return n_edges * s["num_residual_sweeps"] / dt, s, dt
 
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = pyoracle.usable_cores()   # affinity mask capped by the cgroup CPU quota
     rate, s, dt = timed(args.cpu_sample_cams, args.cpu_sample_edges, cores)
     out = {
         "value": rate,
         "unit": "edge-residuals/s",
         "cores": cores,
         "kind": "port",
+        "host": "%d hardware threads visible, %d usable under the cgroup CPU quota" % (os.cpu_count() or 0, cores),
         "sample": "oracle/ (C++ restatement of the reference's Ceres LM path, OpenMP over edges, PCG 1e-14): "
                   "1 full solve of a %d-camera / %d-edge graph from the same generator (same mean degree, %g outliers), "
                   "%d sweeps, %d LM iterations, %.1f s" % (args.cpu_sample_cams, args.cpu_sample_edges, args.outliers,

@@ -20,6 +20,25 @@ def build():
     subprocess.check_call(["make", "-s", "-C", _HERE])
 
 
+def usable_cores():
+    """CPU threads this process can actually keep busy: the affinity mask capped by the cgroup CPU quota (the GPU boxes
+    expose 256 hardware threads under a 16-CPU quota; 256 OpenMP threads on that are throttled into the ground)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]           # cgroup v2
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())                # cgroup v1
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and per > 0:
+                n = min(n, max(1, int(q / per + 0.5)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -47,6 +66,8 @@ def lib():
         L.orc_sampson_residual.restype = C.c_double
         L.orc_homogeneous_plus.argtypes = [C.POINTER(C.c_double)] * 3
         L.orc_homogeneous_jacobian.argtypes = [C.POINTER(C.c_double)] * 2
+        L.orc_set_num_threads.argtypes = [C.c_int]; L.orc_set_num_threads.restype = C.c_int
+        L.orc_set_num_threads(usable_cores())
         _lib = L
     return _lib
 
