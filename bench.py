@@ -39,10 +39,10 @@ def parse():
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
     ap.add_argument("--sweep-reps", type=int, default=20)
     ap.add_argument("--cpu-baseline", type=int, default=1)
-    ap.add_argument("--cpu-sample-cams", type=int, default=20000)
-    ap.add_argument("--cpu-sample-edges", type=int, default=2000000)
-    ap.add_argument("--cpu-single-cams", type=int, default=3000, help="1-thread CPU sample (0 = skip)")
-    ap.add_argument("--cpu-single-edges", type=int, default=300000)
+    ap.add_argument("--cpu-sample-cams", type=int, default=50000)
+    ap.add_argument("--cpu-sample-edges", type=int, default=5000000)
+    ap.add_argument("--cpu-single-cams", type=int, default=10000, help="1-thread CPU sample (0 = skip)")
+    ap.add_argument("--cpu-single-edges", type=int, default=1000000)
     ap.add_argument("--verbose", type=int, default=0)
     return ap.parse_args()
 
