@@ -586,7 +586,8 @@ int read_scalars(gsfm_rot_problem* P, double* h) {
 // relabelling is therefore adopted only if it shrinks the mean |i - j| over the edges by more than half AND brings it
 // under 1024 (neighbours within about +-2000); small problems (< 2048 cameras: everything is cache-resident) are left alone.
 // GSFM_REORDER=0 disables it, =1 forces adoption.  Returns true when `perm` (external -> internal) must be applied.
-bool reorder_for_locality(uint32_t n_cams, uint64_t n_edges, const uint32_t* ei, const uint32_t* ej, std::vector<uint32_t>* perm) {
+bool reorder_for_locality(uint32_t n_cams, uint64_t n_edges, const uint32_t* ei, const uint32_t* ej, const std::vector<uint32_t>& ptr,
+                          const std::vector<uint32_t>& adj /* neighbour | role << 31 */, std::vector<uint32_t>* perm) {
   perm->clear();
   const char* env = getenv("GSFM_REORDER");
   const int mode = env ? atoi(env) : -1;  // -1 auto, 0 off, 1 force
@@ -595,11 +596,26 @@ bool reorder_for_locality(uint32_t n_cams, uint64_t n_edges, const uint32_t* ei,
   for (uint64_t e = 0; e < n_edges; ++e) before += std::fabs((double)ei[e] - (double)ej[e]);
   before /= (double)n_edges;
   if (mode < 0 && before < 256.0) return false;  // already local (a mean index distance of 256 ~ neighbours within +-500)
-  std::vector<uint32_t> ptr((size_t)n_cams + 1, 0);
-  for (uint64_t e = 0; e < n_edges; ++e) { ptr[ei[e] + 1]++; ptr[ej[e] + 1]++; }
-  for (size_t c = 0; c < n_cams; ++c) ptr[c + 1] += ptr[c];
-  std::vector<uint32_t> adj(ptr[n_cams]), fill(ptr.begin(), ptr.end() - 1);
-  for (uint64_t e = 0; e < n_edges; ++e) { adj[fill[ei[e]]++] = ej[e]; adj[fill[ej[e]]++] = ei[e]; }
+  std::vector<uint32_t> stamp(n_cams, 0xffffffffu);
+  if (mode < 0) {
+    // cheap pre-test: in a spatially coherent graph the two-hop neighbourhood of a camera stays small; in a uniformly random
+    // one it floods the graph.  32 probes, each capped at n_cams / 8 cameras.
+    const uint32_t cap = n_cams / 8;
+    int flooded = 0;
+    for (uint32_t s = 0; s < 32; ++s) {
+      const uint32_t c0 = (uint32_t)(((uint64_t)s * n_cams) / 32);
+      uint32_t seen = 0;
+      for (uint32_t d = ptr[c0]; d < ptr[c0 + 1] && seen < cap; ++d) {
+        const uint32_t c1 = adj[d] & 0x7fffffffu;
+        for (uint32_t d2 = ptr[c1]; d2 < ptr[c1 + 1] && seen < cap; ++d2) {
+          const uint32_t c2 = adj[d2] & 0x7fffffffu;
+          if (stamp[c2] != s) { stamp[c2] = s; ++seen; }
+        }
+      }
+      flooded += seen >= cap;
+    }
+    if (flooded > 16) return false;
+  }
   std::vector<uint32_t> by_degree(n_cams);
   for (uint32_t c = 0; c < n_cams; ++c) by_degree[c] = c;
   std::stable_sort(by_degree.begin(), by_degree.end(), [&](uint32_t a, uint32_t b) { return ptr[a + 1] - ptr[a] < ptr[b + 1] - ptr[b]; });
@@ -613,7 +629,7 @@ bool reorder_for_locality(uint32_t n_cams, uint64_t n_edges, const uint32_t* ei,
     order.push_back(s0);
     while (head < order.size()) {
       const uint32_t c = order[head++];
-      for (uint32_t d = ptr[c]; d < ptr[c + 1]; ++d) if (!seen[adj[d]]) { seen[adj[d]] = 1; order.push_back(adj[d]); }
+      for (uint32_t d = ptr[c]; d < ptr[c + 1]; ++d) { const uint32_t m = adj[d] & 0x7fffffffu; if (!seen[m]) { seen[m] = 1; order.push_back(m); } }
     }
   }
   std::vector<uint32_t> p(n_cams);
@@ -775,20 +791,11 @@ struct DeviceGuard {
   ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
 };
 
-int upload_planes(gsfm_rot_problem* P, EdgePlanes& pl, const std::vector<uint32_t>& eid, const double* rel_aa) {
+int upload_planes(gsfm_rot_problem* P, EdgePlanes& pl, const std::vector<uint32_t>& eid, const double* d_rel_aa) {
   pl.n = eid.size();
-  std::vector<double2> q0(pl.n), q1(pl.n);
-  for (size_t t = 0; t < pl.n; ++t) {
-    const double* aa = rel_aa + 3 * (size_t)eid[t];
-    // ceres::AngleAxisToQuaternion (estimator.cpp:132): measured R_ij as a unit quaternion
-    const double t2 = aa[0] * aa[0] + aa[1] * aa[1] + aa[2] * aa[2];
-    double w, k;
-    if (t2 > 0.0) { const double th = std::sqrt(t2); k = std::sin(0.5 * th) / th; w = std::cos(0.5 * th); }
-    else { k = 0.5; w = 1.0; }
-    q0[t] = make_double2(aa[0] * k, aa[1] * k); q1[t] = make_double2(aa[2] * k, w);
-  }
-  if (pl.eid.upload(eid) != hipSuccess || pl.qr0.upload(q0) != hipSuccess || pl.qr1.upload(q1) != hipSuccess)
+  if (pl.eid.upload(eid) != hipSuccess || pl.qr0.alloc(pl.n) != hipSuccess || pl.qr1.alloc(pl.n) != hipSuccess)
     return fail(GSFM_ERR_HIP, "uploading edge planes failed (out of memory?)");
+  if (pl.n) hipLaunchKernelGGL(k_build_qrel, dim3(grid_for(pl.n)), dim3(GSFM_BLOCK), 0, P->stream, d_rel_aa, pl.eid.p, pl.n, pl.qr0.p, pl.qr1.p);
   if (P->wmode == W_MATRIX) {
     if (pl.w0.alloc(pl.n) != hipSuccess || pl.w1.alloc(pl.n) != hipSuccess || pl.w2.alloc(pl.n) != hipSuccess) return fail(GSFM_ERR_HIP, "alloc whitening planes");
   } else if (P->wmode == W_SCALAR) {
@@ -841,6 +848,9 @@ gsfm_status gsfm_rot_problem_create(uint32_t n_cams, uint64_t n_edges, const uin
 
   gsfm_rot_problem* P = new gsfm_rot_problem;
   auto bail = [&](int st) { gsfm_rot_problem_destroy(P); return (gsfm_status)st; };
+  const bool lap_on = getenv("GSFM_CREATE_TIMING") != nullptr;   // phase times of this function on stderr
+  double lap_t = now_ms();
+  auto lap = [&](const char* what) { if (lap_on) { const double t = now_ms(); fprintf(stderr, "gsfm create: %-28s %8.1f ms\n", what, t - lap_t); lap_t = t; } };
   (void)hipGetDevice(&P->device);
   P->n_cams = n_cams; P->n_edges_in = n_edges; P->error_type = error_type;
   P->functor = error_type == GSFM_ROT_QUATERNION_COSINE ? F_QCOS : error_type == GSFM_ROT_QUATERNION_NORM ? F_QNORM
@@ -865,42 +875,45 @@ gsfm_status gsfm_rot_problem_create(uint32_t n_cams, uint64_t n_edges, const uin
   P->own_stream = true;
   P->timer.stream = P->stream; P->timer.init();
 
-  // ---- optional locality relabelling of the cameras (unsharded problems; see reorder_for_locality) ----
+  // ---- host-side structure: directed entries by row (counting sort), cost-owned edges ----
   const uint32_t *edge_i = edge_i_in, *edge_j = edge_j_in;
   std::vector<uint32_t> ei_perm, ej_perm;
-  for (uint64_t e = 0; e < n_edges; ++e)
-    if (edge_i[e] >= n_cams || edge_j[e] >= n_cams || edge_i[e] == edge_j[e]) return bail(fail(GSFM_ERR_INVALID_ARG, "edge with an out-of-range or repeated camera index"));
-  if (!P->sharded && reorder_for_locality(n_cams, n_edges, edge_i, edge_j, &P->perm)) {
+  const uint32_t ob = P->own_begin, oe = P->own_end;
+  auto owned = [&](uint32_t c) { return c >= ob && c < oe; };
+  std::vector<uint32_t> rp, cost_eid, col, deid;
+  auto build_rows = [&]() -> int {
+    rp.assign((size_t)P->n_rows + 1, 0);
+    cost_eid.clear();
+    cost_eid.reserve(P->sharded ? n_edges / 2 + 16 : n_edges);
+    for (uint64_t e = 0; e < n_edges; ++e) {
+      const uint32_t i = edge_i[e], j = edge_j[e];
+      if (i >= n_cams || j >= n_cams || i == j) return fail(GSFM_ERR_INVALID_ARG, "edge with an out-of-range or repeated camera index");
+      if (owned(i)) rp[i - ob + 1]++;
+      if (owned(j)) rp[j - ob + 1]++;
+      // each edge is cost-owned by exactly one rank: the owner of `first` if (i + j) is even, else of `second`
+      const uint32_t c = (((i + j) & 1u) == 0u) ? i : j;
+      if (owned(c)) cost_eid.push_back((uint32_t)e);
+      else if (!owned(i) && !owned(j)) return fail(GSFM_ERR_INVALID_ARG, "sharded problem: edge touches no owned camera");
+    }
+    for (size_t r = 0; r < P->n_rows; ++r) rp[r + 1] += rp[r];
+    col.resize(rp[P->n_rows]); deid.resize(rp[P->n_rows]);
+    std::vector<uint32_t> fill(rp.begin(), rp.end() - 1);
+    for (uint64_t e = 0; e < n_edges; ++e) {
+      const uint32_t i = edge_i[e], j = edge_j[e];
+      if (owned(i)) { const uint32_t d = fill[i - ob]++; col[d] = j; deid[d] = (uint32_t)e; }
+      if (owned(j)) { const uint32_t d = fill[j - ob]++; col[d] = i | 0x80000000u; deid[d] = (uint32_t)e; }
+    }
+    return 0;
+  };
+  if (int st = build_rows()) return bail(st);
+  lap("directed rows (CSR)");
+  // ---- optional locality relabelling of the cameras (unsharded: the rows are the full adjacency; see reorder_for_locality) ----
+  if (!P->sharded && reorder_for_locality(n_cams, n_edges, edge_i, edge_j, rp, col, &P->perm)) {
     ei_perm.resize(n_edges); ej_perm.resize(n_edges);
     for (uint64_t e = 0; e < n_edges; ++e) { ei_perm[e] = P->perm[edge_i[e]]; ej_perm[e] = P->perm[edge_j[e]]; }
     edge_i = ei_perm.data(); edge_j = ej_perm.data();
-  }
-
-  // ---- host-side structure: directed entries by row (counting sort), cost-owned edges ----
-  const uint32_t ob = P->own_begin, oe = P->own_end;
-  auto owned = [&](uint32_t c) { return c >= ob && c < oe; };
-  std::vector<uint32_t> rp((size_t)P->n_rows + 1, 0);
-  std::vector<uint32_t> cost_eid;
-  cost_eid.reserve(P->sharded ? n_edges / 2 + 16 : n_edges);
-  for (uint64_t e = 0; e < n_edges; ++e) {
-    const uint32_t i = edge_i[e], j = edge_j[e];
-    if (i >= n_cams || j >= n_cams || i == j) return bail(fail(GSFM_ERR_INVALID_ARG, "edge with an out-of-range or repeated camera index"));
-    if (owned(i)) rp[i - ob + 1]++;
-    if (owned(j)) rp[j - ob + 1]++;
-    // each edge is cost-owned by exactly one rank: the owner of `first` if (i + j) is even, else of `second`
-    const uint32_t c = (((i + j) & 1u) == 0u) ? i : j;
-    if (owned(c)) cost_eid.push_back((uint32_t)e);
-    else if (!owned(i) && !owned(j)) return bail(fail(GSFM_ERR_INVALID_ARG, "sharded problem: edge touches no owned camera"));
-  }
-  for (size_t r = 0; r < P->n_rows; ++r) rp[r + 1] += rp[r];
-  const size_t nd = rp[P->n_rows];
-  std::vector<uint32_t> col(nd), deid(nd), fill(rp.begin(), rp.end() - 1);
-  for (uint64_t e = 0; e < n_edges; ++e) {
-    const uint32_t i = edge_i[e], j = edge_j[e];
-    if (owned(i)) { const uint32_t d = fill[i - ob]++; col[d] = j; deid[d] = (uint32_t)e; }
-    if (owned(j)) { const uint32_t d = fill[j - ob]++; col[d] = i | 0x80000000u; deid[d] = (uint32_t)e; }
-  }
-  if (!P->perm.empty()) {  // relabelled for locality: order every row by neighbour so that adjacent lanes gather adjacent cameras
+    if (int st = build_rows()) return bail(st);
+    // order every row by neighbour so that adjacent lanes gather adjacent cameras
     std::vector<std::pair<uint32_t, uint32_t>> row;
     for (size_t r = 0; r < P->n_rows; ++r) {
       row.clear();
@@ -912,6 +925,8 @@ gsfm_status gsfm_rot_problem_create(uint32_t n_cams, uint64_t n_edges, const uin
       for (uint32_t d = rp[r]; d < rp[r + 1]; ++d) { col[d] = row[d - rp[r]].first; deid[d] = row[d - rp[r]].second; }
     }
   }
+  lap("locality relabelling");
+  const size_t nd = rp[P->n_rows];
   {
     const double mean_deg = P->n_rows ? (double)nd / P->n_rows : 0.0;
     P->G = mean_deg >= 96 ? 64 : mean_deg >= 48 ? 32 : mean_deg >= 24 ? 16 : mean_deg >= 12 ? 8 : 4;
@@ -973,15 +988,23 @@ gsfm_status gsfm_rot_problem_create(uint32_t n_cams, uint64_t n_edges, const uin
     cidx[t] = P->cost_direct ? make_uint2(edge_i[cost_eid[t]], edge_j[cost_eid[t]]) : make_uint2(edge_i[cost_eid[t]] % idx_mod, edge_j[cost_eid[t]] % idx_mod);
   P->h_cost_eid = cost_eid;
 
+  lap("cost tiles");
   // ---- uploads ----
-  if (int st = upload_planes(P, P->cost, cost_eid, rel_aa)) return bail(st);
-  if (int st = upload_planes(P, P->dir, deid, rel_aa)) return bail(st);
+  {
+    DevBuf<double> d_rel;   // the measurements go up once; both sets of planes are gathered from them on the device
+    if (d_rel.alloc(3 * n_edges) != hipSuccess || hipMemcpy(d_rel.p, rel_aa, 24 * n_edges, hipMemcpyHostToDevice) != hipSuccess)
+      return bail(fail(GSFM_ERR_HIP, "uploading the relative rotations failed"));
+    if (int st = upload_planes(P, P->cost, cost_eid, d_rel.p)) return bail(st);
+    if (int st = upload_planes(P, P->dir, deid, d_rel.p)) return bail(st);
+    if (hipStreamSynchronize(P->stream) != hipSuccess) return bail(fail(GSFM_ERR_HIP, "building the measurement planes failed"));
+  }
   if (P->cost_tiles.upload(tiles) != hipSuccess) return bail(fail(GSFM_ERR_HIP, "uploading cost tiles failed"));
   P->nb_cost = (int)tiles.size();
   if (P->cost_idx.upload(cidx) != hipSuccess || P->row_ptr.upload(rp) != hipSuccess || P->col.upload(col) != hipSuccess)
     return bail(fail(GSFM_ERR_HIP, "uploading graph structure failed"));
   if (P->h0.alloc(nd) != hipSuccess || P->h1.alloc(nd) != hipSuccess || P->h2.alloc(nd) != hipSuccess || P->h3.alloc(nd) != hipSuccess || P->h4.alloc(nd) != hipSuccess)
     return bail(fail(GSFM_ERR_HIP, "allocating normal-equation blocks failed"));
+  lap("edge planes -> device");
   {  // K0 whitening
     DevBuf<double> d_cov, d_inl;
     if (P->wmode != W_NONE) {
@@ -992,6 +1015,7 @@ gsfm_status gsfm_rot_problem_create(uint32_t n_cams, uint64_t n_edges, const uin
       if (hipStreamSynchronize(P->stream) != hipSuccess) return bail(fail(GSFM_ERR_HIP, "whitening kernel failed"));
     }
   }
+  lap("whitening");
   // ---- camera buffers ----
   const size_t N = n_cams, NP = P->n_pad;
   P->nb_cam = grid_for(N);
@@ -1019,6 +1043,7 @@ gsfm_status gsfm_rot_problem_create(uint32_t n_cams, uint64_t n_edges, const uin
     if (P->sharded && hipStreamSynchronize(P->stream) != hipSuccess) return bail(fail(GSFM_ERR_HIP, "active mask all-gather failed"));
   }
   if (int st = prepare_loss(P, nullptr, 0)) return bail(st);
+  lap("camera buffers");
   *out = P;
   return GSFM_OK;
 }

@@ -270,6 +270,19 @@ __device__ __forceinline__ Quat load_q(const double2* __restrict__ q2, uint32_t 
 }
 
 // ------------------------------------------------------------------------------------------
+// K0': measured relative rotations, angle-axis -> unit quaternion planes, gathered into entry order on the device
+// (ceres::AngleAxisToQuaternion, estimator.cpp:132; one upload of the 3E doubles instead of a host gather per entry)
+__global__ void __launch_bounds__(GSFM_BLOCK) k_build_qrel(const double* __restrict__ rel_aa, const uint32_t* __restrict__ eid, size_t n,
+                                                           double2* __restrict__ qr0, double2* __restrict__ qr1) {
+  const size_t t = (size_t)blockIdx.x * GSFM_BLOCK + threadIdx.x;
+  if (t >= n) return;
+  const double* aa = rel_aa + 3 * (size_t)eid[t];
+  const Quat q = aa_to_quat(aa[0], aa[1], aa[2]);
+  qr0[t] = make_double2(q.x, q.y);
+  qr1[t] = make_double2(q.z, q.w);
+}
+
+// ------------------------------------------------------------------------------------------
 // K0: whitening precompute (src/GSfM_nonlinear_rotation_estimator.cpp:251-288), once per problem
 // ------------------------------------------------------------------------------------------
 struct WhitenArgs {
