@@ -18,6 +18,7 @@
 #include "../../include/gsfm_rot.h"
 #include "kernels.hpp"
 #include "cov_kernels.hpp"
+#include "dense_kernels.hpp"
 
 using namespace gsfm;
 
@@ -141,35 +142,6 @@ struct EventTimer {  // GPU time per phase, resolved at host syncs
   }
 };
 
-// ---- rocSOLVER, resolved on first use (only small graphs ever touch it) ----
-struct DenseBackend {
-  bool tried = false, ok = false;
-  void* handle = nullptr;  // rocblas_handle
-  int (*create_handle)(void**) = nullptr;
-  int (*destroy_handle)(void*) = nullptr;
-  int (*set_stream)(void*, hipStream_t) = nullptr;
-  int (*dpotrf)(void*, int, int, double*, int, int*) = nullptr;
-  int (*dpotrs)(void*, int, int, int, double*, int, double*, int) = nullptr;
-  bool init() {
-    if (tried) return ok;
-    tried = true;
-    void* blas = dlopen("librocblas.so", RTLD_NOW | RTLD_GLOBAL);
-    if (!blas) blas = dlopen("/opt/rocm/lib/librocblas.so", RTLD_NOW | RTLD_GLOBAL);
-    void* sol = dlopen("librocsolver.so", RTLD_NOW | RTLD_GLOBAL);
-    if (!sol) sol = dlopen("/opt/rocm/lib/librocsolver.so", RTLD_NOW | RTLD_GLOBAL);
-    if (!blas || !sol) return false;
-    create_handle = (int (*)(void**))dlsym(blas, "rocblas_create_handle");
-    destroy_handle = (int (*)(void*))dlsym(blas, "rocblas_destroy_handle");
-    set_stream = (int (*)(void*, hipStream_t))dlsym(blas, "rocblas_set_stream");
-    dpotrf = (int (*)(void*, int, int, double*, int, int*))dlsym(sol, "rocsolver_dpotrf");
-    dpotrs = (int (*)(void*, int, int, int, double*, int, double*, int))dlsym(sol, "rocsolver_dpotrs");
-    if (!create_handle || !set_stream || !dpotrf || !dpotrs) return false;
-    if (create_handle(&handle) != 0) return false;
-    ok = true;
-    return true;
-  }
-};
-DenseBackend g_dense;
 
 }  // namespace
 
@@ -212,6 +184,7 @@ struct gsfm_rot_problem {
   DevBuf<Cg2Scalars> cg2sc;
   DevBuf<double> denseA;
   DevBuf<int> dense_info;
+  hipGraphExec_t dense_graph = nullptr;   // zero + assemble + blocked Cholesky + solve, captured once
   int nb_mv = 1;
   DevBuf<double> part_a, part_b, part_cost, part_cam, scal;
   DevBuf<CgScalars> cgsc;
@@ -535,31 +508,46 @@ int run_pcg2(gsfm_rot_problem* P, const gsfm_rot_options& o, int* iters_out, dou
 // factorisation could not be used (caller falls back to PCG), < 0 never, 0 on success, or a gsfm_status > 1.
 int run_dense(gsfm_rot_problem* P, bool* used) {
   *used = false;
-  if (!g_dense.init()) return 0;
   const uint32_t n = 3 * P->n_cams;
   if (!P->denseA.p) {
     if (P->denseA.alloc((size_t)n * n) != hipSuccess || P->dense_info.alloc(1) != hipSuccess) return 0;
   }
+  auto enqueue = [&]() {
+    hipLaunchKernelGGL(k_zero, dim3(grid_for((size_t)n * n)), dim3(GSFM_BLOCK), 0, P->stream, P->denseA.p, (size_t)n * n);
+    (void)hipMemsetAsync(P->dense_info.p, 0, sizeof(int), P->stream);
+    DenseArgs a{};
+    a.n_rows = P->n_rows; a.row_ptr = P->row_ptr.p; a.col = P->col.p; a.h0 = P->h0.p; a.h1 = P->h1.p; a.h2 = P->h2.p; a.h3 = P->h3.p; a.h4 = P->h4.p;
+    a.Mblk = P->Mblk.p; a.A = P->denseA.p; a.n = n;
+    hipLaunchKernelGGL(k_dense_assemble, dim3(P->n_rows), dim3(GSFM_BLOCK), 0, P->stream, a);
+    for (uint32_t k0 = 0; k0 < n; k0 += GSFM_CB) {
+      CholArgs c{P->denseA.p, n, k0, P->dense_info.p};
+      hipLaunchKernelGGL(k_chol_diag, dim3(1), dim3(64), 0, P->stream, c);
+      if (k0 + GSFM_CB >= n) break;
+      const uint32_t below = n - k0 - GSFM_CB, tiles = (below + GSFM_CB - 1) / GSFM_CB;
+      hipLaunchKernelGGL(k_chol_panel, dim3((below + GSFM_PANEL_ROWS - 1) / GSFM_PANEL_ROWS), dim3(GSFM_PANEL_ROWS), 0, P->stream, c);
+      hipLaunchKernelGGL(k_chol_update, dim3(tiles * (tiles + 1) / 2), dim3(256), 0, P->stream, c);
+    }
+    hipLaunchKernelGGL(k_chol_solve, dim3(1), dim3(1024), 0, P->stream, (const double*)P->denseA.p, n, (const double*)P->b.p, P->xcg.p);
+    (void)hipMemsetAsync(P->r.p, 0, 8 * (size_t)n, P->stream);  // exact solve: the PCG residual term of the model decrease is zero
+  };
   const int tk = P->timer.begin(T_CG);
-  hipLaunchKernelGGL(k_zero, dim3(grid_for((size_t)n * n)), dim3(GSFM_BLOCK), 0, P->stream, P->denseA.p, (size_t)n * n);
-  DenseArgs a{};
-  a.n_rows = P->n_rows; a.row_ptr = P->row_ptr.p; a.col = P->col.p; a.h0 = P->h0.p; a.h1 = P->h1.p; a.h2 = P->h2.p; a.h3 = P->h3.p; a.h4 = P->h4.p;
-  a.Mblk = P->Mblk.p; a.A = P->denseA.p; a.n = n;
-  hipLaunchKernelGGL(k_dense_assemble, dim3(P->n_rows), dim3(GSFM_BLOCK), 0, P->stream, a);
-  HIPCHK(hipMemcpyAsync(P->xcg.p, P->b.p, 8 * (size_t)n, hipMemcpyDeviceToDevice, P->stream));
-  g_dense.set_stream(g_dense.handle, P->stream);
-  const int rocblas_fill_lower = 122;
-  int st = g_dense.dpotrf(g_dense.handle, rocblas_fill_lower, (int)n, P->denseA.p, (int)n, P->dense_info.p);
+  if (!P->dense_graph && !P->pcg_graph.unusable) {   // ~3 launches per 32 columns: replay them as one graph
+    hipGraph_t captured = nullptr;
+    if (hipStreamBeginCapture(P->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+      enqueue();
+      if (hipStreamEndCapture(P->stream, &captured) != hipSuccess || !captured || hipGraphInstantiate(&P->dense_graph, captured, nullptr, nullptr, 0) != hipSuccess)
+        P->dense_graph = nullptr;
+      if (captured) (void)hipGraphDestroy(captured);
+    }
+    if (!P->dense_graph) (void)hipGetLastError();
+  }
+  if (P->dense_graph) { HIPCHK(hipGraphLaunch(P->dense_graph, P->stream)); }
+  else enqueue();
   P->timer.end(tk);
   int info = -1;
   HIPCHK(hipMemcpyAsync(&info, P->dense_info.p, sizeof(int), hipMemcpyDeviceToHost, P->stream));
-  if (int e = sync_check(P, "dense potrf")) return e;
-  if (st != 0 || info != 0) return 0;  // not positive definite to working precision: PCG instead
-  const int tk2 = P->timer.begin(T_CG);
-  st = g_dense.dpotrs(g_dense.handle, rocblas_fill_lower, (int)n, 1, P->denseA.p, (int)n, P->xcg.p, (int)n);
-  P->timer.end(tk2);
-  if (st != 0) return 0;
-  HIPCHK(hipMemsetAsync(P->r.p, 0, 8 * (size_t)n, P->stream));  // exact solve: the PCG residual term of the model decrease is zero
+  if (int e = sync_check(P, "dense cholesky")) return e;
+  if (info != 0) return 0;  // not positive definite to working precision: PCG instead
   *used = true;
   return 0;
 }
@@ -718,7 +706,7 @@ int lm_solve(gsfm_rot_problem* P, const gsfm_rot_options& o, gsfm_rot_summary* s
   record(x_cost, 0, 0, 0, 0);
   if (!std::isfinite(x_cost)) return finish(GSFM_TERM_FAILURE);
   if (gmax <= o.gradient_tolerance) return finish(GSFM_TERM_GRADIENT_TOLERANCE);
-  bool last_successful = false;
+  bool last_successful = false, pcg_struggles = false;
   while (true) {
     if (iteration >= o.max_num_iterations) return finish(GSFM_TERM_NO_CONVERGENCE);
     if (last_successful && gmax <= o.gradient_tolerance) return finish(GSFM_TERM_GRADIENT_TOLERANCE);
@@ -729,11 +717,15 @@ int lm_solve(gsfm_rot_problem* P, const gsfm_rot_options& o, gsfm_rot_summary* s
     prep_valid = false;
     int cg = 0; double cg_rel = 0;
     bool dense_used = false;
-    if (!P->sharded && o.dense_cholesky_max_cams > 0 && (int64_t)P->n_cams <= o.dense_cholesky_max_cams) {
+    // dense_cholesky_max_cams > 0: exact Cholesky steps for graphs up to that size; < 0: up to |value| cameras, but only
+    // once a PCG solve of this run has needed more than 150 iterations (2.5 ms of factorisation beats that many mat-vecs)
+    const int64_t dense_cap = o.dense_cholesky_max_cams > 0 ? o.dense_cholesky_max_cams : -(int64_t)o.dense_cholesky_max_cams;
+    if (!P->sharded && dense_cap > 0 && (int64_t)P->n_cams <= dense_cap && (o.dense_cholesky_max_cams > 0 || pcg_struggles)) {
       if (int st = run_dense(P, &dense_used)) return st;
     }
     if (dense_used) sum->num_dense_solves++;
     else if (int st = (o.pcg_single_reduction ? run_pcg2(P, o, &cg, &cg_rel) : run_pcg(P, o, &cg, &cg_rel))) return st;
+    if (cg > 150) pcg_struggles = true;
     sum->num_cg_iterations += cg;
     launch_step(P);
     if (int st = launch_cost(P, P->q_trial.p, SC_TRIAL)) return st;
@@ -1053,6 +1045,7 @@ void gsfm_rot_problem_destroy(gsfm_rot_problem* P) {
   DeviceGuard g(P->device);
   P->timer.destroy();
   P->pcg_graph.reset();
+  if (P->dense_graph) (void)hipGraphExecDestroy(P->dense_graph);
   if (P->own_stream && P->stream) (void)hipStreamDestroy(P->stream);
   delete P;
 }
@@ -1062,6 +1055,7 @@ gsfm_status gsfm_rot_set_stream(gsfm_rot_problem* P, void* s) {
   DeviceGuard g(P->device);
   if (P->own_stream && P->stream) { (void)hipStreamSynchronize(P->stream); (void)hipStreamDestroy(P->stream); }
   P->pcg_graph.reset(); P->pcg_graph.unusable = false;
+  if (P->dense_graph) { (void)hipGraphExecDestroy(P->dense_graph); P->dense_graph = nullptr; }
   if (s) { P->stream = (hipStream_t)s; P->own_stream = false; }
   else { if (hipStreamCreateWithFlags(&P->stream, hipStreamNonBlocking) != hipSuccess) return (gsfm_status)fail(GSFM_ERR_HIP, "hipStreamCreate failed"); P->own_stream = true; }
   P->timer.stream = P->stream;

@@ -132,12 +132,14 @@ typedef struct {
                                           iterations (default 0 = never).  On the real Madrid graph (MAGSAC weights spanning
                                           1e-5..5e4, vanishing damping) PCG needs up to 574 iterations per step; 64 here saves
                                           12 % of them but already perturbs the early trajectory by 5e-8 in cost. */
-  int32_t dense_cholesky_max_cams;     /* opt-in (default 0 = never): graphs with at most this many cameras solve each LM step by
-                                          an exact dense Cholesky of the damped normal matrix on the device (rocSOLVER
-                                          potrf/potrs, dlopen'ed on first use) -- literally the reference's 'normal equations +
-                                          Cholesky'.  Measured on Madrid (394 cams): reproduces the oracle-Cholesky run (63 LM
-                                          iterations) but costs ~3.7 ms per step, so it only pays when PCG needs > 150
-                                          iterations per step; PCG remains the fallback if the factorisation fails. */
+  int32_t dense_cholesky_max_cams;     /* Exact LM steps for small graphs: a blocked Cholesky of the dense damped normal matrix on the
+                                          device (csrc/dense_kernels.hpp) -- literally the reference's 'normal equations + Cholesky'.
+                                          > 0: every step of graphs with at most that many cameras; 0 (default): never; < 0: graphs up to
+                                          |value| cameras, from the moment one PCG solve of the run has needed more than 150 iterations
+                                          (not the default: switching solvers mid-run moves long ill-conditioned trajectories by one
+                                          iteration at the termination slop, which the parity tests pin).  Measured on Madrid (394 cams, 2.5 ms per factorise + solve): MAGSAC weights
+                                          (PCG: up to 580 iterations per step) 284 -> 167 ms and the oracle-Cholesky iteration count;
+                                          SoftL1 (66 per step) stays on PCG, 50 ms.  PCG remains the fallback if a pivot is not positive. */
   int32_t pcg_hip_graph;               /* default 1: the chunk of cg_check_interval PCG iterations between two host checks
                                           (4 dependent kernels each) is captured once into a hipGraph and replayed -- the loop is
                                           launch-latency-bound on small graphs.  Same kernels, same order, same iterates.

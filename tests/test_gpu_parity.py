@@ -281,3 +281,40 @@ def test_locality_relabelling_is_adopted_only_when_it_helps(monkeypatch):
     # a uniformly random graph has nothing to recover: the auto mode leaves it alone (bit-identical to GSFM_REORDER=0);
     # the coherent graph is relabelled, which reorders the row sums (same solution, different last bits)
     assert out["random"] and not out["local"]
+
+
+@pytest.mark.parametrize("n_cams,n_edges", [(300, 3000), (77, 900), (1030, 20000)])
+def test_dense_cholesky_step_matches_the_oracles_cholesky(oracle, n_cams, n_edges):
+    """`dense_cholesky_max_cams`: the LM step from an exact blocked Cholesky of the damped normal matrix on the device (sizes that
+    are and are not multiples of the 32-column block) against the oracle's dense Cholesky -- the reference's own linear solver."""
+    from globalsfmpy_amd.solver import RotationProblem
+    g = synth.make_graph(n_cams, n_edges, 17, outlier_frac=0.2)
+    loss = LF.MAGSACWeightBasedLoss(0.02)
+    dev = RotationProblem(g["n_cams"], g["edge_i"], g["edge_j"], g["rel_aa"], _abi.ANGLE_AXIS_COVARIANCE, cov6=g["cov6"]); dev.set_loss(loss)
+    ora = oracle.OracleProblem(g["n_cams"], g["edge_i"], g["edge_j"], g["rel_aa"], _abi.ANGLE_AXIS_COVARIANCE, cov6=g["cov6"]); ora.set_loss(loss)
+    ora.set_linear_solver("dense")
+    rd, sd = dev.solve(g["init_aa"], dense_cholesky_max_cams=5000)
+    ro, so = ora.solve(g["init_aa"])
+    assert sd["num_dense_solves"] == sd["num_iterations"] and sd["num_cg_iterations"] == 0       # every step came from the factorisation
+    assert sd["num_iterations"] == so["num_iterations"] and sd["termination"] == so["termination"]
+    assert abs(sd["final_cost"] - so["final_cost"]) <= 1e-5 * so["final_cost"]                   # MAGSAC staircase, see test_solve_matches_oracle
+    assert synth.angular_distance(synth.align_rotations(rd, ro), ro).mean() <= 1e-6
+    rp, sp = dev.solve(g["init_aa"])                                                               # and the default PCG path agrees with it
+    assert synth.angular_distance(synth.align_rotations(rd, rp), rp).mean() <= 1e-6
+
+
+def test_dense_cholesky_auto_mode_switches_only_when_pcg_struggles(graph):
+    """dense_cholesky_max_cams < 0: PCG until one solve needs more than 150 iterations, exact Cholesky steps afterwards."""
+    from globalsfmpy_amd.solver import RotationProblem
+    easy = RotationProblem(graph["n_cams"], graph["edge_i"], graph["edge_j"], graph["rel_aa"], _abi.ANGLE_AXIS); easy.set_loss(LF.HuberLoss(0.1))
+    _, s = easy.solve(graph["init_aa"], dense_cholesky_max_cams=-100000)
+    assert s["num_dense_solves"] == 0 and s["num_cg_iterations"] > 0
+    hard = RotationProblem(graph["n_cams"], graph["edge_i"], graph["edge_j"], graph["rel_aa"], _abi.ANGLE_AXIS_COV_INLIERS, cov6=graph["cov6"],
+                           inlier_weight=graph["inlier_weight"]); hard.set_loss(LF.MAGSACWeightBasedLoss(0.02))
+    r0, s0 = hard.solve(graph["init_aa"])
+    r1, s1 = hard.solve(graph["init_aa"], dense_cholesky_max_cams=-100000)
+    assert s0["num_dense_solves"] == 0
+    if s0["num_cg_iterations"] > 150 * s0["num_iterations"] // 4:      # this configuration has PCG solves beyond 150 iterations
+        assert 0 < s1["num_dense_solves"] < s1["num_iterations"] and s1["num_cg_iterations"] < s0["num_cg_iterations"]
+    assert abs(s1["final_cost"] - s0["final_cost"]) <= 1e-5 * s0["final_cost"]
+    assert synth.angular_distance(synth.align_rotations(r1, r0), r0).mean() <= 1e-5

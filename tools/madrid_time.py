@@ -23,6 +23,11 @@ for et, loss, name in ((_abi.ANGLE_AXIS_COVARIANCE, LF.MAGSACWeightBasedLoss(0.0
     t = time.perf_counter(); r, s = p.solve(x0); dt = time.perf_counter() - t
     tr = p.trace()
     print("Madrid %-28s %8.1f ms  %3d LM it  %5d cg it (max/it %d)  term %s  gpu ms lin %.1f sweep %.1f pcg %.1f" % (name, dt * 1e3, s["num_iterations"], s["num_cg_iterations"], int(tr[:, 7].max()), s["termination_name"], s["t_linearize_ms"], s["t_sweep_ms"], s["t_cg_ms"]))
+for et, loss, name in ((_abi.ANGLE_AXIS_COVARIANCE, LF.MAGSACWeightBasedLoss(0.02), "cov+MAGSAC"), (_abi.ANGLE_AXIS, LF.SoftLOneLoss(0.1), "SoftL1 (EstimateRotations)"), (_abi.QUATERNION_COSINE, LF.HuberLoss(0.1), "quat Huber")):
+    p = RotationProblem(len(ids), ei, ej, m["rel_aa"], et, cov6=c6); p.set_loss(loss)
+    p.solve(x0, dense_cholesky_max_cams=1000)
+    t = time.perf_counter(); r, s = p.solve(x0, dense_cholesky_max_cams=1000); dt = time.perf_counter() - t
+    print("Madrid %-28s dense Cholesky steps: %8.1f ms  %3d LM it  %d dense solves  term %s  gpu ms linear solve %.1f" % (name, dt * 1e3, s["num_iterations"], s["num_dense_solves"], s["termination_name"], s["t_cg_ms"]))
 print("--- PCG iteration cap experiment (cov+MAGSAC) ---")
 p = RotationProblem(len(ids), ei, ej, m["rel_aa"], _abi.ANGLE_AXIS_COVARIANCE, cov6=c6); p.set_loss(LF.MAGSACWeightBasedLoss(0.02))
 ref, sref = p.solve(x0)
