@@ -1127,40 +1127,39 @@ gsfm_status gsfm_rot_solve_sigma_consensus(gsfm_rot_problem* P, double* rot, int
   const double one_over_sigma = c.C * std::pow(2.0, dof_minus_one_per_two) / sigma_max;
   const double weight_zero = one_over_sigma * (std::tgamma(dof_minus_one_per_two) - c.gk);
   const size_t E = P->n_edges_in;
-  std::vector<double> ones(E, 1.0), s(E), weights(E, 0.0), last_weights(E, 0.0);
   if (!P->s_ext.p && P->s_ext.alloc(E) != hipSuccess) return (gsfm_status)fail(GSFM_ERR_HIP, "alloc");
-  // the weights are a function of the UNWEIGHTED residual norm: evaluate with w = 1, then set w.
+  // scalar-weight planes and the per-edge weight vector live on the device for the whole loop; the first comparison is
+  // against zero weights, like the reference's zero-initialised last_weights (:352-353)
+  if (P->wmode == W_NONE) {
+    if (P->cost.ws.alloc(P->cost.n) != hipSuccess || P->dir.ws.alloc(P->dir.n) != hipSuccess) return (gsfm_status)fail(GSFM_ERR_HIP, "alloc weight planes");
+    P->wmode = W_SCALAR;
+  }
+  if (!P->w_orig.p && P->w_orig.alloc(E) != hipSuccess) return (gsfm_status)fail(GSFM_ERR_HIP, "alloc weights");
+  if (hipMemsetAsync(P->w_orig.p, 0, 8 * E, P->stream) != hipSuccess) return (gsfm_status)fail(GSFM_ERR_HIP, "clear weights");
+  DevBuf<double> d_table, d_part, d_sum;
+  const int nb_sig = grid_for(E);
+  if (d_table.upload(table) != hipSuccess || d_part.alloc(nb_sig) != hipSuccess || d_sum.alloc(1) != hipSuccess) return (gsfm_status)fail(GSFM_ERR_HIP, "alloc sigma consensus buffers");
   int outer = 0;
   for (int it = 0; it < iters_num; ++it) {
     ++outer;
-    if (gsfm_status st = gsfm_rot_set_edge_weights(P, ones.data())) return st;
     if (int st = upload_state(P, rot)) return (gsfm_status)st;
-    {  // K6 = K1 in s-only mode: s_e = ||log(R_j R_i^T R_ij^T)||^2  (:378-398)
+    {  // K6 = K1 in s-only mode with unit weights: s_e = ||log(R_j R_i^T R_ij^T)||^2  (:378-398)
       CostArgs a{};
       a.tiles = P->cost_tiles.p; a.direct = P->cost_direct; a.n_cams = P->n_cams; a.n = P->cost.n; a.idx = P->cost_idx.p; a.qr0 = P->cost.qr0.p; a.qr1 = P->cost.qr1.p; a.ws = P->cost.ws.p;
-      a.q = P->q.p; a.loss = P->d_loss.p; a.eid = P->cost.eid.p; a.partials = P->part_cost.p; a.s_out = P->s_ext.p; a.s_only = 1;
+      a.q = P->q.p; a.loss = P->d_loss.p; a.eid = P->cost.eid.p; a.partials = P->part_cost.p; a.s_out = P->s_ext.p; a.s_only = 1; a.unit_w = 1;
       if (dispatch<CostArgs, CostLauncher>(P, a, P->nb_cost)) return (gsfm_status)fail(GSFM_ERR_UNSUPPORTED, "dispatch");
-      if (hipMemcpyAsync(s.data(), P->s_ext.p, 8 * E, hipMemcpyDeviceToHost, P->stream) != hipSuccess) return (gsfm_status)fail(GSFM_ERR_HIP, "read s");
-      if (int st = sync_check(P, "sigma consensus sweep")) return (gsfm_status)st;
     }
-    for (size_t e = 0; e < E; ++e) {
-      const double residual = std::sqrt(s[e]);
-      double weight;
-      if (residual < std::numeric_limits<double>::epsilon()) weight = weight_zero;  // :400-401
-      else {
-        const double squared_residual = residual * residual;
-        size_t x = (size_t)std::round(1000.0 * squared_residual / squared_sigma_max_2);  // :407
-        // :411-412 clamps to stored_gamma_number3, one past the table's end (an out-of-bounds read in the
-        // reference); the last stored entry is used instead.
-        if ((size_t)c.n - 1 < x) x = (size_t)c.n - 1;
-        weight = one_over_sigma * (table[x] - c.gk);
-      }
-      weights[e] = weight;
-    }
-    double avg = 0; for (size_t e = 0; e < E; ++e) avg += std::fabs(weights[e] - last_weights[e]);
+    SigmaArgs sa{};
+    sa.s = P->s_ext.p; sa.w = P->w_orig.p; sa.n = E; sa.table = d_table.p; sa.table_len = c.n; sa.ssm2 = squared_sigma_max_2;
+    sa.one_over_sigma = one_over_sigma; sa.gk = c.gk; sa.weight_zero = weight_zero; sa.partials = d_part.p;
+    hipLaunchKernelGGL(k_sigma_weights, dim3(nb_sig), dim3(GSFM_BLOCK), 0, P->stream, sa);
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(GSFM_BLOCK), 0, P->stream, d_part.p, nb_sig, d_sum.p);
+    if (P->cost.n) hipLaunchKernelGGL(k_gather_weights, dim3(grid_for(P->cost.n)), dim3(GSFM_BLOCK), 0, P->stream, P->w_orig.p, P->cost.eid.p, P->cost.n, P->cost.ws.p);
+    if (P->dir.n) hipLaunchKernelGGL(k_gather_weights, dim3(grid_for(P->dir.n)), dim3(GSFM_BLOCK), 0, P->stream, P->w_orig.p, P->dir.eid.p, P->dir.n, P->dir.ws.p);
+    double avg = 0.0;
+    if (hipMemcpyAsync(&avg, d_sum.p, 8, hipMemcpyDeviceToHost, P->stream) != hipSuccess) return (gsfm_status)fail(GSFM_ERR_HIP, "read weight change");
+    if (int st = sync_check(P, "sigma consensus weights")) return (gsfm_status)st;
     avg /= (double)E;
-    if (gsfm_status st = gsfm_rot_set_edge_weights(P, weights.data())) return st;
-    std::swap(weights, last_weights);
     if (gsfm_status st = gsfm_rot_solve(P, rot, &o, summary)) return st;
     if (it == 0) total = *summary;
     else {

@@ -334,6 +334,38 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_whiten(WhitenArgs a) {
   }
 }
 
+// sigma-consensus weights (src/GSfM_nonlinear_rotation_estimator.cpp:400-416) from the unweighted s = |e|^2 of every original edge,
+// in place of a device -> host -> device round trip of 3 x 8 B per edge per outer iteration; block partials of |w - w_old|
+struct SigmaArgs {
+  const double* s;        // per original edge
+  double* w;              // in: previous weights, out: new weights
+  size_t n;
+  const double* table;    // Gamma(1, x / 1000), nu = 3
+  int table_len;
+  double ssm2, one_over_sigma, gk, weight_zero;
+  double* partials;       // [gridDim.x]
+};
+__global__ void __launch_bounds__(GSFM_BLOCK) k_sigma_weights(SigmaArgs a) {
+  __shared__ double lds[8];
+  const size_t e = (size_t)blockIdx.x * GSFM_BLOCK + threadIdx.x;
+  double change = 0.0;
+  if (e < a.n) {
+    const double residual = sqrt(a.s[e]);
+    double weight;
+    if (residual < 2.220446049250313e-16) weight = a.weight_zero;
+    else {
+      const double squared_residual = residual * residual;                 // as written in the reference, not s itself
+      double xf = round(1000.0 * squared_residual / a.ssm2);               // std::round: halves away from zero
+      if (!(xf < (double)(a.table_len - 1))) xf = (double)(a.table_len - 1);  // last stored entry (the reference reads one past it)
+      weight = a.one_over_sigma * (a.table[(int)xf] - a.gk);
+    }
+    change = fabs(weight - a.w[e]);
+    a.w[e] = weight;
+  }
+  const double t = block_sum_bcast(change, lds);
+  if (threadIdx.x == 0) a.partials[blockIdx.x] = t;
+}
+
 // scatter per-original-edge scalar weights into an entry-ordered plane (sigma consensus / set_edge_weights)
 __global__ void __launch_bounds__(GSFM_BLOCK) k_gather_weights(const double* __restrict__ w_orig,
                                                                const uint32_t* __restrict__ eid, size_t n,
@@ -365,6 +397,7 @@ struct CostArgs {
   double* r_out;
   int s_only;                // 1: write s_out only, skip the loss (callback path, phase 1)
   int direct;                // 1: k_cost_direct (idx = global camera indices, tiles = plain chunks)
+  int unit_w;                // 1: ignore the scalar weight plane (sigma consensus evaluates the UNWEIGHTED residual norm)
 };
 
 // K1.  FULL = false: the solver's trial-cost sweep (cost only: for MAGSAC the value needs no exp and no division
@@ -424,6 +457,7 @@ __global__ void __launch_bounds__(GSFM_TILE_THREADS) k_cost(CostArgs a) {
       ij[u] = a.idx[e];
       r0[u] = nt_load2(a.qr0 + e); r1[u] = nt_load2(a.qr1 + e);
       Wm[u] = load_w<WM>(a.w0, a.w1, a.w2, a.ws, e);
+      if (WM == W_SCALAR && a.unit_w) Wm[u].l00 = 1.0;
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -458,7 +492,8 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_cost_direct(CostArgs a) {
   for (uint32_t e = tile.begin + threadIdx.x; e < tile.end; e += GSFM_BLOCK) {
     const uint2 ij = a.idx[e];
     const double2 r0 = nt_load2(a.qr0 + e), r1 = nt_load2(a.qr1 + e);
-    const EdgeW W = load_w<WM>(a.w0, a.w1, a.w2, a.ws, e);
+    EdgeW W = load_w<WM>(a.w0, a.w1, a.w2, a.ws, e);
+    if (WM == W_SCALAR && a.unit_w) W.l00 = 1.0;
     const Quat qi = load_q(a.q, ij.x), qj = load_q(a.q, ij.y);
     acc += cost_edge<F, WM, LM, FULL>(a, e, qi, qj, Quat{r0.x, r0.y, r1.x, r1.y}, W);
   }
