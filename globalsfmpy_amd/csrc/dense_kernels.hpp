@@ -22,6 +22,7 @@ struct CholArgs {
   uint32_t n;
   uint32_t k0;    // first row/column of the current block
   int* info;      // 0, or 1 + index of the first non-positive pivot
+  double* Dinv;   // [n / 32 rounded up][32][32]: inverse of every diagonal block L_kk (lower triangular, row-major, zero above)
 };
 
 // One wavefront, no LDS, no barriers: lane i keeps row i of the block in registers; column j is finished with one broadcast of the
@@ -41,13 +42,10 @@ __global__ void __launch_bounds__(64) k_chol_diag(CholArgs a) {
     double piv = readlane_f64(r[j], j);
     if (!(piv > 0.0)) { if (!bad) bad = j + 1; piv = 1.0; }
     const double d = sqrt(piv);
-    if (lane == (uint32_t)j) r[j] = d;
-    else if (lane > (uint32_t)j) r[j] = r[j] / d;
+    r[j] = (lane == (uint32_t)j) ? d : r[j] / d;
+    // no per-step lane masks: entries above the diagonal (lane < c) are never read by anyone, so they may hold anything
 #pragma unroll
-    for (int c = j + 1; c < GSFM_CB; ++c) {
-      const double lcj = readlane_f64(r[j], c);       // L[c][j], held by lane c
-      if (lane >= (uint32_t)c) r[c] -= r[j] * lcj;
-    }
+    for (int c = j + 1; c < GSFM_CB; ++c) r[c] -= r[j] * readlane_f64(r[j], c);   // readlane: L[c][j], held by lane c
   }
   if (lane == 0 && bad && (uint32_t)bad <= nb && *a.info == 0) *a.info = (int)(a.k0 + bad);
   if (rowlive) {
@@ -55,49 +53,59 @@ __global__ void __launch_bounds__(64) k_chol_diag(CholArgs a) {
 #pragma unroll
     for (int c = 0; c < GSFM_CB; ++c) if ((uint32_t)c <= lane) dst[c] = r[c];
   }
+  // X = L^-1 (lower triangular), row i in lane i: x[i][i] = 1 / L[i][i], x[i][j] = -(sum_{t=j+1..i} x[i][t] L[t][j]) / L[j][j].
+  // The panel and the triangular solves then multiply by X instead of running 32-step substitution chains.
+  double x[GSFM_CB];
+#pragma unroll
+  for (int j = GSFM_CB - 1; j >= 0; --j) {
+    const double inv_jj = 1.0 / readlane_f64(r[j], j);
+    double acc = 0.0;
+#pragma unroll
+    for (int t = j + 1; t < GSFM_CB; ++t) {
+      acc += x[t] * readlane_f64(r[j], t);             // L[t][j] from lane t; x[t] is exactly 0 in the lanes above the diagonal
+    }
+    x[j] = (lane == (uint32_t)j) ? inv_jj : (lane > (uint32_t)j ? -acc * inv_jj : 0.0);
+  }
+  if (lane < GSFM_CB) {   // padded rows/columns of a partial last block carry the identity: harmless
+    double* dst = a.Dinv + ((size_t)(a.k0 / GSFM_CB) * GSFM_CB + lane) * GSFM_CB;
+#pragma unroll
+    for (int c = 0; c < GSFM_CB; ++c) dst[c] = x[c];
+  }
 }
 
-// rows below the diagonal block: A[i, block] <- A[i, block] L_kk^-T, one row per lane (the row lives in LDS, column-padded)
-#define GSFM_PANEL_ROWS 128
-__global__ void __launch_bounds__(GSFM_PANEL_ROWS) k_chol_panel(CholArgs a) {
-  __shared__ double L[GSFM_CB][GSFM_CB + 1];
+// rows below the diagonal block: A[i, block] <- A[i, block] L_kk^-T = A[i, block] X^T, a 32-wide product per element (no
+// substitution chain); 64 rows per workgroup, 8 outputs per lane; the result also goes transposed into the upper triangle so
+// that the forward substitution of k_chol_solve reads L[i][k0 + c] with consecutive lanes on consecutive i
+#define GSFM_PANEL_ROWS 64
+__global__ void __launch_bounds__(256) k_chol_panel(CholArgs a) {
+  __shared__ double X[GSFM_CB][GSFM_CB + 1];
   __shared__ double V[GSFM_PANEL_ROWS][GSFM_CB + 1];
   const uint32_t nb = min((uint32_t)GSFM_CB, a.n - a.k0), tid = threadIdx.x;
-  for (uint32_t idx = tid; idx < GSFM_CB * GSFM_CB; idx += GSFM_PANEL_ROWS) {
-    const uint32_t r = idx / GSFM_CB, c = idx % GSFM_CB;
-    L[r][c] = (r < nb && c <= r) ? a.A[(size_t)(a.k0 + r) * a.n + a.k0 + c] : (r == c ? 1.0 : 0.0);
-  }
-  // coalesced load of the block's rows: consecutive lanes read consecutive columns of one row
+  const double* xin = a.Dinv + (size_t)(a.k0 / GSFM_CB) * GSFM_CB * GSFM_CB;
+  for (uint32_t idx = tid; idx < GSFM_CB * GSFM_CB; idx += 256) X[idx / GSFM_CB][idx % GSFM_CB] = xin[idx];
   const uint32_t row0 = a.k0 + nb + blockIdx.x * GSFM_PANEL_ROWS;
-  for (uint32_t idx = tid; idx < GSFM_PANEL_ROWS * GSFM_CB; idx += GSFM_PANEL_ROWS) {
+  for (uint32_t idx = tid; idx < GSFM_PANEL_ROWS * GSFM_CB; idx += 256) {
     const uint32_t r = idx / GSFM_CB, c = idx % GSFM_CB;
     V[r][c] = (row0 + r < a.n && c < nb) ? a.A[(size_t)(row0 + r) * a.n + a.k0 + c] : 0.0;
   }
   __syncthreads();
-  if (row0 + tid < a.n) {
-    // L and V are padded (identity / zeros) to the full 32 columns, so both loops have compile-time bounds and the LDS reads
-    // of one column are all in flight together instead of one ~100-cycle round trip per multiply
-    double v[GSFM_CB];
+  const uint32_t c = tid % GSFM_CB, rg = tid / GSFM_CB;   // column c, rows rg, rg + 8, ...
+  double out[GSFM_PANEL_ROWS / 8];
 #pragma unroll
-    for (int c = 0; c < GSFM_CB; ++c) v[c] = V[tid][c];
+  for (int q = 0; q < GSFM_PANEL_ROWS / 8; ++q) {
+    const uint32_t r = rg + 8 * q;
+    double s2 = 0.0;
 #pragma unroll
-    for (int c = 0; c < GSFM_CB; ++c) {
-      double s = v[c];
-#pragma unroll
-      for (int t = 0; t < c; ++t) s -= v[t] * L[c][t];
-      v[c] = s / L[c][c];
-    }
-#pragma unroll
-    for (int c = 0; c < GSFM_CB; ++c) V[tid][c] = v[c];
-    // the same numbers transposed into the (otherwise unused) upper triangle: the forward substitution of k_chol_solve then
-    // reads L[i][k0 + c] with consecutive lanes on consecutive i, like the backward one
-#pragma unroll
-    for (int c = 0; c < GSFM_CB; ++c) if ((uint32_t)c < nb) a.A[(size_t)(a.k0 + c) * a.n + row0 + tid] = v[c];
+    for (int t = 0; t < GSFM_CB; ++t) s2 += V[r][t] * X[c][t];   // X[c][t] = 0 for t > c
+    out[q] = s2;
   }
-  __syncthreads();
-  for (uint32_t idx = tid; idx < GSFM_PANEL_ROWS * GSFM_CB; idx += GSFM_PANEL_ROWS) {
-    const uint32_t r = idx / GSFM_CB, c = idx % GSFM_CB;
-    if (row0 + r < a.n && c < nb) a.A[(size_t)(row0 + r) * a.n + a.k0 + c] = V[r][c];
+#pragma unroll
+  for (int q = 0; q < GSFM_PANEL_ROWS / 8; ++q) {
+    const uint32_t row = row0 + rg + 8 * q;
+    if (row < a.n && c < nb) {
+      a.A[(size_t)row * a.n + a.k0 + c] = out[q];
+      a.A[(size_t)(a.k0 + c) * a.n + row] = out[q];
+    }
   }
 }
 
@@ -129,64 +137,61 @@ __global__ void __launch_bounds__(256) k_chol_update(CholArgs a) {
   }
 }
 
-// x = (L L^T)^-1 b, one workgroup; every 32 x 32 diagonal system is staged in LDS and solved by the first wavefront with
-// shuffles (reading the pivots from global memory inside the dependent chain cost ~1 us per column)
-__global__ void __launch_bounds__(1024) k_chol_solve(const double* __restrict__ A, uint32_t n, const double* __restrict__ b, double* __restrict__ x) {
+// x = (L L^T)^-1 b, one workgroup.  Per 32-row block: the first wavefront multiplies by the inverse diagonal block (rows of X from
+// LDS, the right-hand side broadcast with v_readlane), then all lanes update the remaining rows from the transposed panel copy.
+__global__ void __launch_bounds__(1024) k_chol_solve(const double* __restrict__ A, const double* __restrict__ Dinv, uint32_t n,
+                                                     const double* __restrict__ b, double* __restrict__ x) {
   __shared__ double yb[GSFM_CB];
-  __shared__ double Ld[GSFM_CB][GSFM_CB + 1];
+  __shared__ double X[GSFM_CB][GSFM_CB + 1];
   const uint32_t tid = threadIdx.x;
   for (uint32_t i = tid; i < n; i += 1024) x[i] = b[i];
   __syncthreads();
   for (uint32_t k0 = 0; k0 < n; k0 += GSFM_CB) {   // L y = b
     const uint32_t nb = min((uint32_t)GSFM_CB, n - k0);
-    { const uint32_t r = tid / GSFM_CB, c = tid % GSFM_CB; Ld[r][c] = (r < nb && c <= r) ? A[(size_t)(k0 + r) * n + k0 + c] : (r == c ? 1.0 : 0.0); }
+    X[tid / GSFM_CB][tid % GSFM_CB] = Dinv[(size_t)(k0 / GSFM_CB) * GSFM_CB * GSFM_CB + tid];
     __syncthreads();
     if (tid < 64) {
       const uint32_t lane = tid < GSFM_CB ? tid : 0;
-      double v = tid < nb ? x[k0 + tid] : 0.0;
-      for (uint32_t t = 0; t < nb; ++t) {
-        const double yt = readlane_f64(v, (int)t) / Ld[t][t];
-        if (tid == t) v = yt;
-        else if (tid > t && tid < nb) v -= Ld[lane][t] * yt;
-      }
-      if (tid < GSFM_CB) yb[tid] = tid < nb ? v : 0.0;
-      if (tid < nb) x[k0 + tid] = v;
+      const double v = tid < nb ? x[k0 + tid] : 0.0;
+      double y = 0.0;
+#pragma unroll
+      for (int t = 0; t < GSFM_CB; ++t) y += X[lane][t] * readlane_f64(v, t);   // y = X b_block
+      if (tid < GSFM_CB) yb[tid] = tid < nb ? y : 0.0;
+      if (tid < nb) x[k0 + tid] = y;
     }
     __syncthreads();
     for (uint32_t i = k0 + nb + tid; i < n; i += 1024) {   // (rows below exist only under full blocks: nb == 32 here)
-      double s = x[i];
+      double s2 = x[i];
 #pragma unroll
-      for (int c = 0; c < GSFM_CB; ++c) s -= A[(size_t)(k0 + c) * n + i] * yb[c];   // L[i][k0 + c] from its transposed copy
-      x[i] = s;
+      for (int c = 0; c < GSFM_CB; ++c) s2 -= A[(size_t)(k0 + c) * n + i] * yb[c];   // L[i][k0 + c] from its transposed copy
+      x[i] = s2;
     }
     __syncthreads();
   }
   const uint32_t nblk = (n + GSFM_CB - 1) / GSFM_CB;
   for (uint32_t kb = nblk; kb-- > 0;) {             // L^T x = y
     const uint32_t k0 = kb * GSFM_CB, nb = min((uint32_t)GSFM_CB, n - k0);
-    { const uint32_t r = tid / GSFM_CB, c = tid % GSFM_CB; Ld[r][c] = (r < nb && c <= r) ? A[(size_t)(k0 + r) * n + k0 + c] : (r == c ? 1.0 : 0.0); }
+    X[tid / GSFM_CB][tid % GSFM_CB] = Dinv[(size_t)kb * GSFM_CB * GSFM_CB + tid];
     __syncthreads();
     if (tid < 64) {
       const uint32_t lane = tid < GSFM_CB ? tid : 0;
-      double v = tid < nb ? x[k0 + tid] : 0.0;
-      for (uint32_t t = nb; t-- > 0;) {
-        const double xt = readlane_f64(v, (int)t) / Ld[t][t];
-        if (tid == t) v = xt;
-        else if (tid < t) v -= Ld[t][lane] * xt;
-      }
-      if (tid < GSFM_CB) yb[tid] = tid < nb ? v : 0.0;
-      if (tid < nb) x[k0 + tid] = v;
+      const double v = tid < nb ? x[k0 + tid] : 0.0;
+      double y = 0.0;
+#pragma unroll
+      for (int t = 0; t < GSFM_CB; ++t) y += X[t][lane] * readlane_f64(v, t);   // x_block = X^T y_block
+      if (tid < GSFM_CB) yb[tid] = tid < nb ? y : 0.0;
+      if (tid < nb) x[k0 + tid] = y;
     }
     __syncthreads();
     for (uint32_t i = tid; i < k0; i += 1024) {
-      double s = x[i];
+      double s2 = x[i];
       if (nb == GSFM_CB) {
 #pragma unroll
-        for (int c = 0; c < GSFM_CB; ++c) s -= A[(size_t)(k0 + c) * n + i] * yb[c];
+        for (int c = 0; c < GSFM_CB; ++c) s2 -= A[(size_t)(k0 + c) * n + i] * yb[c];
       } else {
-        for (uint32_t c = 0; c < nb; ++c) s -= A[(size_t)(k0 + c) * n + i] * yb[c];
+        for (uint32_t c = 0; c < nb; ++c) s2 -= A[(size_t)(k0 + c) * n + i] * yb[c];
       }
-      x[i] = s;
+      x[i] = s2;
     }
     __syncthreads();
   }

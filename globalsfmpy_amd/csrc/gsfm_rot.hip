@@ -182,7 +182,7 @@ struct gsfm_rot_problem {
   DevBuf<double2> q, q_trial;
   DevBuf<double> xcg, r, z, p, Ap, s_dir, part_g2, part_d2;
   DevBuf<Cg2Scalars> cg2sc;
-  DevBuf<double> denseA;
+  DevBuf<double> denseA, denseDinv;
   DevBuf<int> dense_info;
   hipGraphExec_t dense_graph = nullptr;   // zero + assemble + blocked Cholesky + solve, captured once
   int nb_mv = 1;
@@ -510,7 +510,8 @@ int run_dense(gsfm_rot_problem* P, bool* used) {
   *used = false;
   const uint32_t n = 3 * P->n_cams;
   if (!P->denseA.p) {
-    if (P->denseA.alloc((size_t)n * n) != hipSuccess || P->dense_info.alloc(1) != hipSuccess) return 0;
+    if (P->denseA.alloc((size_t)n * n) != hipSuccess || P->dense_info.alloc(1) != hipSuccess ||
+        P->denseDinv.alloc((size_t)((n + GSFM_CB - 1) / GSFM_CB) * GSFM_CB * GSFM_CB) != hipSuccess) return 0;
   }
   auto enqueue = [&]() {
     hipLaunchKernelGGL(k_zero, dim3(grid_for((size_t)n * n)), dim3(GSFM_BLOCK), 0, P->stream, P->denseA.p, (size_t)n * n);
@@ -520,14 +521,14 @@ int run_dense(gsfm_rot_problem* P, bool* used) {
     a.Mblk = P->Mblk.p; a.A = P->denseA.p; a.n = n;
     hipLaunchKernelGGL(k_dense_assemble, dim3(P->n_rows), dim3(GSFM_BLOCK), 0, P->stream, a);
     for (uint32_t k0 = 0; k0 < n; k0 += GSFM_CB) {
-      CholArgs c{P->denseA.p, n, k0, P->dense_info.p};
+      CholArgs c{P->denseA.p, n, k0, P->dense_info.p, P->denseDinv.p};
       hipLaunchKernelGGL(k_chol_diag, dim3(1), dim3(64), 0, P->stream, c);
       if (k0 + GSFM_CB >= n) break;
       const uint32_t below = n - k0 - GSFM_CB, tiles = (below + GSFM_CB - 1) / GSFM_CB;
-      hipLaunchKernelGGL(k_chol_panel, dim3((below + GSFM_PANEL_ROWS - 1) / GSFM_PANEL_ROWS), dim3(GSFM_PANEL_ROWS), 0, P->stream, c);
+      hipLaunchKernelGGL(k_chol_panel, dim3((below + GSFM_PANEL_ROWS - 1) / GSFM_PANEL_ROWS), dim3(256), 0, P->stream, c);
       hipLaunchKernelGGL(k_chol_update, dim3(tiles * (tiles + 1) / 2), dim3(256), 0, P->stream, c);
     }
-    hipLaunchKernelGGL(k_chol_solve, dim3(1), dim3(1024), 0, P->stream, (const double*)P->denseA.p, n, (const double*)P->b.p, P->xcg.p);
+    hipLaunchKernelGGL(k_chol_solve, dim3(1), dim3(1024), 0, P->stream, (const double*)P->denseA.p, (const double*)P->denseDinv.p, n, (const double*)P->b.p, P->xcg.p);
     (void)hipMemsetAsync(P->r.p, 0, 8 * (size_t)n, P->stream);  // exact solve: the PCG residual term of the model decrease is zero
   };
   const int tk = P->timer.begin(T_CG);

@@ -137,8 +137,8 @@ typedef struct {
                                           > 0: every step of graphs with at most that many cameras; 0 (default): never; < 0: graphs up to
                                           |value| cameras, from the moment one PCG solve of the run has needed more than 150 iterations
                                           (not the default: switching solvers mid-run moves long ill-conditioned trajectories by one
-                                          iteration at the termination slop, which the parity tests pin).  Measured on Madrid (394 cams, 2.5 ms per factorise + solve): MAGSAC weights
-                                          (PCG: up to 580 iterations per step) 284 -> 167 ms and the oracle-Cholesky iteration count;
+                                          iteration at the termination slop, which the parity tests pin).  Measured on Madrid (394 cams, 2.2 ms per factorise + solve): MAGSAC weights
+                                          (PCG: up to 580 iterations per step) 284 -> 143 ms and the oracle-Cholesky iteration count;
                                           SoftL1 (66 per step) stays on PCG, 50 ms.  PCG remains the fallback if a pivot is not positive. */
   int32_t pcg_hip_graph;               /* default 1: the chunk of cg_check_interval PCG iterations between two host checks
                                           (4 dependent kernels each) is captured once into a hipGraph and replayed -- the loop is
