@@ -165,7 +165,7 @@ __device__ __forceinline__ double loss_magsac_value(const DevLossNode& n, double
   if (x > (long)n.table_len - 1) x = (long)n.table_len - 1;
   // nu = 3: table[x] = Gamma(1, x/1000) = exp(-x/1000); evaluating it beats a second random gather (the
   // arithmetic of this kernel is hidden behind the streams). Same quantised x, value within 1 ulp of the table.
-  const double tv = (n.nu == 3) ? exp(-((double)x / 1000.0)) : n.table[x];
+  const double tv = (n.nu == 3) ? exp(-1e-3 * (double)x) : n.table[x];
   const double weight = n.aux[4] * (tv - n.aux[7]);
   return n.inverse ? 1.0 / weight : n.aux[5] - weight;
 }

@@ -59,9 +59,12 @@ __device__ __forceinline__ Quat aa_to_quat(double a0, double a1, double a2) {
 __device__ __forceinline__ void quat_log(const Quat& q, double* e, double* s_out, double* theta_out) {
   const double s2 = q.x * q.x + q.y * q.y + q.z * q.z;
   if (s2 > 0.0) {
-    const double s = sqrt(s2);
+    // one reciprocal square root serves both |v| and the division by it (a correctly rounded sqrt followed by an IEEE
+    // division is ~25 instructions more per edge for a result that differs in the last ulp or two)
+    const double rs = rsqrt(s2);
+    const double s = s2 * rs;
     const double two_theta = 2.0 * ((q.w < 0.0) ? atan2(-s, -q.w) : atan2(s, q.w));
-    const double k = two_theta / s;
+    const double k = two_theta * rs;
     e[0] = q.x * k; e[1] = q.y * k; e[2] = q.z * k;
     *s_out = s; *theta_out = two_theta;
   } else {
