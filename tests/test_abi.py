@@ -63,3 +63,17 @@ def test_invalid_loss_programs_are_rejected_by_make_program():
     from globalsfmpy_amd import _abi
     with pytest.raises(ValueError):
         _abi.make_program([(0, 0.0, 0.0, 0.0)] * 17)
+
+
+def test_header_is_valid_pedantic_c99_and_links(tmp_path):
+    """include/gsfm_rot.h is a C header, not a C++ one in disguise: the plain-C example builds with -std=c99 -pedantic -Werror."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    exe = str(tmp_path / "c_abi_minimal")
+    cmd = ["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I" + os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "examples", "c_abi_minimal.c"), "-L" + os.path.join(ROOT, "globalsfmpy_amd"), "-lgsfm_rot",
+           "-Wl,-rpath," + os.path.join(ROOT, "globalsfmpy_amd"), "-lm", "-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr

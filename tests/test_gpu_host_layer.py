@@ -1,6 +1,7 @@
 """-m gpu: the C++ plugin surface (theia::GSfMNonlinearRotationEstimator through the pybind11 module
 GlobalSfMpy) end to end on the device, against the flat-array C-ABI path and the CPU oracle."""
 import os
+import subprocess
 import sys
 
 import numpy as np
@@ -189,3 +190,15 @@ def test_cpp_plugin_surface_without_python(tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     print(r.stdout)
     assert r.returncode == 0 and "PASSED" in r.stdout, r.stdout + r.stderr
+
+
+def test_plain_c_consumer_of_the_c_abi(tmp_path):
+    """examples/c_abi_minimal.c: create / set_loss / solve / destroy from C99 with nothing but include/gsfm_rot.h."""
+    exe = str(tmp_path / "c_abi_minimal")
+    cmd = ["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-I" + os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "examples", "c_abi_minimal.c"), "-L" + os.path.join(ROOT, "globalsfmpy_amd"), "-lgsfm_rot",
+           "-Wl,-rpath," + os.path.join(ROOT, "globalsfmpy_amd"), "-lm", "-o", exe]
+    subprocess.run(cmd, check=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "termination" in r.stdout and "camera 3" in r.stdout
