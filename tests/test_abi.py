@@ -77,3 +77,22 @@ def test_header_is_valid_pedantic_c99_and_links(tmp_path):
            "-Wl,-rpath," + os.path.join(ROOT, "globalsfmpy_amd"), "-lm", "-o", exe]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+def test_shared_libraries_depend_on_nothing_but_the_hip_runtime_and_libc():
+    """The drop-in boundary carries no torch / python / rocSOLVER / RCCL link-time dependency (RCCL is dlopen'ed by the optional
+    communicator library only)."""
+    import shutil
+    import subprocess
+    if shutil.which("readelf") is None:
+        pytest.skip("no readelf")
+    allowed = ("libamdhip64.so", "libstdc++.so", "libm.so", "libgcc_s.so", "libc.so", "libdl.so", "ld-linux", "libpthread.so", "librt.so")
+    for name, extra in (("libgsfm_rot.so", ()), ("libgsfm_rccl.so", ()), ("libgsfm_estimator.so", ("libgsfm_rot.so",))):
+        path = os.path.join(ROOT, "globalsfmpy_amd", name)
+        if not os.path.exists(path):
+            pytest.skip(name + " not built")
+        out = subprocess.run(["readelf", "-d", path], capture_output=True, text=True).stdout
+        needed = re.findall(r"\(NEEDED\)\s+Shared library: \[([^\]]+)\]", out)
+        assert needed, name
+        for lib in needed:
+            assert lib.startswith(allowed + extra), (name, lib)
