@@ -159,13 +159,17 @@ struct gsfm_rot_problem {
   struct PcgGraph {
     hipGraphExec_t exec = nullptr;
     double tol = 0; int max_iters = 0, stall = 0, chunk = 0;
-    bool unusable = false;
+    bool unusable = false, lap = false;
     void reset() { if (exec) (void)hipGraphExecDestroy(exec); exec = nullptr; }
   } pcg_graph;
 
   EdgePlanes cost;            // cost-owned edges
   DevBuf<uint2> cost_idx;
   DevBuf<CostTile> cost_tiles;
+  // Laplacian form of the normal matrix (kernels.hpp, lin_rows): chosen per linearisation; u_rot = R^T p for the mat-vec
+  const double2* q_lin = nullptr;   // quaternions the current blocks were linearised at
+  bool lap = false, lap_capable = false, lin_is_lap = false;   // lin_is_lap: what the stored blocks currently are
+  DevBuf<double> u_rot;
   // locality relabelling adopted at create (empty = identity): internal id = perm[external id]
   std::vector<uint32_t> perm;
   std::vector<double> h_cam;   // staging for permuted per-camera transfers
@@ -185,6 +189,7 @@ struct gsfm_rot_problem {
   DevBuf<double> denseA, denseDinv;
   DevBuf<int> dense_info;
   hipGraphExec_t dense_graph = nullptr;   // zero + assemble + blocked Cholesky + solve, captured once
+  bool dense_graph_lap = false;           // form of the blocks the captured assemble kernel expects
   int nb_mv = 1;
   DevBuf<double> part_a, part_b, part_cost, part_cam, scal;
   DevBuf<CgScalars> cgsc;
@@ -243,8 +248,15 @@ template <int F, int W, int L> struct CostLauncher {
 };
 template <int F, int W, int L> struct LinLauncher {
   static void go(const LinArgs& a, int grid, hipStream_t s) {
-    if constexpr (L != LM_PROGRAM && F != F_RFNORM) hipLaunchKernelGGL((k_lin3<F, W, L>), dim3(grid), dim3(GSFM_BLOCK), 0, s, a);
-    else hipLaunchKernelGGL((k_lin<F, W, L>), dim3(grid), dim3(GSFM_BLOCK), 0, s, a);
+    if constexpr (F == F_AA || F == F_QCOS) {   // functors of R_j R_i^T only: the Laplacian form exists (lin_rows)
+      if (a.lap) {
+        if constexpr (L != LM_PROGRAM) hipLaunchKernelGGL((k_lin3<F, W, L, true>), dim3(grid), dim3(GSFM_BLOCK), 0, s, a);
+        else hipLaunchKernelGGL((k_lin<F, W, L, true>), dim3(grid), dim3(GSFM_BLOCK), 0, s, a);
+        return;
+      }
+    }
+    if constexpr (L != LM_PROGRAM && F != F_RFNORM) hipLaunchKernelGGL((k_lin3<F, W, L, false>), dim3(grid), dim3(GSFM_BLOCK), 0, s, a);
+    else hipLaunchKernelGGL((k_lin<F, W, L, false>), dim3(grid), dim3(GSFM_BLOCK), 0, s, a);
   }
 };
 
@@ -375,7 +387,8 @@ int launch_lin(gsfm_rot_problem* P, const double2* q) {
   a.n_rows = P->n_rows; a.row_base = P->own_begin; a.G = P->G; a.row_ptr = P->row_ptr.p; a.col = P->col.p; a.eid = P->dir.eid.p;
   a.qr0 = P->dir.qr0.p; a.qr1 = P->dir.qr1.p; a.w0 = P->dir.w0.p; a.w1 = P->dir.w1.p; a.w2 = P->dir.w2.p; a.ws = P->dir.ws.p;
   a.q = q; a.loss = P->d_loss.p; a.rho_ext = P->cb ? P->rho_ext.p : nullptr;
-  a.h0 = P->h0.p; a.h1 = P->h1.p; a.h2 = P->h2.p; a.h3 = P->h3.p; a.h4 = P->h4.p; a.gD = P->gD.p;
+  a.h0 = P->h0.p; a.h1 = P->h1.p; a.h2 = P->h2.p; a.h3 = P->h3.p; a.h4 = P->h4.p; a.gD = P->gD.p; a.lap = P->lap;
+  P->lin_is_lap = P->lap; P->q_lin = q;
   const int tk = P->timer.begin(T_LIN);
   if (dispatch<LinArgs, LinLauncher>(P, a, grid_for((size_t)P->n_rows * P->G))) return fail(GSFM_ERR_UNSUPPORTED, "no kernel for this error type");
   P->timer.end(tk);
@@ -396,7 +409,9 @@ int launch_matvec(gsfm_rot_problem* P, const double* Mblk, const double* p, doub
   MatvecArgs a{};
   a.n_rows = P->n_rows; a.row_base = P->own_begin; a.G = P->G; a.row_ptr = P->row_ptr.p; a.col = P->col.p;
   a.h0 = P->h0.p; a.h1 = P->h1.p; a.h2 = P->h2.p; a.h3 = P->h3.p; a.h4 = P->h4.p; a.Mblk = Mblk; a.p = p; a.y = y; a.done = done;
-  hipLaunchKernelGGL(k_matvec, dim3(grid_for((size_t)P->n_rows * P->G)), dim3(GSFM_BLOCK), 0, P->stream, a);
+  a.q = P->q_lin; a.u = P->u_rot.p;   // Laplacian form: the caller keeps u_rot = R^T p (PCG vector kernels, or k_cam_rotT)
+  if (P->lin_is_lap) hipLaunchKernelGGL(k_matvec<true>, dim3(grid_for((size_t)P->n_rows * P->G)), dim3(GSFM_BLOCK), 0, P->stream, a);
+  else hipLaunchKernelGGL(k_matvec<false>, dim3(grid_for((size_t)P->n_rows * P->G)), dim3(GSFM_BLOCK), 0, P->stream, a);
   return all_gather(P, y, (size_t)P->shard.slice_width * 3);
 }
 
@@ -406,6 +421,7 @@ int run_pcg(gsfm_rot_problem* P, const gsfm_rot_options& o, int* iters_out, doub
   a.n = P->n_cams; a.nb = P->nb_cam; a.par = 0; a.tol = o.cg_relative_tolerance; a.max_iters = o.max_cg_iterations; a.stall_limit = o.cg_stall_iterations;
   a.Minv = P->Minv.p; a.b = P->b.p; a.xcg = P->xcg.p; a.r = P->r.p; a.z = P->z.p; a.p = P->p.p; a.Ap = P->Ap.p;
   a.part_a = P->part_a.p; a.part_b = P->part_b.p; a.sc = P->cgsc.p;
+  a.q = P->q_lin; a.u = P->lin_is_lap ? P->u_rot.p : nullptr;
   const dim3 g(P->nb_cam), blk(GSFM_BLOCK);
   const int tk0 = P->timer.begin(T_CG);
   hipLaunchKernelGGL(k_cg_init, g, blk, 0, P->stream, a);
@@ -426,14 +442,14 @@ int run_pcg(gsfm_rot_problem* P, const gsfm_rot_options& o, int* iters_out, doub
   // The chunk between two host checks as one hipGraph launch: 4 * chunk dependent kernels whose arguments never change.
   auto& G = P->pcg_graph;
   bool graph = o.pcg_hip_graph && !P->sharded && chunk % 2 == 0 && !G.unusable;
-  if (graph && (!G.exec || G.tol != a.tol || G.max_iters != a.max_iters || G.stall != a.stall_limit || G.chunk != chunk)) {
+  if (graph && (!G.exec || G.tol != a.tol || G.max_iters != a.max_iters || G.stall != a.stall_limit || G.chunk != chunk || G.lap != P->lin_is_lap)) {
     G.reset();
     hipGraph_t captured = nullptr;
     if (hipStreamBeginCapture(P->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
       const int st = enqueue_chunk();
       const hipError_t e = hipStreamEndCapture(P->stream, &captured);
       if (st == 0 && e == hipSuccess && captured && hipGraphInstantiate(&G.exec, captured, nullptr, nullptr, 0) == hipSuccess) {
-        G.tol = a.tol; G.max_iters = a.max_iters; G.stall = a.stall_limit; G.chunk = chunk;
+        G.tol = a.tol; G.max_iters = a.max_iters; G.stall = a.stall_limit; G.chunk = chunk; G.lap = P->lin_is_lap;
       } else { G.exec = nullptr; }
       if (captured) (void)hipGraphDestroy(captured);
     }
@@ -518,7 +534,7 @@ int run_dense(gsfm_rot_problem* P, bool* used) {
     (void)hipMemsetAsync(P->dense_info.p, 0, sizeof(int), P->stream);
     DenseArgs a{};
     a.n_rows = P->n_rows; a.row_ptr = P->row_ptr.p; a.col = P->col.p; a.h0 = P->h0.p; a.h1 = P->h1.p; a.h2 = P->h2.p; a.h3 = P->h3.p; a.h4 = P->h4.p;
-    a.Mblk = P->Mblk.p; a.A = P->denseA.p; a.n = n;
+    a.Mblk = P->Mblk.p; a.A = P->denseA.p; a.n = n; a.q = P->q_lin; a.lap = P->lin_is_lap;
     hipLaunchKernelGGL(k_dense_assemble, dim3(P->n_rows), dim3(GSFM_BLOCK), 0, P->stream, a);
     for (uint32_t k0 = 0; k0 < n; k0 += GSFM_CB) {
       CholArgs c{P->denseA.p, n, k0, P->dense_info.p, P->denseDinv.p};
@@ -532,7 +548,9 @@ int run_dense(gsfm_rot_problem* P, bool* used) {
     (void)hipMemsetAsync(P->r.p, 0, 8 * (size_t)n, P->stream);  // exact solve: the PCG residual term of the model decrease is zero
   };
   const int tk = P->timer.begin(T_CG);
+  if (P->dense_graph && P->dense_graph_lap != P->lin_is_lap) { (void)hipGraphExecDestroy(P->dense_graph); P->dense_graph = nullptr; }
   if (!P->dense_graph && !P->pcg_graph.unusable) {   // ~3 launches per 32 columns: replay them as one graph
+    P->dense_graph_lap = P->lin_is_lap;
     hipGraph_t captured = nullptr;
     if (hipStreamBeginCapture(P->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
       enqueue();
@@ -674,6 +692,7 @@ int lm_solve(gsfm_rot_problem* P, const gsfm_rot_options& o, gsfm_rot_summary* s
   sum->num_edges_used = P->cost.n;
   P->trace.clear();
   P->timer.acc[0] = P->timer.acc[1] = P->timer.acc[2] = 0;
+  P->lap = P->lap_capable && !o.pcg_single_reduction;   // the single-reduction variant's fused mat-vec keeps the 9-value blocks
   double h[SC_N];
   double radius = o.initial_trust_region_radius, decrease_factor = 2.0;
   int num_invalid = 0, iteration = 0;
@@ -754,7 +773,8 @@ int lm_solve(gsfm_rot_problem* P, const gsfm_rot_options& o, gsfm_rot_summary* s
     if (std::fabs(cost_change) <= o.function_tolerance * x_cost) { record(x_cost, cost_change, step_norm, rel_dec, cg); return finish(GSFM_TERM_FUNCTION_TOLERANCE); }
     if (rel_dec > o.min_relative_decrease) {  // HandleSuccessfulStep
       std::swap(P->x.p, P->x_trial.p);
-      std::swap(P->q.p, P->q_trial.p);
+      // (a copy, not a pointer swap: the captured PCG / Cholesky graphs hold the address of the quaternions they rotate with)
+      HIPCHK(hipMemcpyAsync(P->q.p, P->q_trial.p, 32 * (size_t)P->n_cams, hipMemcpyDeviceToDevice, P->stream));
       x_norm = std::sqrt(h[SC_STEP + 4]);
       x_cost = cand_cost;  // Ceres re-evaluates at the accepted point: same value
       if (int st = launch_lin(P, P->q.p)) return st;
@@ -1020,7 +1040,12 @@ gsfm_status gsfm_rot_problem_create(uint32_t n_cams, uint64_t n_edges, const uin
   ok &= P->Tinv.alloc(9 * N) == hipSuccess; ok &= P->b.alloc(3 * N) == hipSuccess; ok &= P->D6.alloc(6 * N) == hipSuccess;
   ok &= P->q.alloc(2 * N) == hipSuccess; ok &= P->q_trial.alloc(2 * N) == hipSuccess;
   ok &= P->xcg.alloc(3 * N) == hipSuccess; ok &= P->r.alloc(3 * N) == hipSuccess; ok &= P->z.alloc(3 * N) == hipSuccess;
-  ok &= P->p.alloc(3 * NP, true) == hipSuccess; ok &= P->Ap.alloc(3 * NP, true) == hipSuccess;
+  ok &= P->p.alloc(3 * NP, true) == hipSuccess; ok &= P->Ap.alloc(3 * NP, true) == hipSuccess; ok &= P->u_rot.alloc(3 * NP, true) == hipSuccess;
+  {
+    const char* env = getenv("GSFM_LAPLACIAN");   // =0: keep the general 9-value blocks (A/B measurements)
+    P->lap_capable = (P->functor == F_AA || P->functor == F_QCOS) && !(env && atoi(env) == 0);
+    P->lap = P->lap_capable;
+  }
   ok &= P->part_a.alloc(P->nb_cam) == hipSuccess; ok &= P->part_b.alloc(P->nb_cam) == hipSuccess;
   ok &= P->part_cam.alloc((size_t)5 * P->nb_cam) == hipSuccess; ok &= P->part_cost.alloc(P->nb_cost) == hipSuccess;
   ok &= P->scal.alloc(SC_N, true) == hipSuccess; ok &= P->cgsc.alloc(1, true) == hipSuccess;
@@ -1233,6 +1258,7 @@ gsfm_status gsfm_rot_normal_matvec(gsfm_rot_problem* P, const double* v, double*
   // y = T^T B_eta (T v): xcg <- v, p <- T v, Ap <- B p, xcg <- T^T Ap
   if (hipMemcpyAsync(P->xcg.p, to_internal(P, v, 3), 24 * N, hipMemcpyHostToDevice, P->stream) != hipSuccess) return (gsfm_status)fail(GSFM_ERR_HIP, "upload v");
   hipLaunchKernelGGL(k_cam_apply_T, dim3(grid_for(N)), dim3(GSFM_BLOCK), 0, P->stream, P->x.p, P->n_cams, P->param_dim, 0, P->xcg.p, P->p.p);
+  if (P->lin_is_lap) hipLaunchKernelGGL(k_cam_rotT, dim3(grid_for(N)), dim3(GSFM_BLOCK), 0, P->stream, (const double*)P->p.p, P->q_lin, P->n_cams, P->u_rot.p);
   if (int st = launch_matvec(P, P->D6.p, P->p.p, P->Ap.p, nullptr)) return (gsfm_status)st;
   hipLaunchKernelGGL(k_cam_apply_T, dim3(grid_for(N)), dim3(GSFM_BLOCK), 0, P->stream, P->x.p, P->n_cams, P->param_dim, 1, P->Ap.p, P->xcg.p);
   double* dst = y;

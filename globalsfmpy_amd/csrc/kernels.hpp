@@ -533,9 +533,18 @@ struct LinArgs {
   double2 *h0, *h1, *h2, *h3;  // H block planes (row-major 3x3: h0=(H00,H01) h1=(H02,H10) h2=(H11,H12) h3=(H20,H21))
   double* h4;                  // H22
   double* gD;                  // 9 per camera: g(3), D sym(6: d00 d01 d02 d11 d12 d22)
+  int lap;                     // 1: Laplacian form, planes h0..h2 hold the symmetric edge weight B (see lin_rows)
 };
 
-template <int F, int WM, int LM>
+// LAP = true ("Laplacian form", functors that depend on R_j R_i^T only: angle-axis and quaternion-cosine): for those
+// J_i = -J_j Q with Q = R_j R_i^T exactly (also after the Corrector, which multiplies both blocks from the left), hence
+//   H_jj = G, H_ji = -G Q, H_ij = -Q^T G, H_ii = Q^T G Q   with G = J_j^T J_j,
+// i.e. every off-diagonal block is the row camera's own symmetric G_k = J_k^T J_k times a rotation:
+//   H_km p_m = -G_k R_k (R_m^T p_m)   =>   y_k = M_k p_k - sum_{d in row k} G_d (R_k u[col_d]),   u_m = R_m^T p_m.
+// (In the body frame B = R_k^T G_k R_k is the same matrix from either end of the edge: a graph Laplacian with one symmetric
+// 3x3 weight per edge.)  K2 then stores 6 doubles per directed entry instead of 9 (planes h0..h2), needs no neighbour
+// Jacobian, and K3 streams 52 B per entry instead of 76; the rotation by the row's R_k is nine FMAs K3 has room for.
+template <int F, int WM, int LM, bool LAP>
 __device__ __forceinline__ void lin_rows(const LinArgs& a) {
   constexpr int R = ResDim<F>::R;
   const uint32_t G = a.G;
@@ -566,38 +575,46 @@ __device__ __forceinline__ void lin_rows(const LinArgs& a) {
       else rho = loss_eval<LM>(a.loss, s);
       robustify<R>(rho, s, r, Ai, Aj);
       const double* Ar = row_is_second ? Aj : Ai;  // Jacobian of the row camera
-      const double* Ac = row_is_second ? Ai : Aj;  // Jacobian of the neighbour
-      double H[9];
+      const double* Ac = row_is_second ? Ai : Aj;  // Jacobian of the neighbour (dead code when LAP)
 #pragma unroll
       for (int x = 0; x < 3; ++x) {
         double g = 0.0;
 #pragma unroll
         for (int c = 0; c < R; ++c) g += Ar[3 * c + x] * r[c];
         acc[x] += g;
-#pragma unroll
-        for (int y = 0; y < 3; ++y) {
-          double h = 0.0;
-#pragma unroll
-          for (int c = 0; c < R; ++c) h += Ar[3 * c + x] * Ac[3 * c + y];
-          H[3 * x + y] = h;
-        }
       }
-      {
-        double d00 = 0, d01 = 0, d02 = 0, d11 = 0, d12 = 0, d22 = 0;
+      double d00 = 0, d01 = 0, d02 = 0, d11 = 0, d12 = 0, d22 = 0;
 #pragma unroll
-        for (int c = 0; c < R; ++c) {
-          const double x0 = Ar[3 * c], x1 = Ar[3 * c + 1], x2 = Ar[3 * c + 2];
-          d00 += x0 * x0; d01 += x0 * x1; d02 += x0 * x2; d11 += x1 * x1; d12 += x1 * x2; d22 += x2 * x2;
-        }
-        acc[3] += d00; acc[4] += d01; acc[5] += d02; acc[6] += d11; acc[7] += d12; acc[8] += d22;
+      for (int c = 0; c < R; ++c) {
+        const double x0 = Ar[3 * c], x1 = Ar[3 * c + 1], x2 = Ar[3 * c + 2];
+        d00 += x0 * x0; d01 += x0 * x1; d02 += x0 * x2; d11 += x1 * x1; d12 += x1 * x2; d22 += x2 * x2;
       }
+      acc[3] += d00; acc[4] += d01; acc[5] += d02; acc[6] += d11; acc[7] += d12; acc[8] += d22;
       // streamed out once, read back by K3: non-temporal stores avoid the write-allocate fetch that PMC showed
       // (FETCH_SIZE of this kernel was 1.8x its algorithmic reads, profiles/r01_c_pmc_hbm_traffic.txt)
-      nt_store2(a.h0 + d, H[0], H[1]);
-      nt_store2(a.h1 + d, H[2], H[3]);
-      nt_store2(a.h2 + d, H[4], H[5]);
-      nt_store2(a.h3 + d, H[6], H[7]);
-      __builtin_nontemporal_store(H[8], a.h4 + d);
+      if (LAP) {
+        // G = J_k^T J_k of the row camera, as is: H_km p_m = -G_k R_k (R_m^T p_m), the rotation by R_k is applied by K3
+        nt_store2(a.h0 + d, d00, d01);
+        nt_store2(a.h1 + d, d02, d11);
+        nt_store2(a.h2 + d, d12, d22);
+      } else {
+        double H[9];
+#pragma unroll
+        for (int x = 0; x < 3; ++x) {
+#pragma unroll
+          for (int y = 0; y < 3; ++y) {
+            double h = 0.0;
+#pragma unroll
+            for (int c = 0; c < R; ++c) h += Ar[3 * c + x] * Ac[3 * c + y];
+            H[3 * x + y] = h;
+          }
+        }
+        nt_store2(a.h0 + d, H[0], H[1]);
+        nt_store2(a.h1 + d, H[2], H[3]);
+        nt_store2(a.h2 + d, H[4], H[5]);
+        nt_store2(a.h3 + d, H[6], H[7]);
+        __builtin_nontemporal_store(H[8], a.h4 + d);
+      }
     }
   }
   // segmented reduction over the G lanes of the row (rows are G-aligned inside the wavefront)
@@ -613,10 +630,10 @@ __device__ __forceinline__ void lin_rows(const LinArgs& a) {
 }
 // Two entry points over the same body: `k_lin3` asks for at least three waves per SIMD, which is free (no spill) for the
 // instantiations that matter and would spill for the general loss program and the 9-residual functor; the launcher picks.
-template <int F, int WM, int LM>
-__global__ void __launch_bounds__(GSFM_BLOCK) k_lin(LinArgs a) { lin_rows<F, WM, LM>(a); }
-template <int F, int WM, int LM>
-__global__ void __launch_bounds__(GSFM_BLOCK) GSFM_K2_ATTR k_lin3(LinArgs a) { lin_rows<F, WM, LM>(a); }
+template <int F, int WM, int LM, bool LAP>
+__global__ void __launch_bounds__(GSFM_BLOCK) k_lin(LinArgs a) { lin_rows<F, WM, LM, LAP>(a); }
+template <int F, int WM, int LM, bool LAP>
+__global__ void __launch_bounds__(GSFM_BLOCK) GSFM_K2_ATTR k_lin3(LinArgs a) { lin_rows<F, WM, LM, LAP>(a); }
 
 // ------------------------------------------------------------------------------------------
 // K3: y_k = M_k p_k + sum_d H_d p[col_d]   (M = diagonal block incl. LM damping, sym 6)
@@ -631,7 +648,11 @@ struct MatvecArgs {
   const double* p;      // 3 per camera
   double* y;            // 3 per camera
   const int* done;      // PCG convergence flag (may be null)
+  const double2* q;     // LAP: camera quaternions
+  const double* u;      // LAP: u_k = R_k^T p_k, 3 per camera
 };
+// LAP = false: y_k = M_k p_k + sum_d H_d p[col_d], 76 B per entry.  LAP = true: y_k = M_k p_k - sum_d G_d (R_k u[col_d]), 52 B per entry.
+template <bool LAP>
 __global__ void __launch_bounds__(GSFM_BLOCK) k_matvec(MatvecArgs a) {
   if (a.done && *a.done) return;
   const uint32_t G = a.G;
@@ -640,17 +661,29 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_matvec(MatvecArgs a) {
   const bool live = row < a.n_rows;
   double y0 = 0.0, y1 = 0.0, y2 = 0.0;
   if (live) {
+    double Rk[9];
+    if (LAP) qmat(load_q(a.q, a.row_base + row), Rk);
     const uint32_t end = a.row_ptr[row + 1];
     for (uint32_t d = a.row_ptr[row] + lane; d < end; d += G) {
       const uint32_t m = __builtin_nontemporal_load(a.col + d) & 0x7fffffffu;
-      // H is streamed once per mat-vec: non-temporal loads keep the gathered p vector resident in L2
-      const double2 A = nt_load2(a.h0 + d), B = nt_load2(a.h1 + d), C = nt_load2(a.h2 + d), D = nt_load2(a.h3 + d);
-      const double E = __builtin_nontemporal_load(a.h4 + d);
-      const double* pm = a.p + 3 * (size_t)m;
-      const double p0 = pm[0], p1 = pm[1], p2 = pm[2];
-      y0 += A.x * p0 + A.y * p1 + B.x * p2;
-      y1 += B.y * p0 + C.x * p1 + C.y * p2;
-      y2 += D.x * p0 + D.y * p1 + E * p2;
+      // the blocks are streamed once per mat-vec: non-temporal loads keep the gathered vector resident in L2
+      if (LAP) {
+        const double2 A = nt_load2(a.h0 + d), B = nt_load2(a.h1 + d), C = nt_load2(a.h2 + d);   // (g00 g01) (g02 g11) (g12 g22)
+        const double* um = a.u + 3 * (size_t)m;
+        const double u0 = um[0], u1 = um[1], u2 = um[2];
+        const double w0 = Rk[0] * u0 + Rk[1] * u1 + Rk[2] * u2, w1 = Rk[3] * u0 + Rk[4] * u1 + Rk[5] * u2, w2 = Rk[6] * u0 + Rk[7] * u1 + Rk[8] * u2;
+        y0 += A.x * w0 + A.y * w1 + B.x * w2;
+        y1 += A.y * w0 + B.y * w1 + C.x * w2;
+        y2 += B.x * w0 + C.x * w1 + C.y * w2;
+      } else {
+        const double2 A = nt_load2(a.h0 + d), B = nt_load2(a.h1 + d), C = nt_load2(a.h2 + d), D = nt_load2(a.h3 + d);
+        const double E = __builtin_nontemporal_load(a.h4 + d);
+        const double* pm = a.p + 3 * (size_t)m;
+        const double p0 = pm[0], p1 = pm[1], p2 = pm[2];
+        y0 += A.x * p0 + A.y * p1 + B.x * p2;
+        y1 += B.y * p0 + C.x * p1 + C.y * p2;
+        y2 += D.x * p0 + D.y * p1 + E * p2;
+      }
     }
   }
   for (uint32_t off = G >> 1; off > 0; off >>= 1) {
@@ -662,8 +695,25 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_matvec(MatvecArgs a) {
     const double* pk = a.p + 3 * k;
     double mp[3];
     sym3_mulvec(M, pk, mp);
-    a.y[3 * k] = y0 + mp[0]; a.y[3 * k + 1] = y1 + mp[1]; a.y[3 * k + 2] = y2 + mp[2];
+    const double sgn = LAP ? -1.0 : 1.0;
+    a.y[3 * k] = mp[0] + sgn * y0; a.y[3 * k + 1] = mp[1] + sgn * y1; a.y[3 * k + 2] = mp[2] + sgn * y2;
   }
+}
+// u_k = R_k^T p_k (the PCG vector kernels produce it together with p; this is for the other callers of the mat-vec)
+__device__ __forceinline__ void rot_transpose_apply(const Quat& q, const double* p, double* u) {
+  double R[9];
+  qmat(q, R);
+  u[0] = R[0] * p[0] + R[3] * p[1] + R[6] * p[2];
+  u[1] = R[1] * p[0] + R[4] * p[1] + R[7] * p[2];
+  u[2] = R[2] * p[0] + R[5] * p[1] + R[8] * p[2];
+}
+__global__ void __launch_bounds__(GSFM_BLOCK) k_cam_rotT(const double* __restrict__ p, const double2* __restrict__ q, uint32_t n, double* __restrict__ u) {
+  const uint32_t k = blockIdx.x * GSFM_BLOCK + threadIdx.x;
+  if (k >= n) return;
+  const Quat qq{q[2 * (size_t)k].x, q[2 * (size_t)k].y, q[2 * (size_t)k + 1].x, q[2 * (size_t)k + 1].y};
+  double v[3];
+  rot_transpose_apply(qq, p + 3 * (size_t)k, v);
+  u[3 * (size_t)k] = v[0]; u[3 * (size_t)k + 1] = v[1]; u[3 * (size_t)k + 2] = v[2];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -940,6 +990,8 @@ struct CgArgs {
   double* part_a;    // [nb]
   double* part_b;    // [nb]
   CgScalars* sc;
+  const double2* q;  // Laplacian form: camera quaternions and
+  double* u;         //   u_k = R_k^T p_k, written wherever p is (null otherwise)
 };
 
 // x = 0, r = b, z = Minv r, p = z, partial r.z
@@ -954,6 +1006,12 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_cg_init(CgArgs a) {
     sym3_mulvec(a.Minv + 6 * (size_t)k, r, z);
 #pragma unroll
     for (int c = 0; c < 3; ++c) { a.xcg[k3 + c] = 0.0; a.r[k3 + c] = r[c]; a.z[k3 + c] = z[c]; a.p[k3 + c] = z[c]; v += r[c] * z[c]; }
+    if (a.u) {
+      const Quat qq{a.q[2 * (size_t)k].x, a.q[2 * (size_t)k].y, a.q[2 * (size_t)k + 1].x, a.q[2 * (size_t)k + 1].y};
+      double uu[3];
+      rot_transpose_apply(qq, z, uu);
+      a.u[k3] = uu[0]; a.u[k3 + 1] = uu[1]; a.u[k3 + 2] = uu[2];
+    }
   }
   const double t = block_sum_bcast(v, lds);
   if (threadIdx.x == 0) a.part_b[blockIdx.x] = t;
@@ -1009,8 +1067,15 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_cg_pupdate(CgArgs a) {
   const uint32_t k = blockIdx.x * GSFM_BLOCK + threadIdx.x;
   if (k < a.n) {
     const size_t k3 = 3 * (size_t)k;
+    double pn[3];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) a.p[k3 + c] = a.z[k3 + c] + beta * a.p[k3 + c];
+    for (int c = 0; c < 3; ++c) { pn[c] = a.z[k3 + c] + beta * a.p[k3 + c]; a.p[k3 + c] = pn[c]; }
+    if (a.u) {
+      const Quat qq{a.q[2 * (size_t)k].x, a.q[2 * (size_t)k].y, a.q[2 * (size_t)k + 1].x, a.q[2 * (size_t)k + 1].y};
+      double uu[3];
+      rot_transpose_apply(qq, pn, uu);
+      a.u[k3] = uu[0]; a.u[k3 + 1] = uu[1]; a.u[k3 + 2] = uu[2];
+    }
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     a.sc->rz[a.par ^ 1] = rz_new;
@@ -1203,6 +1268,8 @@ struct DenseArgs {
   const double* Mblk;  // 6 per camera
   double* A;           // n x n, zero-filled before the launch
   uint32_t n;
+  const double2* q;    // Laplacian form (lap = 1): planes h0..h2 hold G_k, the block is -G_k R_k R_m^T
+  int lap;
 };
 __global__ void __launch_bounds__(GSFM_BLOCK) k_dense_assemble(DenseArgs a) {
   const uint32_t row = blockIdx.x;
@@ -1214,8 +1281,19 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_dense_assemble(DenseArgs a) {
   }
   for (uint32_t d = a.row_ptr[row] + threadIdx.x; d < a.row_ptr[row + 1]; d += GSFM_BLOCK) {
     const uint32_t m = a.col[d] & 0x7fffffffu;
-    const double2 A0 = a.h0[d], B0 = a.h1[d], C0 = a.h2[d], D0 = a.h3[d];
-    const double H[9] = {A0.x, A0.y, B0.x, B0.y, C0.x, C0.y, D0.x, D0.y, a.h4[d]};
+    double H[9];
+    if (a.lap) {
+      const double2 A0 = a.h0[d], B0 = a.h1[d], C0 = a.h2[d];
+      const double Gm[9] = {A0.x, A0.y, B0.x, A0.y, B0.y, C0.x, B0.x, C0.x, C0.y};
+      double Rk[9], Rm[9], T[9];
+      qmat(load_q(a.q, row), Rk);
+      qmat(load_q(a.q, m), Rm);
+      for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) T[3 * r + c] = Rk[3 * r] * Rm[3 * c] + Rk[3 * r + 1] * Rm[3 * c + 1] + Rk[3 * r + 2] * Rm[3 * c + 2];   // R_k R_m^T
+      for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) H[3 * r + c] = -(Gm[3 * r] * T[c] + Gm[3 * r + 1] * T[3 + c] + Gm[3 * r + 2] * T[6 + c]);
+    } else {
+      const double2 A0 = a.h0[d], B0 = a.h1[d], C0 = a.h2[d], D0 = a.h3[d];
+      H[0] = A0.x; H[1] = A0.y; H[2] = B0.x; H[3] = B0.y; H[4] = C0.x; H[5] = C0.y; H[6] = D0.x; H[7] = D0.y; H[8] = a.h4[d];
+    }
     for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) atomicAdd(&a.A[(size_t)(3 * m + c) * a.n + 3 * row + r], H[3 * r + c]);
   }
 }
