@@ -318,3 +318,24 @@ def test_dense_cholesky_auto_mode_switches_only_when_pcg_struggles(graph):
         assert 0 < s1["num_dense_solves"] < s1["num_iterations"] and s1["num_cg_iterations"] < s0["num_cg_iterations"]
     assert abs(s1["final_cost"] - s0["final_cost"]) <= 1e-5 * s0["final_cost"]
     assert synth.angular_distance(synth.align_rotations(r1, r0), r0).mean() <= 1e-5
+
+
+@pytest.mark.parametrize("et", [_abi.ANGLE_AXIS_COVARIANCE, _abi.QUATERNION_COSINE])
+def test_laplacian_form_equals_the_general_blocks(graph, et, monkeypatch):
+    """H_km = -G_k R_k R_m^T (6 stored doubles per directed entry) against the general 9-value blocks: same mat-vec to rounding,
+    same LM trajectory."""
+    from globalsfmpy_amd.solver import RotationProblem
+    kw = {"cov6": graph["cov6"]} if et == _abi.ANGLE_AXIS_COVARIANCE else {}
+    loss = LF.MAGSACWeightBasedLoss(0.02) if et == _abi.ANGLE_AXIS_COVARIANCE else LF.HuberLoss(0.1)
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("GSFM_LAPLACIAN", mode)
+        p = RotationProblem(graph["n_cams"], graph["edge_i"], graph["edge_j"], graph["rel_aa"], et, **kw); p.set_loss(loss)
+        p.linearize(graph["init_aa"])
+        v = np.random.default_rng(3).standard_normal((graph["n_cams"], 3))
+        out[mode] = (p.normal_matvec(v),) + p.solve(graph["init_aa"])
+    (y0, r0, s0), (y1, r1, s1) = out["0"], out["1"]
+    assert np.abs(y1 - y0).max() < 1e-13 * np.abs(y0).max()
+    assert s1["num_iterations"] == s0["num_iterations"] and s1["termination"] == s0["termination"]
+    assert abs(s1["final_cost"] - s0["final_cost"]) < 1e-9 * s0["final_cost"]
+    assert synth.angular_distance(r1, r0).max() < 1e-9
