@@ -387,6 +387,7 @@ int launch_lin(gsfm_rot_problem* P, const double2* q) {
   a.n_rows = P->n_rows; a.row_base = P->own_begin; a.G = P->G; a.row_ptr = P->row_ptr.p; a.col = P->col.p; a.eid = P->dir.eid.p;
   a.qr0 = P->dir.qr0.p; a.qr1 = P->dir.qr1.p; a.w0 = P->dir.w0.p; a.w1 = P->dir.w1.p; a.w2 = P->dir.w2.p; a.ws = P->dir.ws.p;
   a.q = q; a.loss = P->d_loss.p; a.rho_ext = P->cb ? P->rho_ext.p : nullptr;
+  if (!P->lap && !P->h3.p && (P->h3.alloc(P->dir.n) != hipSuccess || P->h4.alloc(P->dir.n) != hipSuccess)) return fail(GSFM_ERR_HIP, "allocating the general normal-equation blocks failed");
   a.h0 = P->h0.p; a.h1 = P->h1.p; a.h2 = P->h2.p; a.h3 = P->h3.p; a.h4 = P->h4.p; a.gD = P->gD.p; a.lap = P->lap;
   P->lin_is_lap = P->lap; P->q_lin = q;
   const int tk = P->timer.begin(T_LIN);
@@ -1015,7 +1016,8 @@ gsfm_status gsfm_rot_problem_create(uint32_t n_cams, uint64_t n_edges, const uin
   P->nb_cost = (int)tiles.size();
   if (P->cost_idx.upload(cidx) != hipSuccess || P->row_ptr.upload(rp) != hipSuccess || P->col.upload(col) != hipSuccess)
     return bail(fail(GSFM_ERR_HIP, "uploading graph structure failed"));
-  if (P->h0.alloc(nd) != hipSuccess || P->h1.alloc(nd) != hipSuccess || P->h2.alloc(nd) != hipSuccess || P->h3.alloc(nd) != hipSuccess || P->h4.alloc(nd) != hipSuccess)
+  // planes h3, h4 (the last three of the nine values of a general block) are allocated on first use: the Laplacian form needs six
+  if (P->h0.alloc(nd) != hipSuccess || P->h1.alloc(nd) != hipSuccess || P->h2.alloc(nd) != hipSuccess)
     return bail(fail(GSFM_ERR_HIP, "allocating normal-equation blocks failed"));
   lap("edge planes -> device");
   {  // K0 whitening
