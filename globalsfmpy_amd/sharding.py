@@ -187,20 +187,32 @@ class NativeComm(object):
         lib.gsfm_rccl_create.argtypes = [C.c_char_p, C.c_int, C.c_int]
         lib.gsfm_rccl_destroy.argtypes = [C.c_void_p]
         lib.gsfm_rccl_init.argtypes = [C.c_char_p]
+        # Every step that can fail is agreed on by all ranks before the next collective: a rank that raised alone would leave the
+        # others blocked inside ncclCommInitRank (or inside the broadcast of the unique id).
+        def all_ok(flag):
+            t = torch.tensor([1 if flag else 0], dtype=torch.int32, device="cuda" if dist.get_backend(group) == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+            return bool(t.item())
+
         bundled = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
-        if lib.gsfm_rccl_init(bundled.encode() if os.path.exists(bundled) else None) != 0:
-            raise RuntimeError("RCCL not available: %s" % lib.gsfm_rccl_last_error().decode())
+        loaded = lib.gsfm_rccl_init(bundled.encode() if os.path.exists(bundled) else None) == 0
+        if not all_ok(loaded):
+            raise RuntimeError("RCCL not available on every rank: %s" % lib.gsfm_rccl_last_error().decode())
         ident = [None]
         if self.rank == 0:
             buf = C.create_string_buffer(128)
-            if lib.gsfm_rccl_unique_id(buf) != 0:
-                raise RuntimeError("ncclGetUniqueId failed: %s" % lib.gsfm_rccl_last_error().decode())
-            ident[0] = buf.raw
+            if lib.gsfm_rccl_unique_id(buf) == 0:
+                ident[0] = buf.raw
         dist.broadcast_object_list(ident, src=0, group=group)
+        if ident[0] is None:
+            raise RuntimeError("ncclGetUniqueId failed on rank 0: %s" % lib.gsfm_rccl_last_error().decode())
         torch.cuda.synchronize()
         self._ctx = lib.gsfm_rccl_create(ident[0], self.rank, self.world)
-        if not self._ctx:
-            raise RuntimeError("ncclCommInitRank failed: %s" % lib.gsfm_rccl_last_error().decode())
+        if not all_ok(bool(self._ctx)):
+            if self._ctx:
+                lib.gsfm_rccl_destroy(self._ctx)
+                self._ctx = None
+            raise RuntimeError("ncclCommInitRank failed on some rank: %s" % lib.gsfm_rccl_last_error().decode())
         self._lib = lib
         self.backend = "rccl-native"
         self.n_all_gather = self.n_all_reduce = -1  # not counted on this path
