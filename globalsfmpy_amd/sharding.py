@@ -94,6 +94,7 @@ class TorchComm(object):
         self.P = slice_width(n_cams, self.world)
         self._views = {}
         self._host = {}
+        self._ext = {}
         self.n_all_gather = 0
         self.n_all_reduce = 0
         self._ag = _abi.ALL_GATHER_FN(self._all_gather)
@@ -102,10 +103,18 @@ class TorchComm(object):
                                 all_gather=self._ag, all_reduce_sum=self._ar)
 
     def stream_handle(self):
-        """Run the solver on torch's current stream so RCCL ops are ordered with its kernels."""
-        if self.backend == "nccl":
-            return self.torch.cuda.current_stream().cuda_stream
+        """The solver keeps its own stream; the callbacks order torch's collectives against the stream handed to them."""
         return None
+
+    def _on_solver_stream(self, stream):
+        """Context in which torch's current stream IS the solver's stream: ProcessGroupNCCL makes its communication stream wait
+        for the current stream before the collective and the current stream wait for the collective after it."""
+        key = int(stream) if stream else 0
+        ext = self._ext.get(key)
+        if ext is None:
+            ext = self.torch.cuda.ExternalStream(key) if key else self.torch.cuda.current_stream()
+            self._ext[key] = ext
+        return self.torch.cuda.stream(ext)
 
     def _view(self, ptr, count):
         key = (ptr, count)
@@ -135,7 +144,8 @@ class TorchComm(object):
             full = self._view(buf, total)
             mine = full[self.rank * count:(self.rank + 1) * count]
             if self.backend == "nccl":
-                self.dist.all_gather_into_tensor(full, mine, group=self.group)
+                with self._on_solver_stream(stream):
+                    self.dist.all_gather_into_tensor(full, mine, group=self.group)
             else:
                 self._sync_stream(stream)
                 h_in = mine.cpu()
@@ -154,7 +164,8 @@ class TorchComm(object):
             self.n_all_reduce += 1
             t = self._view(buf, count)
             if self.backend == "nccl":
-                self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+                with self._on_solver_stream(stream):
+                    self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
             else:
                 self._sync_stream(stream)
                 h = t.cpu()
