@@ -43,6 +43,9 @@ template <int F> struct ResDim { static constexpr int R = (F == F_QNORM) ? 4 : (
 // SIMD; asking for at least three costs no spill (168 VGPRs) and 7.5 % less time on C5.  Four would spill 37 VGPRs (2x slower).
 #define GSFM_K2_ATTR __attribute__((amdgpu_waves_per_eu(3)))
 #endif
+#ifndef GSFM_GATHER_LOAD
+#define GSFM_GATHER_LOAD(p) (*(p))   // tuning hook: e.g. __builtin_nontemporal_load(p)
+#endif
 #ifndef GSFM_K1_UNROLL
 #define GSFM_K1_UNROLL 1   // edges per lane whose streams are requested before any of them is evaluated
 #endif
@@ -670,7 +673,7 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_matvec(MatvecArgs a) {
       if (LAP) {
         const double2 A = nt_load2(a.h0 + d), B = nt_load2(a.h1 + d), C = nt_load2(a.h2 + d);   // (g00 g01) (g02 g11) (g12 g22)
         const double* um = a.u + 3 * (size_t)m;
-        const double u0 = um[0], u1 = um[1], u2 = um[2];
+        const double u0 = GSFM_GATHER_LOAD(um), u1 = GSFM_GATHER_LOAD(um + 1), u2 = GSFM_GATHER_LOAD(um + 2);
         const double w0 = Rk[0] * u0 + Rk[1] * u1 + Rk[2] * u2, w1 = Rk[3] * u0 + Rk[4] * u1 + Rk[5] * u2, w2 = Rk[6] * u0 + Rk[7] * u1 + Rk[8] * u2;
         y0 += A.x * w0 + A.y * w1 + B.x * w2;
         y1 += A.y * w0 + B.y * w1 + C.x * w2;
