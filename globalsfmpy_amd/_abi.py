@@ -185,6 +185,7 @@ def load_library():
     lib.gsfm_rot_time_sweep.argtypes = [C.c_void_p, _DP, C.c_int32, _DP]; lib.gsfm_rot_time_sweep.restype = C.c_int
     lib.gsfm_rot_time_kernels.argtypes = [C.c_void_p, _DP, C.c_int32, _DP]; lib.gsfm_rot_time_kernels.restype = C.c_int
     lib.gsfm_rot_sweep_bytes.argtypes = [C.c_void_p, _DP, _DP]; lib.gsfm_rot_sweep_bytes.restype = C.c_int
+    lib.gsfm_rot_loss_eval.argtypes = [C.c_void_p, _DP, C.c_uint64, _DP, _DP]; lib.gsfm_rot_loss_eval.restype = C.c_int
     lib.gsfm_cov_estimate.argtypes = [C.c_uint64, C.POINTER(C.c_uint64), _DP, _DP, _DP, _DP, C.c_int32, _DP, _DP, _DP,
                                       C.POINTER(C.c_int32), C.POINTER(C.c_int32), _DP]
     lib.gsfm_cov_estimate.restype = C.c_int

@@ -1271,6 +1271,25 @@ gsfm_status gsfm_rot_normal_matvec(gsfm_rot_problem* P, const double* v, double*
   return GSFM_OK;
 }
 
+gsfm_status gsfm_rot_loss_eval(gsfm_rot_problem* P, const double* s, uint64_t n, double* rho3_out, double* value_out) {
+  if (!P || (n > 0 && !s)) return (gsfm_status)fail(GSFM_ERR_INVALID_ARG, "NULL argument");
+  if (P->cb) return (gsfm_status)fail(GSFM_ERR_UNSUPPORTED, "loss_eval needs a native loss program (a host-callback loss runs on the host)");
+  if (n == 0) return GSFM_OK;
+  DeviceGuard g(P->device);
+  DevBuf<double> ds, d3, dv;
+  if (ds.alloc(n) != hipSuccess || (rho3_out && d3.alloc(3 * n) != hipSuccess) || (value_out && dv.alloc(n) != hipSuccess)) return (gsfm_status)fail(GSFM_ERR_HIP, "alloc");
+  HIPCHK_S(hipMemcpyAsync(ds.p, s, 8 * n, hipMemcpyHostToDevice, P->stream));
+  const dim3 grid(grid_for(n)), blk(GSFM_BLOCK);
+  switch (loss_mode(P)) {   // the specialisation K1 / K2 are dispatched on for this program
+    case LM_SIMPLE: hipLaunchKernelGGL(k_loss_eval<LM_SIMPLE>, grid, blk, 0, P->stream, (const DevLoss*)P->d_loss.p, (const double*)ds.p, (size_t)n, d3.p, dv.p); break;
+    case LM_MAGSAC: hipLaunchKernelGGL(k_loss_eval<LM_MAGSAC>, grid, blk, 0, P->stream, (const DevLoss*)P->d_loss.p, (const double*)ds.p, (size_t)n, d3.p, dv.p); break;
+    default: hipLaunchKernelGGL(k_loss_eval<LM_PROGRAM>, grid, blk, 0, P->stream, (const DevLoss*)P->d_loss.p, (const double*)ds.p, (size_t)n, d3.p, dv.p); break;
+  }
+  if (rho3_out) HIPCHK_S(hipMemcpyAsync(rho3_out, d3.p, 24 * n, hipMemcpyDeviceToHost, P->stream));
+  if (value_out) HIPCHK_S(hipMemcpyAsync(value_out, dv.p, 8 * n, hipMemcpyDeviceToHost, P->stream));
+  return (gsfm_status)sync_check(P, "loss_eval");
+}
+
 int32_t gsfm_rot_get_trace(gsfm_rot_problem* P, double* out, int32_t cap_rows) {
   if (!P) return 0;
   const int rows = (int)(P->trace.size() / GSFM_ROT_TRACE_COLS);

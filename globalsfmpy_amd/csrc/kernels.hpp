@@ -510,6 +510,18 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_cost_direct(CostArgs a) {
   }
 }
 
+// The loss program on given squared norms, through the very routines the sweeps use (device-level pin against the reference's
+// recorded (s, rho, rho', rho'') vectors): rho3 = loss_eval<LM> (K2 and the FULL sweep), val = loss_value<LM> (the cost-only sweep).
+template <int LM>
+__global__ void __launch_bounds__(GSFM_BLOCK) k_loss_eval(const DevLoss* __restrict__ loss, const double* __restrict__ s, size_t n,
+                                                          double* __restrict__ rho3, double* __restrict__ val) {
+  const size_t t = (size_t)blockIdx.x * GSFM_BLOCK + threadIdx.x;
+  if (t >= n) return;
+  const double sq = s[t];
+  if (rho3) { const Rho3 r = loss_eval<LM>(loss, sq); rho3[3 * t] = r.r0; rho3[3 * t + 1] = r.r1; rho3[3 * t + 2] = r.r2; }
+  if (val) val[t] = loss_value<LM>(loss, sq);
+}
+
 // out[0] = sum partials (single block, fixed order)
 __global__ void __launch_bounds__(GSFM_BLOCK) k_sum_partials(const double* __restrict__ partials, int n, double* out) {
   __shared__ double lds[8];

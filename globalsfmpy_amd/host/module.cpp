@@ -426,6 +426,20 @@ PYBIND11_MODULE(_GlobalSfMpy, m) {  // imported through the GlobalSfMpy.py shim 
     for (const auto& kv : rec.orientation) f << kv.first << " " << kv.second[0] << " " << kv.second[1] << " " << kv.second[2] << "\n";
     return (bool)f;
   });
+  // bind :631 / Theia io/write_ply_file.cc:74-123: tracks (3-D points) and the positions of the estimated views as green vertices.
+  // A rotation-only reconstruction has no tracks and no camera positions, so the file holds one green vertex at the origin per
+  // estimated view -- the same header, the same vertex format, so sfm_pipeline.py's __main__ (:146) runs through.
+  m.def("WritePlyFile", [](const std::string& ply_file, const Reconstruction& rec, int /*min_num_observations_per_point*/) {
+    if (ply_file.empty()) throw std::invalid_argument("WritePlyFile: empty file name");
+    std::ofstream f(ply_file);
+    if (!f.is_open()) return false;
+    size_t n = 0;
+    for (const auto& kv : rec.orientation) n += rec.views.count(kv.first);
+    f << "ply\nformat ascii 1.0\nelement vertex " << n
+      << "\nproperty float x\nproperty float y\nproperty float z\nproperty uchar red\nproperty uchar green\nproperty uchar blue\nend_header" << std::endl;
+    for (const auto& kv : rec.orientation) if (rec.views.count(kv.first)) f << "0 0 0 0 255 0\n";
+    return (bool)f;
+  }, py::call_guard<py::gil_scoped_release>());
   // ---- evaluation (bind :387-394, :396-403, :651-664; orientations only) ----
   py::class_<gsfm::CompareInfo>(m, "CompareInfo")
       .def(py::init<>())

@@ -200,6 +200,13 @@ class RotationProblem(ProblemBase):
         self._check(self._lib.gsfm_rot_time_kernels(self._h, _dp(rot), int(reps), _dp(out)), "time_kernels")
         return {"k_cost": out[0], "k_lin": out[1], "k_matvec": out[2]}
 
+    def loss_eval(self, s):
+        """(rho, rho', rho'')(s) and the cost-only rho(s) of the current native loss, evaluated by the device routines."""
+        s = np.ascontiguousarray(s, dtype=np.float64).ravel()
+        rho3, val = np.empty((s.size, 3)), np.empty(s.size)
+        self._check(self._lib.gsfm_rot_loss_eval(self._h, _dp(s), s.size, _dp(rho3), _dp(val)), "loss_eval")
+        return rho3, val
+
     def sweep_bytes(self):
         a, b = C.c_double(0), C.c_double(0)
         self._check(self._lib.gsfm_rot_sweep_bytes(self._h, C.byref(a), C.byref(b)), "sweep_bytes")

@@ -275,6 +275,12 @@ gsfm_status gsfm_rot_linearize(gsfm_rot_problem* p, const double* rot_aa,
 /* y = (J~^T J~) v for the last linearisation (kernel K3), 3 per camera. */
 gsfm_status gsfm_rot_normal_matvec(gsfm_rot_problem* p, const double* v, double* y);
 
+/* The problem's current native loss program evaluated ON THE DEVICE at the given squared norms, through the same device
+ * routines (and kernel specialisation) the sweeps use: rho3_out[3k..] = (rho, rho', rho'')(s[k]) as K2 and the per-edge
+ * sweep compute them, value_out[k] = rho(s[k]) as the solver's cost-only sweep computes it.  Either output may be NULL.
+ * This is how the device is pinned directly against vectors recorded from scripts/loss_functions.py:47-458.              */
+gsfm_status gsfm_rot_loss_eval(gsfm_rot_problem* p, const double* s, uint64_t n, double* rho3_out, double* value_out);
+
 /* Per-iteration trace of the last solve: rows of GSFM_ROT_TRACE_COLS doubles
  * [iteration, cost, cost_change, gradient_max_norm, step_norm, relative_decrease,
  *  trust_region_radius, cg_iterations].  Returns the number of rows available.   */

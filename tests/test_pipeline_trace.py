@@ -66,12 +66,31 @@ def test_compiled_module_answers_every_call_of_the_trace(reference_trace):
     # scripts/get_covariance_from_colmap.py: module functions and builder methods it calls
     for name in reference_trace["get_covariance_from_colmap_calls"]:
         assert hasattr(sfm, name) or hasattr(objs["ReconstructionBuilder()"], name), name
-    # the __main__ block (:114-148): everything but the PLY export, which needs camera positions and points (out of scope)
+    # the __main__ block (:114-148), including the PLY export (a rotation-only reconstruction has views but no points)
     missing = [n for n in reference_trace["main_module_calls"] if not hasattr(sfm, n)]
-    assert missing == ["WritePlyFile"]
+    assert missing == []
     d = reference_trace["main_defaults"]
     assert d["rotation_loss"] == "MAGSACWeightBasedLoss(0.02)" and d["rotation_error_type"] == "ANGLE_AXIS_COVARIANCE"
     assert hasattr(sfm.RotationErrorType, d["rotation_error_type"]) and hasattr(sfm.PositionErrorType, d["position_error_type"])
+
+
+def test_write_ply_file_of_a_rotation_only_reconstruction(tmp_path):
+    """Theia io/write_ply_file.cc:74-123: header + one vertex per track and per ESTIMATED view (green, at its position)."""
+    sys.path.insert(0, os.path.join(ROOT, "globalsfmpy_amd"))
+    sfm = pytest.importorskip("GlobalSfMpy")
+    rec = sfm.Reconstruction()
+    for v in range(5):
+        rec.SetViewName(v, "img%d.jpg" % v)
+    o = sfm.MapViewIdVector3d()
+    for v in (0, 2, 4):
+        o[v] = [0.1 * v, 0.0, 0.0]
+    sfm.SetOrientations(o, rec)
+    path = tmp_path / "out.ply"
+    assert sfm.WritePlyFile(str(path), rec, 2)
+    lines = path.read_text().splitlines()
+    assert lines[:3] == ["ply", "format ascii 1.0", "element vertex 3"] and lines[9] == "end_header"
+    assert lines[10:] == ["0 0 0 0 255 0"] * 3
+    assert not sfm.WritePlyFile(str(tmp_path / "no_such_dir" / "x.ply"), rec, 2)
 
 
 def test_yaml_keys_of_the_reference_main_block_are_the_ones_our_loader_knows(reference_trace, tmp_path):
