@@ -1,9 +1,18 @@
-// Exact LM step for small graphs: blocked right-looking Cholesky of the dense damped normal matrix (3N x 3N, row-major; L in the
-// lower triangle, a transposed copy of its off-diagonal part in the upper) and the two triangular solves -- "normal equations + Cholesky", which is literally what the reference's
-// SPARSE_NORMAL_CHOLESKY does (src/GSfM_nonlinear_rotation_estimator.cpp:72).  Three kernels per 32-column block:
-// diagonal block (one workgroup, LDS), panel (one row per lane), trailing update (32 x 32 tiles); the whole sequence is
-// captured once per problem into a hipGraph.  fp64 VALU throughout: 3N <= ~4000 means <= 20 GFLOP per factorisation
-// and the launch chain, not the arithmetic, sets the time, so MFMA tiles would buy nothing here.
+// Exact LM step for small graphs: Cholesky of the dense damped normal matrix (3N x 3N) and the two triangular solves -- "normal
+// equations + Cholesky", which is literally what the reference's SPARSE_NORMAL_CHOLESKY does
+// (src/GSfM_nonlinear_rotation_estimator.cpp:72-74,176-179,299-302).
+//
+// The regime is launch-latency-bound, not flop-bound (3N <= ~4500: <= 30 GFLOP per factorisation), so the design minimises the
+// length of the dependent chain instead of the arithmetic:
+//   * the matrix lives as 32 x 32 tiles of the lower triangle (8 KiB, contiguous), plus one extra tile row holding the right-hand
+//     side, so the forward substitution L y = b falls out of the factorisation (y is the last row of L);
+//   * ONE kernel per block column k (right-looking): every workgroup factors the 32 x 32 diagonal block A_kk itself (one wavefront,
+//     rows in registers, v_readlane broadcasts: no inter-workgroup dependency inside a step), solves the two panel tiles it needs by
+//     substitution and updates its own trailing tile A_ij -= L_ik L_jk^T.  The redundant work is ~3x the flops of the textbook
+//     schedule and irrelevant here; the chain per step is one kernel instead of three (round 1: 111 launches, 2.2 ms at 3N = 1182);
+//   * L goes to a second buffer (a workgroup's inputs A_kk, A_ik, A_jk are never written during step k, so there is no race);
+//   * the backward substitution L^T x = y is one workgroup sweeping the block rows of L bottom-up.
+// fp64 VALU throughout; MFMA tiles would buy nothing at these sizes.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -11,187 +20,143 @@
 namespace gsfm {
 
 #define GSFM_CB 32
+#define GSFM_TILE_ELEMS (GSFM_CB * GSFM_CB)
+#define GSFM_DENSE_MAX_T 160   // block rows the backward kernel keeps in LDS: 3N <= 5120
+
+__host__ __device__ inline size_t chol_tile_off(uint32_t i, uint32_t j) { return ((size_t)i * (i + 1) / 2 + j) * GSFM_TILE_ELEMS; }
+__host__ __device__ inline size_t chol_num_tiles(uint32_t T) { return (size_t)(T + 1) * (T + 2) / 2; }   // block rows 0..T (row T = rhs)
+
 // broadcast one lane's double through the scalar unit (v_readlane_b32 x 2): a few cycles, where a shuffle through the LDS crossbar
 // (ds_bpermute) is ~120 cycles of latency in a dependent chain.  `lane` must be wave-uniform.
 __device__ __forceinline__ double readlane_f64(double v, int lane) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
   return __hiloint2double(hi, lo);
 }
+
 struct CholArgs {
-  double* A;      // n x n row-major; lower triangle in, L out
-  uint32_t n;
-  uint32_t k0;    // first row/column of the current block
+  double* A;      // tiles (i >= j), block rows 0..T; row T = right-hand side (first row of each tile)
+  double* L;      // same layout: L_ik (i > k), L_kk, and in row T the forward-substituted y = L^-1 b
+  uint32_t T;     // block rows of the matrix proper = ceil(3N / 32)
+  uint32_t k;     // this step's block column
   int* info;      // 0, or 1 + index of the first non-positive pivot
-  double* Dinv;   // [n / 32 rounded up][32][32]: inverse of every diagonal block L_kk (lower triangular, row-major, zero above)
 };
 
-// One wavefront, no LDS, no barriers: lane i keeps row i of the block in registers; column j is finished with one broadcast of the
-// pivot and one broadcast per remaining column (a 256-lane LDS version spent ~0.75 us per column in barriers and LDS latency).
-__global__ void __launch_bounds__(64) k_chol_diag(CholArgs a) {
-  const uint32_t nb = min((uint32_t)GSFM_CB, a.n - a.k0), lane = threadIdx.x;
-  const bool rowlive = lane < nb;
-  double r[GSFM_CB];
-  {
-    const double* src = a.A + (size_t)(a.k0 + (rowlive ? lane : 0)) * a.n + a.k0;
-#pragma unroll
-    for (int c = 0; c < GSFM_CB; ++c) r[c] = (rowlive && (uint32_t)c <= lane && (uint32_t)c < nb) ? src[c] : ((uint32_t)c == lane ? 1.0 : 0.0);
-  }
-  int bad = 0;
-#pragma unroll
-  for (int j = 0; j < GSFM_CB; ++j) {
-    double piv = readlane_f64(r[j], j);
-    if (!(piv > 0.0)) { if (!bad) bad = j + 1; piv = 1.0; }
-    const double d = sqrt(piv);
-    r[j] = (lane == (uint32_t)j) ? d : r[j] / d;
-    // no per-step lane masks: entries above the diagonal (lane < c) are never read by anyone, so they may hold anything
-#pragma unroll
-    for (int c = j + 1; c < GSFM_CB; ++c) r[c] -= r[j] * readlane_f64(r[j], c);   // readlane: L[c][j], held by lane c
-  }
-  if (lane == 0 && bad && (uint32_t)bad <= nb && *a.info == 0) *a.info = (int)(a.k0 + bad);
-  if (rowlive) {
-    double* dst = a.A + (size_t)(a.k0 + lane) * a.n + a.k0;
-#pragma unroll
-    for (int c = 0; c < GSFM_CB; ++c) if ((uint32_t)c <= lane) dst[c] = r[c];
-  }
-  // X = L^-1 (lower triangular), row i in lane i: x[i][i] = 1 / L[i][i], x[i][j] = -(sum_{t=j+1..i} x[i][t] L[t][j]) / L[j][j].
-  // The panel and the triangular solves then multiply by X instead of running 32-step substitution chains.
-  double x[GSFM_CB];
-#pragma unroll
-  for (int j = GSFM_CB - 1; j >= 0; --j) {
-    const double inv_jj = 1.0 / readlane_f64(r[j], j);
-    double acc = 0.0;
-#pragma unroll
-    for (int t = j + 1; t < GSFM_CB; ++t) {
-      acc += x[t] * readlane_f64(r[j], t);             // L[t][j] from lane t; x[t] is exactly 0 in the lanes above the diagonal
-    }
-    x[j] = (lane == (uint32_t)j) ? inv_jj : (lane > (uint32_t)j ? -acc * inv_jj : 0.0);
-  }
-  if (lane < GSFM_CB) {   // padded rows/columns of a partial last block carry the identity: harmless
-    double* dst = a.Dinv + ((size_t)(a.k0 / GSFM_CB) * GSFM_CB + lane) * GSFM_CB;
-#pragma unroll
-    for (int c = 0; c < GSFM_CB; ++c) dst[c] = x[c];
-  }
-}
-
-// rows below the diagonal block: A[i, block] <- A[i, block] L_kk^-T = A[i, block] X^T, a 32-wide product per element (no
-// substitution chain); 64 rows per workgroup, 8 outputs per lane; the result also goes transposed into the upper triangle so
-// that the forward substitution of k_chol_solve reads L[i][k0 + c] with consecutive lanes on consecutive i
-#define GSFM_PANEL_ROWS 64
-__global__ void __launch_bounds__(256) k_chol_panel(CholArgs a) {
-  __shared__ double X[GSFM_CB][GSFM_CB + 1];
-  __shared__ double V[GSFM_PANEL_ROWS][GSFM_CB + 1];
-  const uint32_t nb = min((uint32_t)GSFM_CB, a.n - a.k0), tid = threadIdx.x;
-  const double* xin = a.Dinv + (size_t)(a.k0 / GSFM_CB) * GSFM_CB * GSFM_CB;
-  for (uint32_t idx = tid; idx < GSFM_CB * GSFM_CB; idx += 256) X[idx / GSFM_CB][idx % GSFM_CB] = xin[idx];
-  const uint32_t row0 = a.k0 + nb + blockIdx.x * GSFM_PANEL_ROWS;
-  for (uint32_t idx = tid; idx < GSFM_PANEL_ROWS * GSFM_CB; idx += 256) {
-    const uint32_t r = idx / GSFM_CB, c = idx % GSFM_CB;
-    V[r][c] = (row0 + r < a.n && c < nb) ? a.A[(size_t)(row0 + r) * a.n + a.k0 + c] : 0.0;
-  }
-  __syncthreads();
-  const uint32_t c = tid % GSFM_CB, rg = tid / GSFM_CB;   // column c, rows rg, rg + 8, ...
-  double out[GSFM_PANEL_ROWS / 8];
-#pragma unroll
-  for (int q = 0; q < GSFM_PANEL_ROWS / 8; ++q) {
-    const uint32_t r = rg + 8 * q;
-    double s2 = 0.0;
-#pragma unroll
-    for (int t = 0; t < GSFM_CB; ++t) s2 += V[r][t] * X[c][t];   // X[c][t] = 0 for t > c
-    out[q] = s2;
-  }
-#pragma unroll
-  for (int q = 0; q < GSFM_PANEL_ROWS / 8; ++q) {
-    const uint32_t row = row0 + rg + 8 * q;
-    if (row < a.n && c < nb) {
-      a.A[(size_t)row * a.n + a.k0 + c] = out[q];
-      a.A[(size_t)(a.k0 + c) * a.n + row] = out[q];
-    }
-  }
-}
-
-// trailing update A[i][j] -= sum_c P[i][c] P[j][c] for i >= j >= k0 + 32; one 32 x 32 tile of the lower triangle per workgroup
-__global__ void __launch_bounds__(256) k_chol_update(CholArgs a) {
+// Step k.  Workgroup 0: L_kk and the right-hand side's panel tile; workgroup 1 + t(t+1)/2 + u: trailing tile (k+1+t, k+1+u), u <= t.
+// Wavefront 0 holds the rows of A_kk in lanes 0..31 and the rows of the panel tile A_ik in lanes 32..63, one row per lane in
+// registers, and runs the right-looking elimination on all 64 rows at once: for the lower lanes that is the Cholesky factorisation,
+// for the upper lanes the same instructions are the substitution P_i = A_ik L_kk^-T (the multipliers L[c][c0] are wave-uniform
+// v_readlane broadcasts from the diagonal rows), so the panel costs nothing extra.  Wavefront 1 does the same with A_jk.
+__global__ void __launch_bounds__(256) k_chol_step(CholArgs a) {
   __shared__ double Pi[GSFM_CB][GSFM_CB + 1], Pj[GSFM_CB][GSFM_CB + 1];
-  // linear block index -> (ti, tj), ti >= tj
-  const uint32_t b = blockIdx.x;
-  uint32_t ti = (uint32_t)((sqrt(8.0 * (double)b + 1.0) - 1.0) * 0.5);
-  while ((uint64_t)(ti + 1) * (ti + 2) / 2 <= b) ++ti;
-  while ((uint64_t)ti * (ti + 1) / 2 > b) --ti;
-  const uint32_t tj = b - ti * (ti + 1) / 2;
-  const uint32_t base = a.k0 + GSFM_CB, i0 = base + GSFM_CB * ti, j0 = base + GSFM_CB * tj, tid = threadIdx.x;
-  for (uint32_t idx = tid; idx < GSFM_CB * GSFM_CB; idx += 256) {
-    const uint32_t r = idx / GSFM_CB, c = idx % GSFM_CB;
-    Pi[r][c] = (i0 + r < a.n) ? a.A[(size_t)(i0 + r) * a.n + a.k0 + c] : 0.0;
-    Pj[r][c] = (j0 + r < a.n) ? a.A[(size_t)(j0 + r) * a.n + a.k0 + c] : 0.0;
+  const uint32_t k = a.k, T = a.T, tid = threadIdx.x;
+  uint32_t i, j;
+  const bool diag_wg = blockIdx.x == 0;
+  if (diag_wg) { i = T; j = k; }
+  else {
+    const uint32_t b = blockIdx.x - 1;
+    uint32_t t = (uint32_t)((sqrt(8.0 * (double)b + 1.0) - 1.0) * 0.5);
+    while ((uint64_t)(t + 1) * (t + 2) / 2 <= b) ++t;
+    while ((uint64_t)t * (t + 1) / 2 > b) --t;
+    i = k + 1 + t; j = k + 1 + (b - t * (t + 1) / 2);
+    if (i == T && j == T) return;   // the right-hand side has no diagonal tile
+  }
+  const bool same = !diag_wg && i == j;
+  const uint32_t ur = tid / 8, uc4 = (tid % 8) * 4;   // this lane's 1 x 4 piece of the trailing tile
+  double own[4] = {0, 0, 0, 0};
+  if (!diag_wg) {
+    const double* so = a.A + chol_tile_off(i, j) + ur * GSFM_CB + uc4;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) own[q] = so[q];
+  }
+  const uint32_t wave = tid >> 6, lane = tid & 63;
+  if (wave == 0 || (wave == 1 && !diag_wg && !same)) {
+    const uint32_t rr = lane & 31;
+    const double2* src = (const double2*)(a.A + (lane < 32 ? chol_tile_off(k, k) : chol_tile_off(wave == 0 ? i : j, k)) + rr * GSFM_CB);
+    double r[GSFM_CB];
+#pragma unroll
+    for (int q = 0; q < GSFM_CB / 2; ++q) { const double2 v = src[q]; r[2 * q] = v.x; r[2 * q + 1] = v.y; }
+    int bad = 0;
+#pragma unroll
+    for (int c0 = 0; c0 < GSFM_CB; ++c0) {
+      double piv = readlane_f64(r[c0], c0);
+      if (!(piv > 0.0)) { if (!bad) bad = c0 + 1; piv = 1.0; }
+      const double inv = rsqrt(piv);
+      r[c0] = (lane == (uint32_t)c0) ? piv * inv : r[c0] * inv;
+      // entries above the diagonal of the diagonal rows (lane < c) are never read by anyone, so they may hold anything
+#pragma unroll
+      for (int c = c0 + 1; c < GSFM_CB; ++c) r[c] -= r[c0] * readlane_f64(r[c0], c);   // readlane: L[c][c0], held by lane c
+    }
+    if (lane >= 32) {
+      double (*P)[GSFM_CB + 1] = wave == 0 ? Pi : Pj;
+#pragma unroll
+      for (int c = 0; c < GSFM_CB; ++c) P[rr][c] = r[c];
+    } else if (diag_wg) {
+      double2* dl = (double2*)(a.L + chol_tile_off(k, k) + rr * GSFM_CB);
+#pragma unroll
+      for (int q = 0; q < GSFM_CB / 2; ++q) dl[q] = make_double2((uint32_t)(2 * q) <= lane ? r[2 * q] : 0.0, (uint32_t)(2 * q + 1) <= lane ? r[2 * q + 1] : 0.0);
+      if (lane == 0 && bad && *a.info == 0) *a.info = (int)(k * GSFM_CB + bad);
+    }
   }
   __syncthreads();
-  const uint32_t tc = tid % GSFM_CB, tr = tid / GSFM_CB;   // 8 row groups x 32 columns
+  if (diag_wg) {   // y_k = row T of L
+    double* dy = a.L + chol_tile_off(T, k) + ur * GSFM_CB + uc4;
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const uint32_t r = tr + 8 * q, i = i0 + r, j = j0 + tc;
-    if (i >= a.n || j >= a.n || j > i) continue;
-    double s = 0.0;
-#pragma unroll
-    for (int c = 0; c < GSFM_CB; ++c) s += Pi[r][c] * Pj[tc][c];
-    a.A[(size_t)i * a.n + j] -= s;
+    for (int q = 0; q < 4; ++q) dy[q] = Pi[ur][uc4 + q];
+    return;
   }
+  if (j == k + 1 && i < T) {   // first trailing column: this workgroup publishes L_ik
+    double* dl = a.L + chol_tile_off(i, k) + ur * GSFM_CB + uc4;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) dl[q] = Pi[ur][uc4 + q];
+  }
+  double (*Q)[GSFM_CB + 1] = same ? Pi : Pj;
+  double acc[4] = {0, 0, 0, 0};
+#pragma unroll
+  for (int t = 0; t < GSFM_CB; ++t) {
+    const double pv = Pi[ur][t];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] += pv * Q[uc4 + q][t];
+  }
+  double* d = a.A + chol_tile_off(i, j) + ur * GSFM_CB + uc4;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) d[q] = own[q] - acc[q];
 }
 
-// x = (L L^T)^-1 b, one workgroup.  Per 32-row block: the first wavefront multiplies by the inverse diagonal block (rows of X from
-// LDS, the right-hand side broadcast with v_readlane), then all lanes update the remaining rows from the transposed panel copy.
-__global__ void __launch_bounds__(1024) k_chol_solve(const double* __restrict__ A, const double* __restrict__ Dinv, uint32_t n,
-                                                     const double* __restrict__ b, double* __restrict__ x) {
-  __shared__ double yb[GSFM_CB];
-  __shared__ double X[GSFM_CB][GSFM_CB + 1];
+// x = L^-T y, one workgroup: block rows bottom-up; y stays in LDS.  Per block: a 32-step substitution in one wavefront (the running
+// right-hand side in lane registers, the solved component broadcast with v_readlane), then every lane folds x_k into the
+// right-hand sides of the block rows above (L_kj tiles are contiguous: block row k of L).
+__global__ void __launch_bounds__(1024) k_chol_back(const double* __restrict__ L, uint32_t n, uint32_t T, double* __restrict__ x) {
+  __shared__ double y[GSFM_DENSE_MAX_T * GSFM_CB];
+  __shared__ double Lk[GSFM_CB][GSFM_CB + 1];
+  __shared__ double xk[GSFM_CB];
   const uint32_t tid = threadIdx.x;
-  for (uint32_t i = tid; i < n; i += 1024) x[i] = b[i];
+  for (uint32_t idx = tid; idx < T * GSFM_CB; idx += 1024) y[idx] = L[chol_tile_off(T, idx / GSFM_CB) + idx % GSFM_CB];
   __syncthreads();
-  for (uint32_t k0 = 0; k0 < n; k0 += GSFM_CB) {   // L y = b
-    const uint32_t nb = min((uint32_t)GSFM_CB, n - k0);
-    X[tid / GSFM_CB][tid % GSFM_CB] = Dinv[(size_t)(k0 / GSFM_CB) * GSFM_CB * GSFM_CB + tid];
+  double nxt = L[chol_tile_off(T - 1, T - 1) + tid];
+  for (uint32_t k = T; k-- > 0;) {
+    Lk[tid / GSFM_CB][tid % GSFM_CB] = nxt;
     __syncthreads();
+    if (k > 0) nxt = L[chol_tile_off(k - 1, k - 1) + tid];   // in flight behind the substitution and the update below
     if (tid < 64) {
-      const uint32_t lane = tid < GSFM_CB ? tid : 0;
-      const double v = tid < nb ? x[k0 + tid] : 0.0;
-      double y = 0.0;
+      const uint32_t lane = tid & 31;
+      double v = y[k * GSFM_CB + lane];
+      const double rinv = 1.0 / Lk[lane][lane];   // all reciprocals at once, off the dependent chain
 #pragma unroll
-      for (int t = 0; t < GSFM_CB; ++t) y += X[lane][t] * readlane_f64(v, t);   // y = X b_block
-      if (tid < GSFM_CB) yb[tid] = tid < nb ? y : 0.0;
-      if (tid < nb) x[k0 + tid] = y;
-    }
-    __syncthreads();
-    for (uint32_t i = k0 + nb + tid; i < n; i += 1024) {   // (rows below exist only under full blocks: nb == 32 here)
-      double s2 = x[i];
-#pragma unroll
-      for (int c = 0; c < GSFM_CB; ++c) s2 -= A[(size_t)(k0 + c) * n + i] * yb[c];   // L[i][k0 + c] from its transposed copy
-      x[i] = s2;
-    }
-    __syncthreads();
-  }
-  const uint32_t nblk = (n + GSFM_CB - 1) / GSFM_CB;
-  for (uint32_t kb = nblk; kb-- > 0;) {             // L^T x = y
-    const uint32_t k0 = kb * GSFM_CB, nb = min((uint32_t)GSFM_CB, n - k0);
-    X[tid / GSFM_CB][tid % GSFM_CB] = Dinv[(size_t)kb * GSFM_CB * GSFM_CB + tid];
-    __syncthreads();
-    if (tid < 64) {
-      const uint32_t lane = tid < GSFM_CB ? tid : 0;
-      const double v = tid < nb ? x[k0 + tid] : 0.0;
-      double y = 0.0;
-#pragma unroll
-      for (int t = 0; t < GSFM_CB; ++t) y += X[t][lane] * readlane_f64(v, t);   // x_block = X^T y_block
-      if (tid < GSFM_CB) yb[tid] = tid < nb ? y : 0.0;
-      if (tid < nb) x[k0 + tid] = y;
-    }
-    __syncthreads();
-    for (uint32_t i = tid; i < k0; i += 1024) {
-      double s2 = x[i];
-      if (nb == GSFM_CB) {
-#pragma unroll
-        for (int c = 0; c < GSFM_CB; ++c) s2 -= A[(size_t)(k0 + c) * n + i] * yb[c];
-      } else {
-        for (uint32_t c = 0; c < nb; ++c) s2 -= A[(size_t)(k0 + c) * n + i] * yb[c];
+      for (int t = GSFM_CB - 1; t >= 0; --t) {
+        const double xt = readlane_f64(v * rinv, t);
+        if (lane < (uint32_t)t) v -= Lk[t][lane] * xt;
       }
-      x[i] = s2;
+      // lane t was never modified after step t: v * rinv is x_t
+      if (tid < GSFM_CB) { const double mine = v * rinv; xk[lane] = mine; const uint32_t g = k * GSFM_CB + lane; if (g < n) x[g] = mine; }
+    }
+    __syncthreads();
+    for (uint32_t idx = tid; idx < k * GSFM_CB; idx += 1024) {
+      const uint32_t j = idx / GSFM_CB, c = idx % GSFM_CB;
+      const double* t = L + chol_tile_off(k, j) + c;
+      double s = 0.0;
+#pragma unroll
+      for (int r = 0; r < GSFM_CB; ++r) s += t[r * GSFM_CB] * xk[r];
+      y[idx] -= s;
     }
     __syncthreads();
   }

@@ -186,7 +186,7 @@ struct gsfm_rot_problem {
   DevBuf<double2> q, q_trial;
   DevBuf<double> xcg, r, z, p, Ap, s_dir, part_g2, part_d2;
   DevBuf<Cg2Scalars> cg2sc;
-  DevBuf<double> denseA, denseDinv;
+  DevBuf<double> denseA, denseL;
   DevBuf<int> dense_info;
   hipGraphExec_t dense_graph = nullptr;   // zero + assemble + blocked Cholesky + solve, captured once
   bool dense_graph_lap = false;           // form of the blocks the captured assemble kernel expects
@@ -521,36 +521,34 @@ int run_pcg2(gsfm_rot_problem* P, const gsfm_rot_options& o, int* iters_out, dou
   return 0;
 }
 
-// Exact step for small graphs: dense Cholesky of (J^T J + Lambda) in the left-tangent space. Returns 1 if the
-// factorisation could not be used (caller falls back to PCG), < 0 never, 0 on success, or a gsfm_status > 1.
+// Exact step for small graphs: dense Cholesky of (J^T J + Lambda) in the left-tangent space (dense_kernels.hpp). *used = false if the
+// factorisation could not be used (a non-positive pivot, or no memory): the caller falls back to PCG.  Returns 0 or a gsfm_status.
 int run_dense(gsfm_rot_problem* P, bool* used) {
   *used = false;
-  const uint32_t n = 3 * P->n_cams;
+  const uint32_t n = 3 * P->n_cams, T = (n + GSFM_CB - 1) / GSFM_CB;
+  if (T > GSFM_DENSE_MAX_T) return 0;
+  const size_t elems = chol_num_tiles(T) * GSFM_TILE_ELEMS;
   if (!P->denseA.p) {
-    if (P->denseA.alloc((size_t)n * n) != hipSuccess || P->dense_info.alloc(1) != hipSuccess ||
-        P->denseDinv.alloc((size_t)((n + GSFM_CB - 1) / GSFM_CB) * GSFM_CB * GSFM_CB) != hipSuccess) return 0;
+    if (P->denseA.alloc(elems) != hipSuccess || P->denseL.alloc(elems, true) != hipSuccess || P->dense_info.alloc(1) != hipSuccess) { P->denseA.release(); return 0; }
   }
   auto enqueue = [&]() {
-    hipLaunchKernelGGL(k_zero, dim3(grid_for((size_t)n * n)), dim3(GSFM_BLOCK), 0, P->stream, P->denseA.p, (size_t)n * n);
+    (void)hipMemsetAsync(P->denseA.p, 0, 8 * elems, P->stream);
     (void)hipMemsetAsync(P->dense_info.p, 0, sizeof(int), P->stream);
     DenseArgs a{};
     a.n_rows = P->n_rows; a.row_ptr = P->row_ptr.p; a.col = P->col.p; a.h0 = P->h0.p; a.h1 = P->h1.p; a.h2 = P->h2.p; a.h3 = P->h3.p; a.h4 = P->h4.p;
-    a.Mblk = P->Mblk.p; a.A = P->denseA.p; a.n = n; a.q = P->q_lin; a.lap = P->lin_is_lap;
+    a.Mblk = P->Mblk.p; a.b = P->b.p; a.A = P->denseA.p; a.n = n; a.T = T; a.q = P->q_lin; a.lap = P->lin_is_lap;
     hipLaunchKernelGGL(k_dense_assemble, dim3(P->n_rows), dim3(GSFM_BLOCK), 0, P->stream, a);
-    for (uint32_t k0 = 0; k0 < n; k0 += GSFM_CB) {
-      CholArgs c{P->denseA.p, n, k0, P->dense_info.p, P->denseDinv.p};
-      hipLaunchKernelGGL(k_chol_diag, dim3(1), dim3(64), 0, P->stream, c);
-      if (k0 + GSFM_CB >= n) break;
-      const uint32_t below = n - k0 - GSFM_CB, tiles = (below + GSFM_CB - 1) / GSFM_CB;
-      hipLaunchKernelGGL(k_chol_panel, dim3((below + GSFM_PANEL_ROWS - 1) / GSFM_PANEL_ROWS), dim3(256), 0, P->stream, c);
-      hipLaunchKernelGGL(k_chol_update, dim3(tiles * (tiles + 1) / 2), dim3(256), 0, P->stream, c);
+    for (uint32_t k = 0; k < T; ++k) {
+      CholArgs c{P->denseA.p, P->denseL.p, T, k, P->dense_info.p};
+      const uint32_t m = T - k;
+      hipLaunchKernelGGL(k_chol_step, dim3(1 + m * (m + 1) / 2), dim3(256), 0, P->stream, c);
     }
-    hipLaunchKernelGGL(k_chol_solve, dim3(1), dim3(1024), 0, P->stream, (const double*)P->denseA.p, (const double*)P->denseDinv.p, n, (const double*)P->b.p, P->xcg.p);
+    hipLaunchKernelGGL(k_chol_back, dim3(1), dim3(1024), 0, P->stream, (const double*)P->denseL.p, n, T, P->xcg.p);
     (void)hipMemsetAsync(P->r.p, 0, 8 * (size_t)n, P->stream);  // exact solve: the PCG residual term of the model decrease is zero
   };
   const int tk = P->timer.begin(T_CG);
   if (P->dense_graph && P->dense_graph_lap != P->lin_is_lap) { (void)hipGraphExecDestroy(P->dense_graph); P->dense_graph = nullptr; }
-  if (!P->dense_graph && !P->pcg_graph.unusable) {   // ~3 launches per 32 columns: replay them as one graph
+  if (!P->dense_graph && !P->pcg_graph.unusable) {   // one launch per 32 columns: replay them as one graph
     P->dense_graph_lap = P->lin_is_lap;
     hipGraph_t captured = nullptr;
     if (hipStreamBeginCapture(P->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
@@ -839,7 +837,7 @@ void gsfm_rot_options_default(gsfm_rot_options* o) {
   o->function_tolerance = 1e-6; o->gradient_tolerance = 1e-10; o->parameter_tolerance = 1e-8;
   o->initial_trust_region_radius = 1e4; o->max_trust_region_radius = 1e16; o->min_trust_region_radius = 1e-32;
   o->min_relative_decrease = 1e-3; o->min_lm_diagonal = 1e-6; o->max_lm_diagonal = 1e32;
-  o->jacobi_scaling = 1; o->max_cg_iterations = 1000; o->cg_relative_tolerance = 1e-12; o->cg_check_interval = 8; o->verbose = 0; o->pcg_single_reduction = 0; o->cg_stall_iterations = 0; o->dense_cholesky_max_cams = 0; o->pcg_hip_graph = 1;
+  o->jacobi_scaling = 1; o->max_cg_iterations = 1000; o->cg_relative_tolerance = 1e-12; o->cg_check_interval = 8; o->verbose = 0; o->pcg_single_reduction = 0; o->cg_stall_iterations = 0; o->dense_cholesky_max_cams = 512; o->pcg_hip_graph = 1;
 }
 
 int32_t gsfm_rot_residual_dim(int32_t t) { return t == GSFM_ROT_QUATERNION_NORM ? 4 : t == GSFM_ROT_ROTATION_MAT_FNORM ? 9 : 3; }

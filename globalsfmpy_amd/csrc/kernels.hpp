@@ -1270,9 +1270,10 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_cg2_step(Cg2Args a) {
 }
 
 // ------------------------------------------------------------------------------------------
-// Small graphs: assemble the damped normal matrix densely (column-major n x n, n = 3 * cameras) for an exact
-// Cholesky.  The block-CSR holds both directions of every edge, so every off-diagonal block is written by its
-// own entry; atomicAdd only matters for repeated camera pairs (two contributions commute).
+// Small graphs: assemble the damped normal matrix for the exact Cholesky step (dense_kernels.hpp) -- lower triangle only,
+// as 32 x 32 tiles, plus the right-hand side -g as block row T.  The block-CSR holds both directions of every edge; the
+// lower triangle takes the entry whose row camera has the larger index (H_km for k > m), so atomicAdd only matters for
+// repeated camera pairs (two contributions commute).  A is zero-filled before the launch.
 // ------------------------------------------------------------------------------------------
 struct DenseArgs {
   uint32_t n_rows;
@@ -1281,21 +1282,28 @@ struct DenseArgs {
   const double2 *h0, *h1, *h2, *h3;
   const double* h4;
   const double* Mblk;  // 6 per camera
-  double* A;           // n x n, zero-filled before the launch
-  uint32_t n;
+  const double* b;     // 3 per camera: right-hand side
+  double* A;           // tiles, see chol_tile_off
+  uint32_t n, T;
   const double2* q;    // Laplacian form (lap = 1): planes h0..h2 hold G_k, the block is -G_k R_k R_m^T
   int lap;
 };
+__device__ __forceinline__ double* dense_elem(double* A, uint32_t gr, uint32_t gc) {
+  return A + ((size_t)(gr / 32) * (gr / 32 + 1) / 2 + gc / 32) * 1024 + (gr % 32) * 32 + gc % 32;
+}
 __global__ void __launch_bounds__(GSFM_BLOCK) k_dense_assemble(DenseArgs a) {
   const uint32_t row = blockIdx.x;
   if (row >= a.n_rows) return;
   if (threadIdx.x == 0) {
     const double* M = a.Mblk + 6 * (size_t)row;
     const double m[9] = {M[0], M[1], M[2], M[1], M[3], M[4], M[2], M[4], M[5]};
-    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) a.A[(size_t)(3 * row + c) * a.n + 3 * row + r] = m[3 * r + c];
+    for (int r = 0; r < 3; ++r) for (int c = 0; c <= r; ++c) *dense_elem(a.A, 3 * row + r, 3 * row + c) = m[3 * r + c];
+    for (int c = 0; c < 3; ++c) a.A[(((size_t)a.T * (a.T + 1) / 2) + (3 * row + c) / 32) * 1024 + (3 * row + c) % 32] = a.b[3 * (size_t)row + c];
+    if (row == 0) for (uint32_t g = a.n; g < a.T * 32; ++g) *dense_elem(a.A, g, g) = 1.0;   // padding of the last tile: identity
   }
   for (uint32_t d = a.row_ptr[row] + threadIdx.x; d < a.row_ptr[row + 1]; d += GSFM_BLOCK) {
     const uint32_t m = a.col[d] & 0x7fffffffu;
+    if (m >= row) continue;   // upper triangle (and self loops, which cannot occur)
     double H[9];
     if (a.lap) {
       const double2 A0 = a.h0[d], B0 = a.h1[d], C0 = a.h2[d];
@@ -1309,12 +1317,8 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_dense_assemble(DenseArgs a) {
       const double2 A0 = a.h0[d], B0 = a.h1[d], C0 = a.h2[d], D0 = a.h3[d];
       H[0] = A0.x; H[1] = A0.y; H[2] = B0.x; H[3] = B0.y; H[4] = C0.x; H[5] = C0.y; H[6] = D0.x; H[7] = D0.y; H[8] = a.h4[d];
     }
-    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) atomicAdd(&a.A[(size_t)(3 * m + c) * a.n + 3 * row + r], H[3 * r + c]);
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) atomicAdd(dense_elem(a.A, 3 * row + r, 3 * m + c), H[3 * r + c]);
   }
-}
-__global__ void __launch_bounds__(GSFM_BLOCK) k_zero(double* p, size_t n) {
-  const size_t i = (size_t)blockIdx.x * GSFM_BLOCK + threadIdx.x;
-  if (i < n) p[i] = 0.0;
 }
 
 }  // namespace gsfm

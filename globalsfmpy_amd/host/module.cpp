@@ -150,6 +150,8 @@ py::dict summary_dict(const gsfm_rot_summary& s) {
   d["iters_to_1e6"] = s.iters_to_1e6; d["outer_iterations"] = s.outer_iterations;
   d["initial_cost"] = s.initial_cost; d["final_cost"] = s.final_cost; d["t_total_ms"] = s.t_total_ms;
   d["num_edges_used"] = s.num_edges_used; d["last_weight_change"] = s.last_weight_change;
+  d["num_dense_solves"] = s.num_dense_solves; d["num_linearizations"] = s.num_linearizations;
+  d["t_linearize_ms"] = s.t_linearize_ms; d["t_sweep_ms"] = s.t_sweep_ms; d["t_cg_ms"] = s.t_cg_ms;
   return d;
 }
 

@@ -132,14 +132,17 @@ typedef struct {
                                           iterations (default 0 = never).  On the real Madrid graph (MAGSAC weights spanning
                                           1e-5..5e4, vanishing damping) PCG needs up to 574 iterations per step; 64 here saves
                                           12 % of them but already perturbs the early trajectory by 5e-8 in cost. */
-  int32_t dense_cholesky_max_cams;     /* Exact LM steps for small graphs: a blocked Cholesky of the dense damped normal matrix on the
-                                          device (csrc/dense_kernels.hpp) -- literally the reference's 'normal equations + Cholesky'.
-                                          > 0: every step of graphs with at most that many cameras; 0 (default): never; < 0: graphs up to
-                                          |value| cameras, from the moment one PCG solve of the run has needed more than 150 iterations
-                                          (not the default: switching solvers mid-run moves long ill-conditioned trajectories by one
-                                          iteration at the termination slop, which the parity tests pin).  Measured on Madrid (394 cams, 2.2 ms per factorise + solve): MAGSAC weights
-                                          (PCG: up to 580 iterations per step) 284 -> 143 ms and the oracle-Cholesky iteration count;
-                                          SoftL1 (66 per step) stays on PCG, 50 ms.  PCG remains the fallback if a pivot is not positive. */
+  int32_t dense_cholesky_max_cams;     /* Exact LM steps for small graphs: a tiled Cholesky of the dense damped normal matrix on the
+                                          device (csrc/dense_kernels.hpp) -- literally the reference's 'normal equations + Cholesky'
+                                          (estimator.cpp:72-74), so the step equals the reference's to rounding instead of to the PCG tolerance.
+                                          > 0: every step of graphs with at most that many cameras (default 512; capped at 1706 = 5120 / 3
+                                          unknowns); 0: never (PCG only); < 0: graphs up to |value| cameras, from the moment one PCG solve of
+                                          the run has needed more than 150 iterations.  Measured on MI355X (tools/bench_chol.hip, factor +
+                                          both substitutions as one graph replay): 0.64 ms at 394 cameras, 2.1 ms at 800, 8.1 ms at 1500;
+                                          a PCG iteration of a graph this size costs ~14 us, and real view graphs need 60-570 of them per LM
+                                          step once the damping has vanished.  Madrid (394 cameras, 62 LM iterations, MAGSAC): 49 ms exact vs
+                                          325 ms PCG; SoftL1 35 vs 58 ms; quaternion-Huber 19 vs 26 ms.  PCG remains the fallback when a pivot
+                                          is not positive, and the only solver of sharded problems. */
   int32_t pcg_hip_graph;               /* default 1: the chunk of cg_check_interval PCG iterations between two host checks
                                           (4 dependent kernels each) is captured once into a hipGraph and replayed -- the loop is
                                           launch-latency-bound on small graphs.  Same kernels, same order, same iterates.

@@ -510,7 +510,8 @@ int lm_solve(orc_problem* p, std::vector<double>& x, const gsfm_rot_options& o, 
     for (size_t k = 0; k < n; ++k) D[k] = std::sqrt(std::fmin(std::fmax(diag[k], o.min_lm_diagonal), o.max_lm_diagonal) / radius);
     Jt_times(p, p->rt.data(), rhs.data());
     int cg = 0;
-    const bool dense = p->linear_solver == 1 || (p->linear_solver == 0 && N <= 400);
+    // 'auto' follows the product's rule: exact Cholesky steps up to dense_cholesky_max_cams cameras (default 512), PCG(1e-14 floor) beyond
+    const bool dense = p->linear_solver == 1 || (p->linear_solver == 0 && o.dense_cholesky_max_cams > 0 && (int64_t)N <= (int64_t)o.dense_cholesky_max_cams);
     bool ok = dense ? solve_dense(p, D.data(), rhs.data(), step.data()) : solve_pcg(p, D.data(), rhs.data(), step.data(), &cg);
     sum->num_cg_iterations += cg;
     bool valid = ok;
@@ -580,7 +581,7 @@ void orc_options_default(gsfm_rot_options* o) {
   o->function_tolerance = 1e-6; o->gradient_tolerance = 1e-10; o->parameter_tolerance = 1e-8;
   o->initial_trust_region_radius = 1e4; o->max_trust_region_radius = 1e16; o->min_trust_region_radius = 1e-32;
   o->min_relative_decrease = 1e-3; o->min_lm_diagonal = 1e-6; o->max_lm_diagonal = 1e32;
-  o->jacobi_scaling = 1; o->max_cg_iterations = 1000; o->cg_relative_tolerance = 1e-12; o->cg_check_interval = 8; o->verbose = 0; o->pcg_single_reduction = 0; o->cg_stall_iterations = 0; o->dense_cholesky_max_cams = 0; o->pcg_hip_graph = 1;
+  o->jacobi_scaling = 1; o->max_cg_iterations = 1000; o->cg_relative_tolerance = 1e-12; o->cg_check_interval = 8; o->verbose = 0; o->pcg_single_reduction = 0; o->cg_stall_iterations = 0; o->dense_cholesky_max_cams = 512; o->pcg_hip_graph = 1;
 }
 
 int32_t orc_residual_dim(int32_t t) { return t == GSFM_ROT_QUATERNION_NORM ? 4 : t == GSFM_ROT_ROTATION_MAT_FNORM ? 9 : 3; }

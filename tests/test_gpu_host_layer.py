@@ -153,31 +153,56 @@ def test_madrid_graph_through_the_reference_pipeline_call_sequence(tmp_path, gol
     c6 = np.array([[cov2[k][0][0, 0], cov2[k][0][1, 1], cov2[k][0][2, 2], cov2[k][0][0, 1], cov2[k][0][0, 2], cov2[k][0][1, 2]] for k, _ in edges])
     x0 = np.array([init[int(v)] for v in ids])
     got = np.array([o[int(v)] for v in ids])
-    # (1) While the LM system is numerically well-posed (first 15 iterations, trust radius < 1e12) the device
-    #     follows the oracle's exact-Cholesky trajectory to the parity bar.
     from globalsfmpy_amd.solver import RotationProblem
+    from sensitivity import oracle_spread
+    magsac = LF.MAGSACWeightBasedLoss(0.02)
     dev = RotationProblem(len(ids), ei, ej, rr, _abi.ANGLE_AXIS_COVARIANCE, cov6=c6)
-    dev.set_loss(LF.MAGSACWeightBasedLoss(0.02))
-    ora = oracle.OracleProblem(len(ids), ei, ej, rr, _abi.ANGLE_AXIS_COVARIANCE, cov6=c6)
-    ora.set_loss(LF.MAGSACWeightBasedLoss(0.02))
-    ora.set_linear_solver("dense")
-    rd15, sd15 = dev.solve(x0, max_num_iterations=15)
+    dev.set_loss(magsac)
+
+    def make_oracle(rel, loss=magsac, et=_abi.ANGLE_AXIS_COVARIANCE):
+        o_ = oracle.OracleProblem(len(ids), ei, ej, rel, et, cov6=c6 if et == _abi.ANGLE_AXIS_COVARIANCE else None)
+        o_.set_loss(loss)
+        o_.set_linear_solver("dense")               # the reference's linear solver is a Cholesky (estimator.cpp:299-305)
+        return o_
+    ora = make_oracle(rr)
+    # 394 cameras <= dense_cholesky_max_cams: the pipeline above took exact Cholesky steps, like the reference
+    assert s["num_dense_solves"] == s["num_iterations"] and s["num_cg_iterations"] == 0
+    # (1) MAGSAC, first 15 iterations (trust radius < 1e12, the staircase has not bitten yet): the parity bar, device Cholesky
+    #     against oracle Cholesky -- and the device's PCG path against the same.
     ro15, so15 = ora.solve(x0, max_num_iterations=15)
-    assert abs(sd15["final_cost"] - so15["final_cost"]) <= 1e-8 * so15["final_cost"]   # staircase loss, PCG(1e-12) vs Cholesky
-    print("madrid@15: mean dR %.3e rad" % synth.angular_distance(synth.align_rotations(rd15, ro15), ro15).mean())
-    assert synth.angular_distance(synth.align_rotations(rd15, ro15), ro15).mean() <= 1e-6
-    # (2) To convergence (60+ iterations): beyond radius ~1e12 the damping vanishes, the gauge null space makes
-    #     the normal equations numerically singular and ANY two linear solvers separate -- the oracle's own
-    #     Cholesky and PCG(1e-14) runs differ by 2e-4 rad / one iteration.  Device and
-    #     oracle stop within the function-tolerance slop of each other.
-    ora.set_linear_solver("pcg")
+    for kw in (dict(), dict(dense_cholesky_max_cams=0)):
+        rd15, sd15 = dev.solve(x0, max_num_iterations=15, **kw)
+        assert abs(sd15["final_cost"] - so15["final_cost"]) <= 1e-9 * so15["final_cost"]
+        d15 = synth.angular_distance(synth.align_rotations(rd15, ro15), ro15)
+        print("madrid@15 %s: mean dR %.3e max %.3e rad" % ("pcg" if kw else "cholesky", d15.mean(), d15.max()))
+        assert d15.mean() <= 1e-6
+    # (2) MAGSAC to convergence (62-63 iterations).  Beyond iteration ~20 the staircase loss (table cell = 2 sigma^2 / 1000) makes the
+    #     trajectory sensitive to the last bit of its inputs: the ORACLE'S OWN Cholesky run moves by 2e-4 rad (mean) and one
+    #     iteration when the measurements move by 1 ulp (tests/sensitivity.py; CPU evidence in test_oracle_solver.py).  The device
+    #     has to land inside that spread -- closer agreement than the reference has with itself cannot be asked of anyone.
     ro, so = ora.solve(x0)
     diff = synth.angular_distance(synth.align_rotations(got, ro), ro)
-    print("madrid: device %d it cost %.9e | oracle(pcg) %d it cost %.9e | mean dR %.3e max %.3e rad"
-          % (s["num_iterations"], s["final_cost"], so["num_iterations"], so["final_cost"], diff.mean(), diff.max()))
-    assert abs(s["num_iterations"] - so["num_iterations"]) <= 2
+    means, maxs, iters = oracle_spread(make_oracle, rr, x0, ro, n_runs=2)
+    print("madrid MAGSAC: device %d it cost %.9e | oracle %d it cost %.9e | mean dR %.3e max %.3e rad | 1-ulp oracle runs: %s it, mean dR %s"
+          % (s["num_iterations"], s["final_cost"], so["num_iterations"], so["final_cost"], diff.mean(), diff.max(), iters, ["%.2e" % m for m in means]))
+    assert min(iters + [so["num_iterations"]]) - 2 <= s["num_iterations"] <= max(iters + [so["num_iterations"]]) + 2
     assert abs(s["final_cost"] - so["final_cost"]) <= 3e-6 * so["final_cost"]
-    assert diff.mean() <= 1e-3
+    assert diff.mean() <= max(1e-6, 3.0 * max(means))
+    # (3) The same real graph with the reference's other defaults -- EstimateRotations' SoftL1(0.1) on angle-axis residuals and
+    #     Huber(0.1) on the quaternion residual (sfm_pipeline.py:131) -- is well-posed, and there the north-star bar holds to
+    #     convergence with identical iteration counts, for the Cholesky step and for PCG.
+    for name, loss, et in (("SoftL1/angle-axis", LF.SoftLOneLoss(0.1), _abi.ANGLE_AXIS), ("Huber/quaternion", LF.HuberLoss(0.1), _abi.QUATERNION_COSINE)):
+        d2 = RotationProblem(len(ids), ei, ej, rr, et)
+        d2.set_loss(loss)
+        r_o, s_o = make_oracle(rr, loss, et).solve(x0)
+        for kw in (dict(), dict(dense_cholesky_max_cams=0)):
+            r_d, s_d = d2.solve(x0, **kw)
+            dd = synth.angular_distance(synth.align_rotations(r_d, r_o), r_o)
+            print("madrid %s (%s): %d it, cost rel %.1e, mean dR %.3e max %.3e rad" % (name, "pcg" if kw else "cholesky", s_d["num_iterations"],
+                  abs(s_d["final_cost"] - s_o["final_cost"]) / s_o["final_cost"], dd.mean(), dd.max()))
+            assert s_d["num_iterations"] == s_o["num_iterations"] and s_d["termination"] == s_o["termination"]
+            assert abs(s_d["final_cost"] - s_o["final_cost"]) <= 1e-9 * s_o["final_cost"]
+            assert dd.mean() <= 1e-6 and dd.max() <= 1e-5
 
 
 def test_cpp_plugin_surface_without_python(tmp_path):

@@ -1,57 +1,65 @@
-// Dev check + timing of the blocked Cholesky kernels (globalsfmpy_amd/csrc/dense_kernels.hpp) on a random SPD matrix.
+// Dev check + timing of the tiled Cholesky kernels (globalsfmpy_amd/csrc/dense_kernels.hpp) on a random SPD matrix.
+// hipcc --offload-arch=gfx950 -O3 -o bench_chol bench_chol.hip ; ./bench_chol [n ...]
 #include <hip/hip_runtime.h>
-#include <cmath>
 #include <cstdio>
 #include <cstdlib>
-#include <random>
+#include <cmath>
 #include <vector>
+#include <random>
 #include "../globalsfmpy_amd/csrc/dense_kernels.hpp"
 using namespace gsfm;
-#define CHK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+#define CHK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
+
 int main(int argc, char** argv) {
-  for (uint32_t n : {7u, 32u, 33u, 100u, 231u, 1182u, 3090u}) {
+  std::vector<uint32_t> sizes;
+  for (int k = 1; k < argc; ++k) sizes.push_back(atoi(argv[k]));
+  if (sizes.empty()) sizes = {96, 1182, 2400, 4500};
+  for (uint32_t n : sizes) {
+    const uint32_t T = (n + GSFM_CB - 1) / GSFM_CB;
+    const size_t elems = chol_num_tiles(T) * GSFM_TILE_ELEMS;
     std::mt19937_64 rng(n);
-    std::normal_distribution<double> nd;
-    std::vector<double> B((size_t)n * 8), A((size_t)n * n, 0.0), b(n), x(n);
-    for (auto& v : B) v = nd(rng);
-    for (uint32_t i = 0; i < n; ++i) for (uint32_t j = 0; j < n; ++j) { double s = 0; for (int k = 0; k < 8; ++k) s += B[i * 8 + k] * B[j * 8 + k]; A[(size_t)i * n + j] = s + (i == j ? 5.0 : 0.0); }
-    for (auto& v : b) v = nd(rng);
-    double *dA, *db, *dx, *dDinv; int* dinfo;
-    CHK(hipMalloc(&dA, 8 * (size_t)n * n)); CHK(hipMalloc(&db, 8 * n)); CHK(hipMalloc(&dx, 8 * n)); CHK(hipMalloc(&dinfo, 4)); CHK(hipMalloc(&dDinv, 8 * (size_t)((n + GSFM_CB - 1) / GSFM_CB) * GSFM_CB * GSFM_CB));
-    CHK(hipMemcpy(db, b.data(), 8 * n, hipMemcpyHostToDevice));
-    hipEvent_t e0, e1; CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
-    float best = 1e9, best_solve = 1e9;
-    for (int rep = 0; rep < 3; ++rep) {
-      CHK(hipMemcpy(dA, A.data(), 8 * (size_t)n * n, hipMemcpyHostToDevice)); CHK(hipMemset(dinfo, 0, 4));
-      CHK(hipEventRecord(e0));
-      for (uint32_t k0 = 0; k0 < n; k0 += GSFM_CB) {
-        CholArgs c{dA, n, k0, dinfo, dDinv};
-        hipLaunchKernelGGL(k_chol_diag, dim3(1), dim3(64), 0, 0, c);
-        if (k0 + GSFM_CB >= n) break;
-        const uint32_t below = n - k0 - GSFM_CB, tiles = (below + GSFM_CB - 1) / GSFM_CB;
-        hipLaunchKernelGGL(k_chol_panel, dim3((below + GSFM_PANEL_ROWS - 1) / GSFM_PANEL_ROWS), dim3(256), 0, 0, c);
-        hipLaunchKernelGGL(k_chol_update, dim3(tiles * (tiles + 1) / 2), dim3(256), 0, 0, c);
+    std::normal_distribution<double> N01(0, 1);
+    // A = B B^T / n + I with B n x 8 (cheap SPD with full coupling), dense symmetric
+    std::vector<double> B((size_t)n * 8), A((size_t)n * n), b(n), hA(elems, 0.0);
+    for (auto& v : B) v = N01(rng);
+    for (auto& v : b) v = N01(rng);
+    for (uint32_t r = 0; r < n; ++r) for (uint32_t c = 0; c <= r; ++c) {
+      double s = (r == c) ? 1.0 : 0.0;
+      for (int t = 0; t < 8; ++t) s += B[(size_t)r * 8 + t] * B[(size_t)c * 8 + t] / 8.0;
+      A[(size_t)r * n + c] = A[(size_t)c * n + r] = s;
+      hA[chol_tile_off(r / 32, c / 32) + (r % 32) * 32 + c % 32] = s;
+    }
+    for (uint32_t g = n; g < T * 32; ++g) hA[chol_tile_off(g / 32, g / 32) + (g % 32) * 33] = 1.0;
+    for (uint32_t g = 0; g < n; ++g) hA[chol_tile_off(T, g / 32) + g % 32] = b[g];
+    double *dA0, *dA, *dL, *dx; int* dinfo;
+    CHK(hipMalloc(&dA0, 8 * elems)); CHK(hipMalloc(&dA, 8 * elems)); CHK(hipMalloc(&dL, 8 * elems)); CHK(hipMalloc(&dx, 8 * (size_t)T * 32)); CHK(hipMalloc(&dinfo, 4));
+    CHK(hipMemcpy(dA0, hA.data(), 8 * elems, hipMemcpyHostToDevice)); CHK(hipMemset(dL, 0, 8 * elems)); CHK(hipMemset(dinfo, 0, 4));
+    hipStream_t st; CHK(hipStreamCreate(&st));
+    auto enqueue = [&]() {
+      CHK(hipMemcpyAsync(dA, dA0, 8 * elems, hipMemcpyDeviceToDevice, st));
+      for (uint32_t k = 0; k < T; ++k) {
+        CholArgs c{dA, dL, T, k, dinfo};
+        const uint32_t m = T - k;
+        hipLaunchKernelGGL(k_chol_step, dim3(1 + m * (m + 1) / 2), dim3(256), 0, st, c);
       }
-      CHK(hipEventRecord(e1)); CHK(hipEventSynchronize(e1));
-      float ms; CHK(hipEventElapsedTime(&ms, e0, e1)); best = std::min(best, ms);
-      CHK(hipEventRecord(e0));
-      hipLaunchKernelGGL(k_chol_solve, dim3(1), dim3(1024), 0, 0, (const double*)dA, (const double*)dDinv, n, (const double*)db, dx);
-      CHK(hipEventRecord(e1)); CHK(hipEventSynchronize(e1));
-      CHK(hipEventElapsedTime(&ms, e0, e1)); best_solve = std::min(best_solve, ms);
-    }
-    int info; CHK(hipMemcpy(&info, dinfo, 4, hipMemcpyDeviceToHost)); CHK(hipMemcpy(x.data(), dx, 8 * n, hipMemcpyDeviceToHost));
+      hipLaunchKernelGGL(k_chol_back, dim3(1), dim3(1024), 0, st, (const double*)dL, n, T, dx);
+    };
+    hipGraph_t g; hipGraphExec_t ge;
+    CHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal)); enqueue(); CHK(hipStreamEndCapture(st, &g)); CHK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+    CHK(hipGraphLaunch(ge, st)); CHK(hipStreamSynchronize(st));
+    std::vector<double> x((size_t)T * 32);
+    int info; CHK(hipMemcpy(&info, dinfo, 4, hipMemcpyDeviceToHost)); CHK(hipMemcpy(x.data(), dx, 8 * (size_t)n, hipMemcpyDeviceToHost));
     double rmax = 0, bmax = 0;
-    for (uint32_t i = 0; i < n; ++i) { double s = -b[i]; for (uint32_t j = 0; j < n; ++j) s += A[(size_t)i * n + j] * x[j]; rmax = std::max(rmax, std::fabs(s)); bmax = std::max(bmax, std::fabs(b[i])); }
-    if (n <= 100) {  // compare the factor with a host Cholesky
-      std::vector<double> L(A), Ld((size_t)n * n);
-      for (uint32_t i = 0; i < n; ++i) for (uint32_t j = 0; j <= i; ++j) { double s2 = L[(size_t)i * n + j]; for (uint32_t k = 0; k < j; ++k) s2 -= L[(size_t)i * n + k] * L[(size_t)j * n + k]; L[(size_t)i * n + j] = (i == j) ? std::sqrt(s2) : s2 / L[(size_t)j * n + j]; }
-      CHK(hipMemcpy(Ld.data(), dA, 8 * (size_t)n * n, hipMemcpyDeviceToHost));
-      int shown = 0;
-      for (uint32_t i = 0; i < n && shown < 6; ++i) for (uint32_t j = 0; j <= i && shown < 6; ++j)
-        if (std::fabs(Ld[(size_t)i * n + j] - L[(size_t)i * n + j]) > 1e-9) { printf("   L[%u][%u]: device %.6f host %.6f\n", i, j, Ld[(size_t)i * n + j], L[(size_t)i * n + j]); ++shown; }
-    }
-    printf("n = %5u: info %d, |Ax - b|_inf / |b|_inf = %.2e, factor %.3f ms, solve %.3f ms\n", n, info, rmax / bmax, best, best_solve);
-    hipFree(dA); hipFree(db); hipFree(dx); hipFree(dinfo); hipFree(dDinv);
+    for (uint32_t r = 0; r < n; ++r) { double s = -b[r]; for (uint32_t c = 0; c < n; ++c) s += A[(size_t)r * n + c] * x[c]; rmax = fmax(rmax, fabs(s)); bmax = fmax(bmax, fabs(b[r])); }
+    hipEvent_t e0, e1; CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
+    const int reps = 20;
+    CHK(hipEventRecord(e0, st)); for (int k = 0; k < reps; ++k) CHK(hipGraphLaunch(ge, st)); CHK(hipEventRecord(e1, st)); CHK(hipEventSynchronize(e1));
+    float ms; CHK(hipEventElapsedTime(&ms, e0, e1));
+    // the backward kernel alone
+    CHK(hipEventRecord(e0, st)); for (int k = 0; k < reps; ++k) hipLaunchKernelGGL(k_chol_back, dim3(1), dim3(1024), 0, st, (const double*)dL, n, T, dx); CHK(hipEventRecord(e1, st)); CHK(hipEventSynchronize(e1));
+    float msb; CHK(hipEventElapsedTime(&msb, e0, e1));
+    printf("n = %5u (T = %3u): info %d  max |Ax - b| / max|b| = %.2e   factor+solve %.3f ms (graph replay), backward alone %.3f ms\n", n, T, info, rmax / bmax, ms / reps, msb / reps);
+    CHK(hipFree(dA0)); CHK(hipFree(dA)); CHK(hipFree(dL)); CHK(hipFree(dx)); CHK(hipFree(dinfo));
   }
   return 0;
 }
