@@ -161,7 +161,7 @@ struct gsfm_rot_problem {
     double tol = 0; int max_iters = 0, stall = 0, chunk = 0;
     bool unusable = false, lap = false;
     void reset() { if (exec) (void)hipGraphExecDestroy(exec); exec = nullptr; }
-  } pcg_graph;
+  } pcg_graph, pcg2_graph;
 
   EdgePlanes cost;            // cost-owned edges
   DevBuf<uint2> cost_idx;
@@ -190,7 +190,7 @@ struct gsfm_rot_problem {
   DevBuf<int> dense_info;
   hipGraphExec_t dense_graph = nullptr;   // zero + assemble + blocked Cholesky + solve, captured once
   bool dense_graph_lap = false;           // form of the blocks the captured assemble kernel expects
-  int nb_mv = 1;
+  int nb_mv = 1, mv_reps = 1;
   DevBuf<double> part_a, part_b, part_cost, part_cam, scal;
   DevBuf<CgScalars> cgsc;
   int nb_cam = 1, nb_cost = 1;
@@ -482,43 +482,91 @@ int run_pcg(gsfm_rot_problem* P, const gsfm_rot_options& o, int* iters_out, doub
   return 0;
 }
 
-// single-reduction PCG: 2 kernels per iteration (3 + one all-gather when sharded)
+// single-reduction PCG (Chronopoulos-Gear): 2 kernels per iteration (3 + one all-gather when sharded); the launch-latency regime's
+// default (see use_single_reduction).  The chunk between two host checks replays as one hipGraph, like run_pcg's.
 int run_pcg2(gsfm_rot_problem* P, const gsfm_rot_options& o, int* iters_out, double* rel_out) {
   Cg2Args c{};
-  c.n = P->n_cams; c.nb_cam = P->nb_cam; c.n_part_d = P->sharded ? P->nb_cam : P->nb_mv; c.par = 0; c.first = 1; c.tol = o.cg_relative_tolerance;
+  const int nb_mv = P->nb_mv, reps = P->mv_reps;
+  c.n = P->n_cams; c.nb_cam = P->nb_cam; c.n_part_d = P->sharded ? P->nb_cam : nb_mv; c.par = 0; c.first = 1; c.tol = o.cg_relative_tolerance; c.max_iters = o.max_cg_iterations;
   c.Minv = P->Minv.p; c.b = P->b.p; c.x = P->xcg.p; c.r = P->r.p; c.u = P->z.p; c.w = P->Ap.p; c.p = P->p.p; c.s = P->s_dir.p;
   c.part_g = P->part_g2.p; c.part_d = P->part_d2.p; c.sc = P->cg2sc.p;
+  c.q = P->q_lin; c.urot = P->lin_is_lap ? P->u_rot.p : nullptr;
   MatvecCgArgs m{};
   m.mv.n_rows = P->n_rows; m.mv.row_base = P->own_begin; m.mv.G = P->G; m.mv.row_ptr = P->row_ptr.p; m.mv.col = P->col.p;
   m.mv.h0 = P->h0.p; m.mv.h1 = P->h1.p; m.mv.h2 = P->h2.p; m.mv.h3 = P->h3.p; m.mv.h4 = P->h4.p; m.mv.Mblk = P->Mblk.p;
-  m.mv.p = P->z.p; m.mv.y = P->Ap.p; m.mv.done = nullptr; m.with_dots = P->sharded ? 0 : 1;
-  const dim3 gcam(P->nb_cam), gmv(P->nb_mv), blk(GSFM_BLOCK);
+  m.mv.p = P->z.p; m.mv.y = P->Ap.p; m.mv.done = nullptr; m.mv.q = P->q_lin; m.mv.u = P->u_rot.p; m.with_dots = P->sharded ? 0 : 1; m.reps = (uint32_t)reps;
+  const dim3 gcam(P->nb_cam), gmv(nb_mv), blk(GSFM_BLOCK);
   const int tk0 = P->timer.begin(T_CG);
   hipLaunchKernelGGL(k_cg2_init, gcam, blk, 0, P->stream, c);
   P->timer.end(tk0);
   Cg2Scalars h{};
   const int chunk = std::max(1, o.cg_check_interval);
+  // One iteration = mat-vec (+ delta partials), vector step.  `first` / `par` are by-value kernel arguments: a captured chunk must
+  // start at par == 0, first == 0, so the very first iteration is launched plainly and chunks have even length.
+  auto enqueue_iter = [&]() -> int {
+    m.cg = c;
+    if (P->lin_is_lap) hipLaunchKernelGGL(k_matvec_cg<true>, gmv, blk, 0, P->stream, m);
+    else hipLaunchKernelGGL(k_matvec_cg<false>, gmv, blk, 0, P->stream, m);
+    if (P->sharded) {
+      if (int st = all_gather(P, P->Ap.p, (size_t)P->shard.slice_width * 3)) return st;
+      hipLaunchKernelGGL(k_cg2_dots, gcam, blk, 0, P->stream, c);
+    }
+    hipLaunchKernelGGL(k_cg2_step, gcam, blk, 0, P->stream, c);
+    c.par ^= 1; c.first = 0;
+    return 0;
+  };
   int launched = 0;
+  {  // iterations 0 and 1 (first = 1, then par = 1): plain launches; afterwards par == 0 at every chunk start
+    const int tk = P->timer.begin(T_CG);
+    for (int k = 0; k < 2; ++k) { if (int st = enqueue_iter()) return st; ++launched; }
+    P->timer.end(tk);
+  }
+  auto& G = P->pcg2_graph;
+  bool graph = o.pcg_hip_graph && !P->sharded && chunk % 2 == 0 && !G.unusable && !P->pcg_graph.unusable;
+  if (graph && (!G.exec || G.tol != c.tol || G.max_iters != c.max_iters || G.chunk != chunk || G.lap != P->lin_is_lap)) {
+    G.reset();
+    hipGraph_t captured = nullptr;
+    if (hipStreamBeginCapture(P->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+      int st = 0;
+      for (int k = 0; k < chunk && st == 0; ++k) st = enqueue_iter();
+      const hipError_t e = hipStreamEndCapture(P->stream, &captured);
+      if (st == 0 && e == hipSuccess && captured && hipGraphInstantiate(&G.exec, captured, nullptr, nullptr, 0) == hipSuccess) {
+        G.tol = c.tol; G.max_iters = c.max_iters; G.chunk = chunk; G.lap = P->lin_is_lap;
+      } else { G.exec = nullptr; }
+      if (captured) (void)hipGraphDestroy(captured);
+    }
+    if (!G.exec) { (void)hipGetLastError(); G.unusable = true; graph = false; }
+  }
+  int chunks = 1;
   while (true) {
     const int tk = P->timer.begin(T_CG);
-    for (int k = 0; k < chunk; ++k) {
-      m.cg = c;
-      hipLaunchKernelGGL(k_matvec_cg, gmv, blk, 0, P->stream, m);
-      if (P->sharded) {
-        if (int st = all_gather(P, P->Ap.p, (size_t)P->shard.slice_width * 3)) return st;
-        hipLaunchKernelGGL(k_cg2_dots, gcam, blk, 0, P->stream, c);
-      }
-      hipLaunchKernelGGL(k_cg2_step, gcam, blk, 0, P->stream, c);
-      c.par ^= 1; c.first = 0;
-      ++launched;
+    for (int cc = 0; cc < chunks; ++cc) {
+      if (graph) { HIPCHK(hipGraphLaunch(G.exec, P->stream)); }
+      else { for (int k = 0; k < chunk; ++k) if (int st = enqueue_iter()) return st; }
+      launched += chunk;
     }
     P->timer.end(tk);
     HIPCHK(hipMemcpyAsync(&h, P->cg2sc.p, sizeof(h), hipMemcpyDeviceToHost, P->stream));
     if (int st = sync_check(P, "pcg")) return st;
-    if (h.done || launched >= o.max_cg_iterations) break;
+    if (h.done || launched >= o.max_cg_iterations + chunk + 2) break;
+    chunks = 1;   // same look-ahead as run_pcg: extrapolate the convergence factor, enqueue that many chunks before looking again
+    if (h.iters > 0 && h.last_rel > 0.0 && h.last_rel < 1.0 && c.tol > 0.0 && c.tol < h.last_rel) {
+      const double per_iter = std::log(h.last_rel) / h.iters;
+      const double remaining = std::log(c.tol / h.last_rel) / per_iter;
+      chunks = (int)std::min(8.0, std::max(1.0, std::ceil(remaining / chunk)));
+    }
   }
   *iters_out = h.iters; *rel_out = h.last_rel;
   return 0;
+}
+
+// Which PCG: the single-reduction variant halves the dependent launches per iteration (2 instead of 4), which is what bounds small
+// graphs (tools/small_graph_pcg.py: 22 -> 14 -> 8 us per iteration at C2 size); from ~1M directed entries on the kernels dominate
+// and the textbook recurrence is kept (its residual is the recursively updated one of the reference description).
+bool use_single_reduction(const gsfm_rot_problem* P, const gsfm_rot_options& o) {
+  if (o.pcg_single_reduction >= 0) return o.pcg_single_reduction != 0;
+  if (o.cg_stall_iterations > 0) return false;   // stagnation detection lives in the textbook variant's scalar kernel
+  return !P->sharded && P->dir.n <= (size_t)2000000;
 }
 
 // Exact step for small graphs: dense Cholesky of (J^T J + Lambda) in the left-tangent space (dense_kernels.hpp). *used = false if the
@@ -691,7 +739,7 @@ int lm_solve(gsfm_rot_problem* P, const gsfm_rot_options& o, gsfm_rot_summary* s
   sum->num_edges_used = P->cost.n;
   P->trace.clear();
   P->timer.acc[0] = P->timer.acc[1] = P->timer.acc[2] = 0;
-  P->lap = P->lap_capable && !o.pcg_single_reduction;   // the single-reduction variant's fused mat-vec keeps the 9-value blocks
+  P->lap = P->lap_capable;
   double h[SC_N];
   double radius = o.initial_trust_region_radius, decrease_factor = 2.0;
   int num_invalid = 0, iteration = 0;
@@ -743,7 +791,7 @@ int lm_solve(gsfm_rot_problem* P, const gsfm_rot_options& o, gsfm_rot_summary* s
       if (int st = run_dense(P, &dense_used)) return st;
     }
     if (dense_used) sum->num_dense_solves++;
-    else if (int st = (o.pcg_single_reduction ? run_pcg2(P, o, &cg, &cg_rel) : run_pcg(P, o, &cg, &cg_rel))) return st;
+    else if (int st = (use_single_reduction(P, o) ? run_pcg2(P, o, &cg, &cg_rel) : run_pcg(P, o, &cg, &cg_rel))) return st;
     if (cg > 150) pcg_struggles = true;
     sum->num_cg_iterations += cg;
     launch_step(P);
@@ -837,7 +885,7 @@ void gsfm_rot_options_default(gsfm_rot_options* o) {
   o->function_tolerance = 1e-6; o->gradient_tolerance = 1e-10; o->parameter_tolerance = 1e-8;
   o->initial_trust_region_radius = 1e4; o->max_trust_region_radius = 1e16; o->min_trust_region_radius = 1e-32;
   o->min_relative_decrease = 1e-3; o->min_lm_diagonal = 1e-6; o->max_lm_diagonal = 1e32;
-  o->jacobi_scaling = 1; o->max_cg_iterations = 1000; o->cg_relative_tolerance = 1e-12; o->cg_check_interval = 8; o->verbose = 0; o->pcg_single_reduction = 0; o->cg_stall_iterations = 0; o->dense_cholesky_max_cams = 512; o->pcg_hip_graph = 1;
+  o->jacobi_scaling = 1; o->max_cg_iterations = 1000; o->cg_relative_tolerance = 1e-12; o->cg_check_interval = 8; o->verbose = 0; o->pcg_single_reduction = -1; o->cg_stall_iterations = 0; o->dense_cholesky_max_cams = 512; o->pcg_hip_graph = 1;
 }
 
 int32_t gsfm_rot_residual_dim(int32_t t) { return t == GSFM_ROT_QUATERNION_NORM ? 4 : t == GSFM_ROT_ROTATION_MAT_FNORM ? 9 : 3; }
@@ -1049,7 +1097,11 @@ gsfm_status gsfm_rot_problem_create(uint32_t n_cams, uint64_t n_edges, const uin
   ok &= P->part_a.alloc(P->nb_cam) == hipSuccess; ok &= P->part_b.alloc(P->nb_cam) == hipSuccess;
   ok &= P->part_cam.alloc((size_t)5 * P->nb_cam) == hipSuccess; ok &= P->part_cost.alloc(P->nb_cost) == hipSuccess;
   ok &= P->scal.alloc(SC_N, true) == hipSuccess; ok &= P->cgsc.alloc(1, true) == hipSuccess;
-  P->nb_mv = std::max(1, std::min<int>(GSFM_MV_BLOCKS, (int)(((size_t)P->n_rows * P->G + GSFM_BLOCK - 1) / GSFM_BLOCK)));
+  {  // fused mat-vec of the single-reduction PCG: one row group (256 / G rows) per workgroup unless that leaves too many partials
+    const size_t rows_per_group = GSFM_BLOCK / P->G, groups = (P->n_rows + rows_per_group - 1) / rows_per_group;
+    P->mv_reps = (int)std::max<size_t>(1, (groups + GSFM_MV_MAX_PARTIALS - 1) / GSFM_MV_MAX_PARTIALS);
+    P->nb_mv = (int)std::max<size_t>(1, (groups + P->mv_reps - 1) / P->mv_reps);
+  }
   ok &= P->s_dir.alloc(3 * N, true) == hipSuccess; ok &= P->part_g2.alloc((size_t)2 * P->nb_cam, true) == hipSuccess;
   ok &= P->part_d2.alloc(std::max(P->nb_mv, P->nb_cam), true) == hipSuccess; ok &= P->cg2sc.alloc(1, true) == hipSuccess;
   if (!ok) return bail(fail(GSFM_ERR_HIP, "allocating camera buffers failed"));
@@ -1070,7 +1122,7 @@ void gsfm_rot_problem_destroy(gsfm_rot_problem* P) {
   if (!P) return;
   DeviceGuard g(P->device);
   P->timer.destroy();
-  P->pcg_graph.reset();
+  P->pcg_graph.reset(); P->pcg2_graph.reset();
   if (P->dense_graph) (void)hipGraphExecDestroy(P->dense_graph);
   if (P->own_stream && P->stream) (void)hipStreamDestroy(P->stream);
   delete P;
@@ -1080,7 +1132,7 @@ gsfm_status gsfm_rot_set_stream(gsfm_rot_problem* P, void* s) {
   if (!P) return (gsfm_status)fail(GSFM_ERR_INVALID_ARG, "NULL problem");
   DeviceGuard g(P->device);
   if (P->own_stream && P->stream) { (void)hipStreamSynchronize(P->stream); (void)hipStreamDestroy(P->stream); }
-  P->pcg_graph.reset(); P->pcg_graph.unusable = false;
+  P->pcg_graph.reset(); P->pcg_graph.unusable = false; P->pcg2_graph.reset(); P->pcg2_graph.unusable = false;
   if (P->dense_graph) { (void)hipGraphExecDestroy(P->dense_graph); P->dense_graph = nullptr; }
   if (s) { P->stream = (hipStream_t)s; P->own_stream = false; }
   else { if (hipStreamCreateWithFlags(&P->stream, hipStreamNonBlocking) != hipSuccess) return (gsfm_status)fail(GSFM_ERR_HIP, "hipStreamCreate failed"); P->own_stream = true; }

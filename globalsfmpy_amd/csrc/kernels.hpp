@@ -1117,7 +1117,7 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_cg_pupdate(CgArgs a) {
 // mat-vec; every block re-sums the partials in the same order, so all blocks (and all ranks) see
 // bit-identical scalars and no finalize launch or atomics are needed.
 // ------------------------------------------------------------------------------------------
-#define GSFM_MV_BLOCKS 4096  // persistent grid of the fused mat-vec
+#define GSFM_MV_MAX_PARTIALS 8192   // the fused mat-vec runs `reps` row groups per workgroup so that its delta partials stay below this
 struct Cg2Scalars {
   double gamma[2];   // parity-indexed gamma_i
   double alpha[2];
@@ -1132,6 +1132,7 @@ struct Cg2Args {
   int n_part_d;          // number of delta partials (mat-vec blocks, or nb_cam when sharded)
   int par;               // iteration parity
   int first;             // 1 on iteration 0
+  int max_iters;
   double tol;
   const double* Minv;
   const double* b;
@@ -1139,6 +1140,8 @@ struct Cg2Args {
   double* part_g;        // [2][nb_cam]  (parity-indexed)
   double* part_d;        // [n_part_d]
   Cg2Scalars* sc;
+  const double2* q;      // Laplacian form: camera quaternions and
+  double* urot;          //   urot_k = R_k^T u_k, written wherever u is (null otherwise): the vector the mat-vec gathers
 };
 
 // x = 0, r = b, u = M^-1 r, p = s = 0, gamma_0 partials
@@ -1153,52 +1156,113 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_cg2_init(Cg2Args a) {
     sym3_mulvec(a.Minv + 6 * (size_t)k, r, u);
 #pragma unroll
     for (int c = 0; c < 3; ++c) { a.x[k3 + c] = 0.0; a.r[k3 + c] = r[c]; a.u[k3 + c] = u[c]; a.p[k3 + c] = 0.0; a.s[k3 + c] = 0.0; v += r[c] * u[c]; }
+    if (a.urot) {
+      const Quat qq{a.q[2 * (size_t)k].x, a.q[2 * (size_t)k].y, a.q[2 * (size_t)k + 1].x, a.q[2 * (size_t)k + 1].y};
+      double uu[3];
+      rot_transpose_apply(qq, u, uu);
+      a.urot[k3] = uu[0]; a.urot[k3 + 1] = uu[1]; a.urot[k3 + 2] = uu[2];
+    }
   }
   const double t = block_sum_bcast(v, lds);
   if (threadIdx.x == 0) a.part_g[blockIdx.x] = t;
   if (blockIdx.x == 0 && threadIdx.x == 0) { a.sc->done = 0; a.sc->iters = 0; a.sc->last_rel = 1.0; a.sc->gamma0 = 0.0; }
 }
 
-// Convergence test shared by the mat-vec and the dots kernel: gamma_i from the partials of parity `par`.
-__device__ __forceinline__ bool cg2_converged(const Cg2Args& a, double* lds, double* gamma_out) {
-  const double gamma = sum_partials_bcast(a.part_g + (size_t)a.par * a.nb_cam, a.nb_cam, lds);
-  *gamma_out = gamma;
-  if (a.first) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) { a.sc->gamma0 = gamma; if (!(gamma > 0.0)) a.sc->done = 1; }
-    return !(gamma > 0.0);
+// w = A u on the owned rows (G lanes per row, `reps` row groups per workgroup) + delta partials (unsharded only).
+// Written for the latency regime: every load that does not depend on another load of this kernel -- the PCG scalars, the gamma
+// partials, the row bounds, the first trip's column / blocks and its gathered vector entry -- is requested before the first use of
+// any of them, so a workgroup pays ~3 dependent memory round trips (row bounds -> column -> gather) instead of one per stage.
+struct MatvecCgArgs { MatvecArgs mv; Cg2Args cg; int with_dots; uint32_t reps; };
+template <bool LAP>
+__device__ __forceinline__ void mv_entry(const MatvecArgs& a, const double* Rk, uint32_t m, const double2& A, const double2& B, const double2& C,
+                                         const double2& D, double E, const double* v, double& y0, double& y1, double& y2) {
+  if (LAP) {
+    const double w0 = Rk[0] * v[0] + Rk[1] * v[1] + Rk[2] * v[2], w1 = Rk[3] * v[0] + Rk[4] * v[1] + Rk[5] * v[2], w2 = Rk[6] * v[0] + Rk[7] * v[1] + Rk[8] * v[2];
+    y0 += A.x * w0 + A.y * w1 + B.x * w2;
+    y1 += A.y * w0 + B.y * w1 + C.x * w2;
+    y2 += B.x * w0 + C.x * w1 + C.y * w2;
+  } else {
+    y0 += A.x * v[0] + A.y * v[1] + B.x * v[2];
+    y1 += B.y * v[0] + C.x * v[1] + C.y * v[2];
+    y2 += D.x * v[0] + D.y * v[1] + E * v[2];
   }
-  const double rel = sqrt(gamma / a.sc->gamma0);
-  const bool conv = !(rel > a.tol);
-  if (blockIdx.x == 0 && threadIdx.x == 0) { a.sc->last_rel = rel; if (conv) a.sc->done = 1; }
-  return conv;
 }
-
-// w = A u on the owned rows (persistent grid, G lanes per row) + delta partials (unsharded only)
-struct MatvecCgArgs { MatvecArgs mv; Cg2Args cg; int with_dots; };
+template <bool LAP>
 __global__ void __launch_bounds__(GSFM_BLOCK) k_matvec_cg(MatvecCgArgs aa) {
   __shared__ double lds[8];
   const MatvecArgs& a = aa.mv;
-  if (aa.cg.sc->done) return;
-  double gamma;
-  if (cg2_converged(aa.cg, lds, &gamma)) return;
-  const uint32_t G = a.G, rows_per_block = GSFM_BLOCK / G;
+  const Cg2Args& c = aa.cg;
+  const double* __restrict__ vec = LAP ? a.u : a.p;   // the gathered vector: R^T u (Laplacian form) or u itself
+  // ---- request phase ----
+  const int done = c.sc->done, iters = c.sc->iters;
+  const double gamma0 = c.sc->gamma0;
+  double gpart = 0.0;
+  for (int k = threadIdx.x; k < c.nb_cam; k += GSFM_BLOCK) gpart += c.part_g[(size_t)c.par * c.nb_cam + k];
+  const uint32_t G = a.G, rows_per_group = GSFM_BLOCK / G;
   const uint32_t lane = threadIdx.x % G, sub = threadIdx.x / G;
+  uint32_t row = blockIdx.x * aa.reps * rows_per_group + sub;
+  bool live = row < a.n_rows;
+  uint32_t d = 0, end = 0;
+  if (live) { d = a.row_ptr[row] + lane; end = a.row_ptr[row + 1]; }
+  bool has = live && d < end;
+  uint32_t m = 0;
+  double2 A = make_double2(0, 0), B = A, C = A, D = A;
+  double E = 0.0, v[3] = {0, 0, 0};
+  Quat qk{0, 0, 0, 1};
+  if (live && LAP) qk = load_q(a.q, a.row_base + row);
+  double M0[6] = {0, 0, 0, 0, 0, 0}, pk0[3] = {0, 0, 0};   // the row owner's diagonal block and vector entry (first row group)
+  if (live && lane == 0) {
+    const size_t k = a.row_base + row;
+#pragma unroll
+    for (int t = 0; t < 6; ++t) M0[t] = a.Mblk[6 * k + t];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) pk0[t] = a.p[3 * k + t];
+  }
+  if (has) {
+    m = __builtin_nontemporal_load(a.col + d) & 0x7fffffffu;
+    A = nt_load2(a.h0 + d); B = nt_load2(a.h1 + d); C = nt_load2(a.h2 + d);
+    if (!LAP) { D = nt_load2(a.h3 + d); E = __builtin_nontemporal_load(a.h4 + d); }
+    const double* vm = vec + 3 * (size_t)m;
+    v[0] = vm[0]; v[1] = vm[1]; v[2] = vm[2];
+  }
+  // ---- convergence (same decision in every workgroup: same partials, same order) ----
+  const double gamma = block_sum_bcast(gpart, lds);
+  if (done) return;
+  bool conv;
+  if (c.first) {
+    conv = !(gamma > 0.0);
+    if (blockIdx.x == 0 && threadIdx.x == 0) { c.sc->gamma0 = gamma; if (conv) c.sc->done = 1; }
+  } else {
+    const double rel = sqrt(gamma / gamma0);
+    // the iteration cap is applied here, at a kernel entry, from a counter written by the PREVIOUS launch: every workgroup takes
+    // the same decision, and no workgroup of a vector-update launch can see the flag flip half way through an update of x
+    conv = !(rel > c.tol) || iters >= c.max_iters;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { c.sc->last_rel = rel; if (conv) c.sc->done = 1; }
+  }
+  if (conv) return;
+  // ---- rows ----
   double dpart = 0.0;
-  for (uint32_t row0 = blockIdx.x * rows_per_block; row0 < a.n_rows; row0 += gridDim.x * rows_per_block) {
-    const uint32_t row = row0 + sub;
-    const bool live = row < a.n_rows;
+  for (uint32_t rep = 0; rep < aa.reps; ++rep) {
+    if (rep > 0) {
+      row = (blockIdx.x * aa.reps + rep) * rows_per_group + sub;
+      live = row < a.n_rows;
+      d = 0; end = 0;
+      if (live) { d = a.row_ptr[row] + lane; end = a.row_ptr[row + 1]; if (LAP) qk = load_q(a.q, a.row_base + row); }
+      has = false;   // no prefetched entry: the loop below starts at d
+    }
     double y0 = 0.0, y1 = 0.0, y2 = 0.0;
     if (live) {
-      const uint32_t end = a.row_ptr[row + 1];
-      for (uint32_t d = a.row_ptr[row] + lane; d < end; d += G) {
-        const uint32_t m = __builtin_nontemporal_load(a.col + d) & 0x7fffffffu;
-        const double2 A = nt_load2(a.h0 + d), B = nt_load2(a.h1 + d), C = nt_load2(a.h2 + d), D = nt_load2(a.h3 + d);
-        const double E = __builtin_nontemporal_load(a.h4 + d);
-        const double* pm = a.p + 3 * (size_t)m;
-        const double p0 = pm[0], p1 = pm[1], p2 = pm[2];
-        y0 += A.x * p0 + A.y * p1 + B.x * p2;
-        y1 += B.y * p0 + C.x * p1 + C.y * p2;
-        y2 += D.x * p0 + D.y * p1 + E * p2;
+      double Rk[9];
+      if (LAP) qmat(qk, Rk);
+      if (has) { mv_entry<LAP>(a, Rk, m, A, B, C, D, E, v, y0, y1, y2); d += G; }
+      for (; d < end; d += G) {
+        const uint32_t mm = __builtin_nontemporal_load(a.col + d) & 0x7fffffffu;
+        const double2 A2 = nt_load2(a.h0 + d), B2 = nt_load2(a.h1 + d), C2 = nt_load2(a.h2 + d);
+        double2 D2 = make_double2(0, 0); double E2 = 0.0;
+        if (!LAP) { D2 = nt_load2(a.h3 + d); E2 = __builtin_nontemporal_load(a.h4 + d); }
+        const double* vm = vec + 3 * (size_t)mm;
+        const double vv[3] = {vm[0], vm[1], vm[2]};
+        mv_entry<LAP>(a, Rk, mm, A2, B2, C2, D2, E2, vv, y0, y1, y2);
       }
     }
     for (uint32_t off = G >> 1; off > 0; off >>= 1) {
@@ -1206,12 +1270,18 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_matvec_cg(MatvecCgArgs aa) {
     }
     if (live && lane == 0) {
       const size_t k = a.row_base + row;
-      const double* pk = a.p + 3 * k;
+      if (rep > 0) {
+#pragma unroll
+        for (int t = 0; t < 6; ++t) M0[t] = a.Mblk[6 * k + t];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) pk0[t] = a.p[3 * k + t];
+      }
       double mp[3];
-      sym3_mulvec(a.Mblk + 6 * k, pk, mp);
-      const double w0 = y0 + mp[0], w1 = y1 + mp[1], w2 = y2 + mp[2];
+      sym3_mulvec(M0, pk0, mp);
+      const double sgn = LAP ? -1.0 : 1.0;
+      const double w0 = mp[0] + sgn * y0, w1 = mp[1] + sgn * y1, w2 = mp[2] + sgn * y2;
       a.y[3 * k] = w0; a.y[3 * k + 1] = w1; a.y[3 * k + 2] = w2;
-      dpart += w0 * pk[0] + w1 * pk[1] + w2 * pk[2];
+      dpart += w0 * pk0[0] + w1 * pk0[1] + w2 * pk0[2];
     }
   }
   if (aa.with_dots) {
@@ -1234,35 +1304,54 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_cg2_dots(Cg2Args a) {
   if (threadIdx.x == 0) a.part_d[blockIdx.x] = t;
 }
 
-// alpha, beta and all five vector updates; gamma partials of the next iteration
+// alpha, beta and all five vector updates; gamma partials of the next iteration.  Like the mat-vec above, all loads are requested
+// before the first reduction (one memory round trip, then two workgroup reductions, then the stores).
 __global__ void __launch_bounds__(GSFM_BLOCK) k_cg2_step(Cg2Args a) {
-  if (a.sc->done) return;
   __shared__ double lds[8];
-  const double gamma = sum_partials_bcast(a.part_g + (size_t)a.par * a.nb_cam, a.nb_cam, lds);
-  const double delta = sum_partials_bcast(a.part_d, a.n_part_d, lds);
+  const int done = a.sc->done;
+  const double gamma_prev = a.sc->gamma[a.par ^ 1], alpha_prev = a.sc->alpha[a.par ^ 1];
+  double gpart = 0.0, dsum = 0.0;
+  for (int k = threadIdx.x; k < a.nb_cam; k += GSFM_BLOCK) gpart += a.part_g[(size_t)a.par * a.nb_cam + k];
+  for (int k = threadIdx.x; k < a.n_part_d; k += GSFM_BLOCK) dsum += a.part_d[k];
+  const uint32_t k = blockIdx.x * GSFM_BLOCK + threadIdx.x;
+  const bool live = k < a.n;
+  const size_t k3 = 3 * (size_t)(live ? k : 0);
+  double uo[3], po[3], wo[3], so[3], xo[3], ro[3], Mi[6];
+  Quat qq{0, 0, 0, 1};
+#pragma unroll
+  for (int c = 0; c < 3; ++c) { uo[c] = a.u[k3 + c]; po[c] = a.p[k3 + c]; wo[c] = a.w[k3 + c]; so[c] = a.s[k3 + c]; xo[c] = a.x[k3 + c]; ro[c] = a.r[k3 + c]; }
+#pragma unroll
+  for (int c = 0; c < 6; ++c) Mi[c] = a.Minv[2 * k3 + c];
+  if (a.urot) qq = load_q(a.q, live ? k : 0);
+  const double gamma = block_sum_bcast(gpart, lds);
+  const double delta = block_sum_bcast(dsum, lds);
+  if (done) return;
   double beta, alpha;
   if (a.first) { beta = 0.0; alpha = gamma / delta; }
   else {
-    beta = gamma / a.sc->gamma[a.par ^ 1];
-    alpha = gamma / (delta - beta * gamma / a.sc->alpha[a.par ^ 1]);
+    beta = gamma / gamma_prev;
+    alpha = gamma / (delta - beta * gamma / alpha_prev);
   }
   double v = 0.0;
-  const uint32_t k = blockIdx.x * GSFM_BLOCK + threadIdx.x;
-  if (k < a.n) {
-    const size_t k3 = 3 * (size_t)k;
+  if (live) {
     double r[3], u[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      const double p = a.u[k3 + c] + beta * a.p[k3 + c];
-      const double s = a.w[k3 + c] + beta * a.s[k3 + c];
+      const double p = uo[c] + beta * po[c];
+      const double s = wo[c] + beta * so[c];
       a.p[k3 + c] = p; a.s[k3 + c] = s;
-      a.x[k3 + c] += alpha * p;
-      r[c] = a.r[k3 + c] - alpha * s;
+      a.x[k3 + c] = xo[c] + alpha * p;
+      r[c] = ro[c] - alpha * s;
       a.r[k3 + c] = r[c];
     }
-    sym3_mulvec(a.Minv + 6 * (size_t)k, r, u);
+    sym3_mulvec(Mi, r, u);
 #pragma unroll
     for (int c = 0; c < 3; ++c) { a.u[k3 + c] = u[c]; v += r[c] * u[c]; }
+    if (a.urot) {
+      double uu[3];
+      rot_transpose_apply(qq, u, uu);
+      a.urot[k3] = uu[0]; a.urot[k3 + 1] = uu[1]; a.urot[k3 + 2] = uu[2];
+    }
   }
   const double t = block_sum_bcast(v, lds);
   if (threadIdx.x == 0) a.part_g[(size_t)(a.par ^ 1) * a.nb_cam + blockIdx.x] = t;

@@ -125,9 +125,11 @@ typedef struct {
                                           ill-conditioned real Madrid graph 1e-10 already costs 1e-6 rad mid-trajectory. */
   int32_t cg_check_interval;           /* CG iterations enqueued between host checks (default 8) */
   int32_t verbose;                     /* 1: print one line per LM iteration to stderr */
-  int32_t pcg_single_reduction;        /* 0 (default): textbook PCG, 4 kernels per iteration; 1: Chronopoulos-Gear single-reduction
-                                          PCG, 2 kernels per iteration (same iterates to rounding; measured 13% slower on one GPU
-                                          at C5 because its persistent mat-vec streams less well) */
+  int32_t pcg_single_reduction;        /* 0: textbook PCG, 4 dependent kernels per iteration; 1: Chronopoulos-Gear single-reduction PCG, 2 kernels
+                                          per iteration (mat-vec with the fused w.u partials, then one vector kernel; same iterates to
+                                          rounding); -1 (default): the latter when the problem has at most 2M directed entries and is not
+                                          sharded -- there the iteration is bounded by dependent-launch latency, not by bandwidth
+                                          (C2: 10k cameras / 200k edges).  Large problems keep the textbook recurrence. */
   int32_t cg_stall_iterations;         /* opt-in: stop PCG when the relative residual has not halved for this many
                                           iterations (default 0 = never).  On the real Madrid graph (MAGSAC weights spanning
                                           1e-5..5e4, vanishing damping) PCG needs up to 574 iterations per step; 64 here saves
