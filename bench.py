@@ -128,11 +128,11 @@ def main():
     t_gen = time.perf_counter() - t_gen
 
     t_create = time.perf_counter()
+    part = None
     if world > 1:
-        comm = sharding.make_comm(n_cams)
-        prob, perm = sharding.make_sharded_problem(g, error_type, comm, loss=loss_ctor())
-        init = np.empty_like(g["init_aa"]); init[perm] = g["init_aa"]
-        gt = np.empty_like(g["gt_aa"]); gt[perm] = g["gt_aa"]
+        prob, part = sharding.make_sharded_problem(g, error_type, loss=loss_ctor())
+        comm = prob._comm
+        init, gt = part.scatter(g["init_aa"]), part.scatter(g["gt_aa"])
     else:
         prob = RotationProblem(n_cams, g["edge_i"], g["edge_j"], g["rel_aa"], error_type, cov6=g["cov6"])
         prob.set_loss(loss_ctor())

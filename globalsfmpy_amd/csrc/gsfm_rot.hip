@@ -895,8 +895,10 @@ gsfm_status gsfm_rot_problem_create(uint32_t n_cams, uint64_t n_edges, const uin
                                     const gsfm_rot_shard* shard, gsfm_rot_problem** out) {
   if (!out) return (gsfm_status)fail(GSFM_ERR_INVALID_ARG, "out is NULL");
   *out = nullptr;
-  if (n_cams == 0 || n_edges == 0) return (gsfm_status)fail(GSFM_ERR_EMPTY, "no cameras or no edges");
-  if (!edge_i_in || !edge_j_in || !rel_aa) return (gsfm_status)fail(GSFM_ERR_INVALID_ARG, "NULL edge arrays");
+  // (one rank of a sharded problem may hold no edge at all -- a slice of isolated cameras -- and still takes part in every collective)
+  const bool multi_rank = shard && (shard->world_size > 1 || (shard->world_size == 1 && getenv("GSFM_FORCE_SHARD")));
+  if (n_cams == 0 || (n_edges == 0 && !multi_rank)) return (gsfm_status)fail(GSFM_ERR_EMPTY, "no cameras or no edges");
+  if (n_edges > 0 && (!edge_i_in || !edge_j_in || !rel_aa)) return (gsfm_status)fail(GSFM_ERR_INVALID_ARG, "NULL edge arrays");
   if (error_type < 0 || error_type > 8) return (gsfm_status)fail(GSFM_ERR_INVALID_ARG, "unknown rotation error type");
   if (n_cams >= 0x7fffffffu || n_edges >= 0x7fffffffull) return (gsfm_status)fail(GSFM_ERR_INVALID_ARG, "problem too large for 31-bit indices");
   const bool need_cov = error_type == GSFM_ROT_ANGLE_AXIS_COVARIANCE || error_type == GSFM_ROT_ANGLE_AXIS_COV_INLIERS ||
@@ -907,7 +909,25 @@ gsfm_status gsfm_rot_problem_create(uint32_t n_cams, uint64_t n_edges, const uin
   if (const char* why = no_device_reason("the rotation solver")) return (gsfm_status)fail(GSFM_ERR_NO_DEVICE, why);
 
   gsfm_rot_problem* P = new gsfm_rot_problem;
-  auto bail = [&](int st) { gsfm_rot_problem_destroy(P); return (gsfm_status)st; };
+  // Sharded: a rank-local failure (bad edge, allocation, upload) must not leave the other ranks blocked in the first collective.
+  // Every rank therefore passes through exactly one agreement all-reduce before it -- on the failure path from bail(), on the
+  // success path right before the all-gather of the active mask -- and all ranks give up together if any of them failed.
+  bool agreed = false;
+  DevBuf<double> agree_buf;
+  auto agree = [&](double my_flag) -> int {   // number of ranks that failed, or -1 if the agreement itself could not be run
+    agreed = true;
+    if (!P->sharded) return 0;
+    double h = my_flag;
+    if (agree_buf.alloc(1) != hipSuccess || hipMemcpy(agree_buf.p, &h, 8, hipMemcpyHostToDevice) != hipSuccess) return -1;
+    if (all_reduce(P, agree_buf.p, 1) != 0) return -1;
+    if (hipStreamSynchronize(P->stream) != hipSuccess || hipMemcpy(&h, agree_buf.p, 8, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return (int)(h + 0.5);
+  };
+  auto bail = [&](int st) {
+    if (P->sharded && !agreed) { const std::string keep = g_err; (void)agree(1.0); g_err = keep; }
+    gsfm_rot_problem_destroy(P);
+    return (gsfm_status)st;
+  };
   const bool lap_on = getenv("GSFM_CREATE_TIMING") != nullptr;   // phase times of this function on stderr
   double lap_t = now_ms();
   auto lap = [&](const char* what) { if (lap_on) { const double t = now_ms(); fprintf(stderr, "gsfm create: %-28s %8.1f ms\n", what, t - lap_t); lap_t = t; } };
@@ -921,7 +941,7 @@ gsfm_status gsfm_rot_problem_create(uint32_t n_cams, uint64_t n_edges, const uin
              : (error_type == GSFM_ROT_ANGLE_AXIS_INLIERS || error_type == GSFM_ROT_ANGLE_AXIS_COVTRACE || error_type == GSFM_ROT_ANGLE_AXIS_COVNORM) ? W_SCALAR
              : W_NONE;
   // GSFM_FORCE_SHARD=1 keeps the collective code path alive for a single rank (tests on a 1-GPU box)
-  if (shard && (shard->world_size > 1 || (shard->world_size == 1 && getenv("GSFM_FORCE_SHARD")))) {
+  if (multi_rank) {
     if (!shard->all_gather || !shard->all_reduce_sum || shard->slice_width == 0 || shard->rank < 0 || shard->rank >= shard->world_size ||
         (uint64_t)shard->slice_width * shard->world_size < n_cams)
       return bail(fail(GSFM_ERR_INVALID_ARG, "bad shard descriptor"));
@@ -1052,7 +1072,7 @@ gsfm_status gsfm_rot_problem_create(uint32_t n_cams, uint64_t n_edges, const uin
   // ---- uploads ----
   {
     DevBuf<double> d_rel;   // the measurements go up once; both sets of planes are gathered from them on the device
-    if (d_rel.alloc(3 * n_edges) != hipSuccess || hipMemcpy(d_rel.p, rel_aa, 24 * n_edges, hipMemcpyHostToDevice) != hipSuccess)
+    if (d_rel.alloc(3 * n_edges) != hipSuccess || (n_edges > 0 && hipMemcpy(d_rel.p, rel_aa, 24 * n_edges, hipMemcpyHostToDevice) != hipSuccess))
       return bail(fail(GSFM_ERR_HIP, "uploading the relative rotations failed"));
     if (int st = upload_planes(P, P->cost, cost_eid, d_rel.p)) return bail(st);
     if (int st = upload_planes(P, P->dir, deid, d_rel.p)) return bail(st);
@@ -1109,6 +1129,10 @@ gsfm_status gsfm_rot_problem_create(uint32_t n_cams, uint64_t n_edges, const uin
     std::vector<double> act(NP, 0.0);
     for (uint32_t r = 0; r < P->n_rows; ++r) act[ob + r] = (rp[r + 1] > rp[r]) ? 1.0 : 0.0;
     if (hipMemcpy(P->active.p, act.data(), 8 * NP, hipMemcpyHostToDevice) != hipSuccess) return bail(fail(GSFM_ERR_HIP, "upload active mask"));
+    if (P->sharded) {
+      const int failed = agree(0.0);
+      if (failed != 0) return bail(fail(GSFM_ERR_COMM, failed > 0 ? "problem creation failed on " + std::to_string(failed) + " other rank(s)" : std::string("the create-time agreement all-reduce failed")));
+    }
     if (int st = all_gather(P, P->active.p, P->shard.slice_width)) return bail(st);
     if (P->sharded && hipStreamSynchronize(P->stream) != hipSuccess) return bail(fail(GSFM_ERR_HIP, "active mask all-gather failed"));
   }
@@ -1192,7 +1216,6 @@ gsfm_status gsfm_rot_solve_sigma_consensus(gsfm_rot_problem* P, double* rot, int
                                            const gsfm_rot_options* opt, gsfm_rot_summary* summary) {
   if (!P || !rot) return (gsfm_status)fail(GSFM_ERR_INVALID_ARG, "NULL argument");
   if (P->error_type != GSFM_ROT_ANGLE_AXIS) return (gsfm_status)fail(GSFM_ERR_INVALID_ARG, "sigma consensus needs an ANGLE_AXIS problem");
-  if (P->sharded) return (gsfm_status)fail(GSFM_ERR_UNSUPPORTED, "sigma consensus is single-GPU in this version");
   DeviceGuard g(P->device);
   const gsfm_rot_options o = opt ? *opt : default_options();
   gsfm_rot_summary local, total; if (!summary) summary = &local;
@@ -1215,13 +1238,31 @@ gsfm_status gsfm_rot_solve_sigma_consensus(gsfm_rot_problem* P, double* rot, int
   if (!P->w_orig.p && P->w_orig.alloc(E) != hipSuccess) return (gsfm_status)fail(GSFM_ERR_HIP, "alloc weights");
   if (hipMemsetAsync(P->w_orig.p, 0, 8 * E, P->stream) != hipSuccess) return (gsfm_status)fail(GSFM_ERR_HIP, "clear weights");
   DevBuf<double> d_table, d_part, d_sum;
-  const int nb_sig = grid_for(E);
-  if (d_table.upload(table) != hipSuccess || d_part.alloc(nb_sig) != hipSuccess || d_sum.alloc(1) != hipSuccess) return (gsfm_status)fail(GSFM_ERR_HIP, "alloc sigma consensus buffers");
+  DevBuf<uint8_t> d_counted;
+  const int nb_sig = std::max(1, grid_for(E));
+  if (d_table.upload(table) != hipSuccess || d_part.alloc(nb_sig, true) != hipSuccess || d_sum.alloc(2, true) != hipSuccess) return (gsfm_status)fail(GSFM_ERR_HIP, "alloc sigma consensus buffers");
+  double global_edges = (double)E;
+  if (P->sharded) {
+    // every edge is counted in mean |w - w_old| by exactly one rank: its cost owner
+    std::vector<uint8_t> counted(E, 0);
+    for (uint32_t e : P->h_cost_eid) counted[e] = 1;
+    if (d_counted.upload(counted) != hipSuccess) return (gsfm_status)fail(GSFM_ERR_HIP, "alloc sigma consensus buffers");
+    const double mine = (double)P->h_cost_eid.size();
+    HIPCHK_S(hipMemcpyAsync(d_sum.p + 1, &mine, 8, hipMemcpyHostToDevice, P->stream));
+    if (int st = all_reduce(P, d_sum.p + 1, 1)) return (gsfm_status)st;
+    HIPCHK_S(hipMemcpyAsync(&global_edges, d_sum.p + 1, 8, hipMemcpyDeviceToHost, P->stream));
+    if (int st = sync_check(P, "sigma consensus: edge count")) return (gsfm_status)st;
+  }
   int outer = 0;
   for (int it = 0; it < iters_num; ++it) {
     ++outer;
     if (int st = upload_state(P, rot)) return (gsfm_status)st;
-    {  // K6 = K1 in s-only mode with unit weights: s_e = ||log(R_j R_i^T R_ij^T)||^2  (:378-398)
+    if (P->sharded) {   // s of every edge this rank holds (its rows' entries), not only of the edges it counts in the cost
+      RowSArgs ra{};
+      ra.n_rows = P->n_rows; ra.row_base = P->own_begin; ra.G = P->G; ra.row_ptr = P->row_ptr.p; ra.col = P->col.p; ra.eid = P->dir.eid.p;
+      ra.qr0 = P->dir.qr0.p; ra.qr1 = P->dir.qr1.p; ra.q = P->q.p; ra.s_out = P->s_ext.p;
+      hipLaunchKernelGGL(k_row_s, dim3(grid_for((size_t)P->n_rows * P->G)), dim3(GSFM_BLOCK), 0, P->stream, ra);
+    } else {  // K6 = K1 in s-only mode with unit weights: s_e = ||log(R_j R_i^T R_ij^T)||^2  (:378-398)
       CostArgs a{};
       a.tiles = P->cost_tiles.p; a.direct = P->cost_direct; a.n_cams = P->n_cams; a.n = P->cost.n; a.idx = P->cost_idx.p; a.qr0 = P->cost.qr0.p; a.qr1 = P->cost.qr1.p; a.ws = P->cost.ws.p;
       a.q = P->q.p; a.loss = P->d_loss.p; a.eid = P->cost.eid.p; a.partials = P->part_cost.p; a.s_out = P->s_ext.p; a.s_only = 1; a.unit_w = 1;
@@ -1229,15 +1270,16 @@ gsfm_status gsfm_rot_solve_sigma_consensus(gsfm_rot_problem* P, double* rot, int
     }
     SigmaArgs sa{};
     sa.s = P->s_ext.p; sa.w = P->w_orig.p; sa.n = E; sa.table = d_table.p; sa.table_len = c.n; sa.ssm2 = squared_sigma_max_2;
-    sa.one_over_sigma = one_over_sigma; sa.gk = c.gk; sa.weight_zero = weight_zero; sa.partials = d_part.p;
+    sa.one_over_sigma = one_over_sigma; sa.gk = c.gk; sa.weight_zero = weight_zero; sa.partials = d_part.p; sa.counted = d_counted.p;
     hipLaunchKernelGGL(k_sigma_weights, dim3(nb_sig), dim3(GSFM_BLOCK), 0, P->stream, sa);
     hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(GSFM_BLOCK), 0, P->stream, d_part.p, nb_sig, d_sum.p);
+    if (int st = all_reduce(P, d_sum.p, 1)) return (gsfm_status)st;
     if (P->cost.n) hipLaunchKernelGGL(k_gather_weights, dim3(grid_for(P->cost.n)), dim3(GSFM_BLOCK), 0, P->stream, P->w_orig.p, P->cost.eid.p, P->cost.n, P->cost.ws.p);
     if (P->dir.n) hipLaunchKernelGGL(k_gather_weights, dim3(grid_for(P->dir.n)), dim3(GSFM_BLOCK), 0, P->stream, P->w_orig.p, P->dir.eid.p, P->dir.n, P->dir.ws.p);
     double avg = 0.0;
     if (hipMemcpyAsync(&avg, d_sum.p, 8, hipMemcpyDeviceToHost, P->stream) != hipSuccess) return (gsfm_status)fail(GSFM_ERR_HIP, "read weight change");
     if (int st = sync_check(P, "sigma consensus weights")) return (gsfm_status)st;
-    avg /= (double)E;
+    avg /= global_edges;
     if (gsfm_status st = gsfm_rot_solve(P, rot, &o, summary)) return st;
     if (it == 0) total = *summary;
     else {
@@ -1338,6 +1380,24 @@ gsfm_status gsfm_rot_loss_eval(gsfm_rot_problem* P, const double* s, uint64_t n,
   if (rho3_out) HIPCHK_S(hipMemcpyAsync(rho3_out, d3.p, 24 * n, hipMemcpyDeviceToHost, P->stream));
   if (value_out) HIPCHK_S(hipMemcpyAsync(value_out, dv.p, 8 * n, hipMemcpyDeviceToHost, P->stream));
   return (gsfm_status)sync_check(P, "loss_eval");
+}
+
+int32_t gsfm_rot_locality_order(uint32_t n_cams, uint64_t n_edges, const uint32_t* edge_i, const uint32_t* edge_j, uint32_t* perm_out) {
+  if (!perm_out || (n_edges > 0 && (!edge_i || !edge_j)) || n_cams >= 0x7fffffffu || n_edges >= 0x7fffffffull) { fail(GSFM_ERR_INVALID_ARG, "bad argument"); return -1; }
+  std::vector<uint32_t> ptr((size_t)n_cams + 1, 0), adj(2 * n_edges);
+  for (uint64_t e = 0; e < n_edges; ++e) {
+    if (edge_i[e] >= n_cams || edge_j[e] >= n_cams || edge_i[e] == edge_j[e]) { fail(GSFM_ERR_INVALID_ARG, "edge with an out-of-range or repeated camera index"); return -1; }
+    ptr[edge_i[e] + 1]++; ptr[edge_j[e] + 1]++;
+  }
+  for (size_t c = 0; c < n_cams; ++c) ptr[c + 1] += ptr[c];
+  {
+    std::vector<uint32_t> fill(ptr.begin(), ptr.end() - 1);
+    for (uint64_t e = 0; e < n_edges; ++e) { adj[fill[edge_i[e]]++] = edge_j[e]; adj[fill[edge_j[e]]++] = edge_i[e] | 0x80000000u; }
+  }
+  std::vector<uint32_t> perm;
+  const bool adopted = n_edges > 0 && reorder_for_locality(n_cams, n_edges, edge_i, edge_j, ptr, adj, &perm);
+  for (uint32_t c = 0; c < n_cams; ++c) perm_out[c] = adopted ? perm[c] : c;
+  return adopted ? 1 : 0;
 }
 
 int32_t gsfm_rot_get_trace(gsfm_rot_problem* P, double* out, int32_t cap_rows) {

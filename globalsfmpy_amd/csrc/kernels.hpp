@@ -342,6 +342,7 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_whiten(WhitenArgs a) {
 struct SigmaArgs {
   const double* s;        // per original edge
   double* w;              // in: previous weights, out: new weights
+  const uint8_t* counted; // sharded: 1 where this rank counts the edge in sum |w - w_old| (its cost-owned edges); null = all
   size_t n;
   const double* table;    // Gamma(1, x / 1000), nu = 3
   int table_len;
@@ -362,11 +363,42 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_sigma_weights(SigmaArgs a) {
       if (!(xf < (double)(a.table_len - 1))) xf = (double)(a.table_len - 1);  // last stored entry (the reference reads one past it)
       weight = a.one_over_sigma * (a.table[(int)xf] - a.gk);
     }
-    change = fabs(weight - a.w[e]);
+    change = (!a.counted || a.counted[e]) ? fabs(weight - a.w[e]) : 0.0;
     a.w[e] = weight;
   }
   const double t = block_sum_bcast(change, lds);
   if (threadIdx.x == 0) a.partials[blockIdx.x] = t;
+}
+
+// sigma consensus on a sharded problem: the unweighted s = |log(R_j R_i^T R_ij^T)|^2 of EVERY edge this rank holds (each touches one of
+// its rows), written per local edge.  Same device routine as K1's s-only mode, so the weights equal the single-GPU ones bit for bit.
+struct RowSArgs {
+  uint32_t n_rows, row_base, G;
+  const uint32_t* row_ptr;
+  const uint32_t* col;
+  const uint32_t* eid;
+  const double2 *qr0, *qr1;
+  const double2* q;
+  double* s_out;          // per local edge
+};
+__global__ void __launch_bounds__(GSFM_BLOCK) k_row_s(RowSArgs a) {
+  const uint32_t t = blockIdx.x * GSFM_BLOCK + threadIdx.x;
+  const uint32_t row = t / a.G, lane = t % a.G;
+  if (row >= a.n_rows) return;
+  const Quat qk = load_q(a.q, a.row_base + row);
+  EdgeW W;
+  W.l00 = 1.0; W.l01 = W.l02 = W.l12 = 0.0; W.l11 = W.l22 = 1.0;
+  const uint32_t end = a.row_ptr[row + 1];
+  for (uint32_t d = a.row_ptr[row] + lane; d < end; d += a.G) {
+    const uint32_t cr = a.col[d];
+    const Quat qm = load_q(a.q, cr & 0x7fffffffu);
+    const double2 r0 = a.qr0[d], r1 = a.qr1[d];
+    const Quat qr{r0.x, r0.y, r1.x, r1.y};
+    double r[3];
+    if (cr >> 31) edge_residual<F_AA, W_SCALAR>(qm, qk, qr, W, r);
+    else edge_residual<F_AA, W_SCALAR>(qk, qm, qr, W, r);
+    a.s_out[a.eid[d]] = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
+  }
 }
 
 // scatter per-original-edge scalar weights into an entry-ordered plane (sigma consensus / set_edge_weights)

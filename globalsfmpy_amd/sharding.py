@@ -16,61 +16,95 @@ import numpy as np
 from . import _abi
 
 
-def slice_width(n_cams, world_size):
-    return (int(n_cams) + world_size - 1) // world_size
+class Partition(object):
+    """Cameras -> ranks.  The C-ABI shards by contiguous slices of equal width P (gsfm_rot_shard.slice_width), so a partition is a
+    relabelling of the cameras into the padded index space [0, world * P): rank r's cameras get the ids r*P, r*P + 1, ... and the
+    rest of its slice is padding (cameras without edges, which the solver leaves untouched).  `new_id[old]` is that relabelling."""
+
+    def __init__(self, n_cams, world, width, new_id, entries_per_rank):
+        self.n_cams, self.world, self.width = int(n_cams), int(world), int(width)
+        self.n_pad = self.world * self.width
+        self.new_id = new_id
+        self.entries_per_rank = entries_per_rank
+
+    def scatter(self, per_camera, fill=0.0):
+        """(n_cams, ...) in the caller's numbering -> (n_pad, ...) in the problem's."""
+        a = np.asarray(per_camera)
+        out = np.full((self.n_pad,) + a.shape[1:], fill, dtype=a.dtype)
+        out[self.new_id] = a
+        return out
+
+    def gather(self, padded):
+        return np.asarray(padded)[self.new_id]
+
+    def relabel(self, cams):
+        return self.new_id[np.asarray(cams, dtype=np.int64)].astype(np.uint32)
 
 
-def balance_permutation(n_cams, edge_i, edge_j, world_size):
-    """Relabel cameras so that contiguous slices carry equal numbers of directed entries
-    (greedy snake over the degree-sorted cameras).  Returns perm with new_id = perm[old_id]."""
-    deg = np.bincount(np.asarray(edge_i, dtype=np.int64), minlength=n_cams) + \
-        np.bincount(np.asarray(edge_j, dtype=np.int64), minlength=n_cams)
-    order = np.argsort(-deg, kind="stable")
-    P = slice_width(n_cams, world_size)
-    # deal the cameras out to the slices boustrophedon-wise: slice loads stay within one degree of each other
-    k = np.arange(n_cams)
-    rnd, pos = k // world_size, k % world_size
-    part = np.where(rnd % 2 == 0, pos, world_size - 1 - pos)
-    part = np.minimum(part, world_size - 1)
+def locality_order(n_cams, edge_i, edge_j):
+    """Camera order in which neighbours sit close together (the reverse Cuthill-McKee relabelling gsfm_rot_problem_create applies
+    to unsharded problems, adopted under the same criterion), or the identity when the graph has no locality to recover (e.g. the
+    uniformly random C5 graph).  Returns `order` with order[k] = the camera placed k-th."""
+    lib = _abi.load_library()
+    ei = np.ascontiguousarray(edge_i, dtype=np.uint32)
+    ej = np.ascontiguousarray(edge_j, dtype=np.uint32)
+    perm = np.empty(int(n_cams), dtype=np.uint32)
+    adopted = lib.gsfm_rot_locality_order(int(n_cams), int(ei.size), ei.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                          ej.ctypes.data_as(C.POINTER(C.c_uint32)), perm.ctypes.data_as(C.POINTER(C.c_uint32)))
+    if adopted < 0:
+        raise ValueError("gsfm_rot_locality_order rejected the edge list")
+    order = np.empty(int(n_cams), dtype=np.int64)
+    order[perm.astype(np.int64)] = np.arange(int(n_cams))
+    return order
+
+
+def partition_cameras(n_cams, edge_i, edge_j, world_size, order=None):
+    """Contiguous slices of the locality ordering, cut so that every rank owns (nearly) the same number of directed entries
+    (= block-CSR rows' worth of mat-vec work), every rank at least one camera.  In a spatially coherent view graph most
+    neighbours of a rank's cameras then live on the same rank, so the gathers of the mat-vec stay inside its own slice; in a
+    uniformly random graph every balanced partition cuts (world-1)/world of the edges and only the balance matters."""
+    n_cams, world_size = int(n_cams), int(world_size)
+    if world_size < 1 or n_cams < world_size:
+        raise ValueError("need at least one camera per rank (%d cameras, %d ranks)" % (n_cams, world_size))
+    if order is None:
+        order = locality_order(n_cams, edge_i, edge_j)
+    order = np.asarray(order, dtype=np.int64)
+    deg = np.bincount(np.asarray(edge_i, dtype=np.int64), minlength=n_cams) + np.bincount(np.asarray(edge_j, dtype=np.int64), minlength=n_cams)
+    csum = np.cumsum(deg[order])
+    total = int(csum[-1]) if n_cams else 0
+    cuts = [0]
+    for r in range(1, world_size):
+        c = int(np.searchsorted(csum, r * total / world_size, side="left")) + 1 if total else (r * n_cams) // world_size
+        c = max(c, cuts[-1] + 1)                           # at least one camera per rank ...
+        c = min(c, n_cams - (world_size - r))              # ... also for the ranks still to come
+        cuts.append(c)
+    cuts.append(n_cams)
+    width = max(cuts[r + 1] - cuts[r] for r in range(world_size))
     new_id = np.empty(n_cams, dtype=np.int64)
-    fill = np.zeros(world_size, dtype=np.int64)
-    # stable placement inside each slice
+    entries = []
     for r in range(world_size):
-        members = order[part == r]
-        cap = min(P, n_cams - r * P)
-        if members.size > cap:  # overflow: spill later (rare, only when n_cams % world_size != 0)
-            members = members[:cap]
-        new_id[members] = r * P + np.arange(members.size)
-        fill[r] = members.size
-    placed = np.zeros(n_cams, dtype=bool)
-    for r in range(world_size):
-        placed[order[part == r][:fill[r]]] = True
-    rest = np.flatnonzero(~placed)
-    if rest.size:
-        free = []
-        for r in range(world_size):
-            cap = min(P, max(0, n_cams - r * P))
-            free.extend(range(r * P + int(fill[r]), r * P + cap))
-        new_id[rest] = np.asarray(free[:rest.size], dtype=np.int64)
-    return new_id
+        members = order[cuts[r]:cuts[r + 1]]
+        new_id[members] = r * width + np.arange(members.size)
+        entries.append(int(deg[members].sum()))
+    part = Partition(n_cams, world_size, width, new_id, entries)
+    assert np.unique(new_id).size == n_cams and new_id.min() >= 0 and new_id.max() < part.n_pad
+    return part
 
 
-def local_edge_mask(n_cams, edge_i, edge_j, rank, world_size):
-    """Edges a rank must hold: those touching one of its cameras."""
-    P = slice_width(n_cams, world_size)
-    lo, hi = rank * P, min((rank + 1) * P, n_cams)
+def local_edge_mask(part, edge_i, edge_j, rank):
+    """Edges a rank must hold: those touching one of its cameras (edge ids in the partition's numbering)."""
+    lo, hi = rank * part.width, (rank + 1) * part.width
     ei = np.asarray(edge_i, dtype=np.int64)
     ej = np.asarray(edge_j, dtype=np.int64)
     return ((ei >= lo) & (ei < hi)) | ((ej >= lo) & (ej < hi))
 
 
-def cost_owner(n_cams, edge_i, edge_j, world_size):
+def cost_owner(part, edge_i, edge_j):
     """The rank that counts an edge's rho in the cost (rule of gsfm_rot_problem_create)."""
-    P = slice_width(n_cams, world_size)
     ei = np.asarray(edge_i, dtype=np.int64)
     ej = np.asarray(edge_j, dtype=np.int64)
     c = np.where(((ei + ej) & 1) == 0, ei, ej)
-    return c // P
+    return c // part.width
 
 
 class _DevView(object):
@@ -83,15 +117,14 @@ class _DevView(object):
 class TorchComm(object):
     """Owns the ctypes callbacks handed to the library through gsfm_rot_shard."""
 
-    def __init__(self, n_cams, group=None):
+    def __init__(self, width, group=None):
         import torch
         import torch.distributed as dist
         self.torch, self.dist, self.group = torch, dist, group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
         self.backend = dist.get_backend(group)
-        self.n_cams = int(n_cams)
-        self.P = slice_width(n_cams, self.world)
+        self.P = int(width)
         self._views = {}
         self._host = {}
         self._ext = {}
@@ -183,14 +216,13 @@ class NativeComm(object):
     """The same two collectives issued by C++ (globalsfmpy_amd/csrc/gsfm_rccl.cpp) straight into RCCL on the
     solver's own stream.  torch.distributed is used once, to hand the ncclUniqueId to every rank."""
 
-    def __init__(self, n_cams, group=None):
+    def __init__(self, width, group=None):
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
-        self.n_cams = int(n_cams)
-        self.P = slice_width(n_cams, self.world)
+        self.P = int(width)
         here = os.path.dirname(os.path.abspath(__file__))
         lib = C.CDLL(os.path.join(here, "libgsfm_rccl.so"))
         lib.gsfm_rccl_last_error.restype = C.c_char_p
@@ -214,7 +246,8 @@ class NativeComm(object):
             buf = C.create_string_buffer(128)
             if lib.gsfm_rccl_unique_id(buf) == 0:
                 ident[0] = buf.raw
-        dist.broadcast_object_list(ident, src=0, group=group)
+        # (`src` is a GLOBAL rank: group rank 0 of a sub-group need not be global rank 0)
+        dist.broadcast_object_list(ident, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
         if ident[0] is None:
             raise RuntimeError("ncclGetUniqueId failed on rank 0: %s" % lib.gsfm_rccl_last_error().decode())
         torch.cuda.synchronize()
@@ -241,32 +274,36 @@ class NativeComm(object):
             self._ctx = None
 
 
-def make_comm(n_cams, prefer_native=True, group=None):
-    """NativeComm when RCCL can be driven from C++ (backend nccl), else the torch.distributed callbacks."""
+def make_comm(width, prefer_native=True, group=None):
+    """The two collectives for slices of `width` cameras (Partition.width): NativeComm when RCCL can be driven from C++ (backend nccl),
+    else the torch.distributed callbacks."""
     import torch.distributed as dist
     if prefer_native and dist.get_backend(group) == "nccl" and os.environ.get("GSFM_NO_NATIVE_RCCL") is None:
         try:
-            return NativeComm(n_cams, group)
+            return NativeComm(width, group)
         except Exception as e:  # noqa: BLE001
             import sys
             print("gsfm: native RCCL unavailable (%r); falling back to torch.distributed collectives" % (e,), file=sys.stderr)
-    return TorchComm(n_cams, group)
+    return TorchComm(width, group)
 
 
-def make_sharded_problem(graph, error_type, comm, loss=None):
-    """graph: dict from synth.make_graph (global, identical on every rank).  Returns (problem, perm)
-    where perm maps original camera ids to the balanced numbering used by the problem."""
+def make_sharded_problem(graph, error_type, loss=None, prefer_native=True, group=None, part=None):
+    """graph: dict from synth.make_graph (global, identical on every rank).  Partitions the cameras, builds this rank's share of the
+    problem and returns (problem, partition); per-camera arrays enter and leave through partition.scatter / .gather."""
+    import torch.distributed as dist
     from .solver import RotationProblem
     n = graph["n_cams"]
-    perm = balance_permutation(n, graph["edge_i"], graph["edge_j"], comm.world)
-    ei = perm[np.asarray(graph["edge_i"], dtype=np.int64)].astype(np.uint32)
-    ej = perm[np.asarray(graph["edge_j"], dtype=np.int64)].astype(np.uint32)
-    m = local_edge_mask(n, ei, ej, comm.rank, comm.world)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if part is None:
+        part = partition_cameras(n, graph["edge_i"], graph["edge_j"], world)
+    comm = make_comm(part.width, prefer_native, group)
+    ei, ej = part.relabel(graph["edge_i"]), part.relabel(graph["edge_j"])
+    m = local_edge_mask(part, ei, ej, rank)
     cov6 = graph["cov6"][m] if graph.get("cov6") is not None else None
     inl = graph["inlier_weight"][m] if graph.get("inlier_weight") is not None else None
-    prob = RotationProblem(n, ei[m], ej[m], graph["rel_aa"][m], error_type, cov6=cov6, inlier_weight=inl,
+    prob = RotationProblem(part.n_pad, ei[m], ej[m], graph["rel_aa"][m], error_type, cov6=cov6, inlier_weight=inl,
                            shard=comm.shard, stream=comm.stream_handle())
     prob._comm = comm
     if loss is not None:
         prob.set_loss(loss)
-    return prob, perm
+    return prob, part

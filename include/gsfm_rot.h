@@ -280,6 +280,13 @@ gsfm_status gsfm_rot_linearize(gsfm_rot_problem* p, const double* rot_aa,
 /* y = (J~^T J~) v for the last linearisation (kernel K3), 3 per camera. */
 gsfm_status gsfm_rot_normal_matvec(gsfm_rot_problem* p, const double* v, double* y);
 
+/* Host-only helper for partitioners: the locality relabelling gsfm_rot_problem_create would adopt for this graph on one GPU
+ * (reverse Cuthill-McKee, kept only if it halves the mean index distance of the edges and brings it under 1024).
+ * perm_out[c] = position of camera c in that order (the identity if nothing is to be gained).  Returns 1 if adopted, 0 if the
+ * identity was returned, -1 on bad input.  Needs no device.  globalsfmpy_amd/sharding.py cuts the order into per-GPU slices. */
+int32_t gsfm_rot_locality_order(uint32_t n_cams, uint64_t n_edges, const uint32_t* edge_i, const uint32_t* edge_j,
+                                uint32_t* perm_out);
+
 /* The problem's current native loss program evaluated ON THE DEVICE at the given squared norms, through the same device
  * routines (and kernel specialisation) the sweeps use: rho3_out[3k..] = (rho, rho', rho'')(s[k]) as K2 and the per-edge
  * sweep compute them, value_out[k] = rho(s[k]) as the solver's cost-only sweep computes it.  Either output may be NULL.

@@ -20,16 +20,37 @@ def main():
         dist.init_process_group("gloo")
     from globalsfmpy_amd import _abi, sharding, synth
     from globalsfmpy_amd.loss_functions import MAGSACWeightBasedLoss
+    case = sys.argv[4] if len(sys.argv) > 4 else "default"
     g = synth.make_graph(1203, 40000, seed=23, outlier_frac=0.3)
-    comm = sharding.make_comm(g["n_cams"], prefer_native=(len(sys.argv) > 3 and sys.argv[3] == "native"))
-    prob, perm = sharding.make_sharded_problem(g, _abi.ANGLE_AXIS_COVARIANCE, comm, loss=MAGSACWeightBasedLoss(0.02))
-    init = np.empty_like(g["init_aa"]); init[perm] = g["init_aa"]
-    rot, summ = prob.solve(init)
+    if case == "isolated":   # the last cameras carry no edge at all: with 8 ranks the last slice holds nothing but isolated cameras
+        keep = (g["edge_i"] < 1100) & (g["edge_j"] < 1100)
+        for k in ("edge_i", "edge_j", "rel_aa", "cov6", "inlier_weight"):
+            g[k] = g[k][keep]
+    prefer_native = len(sys.argv) > 3 and sys.argv[3] == "native"
+    world = dist.get_world_size()
+    if case == "isolated":   # hand-made partition: ranks 0..world-2 share the 1100 connected cameras, the last rank owns only isolated ones
+        cuts = [int(v) for v in np.linspace(0, 1100, world)] + [g["n_cams"]]
+        width = max(cuts[r + 1] - cuts[r] for r in range(world))
+        new_id = np.concatenate([r * width + np.arange(cuts[r + 1] - cuts[r]) for r in range(world)])
+        part = sharding.Partition(g["n_cams"], world, width, new_id, [0] * world)
+    else:
+        part = sharding.partition_cameras(g["n_cams"], g["edge_i"], g["edge_j"], world)
+    if case == "sigma":   # EstimateRotationsWithSigmaConsensus on a sharded problem
+        from globalsfmpy_amd.loss_functions import TrivialLoss
+        prob, part = sharding.make_sharded_problem(g, _abi.ANGLE_AXIS, loss=TrivialLoss(), prefer_native=prefer_native, part=part)
+        comm = prob._comm
+        init = part.scatter(g["init_aa"])
+        rot, summ = prob.solve_sigma_consensus(init, 4, 0.05)
+    else:
+        prob, part = sharding.make_sharded_problem(g, _abi.ANGLE_AXIS_COVARIANCE, loss=MAGSACWeightBasedLoss(0.02), prefer_native=prefer_native, part=part)
+        comm = prob._comm
+        init = part.scatter(g["init_aa"])
+        rot, summ = prob.solve(init)
     sweep_ms = prob.time_sweep(init, reps=3)
     if dist.get_rank() == 0:
-        np.savez(out, rot=rot[perm], cost=summ["final_cost"], iters=summ["num_iterations"], cg=summ["num_cg_iterations"],
+        np.savez(out, rot=part.gather(rot), cost=summ["final_cost"], iters=summ["num_iterations"], cg=summ["num_cg_iterations"],
                  term=summ["termination"], backend=comm.backend, n_ag=comm.n_all_gather, n_ar=comm.n_all_reduce, sweep_ms=sweep_ms,
-                 trace=prob.trace())
+                 trace=prob.trace(), outer=summ["outer_iterations"], wchange=summ["last_weight_change"])
     dist.barrier()
     dist.destroy_process_group()
 

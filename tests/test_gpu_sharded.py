@@ -17,22 +17,26 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _reference():
+def _reference(case="default"):
     from globalsfmpy_amd.solver import RotationProblem
     g = synth.make_graph(1203, 40000, seed=23, outlier_frac=0.3)
+    if case == "isolated":
+        keep = (g["edge_i"] < 1100) & (g["edge_j"] < 1100)
+        for k in ("edge_i", "edge_j", "rel_aa", "cov6", "inlier_weight"):
+            g[k] = g[k][keep]
     p = RotationProblem(g["n_cams"], g["edge_i"], g["edge_j"], g["rel_aa"], _abi.ANGLE_AXIS_COVARIANCE, cov6=g["cov6"])
     p.set_loss(MAGSACWeightBasedLoss(0.02))
     rot, s = p.solve(g["init_aa"])
     return rot, s, p.trace()
 
 
-def _launch(nproc, backend, out, extra_env=None, mode="torch"):
+def _launch(nproc, backend, out, extra_env=None, mode="torch", case="default"):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.update(extra_env or {})
     port = 29600 + (os.getpid() % 300) + (0 if backend == "gloo" else 1)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "sharded_worker.py"), backend, out, mode]
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "sharded_worker.py"), backend, out, mode, case]
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     return np.load(out)
@@ -48,11 +52,38 @@ def _compare(res, ref):
 
 @pytest.mark.parametrize("world", [2, 3, 8])
 def test_ranks_share_one_gpu_over_gloo(tmp_path, world):
-    """1203 cameras: slices of 602 / 401 / 151 cameras, the last rank's slice short (padding rows) in every case."""
+    """1203 cameras cut into slices of equal directed-entry counts (unequal camera counts: every slice but the widest is padded)."""
     res = _launch(world, "gloo", str(tmp_path / ("gloo%d.npz" % world)))
     _compare(res, _reference())
     assert int(res["n_ag"]) > int(res["cg"])      # one all-gather per PCG iteration + per linearisation
     assert int(res["n_ar"]) >= 2                  # cost all-reduces
+
+
+def test_a_rank_that_holds_only_isolated_cameras(tmp_path):
+    """8 ranks, the last 103 cameras without any edge and a partition that gives exactly those to the last rank: it holds no edge at all, still
+    has to take part in every collective (problem creation with zero local edges), and the isolated cameras keep their input rotation."""
+    res = _launch(8, "gloo", str(tmp_path / "iso.npz"), case="isolated")
+    ref = _reference("isolated")
+    _compare(res, ref)
+    g0 = synth.make_graph(1203, 40000, seed=23, outlier_frac=0.3)
+    assert np.array_equal(res["rot"][1100:], g0["init_aa"][1100:])
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sigma_consensus_on_a_sharded_problem(tmp_path, world):
+    """EstimateRotationsWithSigmaConsensus (estimator.cpp:314-457) across ranks: every rank weights ALL the edges it holds from the same
+    rotations, the mean weight change is summed over each edge's cost owner.  Same outer iterations, same weights, same rotations."""
+    from globalsfmpy_amd.loss_functions import TrivialLoss
+    from globalsfmpy_amd.solver import RotationProblem
+    g = synth.make_graph(1203, 40000, seed=23, outlier_frac=0.3)
+    p = RotationProblem(g["n_cams"], g["edge_i"], g["edge_j"], g["rel_aa"], _abi.ANGLE_AXIS)
+    p.set_loss(TrivialLoss())
+    rot, s = p.solve_sigma_consensus(g["init_aa"], 4, 0.05, dense_cholesky_max_cams=0)
+    res = _launch(world, "gloo", str(tmp_path / ("sigma%d.npz" % world)), case="sigma")
+    assert int(res["outer"]) == s["outer_iterations"] and int(res["iters"]) == s["num_iterations"]
+    assert abs(float(res["wchange"]) - s["last_weight_change"]) <= 1e-9 * max(1e-12, s["last_weight_change"])
+    assert abs(float(res["cost"]) - s["final_cost"]) <= 1e-9 * s["final_cost"]
+    assert synth.angular_distance(synth.align_rotations(res["rot"], rot), rot).mean() <= 1e-6
 
 
 def test_forced_single_rank_shard_over_rccl(tmp_path):
