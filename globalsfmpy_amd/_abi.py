@@ -64,7 +64,7 @@ class Summary(C.Structure):
         ("last_weight_change", C.c_double),
         ("t_total_ms", C.c_double), ("t_linearize_ms", C.c_double),
         ("t_sweep_ms", C.c_double), ("t_cg_ms", C.c_double),
-        ("num_dense_solves", C.c_int32), ("reserved2", C.c_int32),
+        ("num_dense_solves", C.c_int32), ("num_graph_launches", C.c_int32),
     ]
 
     def as_dict(self):
@@ -78,10 +78,13 @@ ALL_REDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_voi
 LOSS_CALLBACK_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_double, C.POINTER(C.c_double))
 
 
+SHARD_CAPTURABLE = 1
+
+
 class Shard(C.Structure):
     _fields_ = [
         ("rank", C.c_int32), ("world_size", C.c_int32),
-        ("slice_width", C.c_uint32), ("reserved", C.c_uint32),
+        ("slice_width", C.c_uint32), ("flags", C.c_uint32),
         ("ctx", C.c_void_p), ("all_gather", ALL_GATHER_FN), ("all_reduce_sum", ALL_REDUCE_FN),
     ]
 

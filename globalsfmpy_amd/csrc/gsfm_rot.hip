@@ -205,6 +205,7 @@ struct gsfm_rot_problem {
   std::vector<double> h_s, h_rho;
 
   bool have_lin = false;
+  int graph_launches = 0;
   std::vector<double> trace;
   EventTimer timer;
 };
@@ -442,7 +443,7 @@ int run_pcg(gsfm_rot_problem* P, const gsfm_rot_options& o, int* iters_out, doub
   };
   // The chunk between two host checks as one hipGraph launch: 4 * chunk dependent kernels whose arguments never change.
   auto& G = P->pcg_graph;
-  bool graph = o.pcg_hip_graph && !P->sharded && chunk % 2 == 0 && !G.unusable;
+  bool graph = o.pcg_hip_graph && (!P->sharded || (o.pcg_hip_graph >= 2 && (P->shard.flags & GSFM_SHARD_CAPTURABLE))) && chunk % 2 == 0 && !G.unusable;
   if (graph && (!G.exec || G.tol != a.tol || G.max_iters != a.max_iters || G.stall != a.stall_limit || G.chunk != chunk || G.lap != P->lin_is_lap)) {
     G.reset();
     hipGraph_t captured = nullptr;
@@ -460,7 +461,7 @@ int run_pcg(gsfm_rot_problem* P, const gsfm_rot_options& o, int* iters_out, doub
   while (true) {
     const int tk = P->timer.begin(T_CG);
     for (int c = 0; c < chunks; ++c) {
-      if (graph) { HIPCHK(hipGraphLaunch(G.exec, P->stream)); }
+      if (graph) { HIPCHK(hipGraphLaunch(G.exec, P->stream)); P->graph_launches++; }
       else if (int st = enqueue_chunk()) return st;
       launched += chunk;
     }
@@ -522,7 +523,7 @@ int run_pcg2(gsfm_rot_problem* P, const gsfm_rot_options& o, int* iters_out, dou
     P->timer.end(tk);
   }
   auto& G = P->pcg2_graph;
-  bool graph = o.pcg_hip_graph && !P->sharded && chunk % 2 == 0 && !G.unusable && !P->pcg_graph.unusable;
+  bool graph = o.pcg_hip_graph && (!P->sharded || (o.pcg_hip_graph >= 2 && (P->shard.flags & GSFM_SHARD_CAPTURABLE))) && chunk % 2 == 0 && !G.unusable && !P->pcg_graph.unusable;
   if (graph && (!G.exec || G.tol != c.tol || G.max_iters != c.max_iters || G.chunk != chunk || G.lap != P->lin_is_lap)) {
     G.reset();
     hipGraph_t captured = nullptr;
@@ -541,7 +542,7 @@ int run_pcg2(gsfm_rot_problem* P, const gsfm_rot_options& o, int* iters_out, dou
   while (true) {
     const int tk = P->timer.begin(T_CG);
     for (int cc = 0; cc < chunks; ++cc) {
-      if (graph) { HIPCHK(hipGraphLaunch(G.exec, P->stream)); }
+      if (graph) { HIPCHK(hipGraphLaunch(G.exec, P->stream)); P->graph_launches++; }
       else { for (int k = 0; k < chunk; ++k) if (int st = enqueue_iter()) return st; }
       launched += chunk;
     }
@@ -607,7 +608,7 @@ int run_dense(gsfm_rot_problem* P, bool* used) {
     }
     if (!P->dense_graph) (void)hipGetLastError();
   }
-  if (P->dense_graph) { HIPCHK(hipGraphLaunch(P->dense_graph, P->stream)); }
+  if (P->dense_graph) { HIPCHK(hipGraphLaunch(P->dense_graph, P->stream)); P->graph_launches++; }
   else enqueue();
   P->timer.end(tk);
   int info = -1;
@@ -739,6 +740,7 @@ int lm_solve(gsfm_rot_problem* P, const gsfm_rot_options& o, gsfm_rot_summary* s
   sum->num_edges_used = P->cost.n;
   P->trace.clear();
   P->timer.acc[0] = P->timer.acc[1] = P->timer.acc[2] = 0;
+  P->graph_launches = 0;
   P->lap = P->lap_capable;
   double h[SC_N];
   double radius = o.initial_trust_region_radius, decrease_factor = 2.0;
@@ -754,6 +756,7 @@ int lm_solve(gsfm_rot_problem* P, const gsfm_rot_options& o, gsfm_rot_summary* s
   auto finish = [&](int term) {
     sum->termination = term; sum->num_iterations = iteration; sum->final_cost = x_cost; sum->final_gradient_max_norm = gmax;
     sum->final_radius = radius; sum->t_total_ms = now_ms() - t0;
+    sum->num_graph_launches = P->graph_launches;
     sum->t_linearize_ms = P->timer.acc[T_LIN]; sum->t_sweep_ms = P->timer.acc[T_SWEEP]; sum->t_cg_ms = P->timer.acc[T_CG];
     if (!std::isfinite(x_cost)) sum->nonfinite = 1;
     return 0;
@@ -1288,7 +1291,7 @@ gsfm_status gsfm_rot_solve_sigma_consensus(gsfm_rot_problem* P, double* rot, int
       total.num_linearizations += summary->num_linearizations; total.num_cg_iterations += summary->num_cg_iterations;
       total.final_cost = summary->final_cost; total.termination = summary->termination;
       total.final_gradient_max_norm = summary->final_gradient_max_norm; total.final_radius = summary->final_radius;
-      total.num_dense_solves += summary->num_dense_solves;
+      total.num_dense_solves += summary->num_dense_solves; total.num_graph_launches += summary->num_graph_launches;
       total.t_linearize_ms += summary->t_linearize_ms; total.t_sweep_ms += summary->t_sweep_ms; total.t_cg_ms += summary->t_cg_ms;
     }
     total.num_residual_sweeps += 1;  // the weight sweep

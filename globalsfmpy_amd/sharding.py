@@ -132,7 +132,7 @@ class TorchComm(object):
         self.n_all_reduce = 0
         self._ag = _abi.ALL_GATHER_FN(self._all_gather)
         self._ar = _abi.ALL_REDUCE_FN(self._all_reduce)
-        self.shard = _abi.Shard(rank=self.rank, world_size=self.world, slice_width=self.P, reserved=0, ctx=None,
+        self.shard = _abi.Shard(rank=self.rank, world_size=self.world, slice_width=self.P, flags=0, ctx=None,
                                 all_gather=self._ag, all_reduce_sum=self._ar)
 
     def stream_handle(self):
@@ -262,7 +262,7 @@ class NativeComm(object):
         self.n_all_gather = self.n_all_reduce = -1  # not counted on this path
         ag = C.cast(lib.gsfm_rccl_all_gather, C.c_void_p).value
         ar = C.cast(lib.gsfm_rccl_all_reduce_sum, C.c_void_p).value
-        self.shard = _abi.Shard(rank=self.rank, world_size=self.world, slice_width=self.P, reserved=0, ctx=self._ctx,
+        self.shard = _abi.Shard(rank=self.rank, world_size=self.world, slice_width=self.P, flags=_abi.SHARD_CAPTURABLE, ctx=self._ctx,
                                 all_gather=_abi.ALL_GATHER_FN(ag), all_reduce_sum=_abi.ALL_REDUCE_FN(ar))
 
     def stream_handle(self):

@@ -146,10 +146,13 @@ typedef struct {
                                           325 ms PCG; SoftL1 35 vs 58 ms; quaternion-Huber 19 vs 26 ms.  PCG remains the fallback when a pivot
                                           is not positive, and the only solver of sharded problems. */
   int32_t pcg_hip_graph;               /* default 1: the chunk of cg_check_interval PCG iterations between two host checks
-                                          (4 dependent kernels each) is captured once into a hipGraph and replayed -- the loop is
-                                          launch-latency-bound on small graphs.  Same kernels, same order, same iterates.
-                                          Ignored when sharded (the collective callbacks are not captured) or when the
-                                          problem runs on a stream that cannot be captured (the legacy default stream). */
+                                          (2-4 dependent kernels each) is captured once into a hipGraph and replayed -- the loop is
+                                          launch-latency-bound on small graphs.  Same kernels, same order, same iterates.  Falls back to
+                                          plain launches when the problem runs on a stream that cannot be captured (the legacy default stream).
+                                          On a sharded problem the chunk contains the collective callbacks: 1 leaves it to plain launches,
+                                          2 captures it too -- only honoured when the shard descriptor carries GSFM_SHARD_CAPTURABLE (the native RCCL
+                                          communicator, csrc/gsfm_rccl.cpp: RCCL collectives are stream-capturable); host-staged callbacks
+                                          (gloo) keep plain launches. */
 } gsfm_rot_options;
 
 typedef enum {
@@ -182,7 +185,7 @@ typedef struct {
   double t_sweep_ms;              /* GPU time in the residual+reweight cost sweep */
   double t_cg_ms;                 /* GPU time in PCG kernels (and dense solves) */
   int32_t num_dense_solves;       /* LM steps solved by the dense Cholesky path */
-  int32_t reserved2;
+  int32_t num_graph_launches;     /* hipGraph replays of PCG chunks / dense solves in this call (0 = every kernel was launched plainly) */
 } gsfm_rot_summary;
 
 /* ------------------------------------------------------------------------- */
@@ -195,11 +198,13 @@ typedef struct {
  * need no reduction: slices are exchanged with an in-place all-gather; scalars
  * (cost, dot products) with a sum all-reduce.  Both callbacks receive DEVICE
  * pointers and must enqueue on `hip_stream` (or make it wait).                 */
+#define GSFM_SHARD_CAPTURABLE 1u
 typedef struct {
   int32_t rank;
   int32_t world_size;
   uint32_t slice_width;
-  uint32_t reserved;
+  uint32_t flags;       /* GSFM_SHARD_CAPTURABLE: the callbacks only enqueue stream-ordered device work (no host synchronisation, no
+                           host staging), so a chunk of PCG iterations containing them may be captured into a hipGraph (pcg_hip_graph = 2) */
   void* ctx;
   /* buf holds world_size * count doubles; rank r's input already sits at buf + r*count */
   int (*all_gather)(void* ctx, double* buf_dev, size_t count, void* hip_stream);

@@ -45,12 +45,14 @@ def main():
         prob, part = sharding.make_sharded_problem(g, _abi.ANGLE_AXIS_COVARIANCE, loss=MAGSACWeightBasedLoss(0.02), prefer_native=prefer_native, part=part)
         comm = prob._comm
         init = part.scatter(g["init_aa"])
-        rot, summ = prob.solve(init)
+        opts = {"pcg_hip_graph": int(os.environ["GSFM_TEST_PCG_GRAPH"])} if "GSFM_TEST_PCG_GRAPH" in os.environ else {}
+        rot, summ = prob.solve(init, **opts)
     sweep_ms = prob.time_sweep(init, reps=3)
     if dist.get_rank() == 0:
         np.savez(out, rot=part.gather(rot), cost=summ["final_cost"], iters=summ["num_iterations"], cg=summ["num_cg_iterations"],
                  term=summ["termination"], backend=comm.backend, n_ag=comm.n_all_gather, n_ar=comm.n_all_reduce, sweep_ms=sweep_ms,
-                 trace=prob.trace(), outer=summ["outer_iterations"], wchange=summ["last_weight_change"])
+                 trace=prob.trace(), outer=summ["outer_iterations"], wchange=summ["last_weight_change"],
+                 graph_launches=summ["num_graph_launches"])
     dist.barrier()
     dist.destroy_process_group()
 

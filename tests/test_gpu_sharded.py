@@ -97,3 +97,18 @@ def test_forced_single_rank_shard_over_native_rccl(tmp_path):
     res = _launch(1, "nccl", str(tmp_path / "native1.npz"), {"GSFM_FORCE_SHARD": "1"}, mode="native")
     assert str(res["backend"]) == "rccl-native"
     _compare(res, _reference())
+
+
+def test_sharded_pcg_chunk_replays_as_a_hipgraph_with_the_native_communicator(tmp_path):
+    """pcg_hip_graph = 2: the chunk of PCG iterations INCLUDING its all-gathers is captured once and replayed (RCCL collectives are
+    stream-capturable; the native communicator enqueues them on the solver's stream and does nothing else).  Same trajectory."""
+    res = _launch(1, "nccl", str(tmp_path / "native_graph.npz"), {"GSFM_FORCE_SHARD": "1", "GSFM_TEST_PCG_GRAPH": "2"}, mode="native")
+    assert str(res["backend"]) == "rccl-native"
+    _compare(res, _reference())
+    assert int(res["graph_launches"]) > 0
+
+
+def test_host_staged_collectives_fall_back_to_plain_launches_when_capture_is_requested(tmp_path):
+    res = _launch(2, "gloo", str(tmp_path / "gloo_graph.npz"), {"GSFM_TEST_PCG_GRAPH": "2"})
+    _compare(res, _reference())
+    assert int(res["graph_launches"]) == 0
