@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--cpu-single-cams", type=int, default=10000, help="1-thread CPU sample (0 = skip)")
     ap.add_argument("--cpu-single-edges", type=int, default=1000000)
     ap.add_argument("--verbose", type=int, default=0)
+    ap.add_argument("--sigma-pass", type=int, default=1, help="time the sigma-consensus weight pass on an ANGLE_AXIS problem of the same graph")
+    ap.add_argument("--small-graphs", type=int, default=1, help="also time the latency-regime configurations (C1 Madrid, C2)")
     return ap.parse_args()
 
 
@@ -85,6 +87,69 @@ def cpu_baseline(args, loss_ctor, error_type):
         out["single_thread"] = {"value": r1, "unit": "edge-residuals/s", "cores": 1,
                                 "sample": "same oracle, OpenMP pinned to 1 thread: %d cameras / %d edges, %d sweeps, %.1f s"
                                           % (args.cpu_single_cams, args.cpu_single_edges, s1["num_residual_sweeps"], dt1)}
+    return out
+
+
+def small_graph_timings(args):
+    """The BASELINE configurations that live in the launch-latency regime, one full solve each (best of 3, host wall time of
+    gsfm_rot_solve): C1 = the real Madrid_Metropolis view graph (394 views / 23 784 edges, tests/golden/madrid_graph.npz; synthetic
+    covariances as in the tests, spanning-tree initialisation), C2 = synthetic 10k cameras / 200k edges."""
+    from globalsfmpy_amd import _abi, synth
+    from globalsfmpy_amd import loss_functions as LF
+    from globalsfmpy_amd.solver import RotationProblem
+    out = {}
+
+    def best(p, x0):
+        ts, s = [], None
+        p.solve(x0)
+        for _ in range(3):
+            t = time.perf_counter()
+            _, s = p.solve(x0)
+            ts.append(time.perf_counter() - t)
+        return {"ms": 1e3 * min(ts), "lm_iterations": s["num_iterations"], "cg_iterations": s["num_cg_iterations"], "dense_cholesky_steps": s["num_dense_solves"]}
+
+    g = synth.make_graph(10000, 200000, 11, outlier_frac=0.1)
+    p = RotationProblem(g["n_cams"], g["edge_i"], g["edge_j"], g["rel_aa"], _abi.ANGLE_AXIS)
+    p.set_loss(LF.GemanMcClureLoss(0.1, 1.0))
+    out["C2_10k_cams_200k_edges_geman_mcclure"] = best(p, g["init_aa"])
+    p.close()
+    p = RotationProblem(g["n_cams"], g["edge_i"], g["edge_j"], g["rel_aa"], _abi.ANGLE_AXIS_COVARIANCE, cov6=g["cov6"])
+    p.set_loss(LF.MAGSACWeightBasedLoss(0.02))
+    out["C2_10k_cams_200k_edges_cov_magsac"] = best(p, g["init_aa"])
+    p.close()
+    path = os.path.join(ROOT, "tests", "golden", "madrid_graph.npz")
+    if os.path.exists(path):
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "globalsfmpy_amd"))
+            import GlobalSfMpy as sfm
+            m = np.load(path)
+            ids = np.sort(m["view_ids"])
+            idx = {int(v): k for k, v in enumerate(ids)}
+            vg = sfm.ViewGraph()
+            for a_, b_, r_ in zip(m["edge_a"], m["edge_b"], m["rel_aa"]):
+                info = sfm.TwoViewInfo()
+                info.rotation_2 = r_
+                info.num_verified_matches = 1
+                vg.AddEdge(int(a_), int(b_), info)
+            init = sfm.MapViewIdVector3d()
+            sfm.OrientationsFromMaximumSpanningTree(vg, init)
+            x0 = np.array([init[int(v)] for v in ids])
+            ei = np.array([idx[int(v)] for v in m["edge_a"]], dtype=np.uint32)
+            ej = np.array([idx[int(v)] for v in m["edge_b"]], dtype=np.uint32)
+            rng = np.random.default_rng(7)
+            A = rng.standard_normal((len(ei), 3, 3))
+            S = (A @ np.transpose(A, (0, 2, 1)) + 0.5 * np.eye(3)) * 3e-8
+            c6 = np.stack([S[:, 0, 0], S[:, 1, 1], S[:, 2, 2], S[:, 0, 1], S[:, 0, 2], S[:, 1, 2]], axis=1)
+            p = RotationProblem(len(ids), ei, ej, m["rel_aa"], _abi.ANGLE_AXIS_COVARIANCE, cov6=c6)
+            p.set_loss(LF.MAGSACWeightBasedLoss(0.02))
+            out["C1_madrid_394_views_23784_edges_cov_magsac"] = best(p, x0)
+            p.close()
+            p = RotationProblem(len(ids), ei, ej, m["rel_aa"], _abi.ANGLE_AXIS)
+            p.set_loss(LF.SoftLOneLoss(0.1))
+            out["C1_madrid_softl1_EstimateRotations_default"] = best(p, x0)
+            p.close()
+        except Exception as e:  # noqa: BLE001  (the extra keys never take the headline down with them)
+            out["C1_madrid_error"] = repr(e)
     return out
 
 
@@ -174,26 +239,64 @@ def main():
                 "lm_iterations": sf["num_iterations"], "cg_iterations": sf["num_cg_iterations"],
                 "mean_rotation_change_vs_default_rad": float(dev.mean()), "max_rotation_change_vs_default_rad": float(dev.max())}
 
-    # K1 sweep kernel, timed live with HIP events on the solver's stream (this rank's cost-owned edges)
-    sweep_ms = prob.time_sweep(init, reps=args.sweep_reps)
-    alg_b, lay_b = prob.sweep_bytes()
+    # ---- kernels, timed live with HIP events on the solver's stream (this rank's share of the problem) ----
     e_local = summ["num_edges_used"]
-    achieved = (e_local * alg_b + 24.0 * n_cams) / (sweep_ms * 1e-3) / 1e9
-    kt = prob.time_kernels(init, reps=10)   # contains collectives when sharded: every rank must call it
+    kt = prob.time_kernels(init, reps=10)   # k_cost (trial cost), k_lin, k_matvec; contains collectives when sharded: every rank must call it
+    variants = prob.time_sweep_variants(init, reps=args.sweep_reps) if world == 1 else None
+    alg_b, lay_b = prob.sweep_bytes()
 
-    traffic, traffic_src = None, None
-    try:  # committed PMC measurement of the same kernel on the same workload (bench.py cannot run rocprofv3 on itself)
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-        if world == 1 and pm["workload"] == {"cams": n_cams, "edges": n_edges}:
-            traffic = pm["k_cost"]["fetch_bytes"] + pm["k_cost"]["write_bytes"]
-            traffic_src = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2 gfx950 correction)"
+    sigma_pass = None
+    if world == 1 and args.sigma_pass:
+        # K6, the sigma-consensus weight pass (EstimateRotationsWithSigmaConsensus): needs an ANGLE_AXIS problem of the same graph
+        from globalsfmpy_amd.loss_functions import TrivialLoss
+        p6 = RotationProblem(n_cams, g["edge_i"], g["edge_j"], g["rel_aa"], _abi.ANGLE_AXIS)
+        p6.set_loss(TrivialLoss())
+        p6.set_edge_weights(np.ones(n_edges))
+        v6 = p6.time_sweep_variants(init, reps=args.sweep_reps)
+        sigma_pass = {"s_only_sweep_ms": v6["s_only"], "weight_pass_ms": v6["sigma_weight_pass"]}
+        p6.close()
+
+    small = None
+    if world == 1 and args.small_graphs:
+        small = small_graph_timings(args)
+
+    pmc = None
+    try:  # committed PMC measurement of the same kernels on the same workload (bench.py cannot run rocprofv3 on itself)
+        for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+            path = os.path.join(ROOT, "profiles", name)
+            if os.path.exists(path):
+                pm = json.load(open(path))
+                if world == 1 and pm["workload"] == {"cams": n_cams, "edges": n_edges}:
+                    pmc = (pm, "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH x2 gfx950 correction)" % name)
+                break
     except Exception:
         pass
 
+    def pmc_bytes(kernel):
+        if pmc is None or kernel not in pmc[0]:
+            return None
+        return pmc[0][kernel]["fetch_bytes"] + pmc[0][kernel]["write_bytes"]
+
     if rank == 0:
-        aligned = synth.align_rotations(rot, gt)
-        err = synth.angular_distance(aligned, gt)
+        rot_cmp, gt_cmp = (part.gather(rot), g["gt_aa"]) if part is not None else (rot, gt)
+        err = synth.angular_distance(synth.align_rotations(rot_cmp, gt_cmp), gt_cmp)
         value = n_edges * sweeps / elapsed
+        # algorithmic bytes per launch.  Directed entries = 2 per edge on one GPU.
+        lap = os.environ.get("GSFM_LAPLACIAN", "1") != "0"     # angle-axis / quaternion-cosine problems: 6 doubles per directed entry instead of 9
+        blk = 48.0 if lap else 72.0
+        nd = 2.0 * e_local if part is None else float(part.entries_per_rank[rank])   # (sharded: rank 0's rows)
+        mv_bytes = nd * (blk + 4.0) + 2 * 24.0 * n_cams
+        lin_bytes = nd * (84.0 + blk) + 72.0 * n_cams
+        sweep_bytes = e_local * lay_b + 32.0 * n_cams          # as laid out: idx 8 + q_rel 32 + Lt 48 per edge, the quaternions once
+
+        def roof(bytes_per_launch, ms, **extra):
+            ach = bytes_per_launch / (ms * 1e-3) / 1e9
+            d = {"achieved": ach, "unit": "GB/s", "peak": HBM_PEAK_GBPS, "frac": ach / HBM_PEAK_GBPS, "kernel_ms": ms,
+                 "algorithmic_bytes_per_launch": bytes_per_launch}
+            d.update(extra)
+            return d
+
+        mv_share = summ["num_cg_iterations"] * kt["k_matvec"] / max(1e-9, summ["t_linearize_ms"] + summ["t_sweep_ms"] + summ["t_cg_ms"])
         out = {
             "metric": "edge_residuals_per_sec", "value": value, "unit": "edge-residuals/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
@@ -210,30 +313,40 @@ def main():
             "mean_angular_error_vs_ground_truth_deg": float(np.rad2deg(err.mean())),
             "gpu_ms_per_solve": {"linearize": summ["t_linearize_ms"], "sweep": summ["t_sweep_ms"], "pcg": summ["t_cg_ms"]},
             "setup_s": {"generate": t_gen, "create_problem": t_create},
-            "roofline": {"bound": "hbm", "kernel": "k_cost (K1 residual + robust reweight sweep)",
-                         "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                         "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": e_local * alg_b + 24.0 * n_cams,
-                         "algorithmic_bytes_per_edge": alg_b, "layout_bytes_per_edge": lay_b,
-                         "edges_per_launch": int(e_local), "kernel_ms": sweep_ms,
-                         "sweep_rate_edges_per_s": e_local / (sweep_ms * 1e-3)},
+            # the time-dominant kernel: one launch per PCG iteration
+            "roofline": dict(roof(mv_bytes, kt["k_matvec"]), bound="hbm",
+                             kernel="k_matvec<LAP> (K3: normal-equation mat-vec of the Laplacian form, one launch per PCG iteration, %.0f %% of the solve's GPU time)%s"
+                                    % (100.0 * mv_share, "" if world == 1 else "; rank 0's rows, kernel_ms includes the all-gather of A.p that follows every launch"),
+                             traffic=pmc_bytes("k_matvec"), traffic_unit="bytes per launch", traffic_source=(pmc[1] if pmc else None),
+                             bytes_per_directed_entry=blk + 4.0, directed_entries_per_launch=int(nd), launches_per_solve=summ["num_cg_iterations"]),
         }
         if fast is not None:
             out["inexact_pcg_option"] = fast
-        nd = 2.0 * e_local if world == 1 else None
         out["kernels_us"] = {k: 1e3 * v for k, v in kt.items()}
-        if nd is not None:  # algorithmic bytes of the other two hot kernels, per launch
-            # angle-axis / quaternion-cosine problems use the Laplacian form: 6 doubles per directed entry instead of 9
-            lap = os.environ.get("GSFM_LAPLACIAN", "1") != "0"
-            blk = 48.0 if lap else 72.0
-            mv_bytes = nd * (blk + 4.0) + 2 * 24.0 * n_cams
-            lin_bytes = nd * (84.0 + blk) + 72.0 * n_cams
-            out["roofline_other"] = {
-                "block_bytes_per_entry": blk,
-                "k_matvec": {"achieved": mv_bytes / (kt["k_matvec"] * 1e-3) / 1e9, "unit": "GB/s", "peak": HBM_PEAK_GBPS,
-                             "frac": mv_bytes / (kt["k_matvec"] * 1e-3) / 1e9 / HBM_PEAK_GBPS},
-                "k_lin": {"achieved": lin_bytes / (kt["k_lin"] * 1e-3) / 1e9, "unit": "GB/s", "peak": HBM_PEAK_GBPS,
-                          "frac": lin_bytes / (kt["k_lin"] * 1e-3) / 1e9 / HBM_PEAK_GBPS}}
+        if world == 1:
+            other = {
+                "k_lin": dict(roof(lin_bytes, kt["k_lin"]), kernel="K2: residual, Jacobians, robust weights (rho', rho''), gradient, diagonal blocks, edge blocks; once per accepted LM step",
+                              traffic=pmc_bytes("k_lin"), bytes_per_directed_entry=84.0 + blk),
+                "k_cost_trial": dict(roof(sweep_bytes, variants["trial_cost"]), kernel="K1 k_cost<FULL=false>: residual + rho VALUE, block-reduced; the solver's trial-cost sweep (no rho', no per-edge store)",
+                                     traffic=pmc_bytes("k_cost"), bytes_per_edge=lay_b, survey_8d_bytes_per_edge=alg_b,
+                                     sweep_rate_edges_per_s=e_local / (variants["trial_cost"] * 1e-3)),
+                "k_cost_full": dict(roof(sweep_bytes + 32.0 * e_local, variants["full_reweight"]),
+                                    kernel="K1 k_cost<FULL=true>: residual, s, (rho, rho', rho'') stored per edge in the caller's edge order (gsfm_rot_residuals)",
+                                    traffic=pmc_bytes("k_cost_full"), bytes_per_edge=lay_b + 32.0, sweep_rate_edges_per_s=e_local / (variants["full_reweight"] * 1e-3)),
+                "k_cost_s_only": dict(roof(sweep_bytes + 8.0 * e_local, variants["s_only"]),
+                                      kernel="K1 s-only mode: s stored per edge (pass 1 of sigma consensus and of host-callback losses), on this problem's whitened residuals",
+                                      bytes_per_edge=lay_b + 8.0, sweep_rate_edges_per_s=e_local / (variants["s_only"] * 1e-3)),
+            }
+            if sigma_pass is not None:
+                # ANGLE_AXIS problem: idx 8 + q_rel 32 + scalar weight 8 in, s 8 out; then s 8 + w 8 in/out + 2 x (eid 4 + w gather 8 + store 8) per entry
+                other["sigma_consensus_K6"] = {
+                    "kernel": "K6 on an ANGLE_AXIS problem of the same graph: K1 s-only sweep (unit weights), then k_sigma_weights + the gathers into the cost and directed weight planes",
+                    "s_only_sweep": roof(e_local * (48.0 + 8.0) + 32.0 * n_cams, sigma_pass["s_only_sweep_ms"]),
+                    "weight_pass": roof(e_local * 24.0 + 3.0 * e_local * 20.0, sigma_pass["weight_pass_ms"]),
+                    "edges_per_s": e_local / ((sigma_pass["s_only_sweep_ms"] + sigma_pass["weight_pass_ms"]) * 1e-3)}
+            out["roofline_other"] = other
+        if small is not None:
+            out["small_graph_ms"] = small
         if args.cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args, loss_ctor, error_type)
         print(json.dumps(out), flush=True)

@@ -187,6 +187,7 @@ def load_library():
     lib.gsfm_rot_residual_dim.argtypes = [C.c_int32]; lib.gsfm_rot_residual_dim.restype = C.c_int32
     lib.gsfm_rot_time_sweep.argtypes = [C.c_void_p, _DP, C.c_int32, _DP]; lib.gsfm_rot_time_sweep.restype = C.c_int
     lib.gsfm_rot_time_kernels.argtypes = [C.c_void_p, _DP, C.c_int32, _DP]; lib.gsfm_rot_time_kernels.restype = C.c_int
+    lib.gsfm_rot_time_sweep_variants.argtypes = [C.c_void_p, _DP, C.c_int32, _DP]; lib.gsfm_rot_time_sweep_variants.restype = C.c_int
     lib.gsfm_rot_sweep_bytes.argtypes = [C.c_void_p, _DP, _DP]; lib.gsfm_rot_sweep_bytes.restype = C.c_int
     lib.gsfm_rot_loss_eval.argtypes = [C.c_void_p, _DP, C.c_uint64, _DP, _DP]; lib.gsfm_rot_loss_eval.restype = C.c_int
     lib.gsfm_rot_locality_order.argtypes = [C.c_uint32, C.c_uint64, _U32P, _U32P, _U32P]; lib.gsfm_rot_locality_order.restype = C.c_int32

@@ -1434,6 +1434,63 @@ gsfm_status gsfm_rot_time_sweep(gsfm_rot_problem* P, const double* rot, int32_t 
   return (gsfm_status)st;
 }
 
+gsfm_status gsfm_rot_time_sweep_variants(gsfm_rot_problem* P, const double* rot, int32_t reps, double* out_ms4) {
+  if (!P || !rot || !out_ms4 || reps <= 0) return (gsfm_status)fail(GSFM_ERR_INVALID_ARG, "bad argument");
+  if (P->cb) return (gsfm_status)fail(GSFM_ERR_UNSUPPORTED, "time_sweep_variants needs a native loss");
+  DeviceGuard g(P->device);
+  const size_t E = P->n_edges_in;
+  if (int st = upload_state(P, rot)) return (gsfm_status)st;
+  DevBuf<double> ds, drho, dw, dpart, dsum;
+  if (ds.alloc(E, true) != hipSuccess || drho.alloc(3 * E, true) != hipSuccess) return (gsfm_status)fail(GSFM_ERR_HIP, "alloc outputs");
+  CostArgs base{};
+  base.tiles = P->cost_tiles.p; base.direct = P->cost_direct; base.n_cams = P->n_cams; base.n = P->cost.n; base.idx = P->cost_idx.p; base.qr0 = P->cost.qr0.p; base.qr1 = P->cost.qr1.p;
+  base.w0 = P->cost.w0.p; base.w1 = P->cost.w1.p; base.w2 = P->cost.w2.p; base.ws = P->cost.ws.p;
+  base.q = P->q.p; base.loss = P->d_loss.p; base.eid = P->cost.eid.p; base.partials = P->part_cost.p;
+  hipEvent_t e0, e1;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return (gsfm_status)fail(GSFM_ERR_HIP, "event create");
+  auto timed = [&](auto&& launch, double* out) -> int {
+    for (int k = -2; k < reps; ++k) { if (k == 0) (void)hipEventRecord(e0, P->stream); launch(); }
+    (void)hipEventRecord(e1, P->stream);
+    if (int st = sync_check(P, "time_sweep_variants")) return st;
+    float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1); *out = ms / reps; return 0;
+  };
+  int st = 0;
+  out_ms4[0] = out_ms4[1] = out_ms4[2] = out_ms4[3] = 0.0;
+  { CostArgs a = base; st = timed([&] { dispatch<CostArgs, CostLauncher>(P, a, P->nb_cost); }, &out_ms4[0]); }                                   // trial cost: rho value only
+  if (!st) { CostArgs a = base; a.s_out = ds.p; a.rho_out = drho.p; st = timed([&] { dispatch<CostArgs, CostLauncher>(P, a, P->nb_cost); }, &out_ms4[1]); }  // full reweight sweep with per-edge stores
+  if (!st) { CostArgs a = base; a.s_out = ds.p; a.s_only = 1; a.unit_w = 1; st = timed([&] { dispatch<CostArgs, CostLauncher>(P, a, P->nb_cost); }, &out_ms4[2]); }
+  if (!st && P->functor == F_AA && P->wmode == W_SCALAR && P->cost.ws.p && P->dir.ws.p) {   // sigma-consensus weight pass (estimator.cpp:400-416) on the s just written
+    const MagsacConst c = magsac_const(3);
+    DevBuf<double> d_table;
+    const int nb_sig = std::max(1, grid_for(E));
+    if (d_table.upload(magsac_table(3)) != hipSuccess || dw.alloc(E, true) != hipSuccess || dpart.alloc(nb_sig, true) != hipSuccess || dsum.alloc(1, true) != hipSuccess) st = fail(GSFM_ERR_HIP, "alloc");
+    if (!st) {
+      const double sigma_max = 0.02, one_over_sigma = c.C * std::pow(2.0, (c.nu - 1.0) / 2.0) / sigma_max;
+      SigmaArgs sa{};
+      sa.s = ds.p; sa.w = dw.p; sa.n = E; sa.table = d_table.p; sa.table_len = c.n; sa.ssm2 = 2.0 * sigma_max * sigma_max; sa.one_over_sigma = one_over_sigma;
+      sa.gk = c.gk; sa.weight_zero = one_over_sigma * (std::tgamma((c.nu - 1.0) / 2.0) - c.gk); sa.partials = dpart.p;
+      // the gathers write the problem's own weight planes: save and restore them around the timing
+      DevBuf<double> keep_c, keep_d;
+      if (keep_c.alloc(P->cost.n) != hipSuccess || keep_d.alloc(P->dir.n) != hipSuccess) st = fail(GSFM_ERR_HIP, "alloc");
+      if (!st) {
+        (void)hipMemcpyAsync(keep_c.p, P->cost.ws.p, 8 * P->cost.n, hipMemcpyDeviceToDevice, P->stream);
+        (void)hipMemcpyAsync(keep_d.p, P->dir.ws.p, 8 * P->dir.n, hipMemcpyDeviceToDevice, P->stream);
+        st = timed([&] {
+          hipLaunchKernelGGL(k_sigma_weights, dim3(nb_sig), dim3(GSFM_BLOCK), 0, P->stream, sa);
+          hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(GSFM_BLOCK), 0, P->stream, dpart.p, nb_sig, dsum.p);
+          if (P->cost.n) hipLaunchKernelGGL(k_gather_weights, dim3(grid_for(P->cost.n)), dim3(GSFM_BLOCK), 0, P->stream, dw.p, P->cost.eid.p, P->cost.n, P->cost.ws.p);
+          if (P->dir.n) hipLaunchKernelGGL(k_gather_weights, dim3(grid_for(P->dir.n)), dim3(GSFM_BLOCK), 0, P->stream, dw.p, P->dir.eid.p, P->dir.n, P->dir.ws.p);
+        }, &out_ms4[3]);
+        (void)hipMemcpyAsync(P->cost.ws.p, keep_c.p, 8 * P->cost.n, hipMemcpyDeviceToDevice, P->stream);
+        (void)hipMemcpyAsync(P->dir.ws.p, keep_d.p, 8 * P->dir.n, hipMemcpyDeviceToDevice, P->stream);
+        if (int s2 = sync_check(P, "time_sweep_variants restore")) st = st ? st : s2;
+      }
+    }
+  }
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  return (gsfm_status)st;
+}
+
 gsfm_status gsfm_rot_time_kernels(gsfm_rot_problem* P, const double* rot, int32_t reps, double* out_ms3) {
   if (!P || !rot || !out_ms3 || reps <= 0) return (gsfm_status)fail(GSFM_ERR_INVALID_ARG, "bad argument");
   if (P->cb) return (gsfm_status)fail(GSFM_ERR_UNSUPPORTED, "time_kernels needs a native loss");

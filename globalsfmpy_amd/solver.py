@@ -207,6 +207,13 @@ class RotationProblem(ProblemBase):
         self._check(self._lib.gsfm_rot_loss_eval(self._h, _dp(s), s.size, _dp(rho3), _dp(val)), "loss_eval")
         return rho3, val
 
+    def time_sweep_variants(self, rot_aa, reps=10):
+        """Mean HIP-event time (ms) of the K1 variants: trial-cost, full reweight sweep with per-edge stores, s-only, sigma-consensus weight pass."""
+        rot = np.ascontiguousarray(rot_aa, dtype=np.float64).reshape(self.n_cams, 3)
+        out = np.zeros(4)
+        self._check(self._lib.gsfm_rot_time_sweep_variants(self._h, _dp(rot), int(reps), _dp(out)), "time_sweep_variants")
+        return {"trial_cost": out[0], "full_reweight": out[1], "s_only": out[2], "sigma_weight_pass": out[3]}
+
     def sweep_bytes(self):
         a, b = C.c_double(0), C.c_double(0)
         self._check(self._lib.gsfm_rot_sweep_bytes(self._h, C.byref(a), C.byref(b)), "sweep_bytes")

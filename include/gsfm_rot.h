@@ -309,6 +309,15 @@ int32_t gsfm_rot_get_trace(gsfm_rot_problem* p, double* out, int32_t cap_rows);
 gsfm_status gsfm_rot_time_sweep(gsfm_rot_problem* p, const double* rot_aa, int32_t reps,
                                 double* mean_kernel_ms);
 
+/* The variants of the edge sweep K1, each as the mean of `reps` launches (HIP events on the problem's stream, operands resident):
+ *   out_ms[0]  trial-cost sweep, as the solver launches it after every step: residual + rho VALUE, block-reduced, no per-edge store
+ *   out_ms[1]  full reweight sweep: residual, s and (rho, rho', rho'') stored per edge in the caller's edge order (gsfm_rot_residuals)
+ *   out_ms[2]  s-only sweep with unit weights: pass 1 of the sigma-consensus weight update and of host-callback losses
+ *   out_ms[3]  sigma-consensus weight pass on that s: weights, their mean change, and the gathers into both entry-ordered weight
+ *              planes (0 unless the problem is an ANGLE_AXIS one that carries scalar weights, i.e. sigma consensus / set_edge_weights ran)
+ * (In the solver the robust weights rho', rho'' of an accepted point are evaluated inside K2, the linearisation; see time_kernels.) */
+gsfm_status gsfm_rot_time_sweep_variants(gsfm_rot_problem* p, const double* rot_aa, int32_t reps, double* out_ms4);
+
 /* Same for the three hot kernels: out_ms[0] = K1 k_cost, [1] = K2 k_lin, [2] = K3 k_matvec (mean of `reps`
  * launches each, HIP events on the problem's stream, operands resident in HBM).                      */
 gsfm_status gsfm_rot_time_kernels(gsfm_rot_problem* p, const double* rot_aa, int32_t reps, double* out_ms3);

@@ -1,0 +1,49 @@
+"""-m gpu: bench.py end to end at reduced size -- the single-GPU contract line, and the N > 1 launch path (two ranks sharing the one
+GPU of the test box over gloo) that the driver only ever runs on an 8-GPU node."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SMALL = ["--cams", "20000", "--edges", "400000", "--steps", "2", "--warmup", "1", "--cpu-baseline", "0", "--small-graphs", "0", "--sweep-reps", "3"]
+
+
+def _json_line(stdout):
+    lines = [ln for ln in stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_single_gpu_contract_line():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + SMALL, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    out = _json_line(r.stdout)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in out, key
+    assert out["n_gpus"] == 1 and out["steps"] == 2 and out["value"] > 0 and out["dtype"] == "f64" and "workload" in out["config"]
+    ro = out["roofline"]
+    assert ro["bound"] == "hbm" and "k_matvec" in ro["kernel"] and abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-12
+    assert abs(ro["achieved"] - ro["algorithmic_bytes_per_launch"] / (ro["kernel_ms"] * 1e-3) / 1e9) < 1e-6 * ro["achieved"]
+    other = out["roofline_other"]
+    assert {"k_lin", "k_cost_trial", "k_cost_full", "k_cost_s_only", "sigma_consensus_K6"} <= set(other)
+    assert other["k_cost_full"]["kernel_ms"] >= other["k_cost_trial"]["kernel_ms"] * 0.9   # the stores cost something
+
+
+def test_bench_two_ranks_on_one_gpu_over_gloo():
+    """`python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2`: camera partition, sharded problem creation (with its
+    agreement all-reduce), all-gathers inside PCG, max-over-ranks timing, rank 0's JSON line."""
+    env = dict(os.environ, GSFM_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    port = 29900 + os.getpid() % 90
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2"] + SMALL
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    out = _json_line(r.stdout)
+    assert out["n_gpus"] == 2 and out["value"] > 0 and out["config"]["parallelism"] == "camera-slice x2" and out["config"]["collectives"] == "gloo"
+    one = _json_line(subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + SMALL + ["--sigma-pass", "0"], cwd=ROOT, capture_output=True, text=True, timeout=900).stdout)
+    assert out["lm_iterations"] == one["lm_iterations"] and out["residual_sweeps_per_solve"] == one["residual_sweeps_per_solve"]
+    assert abs(out["final_cost"] - one["final_cost"]) <= 1e-6 * one["final_cost"]
