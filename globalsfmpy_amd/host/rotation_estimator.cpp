@@ -8,6 +8,8 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <exception>
+#include <limits>
 #include <vector>
 
 #include "../../include/gsfm/GSfM_nonlinear_rotation_estimator.hpp"
@@ -16,9 +18,26 @@ namespace theia {
 
 namespace {
 
+// The user's Evaluate may throw (a Python exception surfaces as pybind11::error_already_set).  Nothing may unwind through the
+// extern "C" frames of the solver: the first exception is parked, the edge gets NaN -- the solve then ends with FAILURE /
+// nonfinite instead of running on stale values -- and Run() rethrows it once the device problem has been released.
+struct HostLossCall {
+  const ceres::LossFunction* loss;
+  std::exception_ptr error;
+};
 void host_loss_trampoline(void* user, double s, double out[3]) {
-  static_cast<const ceres::LossFunction*>(user)->Evaluate(s, out);
+  HostLossCall* call = static_cast<HostLossCall*>(user);
+  try {
+    call->loss->Evaluate(s, out);
+  } catch (...) {
+    if (!call->error) call->error = std::current_exception();
+    out[0] = out[1] = out[2] = std::numeric_limits<double>::quiet_NaN();
+  }
 }
+struct ProblemOwner {   // the device problem is released on every path out of Run()
+  gsfm_rot_problem* p = nullptr;
+  ~ProblemOwner() { if (p) gsfm_rot_problem_destroy(p); }
+};
 
 bool needs_cov(RotationErrorType t) {
   return t == RotationErrorType::ANGLE_AXIS_COVARIANCE || t == RotationErrorType::ANGLE_AXIS_COV_INLIERS ||
@@ -89,12 +108,14 @@ bool GSfMNonlinearRotationEstimator::Run(const std::unordered_map<ViewIdPair, Tw
   }
   if (E == 0) return true;  // Ceres would solve an empty problem and the reference returns true
 
-  gsfm_rot_problem* P = nullptr;
+  ProblemOwner owner;
   gsfm_status st = gsfm_rot_problem_create((uint32_t)N, E, ei.data(), ej.data(), rel.data(), (int32_t)type,
-                                           cov6.empty() ? nullptr : cov6.data(), inl.empty() ? nullptr : inl.data(), nullptr, &P);
+                                           cov6.empty() ? nullptr : cov6.data(), inl.empty() ? nullptr : inl.data(), nullptr, &owner.p);
   if (st != GSFM_OK) { error_ = gsfm_last_error(); return false; }
+  gsfm_rot_problem* P = owner.p;
 
   // loss: built-in descriptor > self-describing loss > host callback > NULL (Ceres' trivial loss)
+  HostLossCall host_call{loss_function, nullptr};
   if (builtin_loss) st = gsfm_rot_set_loss(P, builtin_loss, 1);
   else if (loss_function == nullptr) st = gsfm_rot_set_loss(P, nullptr, 0);
   else {
@@ -102,9 +123,9 @@ bool GSfMNonlinearRotationEstimator::Run(const std::unordered_map<ViewIdPair, Tw
     int n = -1;
     if (const gsfm::DescribedLoss* d = dynamic_cast<const gsfm::DescribedLoss*>(loss_function)) n = d->NativeProgram(prog, GSFM_LOSS_MAX_NODES);
     if (n >= 0) st = gsfm_rot_set_loss(P, prog, n);
-    else st = gsfm_rot_set_loss_callback(P, host_loss_trampoline, loss_function);
+    else st = gsfm_rot_set_loss_callback(P, host_loss_trampoline, &host_call);
   }
-  if (st != GSFM_OK) { error_ = gsfm_last_error(); gsfm_rot_problem_destroy(P); return false; }
+  if (st != GSFM_OK) { error_ = gsfm_last_error(); return false; }
 
   gsfm_rot_options opt;
   if (options_set_) opt = options_;
@@ -113,7 +134,11 @@ bool GSfMNonlinearRotationEstimator::Run(const std::unordered_map<ViewIdPair, Tw
   if (sigma_iters > 0) st = gsfm_rot_solve_sigma_consensus(P, rot.data(), sigma_iters, sigma_max, &opt, &summary_);
   else st = gsfm_rot_solve(P, rot.data(), &opt, &summary_);
   if (st != GSFM_OK) error_ = gsfm_last_error();
-  gsfm_rot_problem_destroy(P);
+  if (host_call.error) {   // the user's loss threw: release the device problem first, then let the exception continue to the caller
+    gsfm_rot_problem_destroy(owner.p);
+    owner.p = nullptr;
+    std::rethrow_exception(host_call.error);
+  }
   if (st != GSFM_OK) return false;
 
   for (size_t k = 0; k < N; ++k) {

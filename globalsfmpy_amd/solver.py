@@ -76,13 +76,27 @@ class ProblemBase(object):
         self._check(self._fn("set_loss")(self._h, arr, n), "set_loss")
 
     def set_loss_callback(self, evaluate):
+        """Host-callback loss.  An exception raised by `evaluate` cannot cross the C boundary: it is recorded, the edge gets NaN
+        (the solve then ends with FAILURE / nonfinite instead of running on stale values) and solve() re-raises it."""
+        self._cb_error = None
+
         def _cb(_user, s, out):
-            buf = [0.0, 0.0, 0.0]
-            evaluate(s, buf)
-            out[0], out[1], out[2] = buf[0], buf[1], buf[2]
+            try:
+                buf = [0.0, 0.0, 0.0]
+                evaluate(s, buf)
+                out[0], out[1], out[2] = buf[0], buf[1], buf[2]
+            except BaseException as e:  # noqa: BLE001
+                if self._cb_error is None:
+                    self._cb_error = e
+                out[0] = out[1] = out[2] = float("nan")
         cb = _abi.LOSS_CALLBACK_FN(_cb)
         self._keep.append(cb)
         self._check(self._fn("set_loss_callback")(self._h, cb, None), "set_loss_callback")
+
+    def _reraise_callback_error(self):
+        e, self._cb_error = getattr(self, "_cb_error", None), None
+        if e is not None:
+            raise e
 
     def set_edge_weights(self, w):
         w = np.ascontiguousarray(w, dtype=np.float64)
@@ -96,7 +110,9 @@ class ProblemBase(object):
         rho = np.empty((self.n_edges, 3))
         r = np.empty((self.n_edges, self.residual_dim)) if want_residuals else None
         cost = C.c_double(0)
-        self._check(self._fn("residuals")(self._h, _dp(rot), _dp(s), _dp(rho), _dp(r), C.byref(cost)), "residuals")
+        st = self._fn("residuals")(self._h, _dp(rot), _dp(s), _dp(rho), _dp(r), C.byref(cost))
+        self._reraise_callback_error()
+        self._check(st, "residuals")
         return {"s": s, "rho": rho, "residuals": r, "cost": cost.value}
 
     def linearize(self, rot_aa):
@@ -132,6 +148,7 @@ class ProblemBase(object):
         o = self._options(options)
         s = _abi.Summary()
         st = self._fn("solve")(self._h, _dp(rot), C.byref(o), C.byref(s))
+        self._reraise_callback_error()
         self._check(st, "solve")
         return rot, s.as_dict()
 
@@ -140,6 +157,7 @@ class ProblemBase(object):
         o = self._options(options)
         s = _abi.Summary()
         st = self._fn("solve_sigma_consensus")(self._h, _dp(rot), int(iters_num), float(sigma_max), C.byref(o), C.byref(s))
+        self._reraise_callback_error()
         self._check(st, "solve_sigma_consensus")
         return rot, s.as_dict()
 

@@ -227,3 +227,49 @@ def test_plain_c_consumer_of_the_c_abi(tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "termination" in r.stdout and "camera 3" in r.stdout
+
+
+def test_exceptions_in_a_python_loss_reach_the_caller_and_leave_no_garbage():
+    """Round-1 advisor finding: an exception inside Evaluate() was swallowed on the ctypes path (the solve ran on stale rho values) and
+    unwound through extern "C" frames on the pybind path (leaking the device problem).  Both now stop the solve and re-raise."""
+    from globalsfmpy_amd.solver import RotationProblem
+
+    class Boom(RuntimeError):
+        pass
+
+    g = synth.make_graph(40, 200, seed=5)
+    calls = {"n": 0}
+
+    def evaluate(s, out):
+        calls["n"] += 1
+        if calls["n"] > 250:
+            raise Boom("loss failed at call %d" % calls["n"])
+        out[0], out[1], out[2] = s, 1.0, 0.0
+
+    p = RotationProblem(g["n_cams"], g["edge_i"], g["edge_j"], g["rel_aa"], _abi.ANGLE_AXIS)
+    p.set_loss_callback(evaluate)
+    with pytest.raises(Boom):
+        p.solve(g["init_aa"])
+    calls["n"] = -10 ** 9                               # the problem is still usable afterwards
+    r, s = p.solve(g["init_aa"])
+    assert s["termination_name"] != "FAILURE" and np.isfinite(r).all()
+
+    class BadLoss(sfm.LossFunction):                    # pybind trampoline path (no native_program)
+        def __init__(self):
+            sfm.LossFunction.__init__(self)
+            self.n = 0
+
+        def Evaluate(self, s, out):
+            self.n += 1
+            if self.n > 250:
+                raise Boom("python loss failed")
+            out[0], out[1], out[2] = s, 1.0, 0.0
+
+    vg, cov, o = _maps(g)
+    before = {k: np.array(v) for k, v in o.items()}
+    est = sfm.NonlinearRotationEstimator()
+    with pytest.raises(Exception) as ei:
+        est.EstimateRotationsWithCustomizedLoss(vg.GetAllEdges(), o, BadLoss(), 1, sfm.RotationErrorType.QUATERNION_COSINE)
+    assert "python loss failed" in str(ei.value)
+    assert all(np.array_equal(before[k], np.array(o[k])) for k in before)      # rotations untouched
+    assert est.EstimateRotations(vg.GetAllEdges(), o)                          # and the estimator still works

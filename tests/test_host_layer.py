@@ -153,3 +153,26 @@ def test_reference_return_values_for_empty_inputs():
     o[0] = np.zeros(3)
     assert est.EstimateRotations(sfm.MapEdges(), o) is False
     assert est.EstimateRotationsWithSigmaConsensus(sfm.MapEdges(), o, None, 1, 5, 0.1) is False
+
+
+def test_a_subclass_that_overrides_evaluate_is_not_replaced_by_its_parents_descriptor():
+    """Round-1 advisor finding: class MyHuber(HuberLoss) with its own Evaluate must not silently run HuberLoss's device program --
+    the reference always calls the Python Evaluate (bind_src/GlobalSfMpy.cpp:33-65)."""
+    from globalsfmpy_amd import loss_functions as LF2
+
+    class Tweaked(LF2.HuberLoss):
+        def Evaluate(self, s, out):
+            out[0], out[1], out[2] = 2.0 * s, 2.0, 0.0
+
+    class Described(LF2.HuberLoss):          # overrides both: the new descriptor is the contract
+        def Evaluate(self, s, out):
+            out[0], out[1], out[2] = 2.0 * s, 2.0, 0.0
+
+        def native_program(self):
+            return LF2.ScaledLoss(LF2.TrivialLoss(), 2.0).native_program()
+
+    assert LF2.HuberLoss(0.1).native_program() is not None
+    assert Tweaked(0.1).native_program() is None                       # -> host-callback path
+    assert Described(0.1).native_program() is not None
+    assert LF2.ScaledLoss(Tweaked(0.1), 3.0).native_program() is None  # composites inherit the verdict
+    assert LF2.ComposedLoss(LF2.CauchyLoss(0.3), Tweaked(0.1)).native_program() is None
