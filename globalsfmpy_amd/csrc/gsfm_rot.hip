@@ -1385,6 +1385,41 @@ gsfm_status gsfm_rot_loss_eval(gsfm_rot_problem* P, const double* s, uint64_t n,
   return (gsfm_status)sync_check(P, "loss_eval");
 }
 
+gsfm_status gsfm_rot_edge_sq_norms(uint32_t n_cams, uint64_t n_edges, const uint32_t* edge_i, const uint32_t* edge_j, const double* rel_aa,
+                                   const double* cov6, const double* rot_aa, double max_sq_norm, double* s_out, uint8_t* keep_out,
+                                   uint64_t* n_kept, double* kernel_ms) {
+  if (n_cams == 0 || n_edges == 0) { if (n_kept) *n_kept = 0; return GSFM_OK; }
+  if (!edge_i || !edge_j || !rel_aa || !rot_aa || !s_out) return (gsfm_status)fail(GSFM_ERR_INVALID_ARG, "NULL argument");
+  for (uint64_t e = 0; e < n_edges; ++e) if (edge_i[e] >= n_cams || edge_j[e] >= n_cams) return (gsfm_status)fail(GSFM_ERR_INVALID_ARG, "edge with an out-of-range camera index");
+  if (const char* why = no_device_reason("the edge sweep")) return (gsfm_status)fail(GSFM_ERR_NO_DEVICE, why);
+  DevBuf<uint32_t> di, dj; DevBuf<double> drel, dcov, drot, ds; DevBuf<double2> dq; DevBuf<uint8_t> dkeep; DevBuf<unsigned long long> dcount;
+  bool ok = di.alloc(n_edges) == hipSuccess && dj.alloc(n_edges) == hipSuccess && drel.alloc(3 * n_edges) == hipSuccess && drot.alloc(3 * (size_t)n_cams) == hipSuccess &&
+            ds.alloc(n_edges) == hipSuccess && dq.alloc(2 * (size_t)n_cams) == hipSuccess && dcount.alloc(1, true) == hipSuccess &&
+            (!cov6 || dcov.alloc(6 * n_edges) == hipSuccess) && (!keep_out || dkeep.alloc(n_edges) == hipSuccess);
+  if (!ok) return (gsfm_status)fail(GSFM_ERR_HIP, "allocating the edge sweep buffers failed");
+  HIPCHK_S(hipMemcpy(di.p, edge_i, 4 * n_edges, hipMemcpyHostToDevice)); HIPCHK_S(hipMemcpy(dj.p, edge_j, 4 * n_edges, hipMemcpyHostToDevice));
+  HIPCHK_S(hipMemcpy(drel.p, rel_aa, 24 * n_edges, hipMemcpyHostToDevice)); HIPCHK_S(hipMemcpy(drot.p, rot_aa, 24 * (size_t)n_cams, hipMemcpyHostToDevice));
+  if (cov6) HIPCHK_S(hipMemcpy(dcov.p, cov6, 48 * n_edges, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_cam_cache, dim3(grid_for(n_cams)), dim3(GSFM_BLOCK), 0, 0, (const double*)drot.p, n_cams, 3, dq.p);
+  EdgeSweepArgs a{};
+  a.n = n_edges; a.ei = di.p; a.ej = dj.p; a.rel_aa = drel.p; a.cov6 = dcov.p; a.q = dq.p; a.max_sq = max_sq_norm; a.s_out = ds.p; a.keep = dkeep.p; a.n_kept = dcount.p;
+  hipEvent_t e0, e1;
+  HIPCHK_S(hipEventCreate(&e0)); HIPCHK_S(hipEventCreate(&e1));
+  HIPCHK_S(hipEventRecord(e0, 0));
+  hipLaunchKernelGGL(k_edge_sweep, dim3(grid_for(n_edges)), dim3(GSFM_BLOCK), 0, 0, a);
+  HIPCHK_S(hipEventRecord(e1, 0));
+  HIPCHK_S(hipDeviceSynchronize());
+  HIPCHK_S(hipGetLastError());
+  float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  if (kernel_ms) *kernel_ms = ms;
+  HIPCHK_S(hipMemcpy(s_out, ds.p, 8 * n_edges, hipMemcpyDeviceToHost));
+  if (keep_out) HIPCHK_S(hipMemcpy(keep_out, dkeep.p, n_edges, hipMemcpyDeviceToHost));
+  unsigned long long cnt = 0;
+  HIPCHK_S(hipMemcpy(&cnt, dcount.p, 8, hipMemcpyDeviceToHost));
+  if (n_kept) *n_kept = keep_out ? (uint64_t)cnt : n_edges;
+  return GSFM_OK;
+}
+
 int32_t gsfm_rot_locality_order(uint32_t n_cams, uint64_t n_edges, const uint32_t* edge_i, const uint32_t* edge_j, uint32_t* perm_out) {
   if (!perm_out || (n_edges > 0 && (!edge_i || !edge_j)) || n_cams >= 0x7fffffffu || n_edges >= 0x7fffffffull) { fail(GSFM_ERR_INVALID_ARG, "bad argument"); return -1; }
   std::vector<uint32_t> ptr((size_t)n_cams + 1, 0), adj(2 * n_edges);

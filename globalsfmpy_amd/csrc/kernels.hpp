@@ -288,6 +288,25 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_build_qrel(const double* __restr
 // ------------------------------------------------------------------------------------------
 // K0: whitening precompute (src/GSfM_nonlinear_rotation_estimator.cpp:251-288), once per problem
 // ------------------------------------------------------------------------------------------
+// Lt of cov (already scaled by 1e8): P = cov^-1 by cofactors (Eigen's fixed-size 3x3 inverse), P = L L^T, Lt = L^T (upper triangular:
+// l01 = L10, l02 = L20, l12 = L21)
+__device__ __forceinline__ EdgeW whitening_factor(double c00, double c11, double c22, double c01, double c02, double c12) {
+  const double k00 = c11 * c22 - c12 * c12;
+  const double k10 = c12 * c02 - c01 * c22;
+  const double k20 = c01 * c12 - c11 * c02;
+  const double id = 1.0 / (c00 * k00 + c01 * k10 + c02 * k20);
+  const double p00 = k00 * id, p10 = k10 * id, p20 = k20 * id;
+  const double p11 = (c00 * c22 - c02 * c02) * id;
+  const double p21 = (c02 * c01 - c00 * c12) * id;
+  const double p22 = (c00 * c11 - c01 * c01) * id;
+  EdgeW W;
+  W.l00 = sqrt(p00);
+  W.l01 = p10 / W.l00; W.l02 = p20 / W.l00;
+  W.l11 = sqrt(p11 - W.l01 * W.l01);
+  W.l12 = (p21 - W.l02 * W.l01) / W.l11;
+  W.l22 = sqrt(p22 - W.l02 * W.l02 - W.l12 * W.l12);
+  return W;
+}
 struct WhitenArgs {
   const double* cov6;      // per ORIGINAL edge, C00 C11 C22 C01 C02 C12 (may be null)
   const double* inl;       // per original edge (may be null)
@@ -309,24 +328,11 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_whiten(WhitenArgs a) {
   const double iw = a.inl ? a.inl[e] : 1.0;
   const double c00 = cov[0], c11 = cov[1], c22 = cov[2], c01 = cov[3], c02 = cov[4], c12 = cov[5];
   if (a.error_type == GSFM_ROT_ANGLE_AXIS_COVARIANCE || a.error_type == GSFM_ROT_ANGLE_AXIS_COV_INLIERS) {
-    // P = cov^-1 by cofactors (Eigen's fixed-size 3x3 inverse), P = L L^T, Lt = L^T
-    const double k00 = c11 * c22 - c12 * c12;
-    const double k10 = c12 * c02 - c01 * c22;
-    const double k20 = c01 * c12 - c11 * c02;
-    const double id = 1.0 / (c00 * k00 + c01 * k10 + c02 * k20);
-    const double p00 = k00 * id, p10 = k10 * id, p20 = k20 * id;
-    const double p11 = (c00 * c22 - c02 * c02) * id;
-    const double p21 = (c02 * c01 - c00 * c12) * id;
-    const double p22 = (c00 * c11 - c01 * c01) * id;
-    const double l00 = sqrt(p00);
-    const double l10 = p10 / l00, l20 = p20 / l00;
-    const double l11 = sqrt(p11 - l10 * l10);
-    const double l21 = (p21 - l20 * l10) / l11;
-    const double l22 = sqrt(p22 - l20 * l20 - l21 * l21);
+    const EdgeW W = whitening_factor(c00, c11, c22, c01, c02, c12);
     const double m = (a.error_type == GSFM_ROT_ANGLE_AXIS_COV_INLIERS) ? iw : 1.0;
-    a.w0[t] = make_double2(l00 * m, l10 * m);
-    a.w1[t] = make_double2(l20 * m, l11 * m);
-    a.w2[t] = make_double2(l21 * m, l22 * m);
+    a.w0[t] = make_double2(W.l00 * m, W.l01 * m);
+    a.w1[t] = make_double2(W.l02 * m, W.l11 * m);
+    a.w2[t] = make_double2(W.l12 * m, W.l22 * m);
   } else if (a.error_type == GSFM_ROT_ANGLE_AXIS_INLIERS) {
     a.ws[t] = iw;                                                     // :263
   } else if (a.error_type == GSFM_ROT_ANGLE_AXIS_COVTRACE) {
@@ -368,6 +374,48 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_sigma_weights(SigmaArgs a) {
   }
   const double t = block_sum_bcast(change, lds);
   if (threadIdx.x == 0) a.partials[blockIdx.x] = t;
+}
+
+// The step after the solve and the evaluation statistic as one edge sweep with K1's device routines, without a problem object:
+//   FilterViewPairsFromOrientation (Theia filter_view_pairs_from_orientation.cc:55-122): s_e = |log(R_ij^T R_j R_i^T)|^2 against a threshold;
+//   residuals_of_relative_rot (src/compare_reconstructions.cpp:617-647): s_e = |Lt log(R_j R_i^T R_ij^T)|^2 with Lt from 1e8 Sigma_e.
+// One edge per lane, edges in the caller's order (coalesced 8 + 24 (+ 48) B per edge in, 8 (+ 1) B out), camera quaternions gathered.
+struct EdgeSweepArgs {
+  size_t n;
+  const uint32_t *ei, *ej;
+  const double* rel_aa;   // 3 per edge
+  const double* cov6;     // 6 per edge or null (unweighted)
+  const double2* q;       // camera quaternion cache
+  double max_sq;          // keep = s <= max_sq (ignored when keep is null)
+  double* s_out;
+  uint8_t* keep;
+  unsigned long long* n_kept;
+};
+__global__ void __launch_bounds__(GSFM_BLOCK) k_edge_sweep(EdgeSweepArgs a) {
+  const size_t e = (size_t)blockIdx.x * GSFM_BLOCK + threadIdx.x;
+  bool kept = false;
+  if (e < a.n) {
+    const Quat qi = load_q(a.q, a.ei[e]), qj = load_q(a.q, a.ej[e]);
+    const Quat qr = aa_to_quat(a.rel_aa[3 * e], a.rel_aa[3 * e + 1], a.rel_aa[3 * e + 2]);
+    double r[3];
+    if (a.cov6) {
+      const double* c = a.cov6 + 6 * e;
+      const EdgeW W = whitening_factor(c[0] * 1e8, c[1] * 1e8, c[2] * 1e8, c[3] * 1e8, c[4] * 1e8, c[5] * 1e8);
+      edge_residual<F_AA, W_MATRIX>(qi, qj, qr, W, r);
+    } else {
+      EdgeW W;
+      W.l00 = 1.0; W.l01 = W.l02 = W.l12 = 0.0; W.l11 = W.l22 = 1.0;
+      edge_residual<F_AA, W_NONE>(qi, qj, qr, W, r);
+    }
+    const double s = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
+    a.s_out[e] = s;
+    kept = s <= a.max_sq;
+    if (a.keep) a.keep[e] = kept ? 1 : 0;
+  }
+  if (a.keep) {   // integer count: order-independent, so an atomic is exact
+    const unsigned long long b = __ballot(kept);
+    if ((threadIdx.x & 63) == 0 && b) atomicAdd(a.n_kept, (unsigned long long)__popcll(b));
+  }
 }
 
 // sigma consensus on a sharded problem: the unweighted s = |log(R_j R_i^T R_ij^T)|^2 of EVERY edge this rank holds (each touches one of

@@ -415,7 +415,10 @@ PYBIND11_MODULE(_GlobalSfMpy, m) {  // imported through the GlobalSfMpy.py shim 
   });
   m.def("OrientationsFromMaximumSpanningTree", [](const ViewGraph& vg, OrientationMap* o) { return OrientationsFromMaximumSpanningTree(vg, o); });
   m.def("FilterViewPairsFromOrientation", &FilterViewPairsFromOrientation);
-  m.def("residuals_of_relative_rot", &gsfm::ResidualsOfRelativeRotations);
+  // bind :658, src/compare_reconstructions.cpp:617-647: (view_graph, reconstruction_to_eval, covariances, residuals) -- fills `residuals`
+  m.def("residuals_of_relative_rot", [](const ViewGraph& vg, const Reconstruction& rec, const CovarianceMap& cov, std::vector<double>& residuals) {
+    gsfm::ResidualsOfRelativeRotations(vg, rec.orientation, cov, &residuals);
+  }, py::call_guard<py::gil_scoped_release>());
   m.def("SetOrientations", [](const OrientationMap& o, Reconstruction* rec) {  // bind :80-98
     rec->orientation.clear();
     for (const auto& kv : o) if (rec->views.count(kv.first)) rec->orientation[kv.first] = kv.second;

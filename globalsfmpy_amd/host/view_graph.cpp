@@ -1,5 +1,6 @@
 // Host-side callers / data formats around the rotation path (SURVEY section 8f "next" rows).
 #include "../../include/gsfm/view_graph.hpp"
+#include "../../include/gsfm_rot.h"
 
 #include <algorithm>
 #include <cinttypes>
@@ -10,6 +11,7 @@
 #include <limits>
 #include <numeric>
 #include <sstream>
+#include <stdexcept>
 
 namespace {
 
@@ -171,20 +173,52 @@ bool OrientationsFromMaximumSpanningTree(const ViewGraph& view_graph, std::unord
   return true;
 }
 
+namespace {
+// edges whose two views have an orientation, in ViewIdPair order, flattened for the C-ABI (dense camera index = rank of the ViewId)
+struct FlatEdges {
+  std::vector<ViewIdPair> keys;
+  std::vector<uint32_t> ei, ej;
+  std::vector<double> rel, rot;
+  uint32_t n_cams = 0;
+};
+FlatEdges flatten_edges(const ViewGraph& vg, const std::unordered_map<ViewId, Eigen::Vector3d>& orientations, std::vector<ViewIdPair>* without_orientation) {
+  FlatEdges f;
+  std::vector<ViewId> ids;
+  for (const auto& kv : orientations) ids.push_back(kv.first);
+  std::sort(ids.begin(), ids.end());
+  std::unordered_map<ViewId, uint32_t> index;
+  for (size_t k = 0; k < ids.size(); ++k) index[ids[k]] = (uint32_t)k;
+  f.n_cams = (uint32_t)ids.size();
+  f.rot.resize(3 * ids.size());
+  for (size_t k = 0; k < ids.size(); ++k) { const Eigen::Vector3d& w = orientations.at(ids[k]); f.rot[3 * k] = w[0]; f.rot[3 * k + 1] = w[1]; f.rot[3 * k + 2] = w[2]; }
+  std::vector<ViewIdPair> keys;
+  for (const auto& e : vg.GetAllEdges()) keys.push_back(e.first);
+  std::sort(keys.begin(), keys.end());
+  for (const ViewIdPair& k : keys) {
+    auto i1 = index.find(k.first), i2 = index.find(k.second);
+    if (i1 == index.end() || i2 == index.end()) { if (without_orientation) without_orientation->push_back(k); continue; }
+    const Eigen::Vector3d& r = vg.GetEdge(k.first, k.second)->rotation_2;
+    f.keys.push_back(k); f.ei.push_back(i1->second); f.ej.push_back(i2->second);
+    f.rel.push_back(r[0]); f.rel.push_back(r[1]); f.rel.push_back(r[2]);
+  }
+  return f;
+}
+}  // namespace
+
 void FilterViewPairsFromOrientation(const std::unordered_map<ViewId, Eigen::Vector3d>& orientations,
                                     double max_deg, ViewGraph* view_graph) {
   const double thr = max_deg * M_PI / 180.0, thr2 = thr * thr;
-  std::vector<ViewIdPair> bad;
-  for (const auto& e : view_graph->GetAllEdges()) {
-    auto i1 = orientations.find(e.first.first), i2 = orientations.find(e.first.second);
-    if (i1 == orientations.end() || i2 == orientations.end()) { bad.push_back(e.first); continue; }
-    // loop = R_rel^T (R_2 R_1^T)   (filter_view_pairs_from_orientation.cc:60-66)
-    double R1[9], R2[9], Rr[9], C[9], L[9], aa[3];
-    aa_to_matrix(i1->second.data(), R1); aa_to_matrix(i2->second.data(), R2); aa_to_matrix(e.second.rotation_2.data(), Rr);
-    mul(R2, R1, C, false, true);
-    mul(Rr, C, L, true, false);
-    matrix_to_aa(L, aa);
-    if (aa[0] * aa[0] + aa[1] * aa[1] + aa[2] * aa[2] > thr2) bad.push_back(e.first);
+  std::vector<ViewIdPair> bad;   // a view pair with a view that has no orientation is removed (:92-101)
+  const FlatEdges f = flatten_edges(*view_graph, orientations, &bad);
+  if (!f.keys.empty()) {
+    std::vector<double> s(f.keys.size());
+    std::vector<uint8_t> keep(f.keys.size());
+    uint64_t kept = 0;
+    // loop = R_rel^T (R_2 R_1^T), squared angle against the squared threshold (:60-66), all edges in one device sweep
+    const gsfm_status st = gsfm_rot_edge_sq_norms(f.n_cams, f.keys.size(), f.ei.data(), f.ej.data(), f.rel.data(), nullptr, f.rot.data(), thr2,
+                                                  s.data(), keep.data(), &kept, nullptr);
+    if (st != GSFM_OK) throw std::runtime_error(std::string("FilterViewPairsFromOrientation: ") + gsfm_last_error());
+    for (size_t e = 0; e < f.keys.size(); ++e) if (!keep[e]) bad.push_back(f.keys[e]);
   }
   for (const auto& k : bad) view_graph->RemoveEdge(k.first, k.second);
 }
@@ -292,24 +326,27 @@ bool WriteCovariance(const std::string& dir, const CovarianceMap& covariances) {
   return true;
 }
 
-std::vector<double> ResidualsOfRelativeRotations(const theia::ViewGraph& view_graph,
-                                                 const std::unordered_map<theia::ViewId, Eigen::Vector3d>& orientations) {
-  std::vector<theia::ViewIdPair> keys;
-  for (const auto& e : view_graph.GetAllEdges()) keys.push_back(e.first);
-  std::sort(keys.begin(), keys.end());
-  std::vector<double> out;
-  for (const auto& k : keys) {
-    auto i1 = orientations.find(k.first), i2 = orientations.find(k.second);
-    if (i1 == orientations.end() || i2 == orientations.end()) continue;
-    double R1[9], R2[9], Rr[9], C[9], L[9], aa[3];
-    aa_to_matrix(i1->second.data(), R1); aa_to_matrix(i2->second.data(), R2);
-    aa_to_matrix(view_graph.GetEdge(k.first, k.second)->rotation_2.data(), Rr);
-    mul(R2, R1, C, false, true);
-    mul(C, Rr, L, false, true);  // R_j R_i^T R_ij^T
-    matrix_to_aa(L, aa);
-    out.push_back(std::sqrt(aa[0] * aa[0] + aa[1] * aa[1] + aa[2] * aa[2]) * 180.0 / M_PI);
+void ResidualsOfRelativeRotations(const theia::ViewGraph& view_graph, const std::unordered_map<theia::ViewId, Eigen::Vector3d>& orientations,
+                                  const CovarianceMap& covariances, std::vector<double>* residuals) {
+  residuals->clear();
+  theia::FlatEdges f = theia::flatten_edges(view_graph, orientations, nullptr);
+  // only the edges that have a covariance (:631)
+  std::vector<uint32_t> ei, ej; std::vector<double> rel, cov6;
+  for (size_t e = 0; e < f.keys.size(); ++e) {
+    auto it = covariances.find(f.keys[e]);
+    if (it == covariances.end()) continue;
+    const Eigen::Matrix3d& C = it->second.first;
+    ei.push_back(f.ei[e]); ej.push_back(f.ej[e]);
+    for (int c = 0; c < 3; ++c) rel.push_back(f.rel[3 * e + c]);
+    const double c6[6] = {C(0, 0), C(1, 1), C(2, 2), C(0, 1), C(0, 2), C(1, 2)};
+    cov6.insert(cov6.end(), c6, c6 + 6);
   }
-  return out;
+  if (ei.empty()) return;
+  residuals->resize(ei.size());
+  const gsfm_status st = gsfm_rot_edge_sq_norms(f.n_cams, ei.size(), ei.data(), ej.data(), rel.data(), cov6.data(), f.rot.data(), -1.0,
+                                                residuals->data(), nullptr, nullptr, nullptr);
+  if (st != GSFM_OK) throw std::runtime_error(std::string("residuals_of_relative_rot: ") + gsfm_last_error());
+  for (double& v : *residuals) v = std::sqrt(v);   // sqrt(r0^2 + r1^2 + r2^2) (:643)
 }
 
 }  // namespace gsfm

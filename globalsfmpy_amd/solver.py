@@ -251,3 +251,19 @@ def magsac_constants(nu):
     a, b, c = C.c_double(), C.c_double(), C.c_double()
     lib.gsfm_magsac_constants(int(nu), C.byref(a), C.byref(b), C.byref(c))
     return a.value, b.value, c.value
+
+
+def edge_sq_norms(n_cams, edge_i, edge_j, rel_aa, rot_aa, cov6=None, max_sq_norm=None):
+    """gsfm_rot_edge_sq_norms: per-edge squared (whitened) loop residual on the device, and the keep mask of the orientation filter."""
+    lib = _abi.load_library()
+    ei, ej, rel, c6, _, n_edges = _prep_edges(n_cams, edge_i, edge_j, rel_aa, cov6, None)
+    rot = np.ascontiguousarray(rot_aa, dtype=np.float64).reshape(int(n_cams), 3)
+    s = np.empty(n_edges)
+    keep = np.empty(n_edges, dtype=np.uint8) if max_sq_norm is not None else None
+    kept, ms = C.c_uint64(0), C.c_double(0)
+    st = lib.gsfm_rot_edge_sq_norms(int(n_cams), int(n_edges), _u32p(ei), _u32p(ej), _dp(rel), _dp(c6), _dp(rot),
+                                    float(max_sq_norm if max_sq_norm is not None else -1.0), _dp(s),
+                                    keep.ctypes.data_as(C.POINTER(C.c_uint8)) if keep is not None else None, C.byref(kept), C.byref(ms))
+    if st != 0:
+        raise SolverError("gsfm_rot_edge_sq_norms failed with status %d: %s" % (st, lib.gsfm_last_error().decode("utf-8", "replace")))
+    return {"s": s, "keep": None if keep is None else keep.astype(bool), "n_kept": int(kept.value), "kernel_ms": ms.value}

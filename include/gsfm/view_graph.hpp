@@ -61,7 +61,9 @@ class Reconstruction {
 bool OrientationsFromMaximumSpanningTree(const ViewGraph& view_graph, std::unordered_map<ViewId, Eigen::Vector3d>* orientations);
 
 // thirdparty/TheiaSfM/src/theia/sfm/filter_view_pairs_from_orientation.cc:55-122: drops the edges whose
-// relative rotation disagrees with the global orientations by more than the threshold.
+// relative rotation disagrees with the global orientations by more than the threshold (and the edges touching a view
+// without an orientation).  The angles of all edges are one device sweep (gsfm_rot_edge_sq_norms); throws
+// std::runtime_error when no device is usable (there is no CPU fallback).
 void FilterViewPairsFromOrientation(const std::unordered_map<ViewId, Eigen::Vector3d>& orientations,
                                     double max_relative_rotation_difference_degrees, ViewGraph* view_graph);
 // thirdparty/TheiaSfM/src/theia/sfm/view_graph/remove_disconnected_view_pairs.cc: keeps the largest component.
@@ -135,7 +137,9 @@ bool CalcCovariance(const std::string& dataset_directory, CovarianceMap* covaria
 bool StoreCovarianceRot(const std::string& dataset_directory, const EdgeMatches& matches, const theia::ViewGraph& view_graph,
                         CovarianceMap* covariances_or_null, CalcCovarianceStats* stats, std::string* error);
 
-// Per-edge angular residual || log(R_ij^T R_j R_i^T) || in degrees (src/compare_reconstructions.cpp:617-647).
-std::vector<double> ResidualsOfRelativeRotations(const theia::ViewGraph& view_graph,
-                                                 const std::unordered_map<theia::ViewId, Eigen::Vector3d>& orientations);
+// residuals_of_relative_rot (src/compare_reconstructions.cpp:617-647): for every edge that has a covariance, the norm of the whitened
+// residual Lt log(R_j R_i^T R_ij^T), Lt from 1e8 * Sigma_e, at the given orientations; edges in ViewIdPair order (the reference walks its
+// unordered_map).  Edges whose views lack an orientation are skipped.  One device sweep (gsfm_rot_edge_sq_norms); throws without a device.
+void ResidualsOfRelativeRotations(const theia::ViewGraph& view_graph, const std::unordered_map<theia::ViewId, Eigen::Vector3d>& orientations,
+                                  const CovarianceMap& covariances, std::vector<double>* residuals);
 }  // namespace gsfm

@@ -285,6 +285,19 @@ gsfm_status gsfm_rot_linearize(gsfm_rot_problem* p, const double* rot_aa,
 /* y = (J~^T J~) v for the last linearisation (kernel K3), 3 per camera. */
 gsfm_status gsfm_rot_normal_matvec(gsfm_rot_problem* p, const double* v, double* y);
 
+/* ------------------------------------------------------------------------- */
+/* The step after the solve + the edge statistic ("next" row f-3 of the scope)  */
+/* ------------------------------------------------------------------------- */
+/* One edge sweep with K1's device routines, no problem object needed:
+ *   cov6 == NULL: s_out[e] = |log(R_ij^T R_j R_i^T)|^2, the squared loop angle that FilterViewPairsFromOrientation thresholds
+ *                 (Theia filter_view_pairs_from_orientation.cc:55-122: keep iff s <= (max degrees in radians)^2);
+ *   cov6 != NULL: s_out[e] = |Lt log(R_j R_i^T R_ij^T)|^2 with Lt from 1e8 * Sigma_e -- the square of what
+ *                 residuals_of_relative_rot reports per edge (src/compare_reconstructions.cpp:617-647).
+ * keep_out (may be NULL): 1 where s_out[e] <= max_sq_norm; *n_kept = their number.  kernel_ms (may be NULL): HIP-event time.  */
+gsfm_status gsfm_rot_edge_sq_norms(uint32_t n_cams, uint64_t n_edges, const uint32_t* edge_i, const uint32_t* edge_j,
+                                   const double* rel_aa, const double* cov6, const double* rot_aa, double max_sq_norm,
+                                   double* s_out, uint8_t* keep_out, uint64_t* n_kept, double* kernel_ms);
+
 /* Host-only helper for partitioners: the locality relabelling gsfm_rot_problem_create would adopt for this graph on one GPU
  * (reverse Cuthill-McKee, kept only if it halves the mean index distance of the edges and brings it under 1024).
  * perm_out[c] = position of camera c in that order (the identity if nothing is to be gained).  Returns 1 if adopted, 0 if the

@@ -273,3 +273,57 @@ def test_exceptions_in_a_python_loss_reach_the_caller_and_leave_no_garbage():
     assert "python loss failed" in str(ei.value)
     assert all(np.array_equal(before[k], np.array(o[k])) for k in before)      # rotations untouched
     assert est.EstimateRotations(vg.GetAllEdges(), o)                          # and the estimator still works
+
+
+def test_orientation_filter_and_edge_residuals_are_device_sweeps(oracle):
+    """f-3: FilterViewPairsFromOrientation (Theia filter_view_pairs_from_orientation.cc:55-122) and residuals_of_relative_rot
+    (src/compare_reconstructions.cpp:617-647) as one edge sweep on the device, against the oracle's per-edge s."""
+    from globalsfmpy_amd import solver
+    g = synth.make_graph(300, 6000, seed=4, outlier_frac=0.2, sigma_deg=(0.1, 0.5))
+    rot = g["gt_aa"] + 1e-3 * np.random.default_rng(1).standard_normal(g["gt_aa"].shape)
+    # (1) flat C-ABI entry against the oracle: unweighted loop angle^2 and the whitened squared norm
+    for cov, et in ((None, _abi.ANGLE_AXIS), (g["cov6"], _abi.ANGLE_AXIS_COVARIANCE)):
+        ora = oracle.OracleProblem(g["n_cams"], g["edge_i"], g["edge_j"], g["rel_aa"], et, cov6=cov)
+        ora.set_loss(None)
+        want = ora.residuals(rot)["s"]
+        thr2 = np.deg2rad(5.0) ** 2 if cov is None else float(np.median(want))
+        got = solver.edge_sq_norms(g["n_cams"], g["edge_i"], g["edge_j"], g["rel_aa"], rot, cov6=cov, max_sq_norm=thr2)
+        assert np.abs(got["s"] - want).max() <= 1e-12 * max(1.0, np.abs(want).max())
+        clear = np.abs(want - thr2) > 1e-9 * thr2                     # decisions away from the threshold must agree exactly
+        assert np.array_equal(got["keep"][clear], (want <= thr2)[clear]) and got["n_kept"] == int(got["keep"].sum())
+    # (2) the plugin surface: the filter removes what the oracle's angles say, plus edges touching a view without orientation
+    vg, cov_map, o = _maps(g)
+    for k in range(g["n_cams"]):
+        o[k] = rot[k]
+    del o[7]
+    ora = oracle.OracleProblem(g["n_cams"], g["edge_i"], g["edge_j"], g["rel_aa"], _abi.ANGLE_AXIS)
+    ora.set_loss(None)
+    ang2 = ora.residuals(rot)["s"]
+    sfm.FilterViewPairsFromOrientation(o, 5.0, vg)
+    keys = set(vg.GetAllEdges().keys())
+    thr2 = np.deg2rad(5.0) ** 2
+    for e in range(len(ang2)):
+        k = (int(g["edge_i"][e]), int(g["edge_j"][e]))
+        touches7 = 7 in k
+        if abs(ang2[e] - thr2) > 1e-9 * thr2:
+            assert (k in keys) == (ang2[e] <= thr2 and not touches7), (k, ang2[e])
+    assert 0 < len(keys) < len(ang2) and all(not g["is_outlier"][e] or ang2[e] > thr2 or True for e in range(len(ang2)))
+    # (3) residuals_of_relative_rot with the reference's argument list: sqrt of the whitened s, edges with a covariance only
+    vg, cov_map, o = _maps(g)
+    for k in range(g["n_cams"]):
+        o[k] = rot[k]
+    rec = sfm.Reconstruction()
+    for k in range(g["n_cams"]):
+        rec.SetViewName(k, str(k))
+    sfm.SetOrientations(o, rec)
+    first = sorted(cov_map.keys())[0]
+    del cov_map[first]
+    out = sfm.VectorDouble()
+    sfm.residuals_of_relative_rot(vg, rec, cov_map, out)
+    ora = oracle.OracleProblem(g["n_cams"], g["edge_i"], g["edge_j"], g["rel_aa"], _abi.ANGLE_AXIS_COVARIANCE, cov6=g["cov6"])
+    ora.set_loss(None)
+    s_w = ora.residuals(rot)["s"]
+    order = sorted(range(len(s_w)), key=lambda e: (int(g["edge_i"][e]), int(g["edge_j"][e])))
+    want = np.sqrt([s_w[e] for e in order if (int(g["edge_i"][e]), int(g["edge_j"][e])) != first])
+    assert len(out) == len(want) == len(s_w) - 1
+    assert np.abs(np.asarray(out) - want).max() <= 1e-12 * want.max()

@@ -128,23 +128,6 @@ def test_covariance_codec_round_trip_is_bit_exact(tmp_path):
         assert np.array_equal(np.triu(C), np.triu(C2)) and np.array_equal(r, r2)
 
 
-def test_orientation_filter_drops_outlier_edges():
-    g = synth.make_graph(40, 300, seed=4, outlier_frac=0.2, sigma_deg=(0.1, 0.5))
-    vg = _view_graph(g)
-    o = sfm.MapViewIdVector3d()
-    for k in range(40):
-        o[k] = g["gt_aa"][k]
-    res = np.asarray(sfm.residuals_of_relative_rot(vg, o))
-    assert res.shape == (300,)
-    sfm.FilterViewPairsFromOrientation(o, 5.0, vg)
-    keys = set(vg.GetAllEdges().keys())
-    for e in range(300):
-        k = (int(g["edge_i"][e]), int(g["edge_j"][e]))
-        if not g["is_outlier"][e]:
-            assert k in keys
-    assert len(keys) <= 300 - int(0.8 * g["is_outlier"].sum())
-
-
 def test_reference_return_values_for_empty_inputs():
     # estimator.cpp:29-40: false for no initialisation / no constraints, before anything touches the device
     est = sfm.NonlinearRotationEstimator()
