@@ -327,3 +327,50 @@ def test_orientation_filter_and_edge_residuals_are_device_sweeps(oracle):
     want = np.sqrt([s_w[e] for e in order if (int(g["edge_i"][e]), int(g["edge_j"][e])) != first])
     assert len(out) == len(want) == len(s_w) - 1
     assert np.abs(np.asarray(out) - want).max() <= 1e-12 * want.max()
+
+
+def test_the_four_global_rotation_wrappers_against_the_oracle_from_the_same_initialisation(oracle):
+    """f-1: GlobalReconstructionEstimator.EstimateGlobalRotations / ...Uncertainty / ...WithSigmaConsensus (reference
+    src/GSfM_global_reconstruction_estimator.cpp:397-507): spanning-tree initialisation, then the estimator entry point.  Each wrapper's
+    result must equal the oracle's solve started from the same initialisation."""
+    g = synth.make_graph(120, 1500, seed=21, outlier_frac=0.15)
+    ids = np.arange(g["n_cams"])
+
+    def fresh():
+        vg, cov, _ = _maps(g)
+        rec = sfm.Reconstruction()
+        est = sfm.GlobalReconstructionEstimator(sfm.ReconstructionBuilderOptions().reconstruction_estimator_options)
+        assert est.FilterInitialViewGraphAndCalibrateCameras(vg, rec)
+        init = sfm.MapViewIdVector3d()
+        assert sfm.OrientationsFromMaximumSpanningTree(vg, init)
+        return vg, cov, est, _array(init, ids)
+
+    def check(est, ro, so, tol=1e-6):
+        got = _array(est.orientations, ids)
+        s = est.LastSummary()
+        assert s["num_iterations"] == so["num_iterations"], (s["num_iterations"], so["num_iterations"])
+        assert abs(s["final_cost"] - so["final_cost"]) <= 1e-9 * max(1.0, so["final_cost"])
+        assert synth.angular_distance(synth.align_rotations(got, ro), ro).mean() <= tol
+
+    # EstimateGlobalRotations(loss, QUATERNION_COSINE)
+    vg, cov, est, x0 = fresh()
+    assert est.EstimateGlobalRotations(LF.HuberLoss(0.1), sfm.RotationErrorType.QUATERNION_COSINE)
+    ora = oracle.OracleProblem(g["n_cams"], g["edge_i"], g["edge_j"], g["rel_aa"], _abi.QUATERNION_COSINE)
+    ora.set_loss(LF.HuberLoss(0.1))
+    check(est, *ora.solve(x0))
+    # EstimateGlobalRotationsUncertainty(loss, covariances, ANGLE_AXIS_COVTRACE)
+    vg, cov, est, x0 = fresh()
+    assert est.EstimateGlobalRotationsUncertainty(LF.SoftLOneLoss(0.5), cov, sfm.RotationErrorType.ANGLE_AXIS_COVTRACE)
+    ora = oracle.OracleProblem(g["n_cams"], g["edge_i"], g["edge_j"], g["rel_aa"], _abi.ANGLE_AXIS_COVTRACE, cov6=g["cov6"])
+    ora.set_loss(LF.SoftLOneLoss(0.5))
+    check(est, *ora.solve(x0))
+    # EstimateGlobalRotationsWithSigmaConsensus(loss, iters, sigma_max)
+    vg, cov, est, x0 = fresh()
+    assert est.EstimateGlobalRotationsWithSigmaConsensus(LF.TrivialLoss(), 3, 0.05)
+    ora = oracle.OracleProblem(g["n_cams"], g["edge_i"], g["edge_j"], g["rel_aa"], _abi.ANGLE_AXIS)
+    ora.set_loss(LF.TrivialLoss())
+    ro, so = ora.solve_sigma_consensus(x0, 3, 0.05)
+    got = _array(est.orientations, ids)
+    s = est.LastSummary()
+    assert s["outer_iterations"] == so["outer_iterations"] and s["num_iterations"] == so["num_iterations"]
+    assert synth.angular_distance(synth.align_rotations(got, ro), ro).mean() <= 1e-6

@@ -159,3 +159,52 @@ def test_a_subclass_that_overrides_evaluate_is_not_replaced_by_its_parents_descr
     assert Described(0.1).native_program() is not None
     assert LF2.ScaledLoss(Tweaked(0.1), 3.0).native_program() is None  # composites inherit the verdict
     assert LF2.ComposedLoss(LF2.CauchyLoss(0.3), Tweaked(0.1)).native_program() is None
+
+
+def test_spanning_tree_initialisation_against_an_independent_scipy_construction():
+    """f-1 oracle: OrientationsFromMaximumSpanningTree (Theia orientations_from_maximum_spanning_tree.cc:62-181) against scipy's
+    minimum spanning tree of the negated match counts + a plain BFS composition.  Distinct weights make the maximum spanning tree
+    unique, so the two constructions must pick the same tree; only the largest connected component is initialised (:116-119)."""
+    from scipy.sparse import coo_matrix
+    from scipy.sparse.csgraph import connected_components, minimum_spanning_tree
+    from scipy.spatial.transform import Rotation as R
+    g = synth.make_graph(80, 500, seed=12, outlier_frac=0.2, full_so3=True)
+    rng = np.random.default_rng(5)
+    keep = ~((g["edge_i"] >= 70) ^ (g["edge_j"] >= 70))     # cameras 70..79 form their own (smaller) component
+    ei, ej, rel = g["edge_i"][keep], g["edge_j"][keep], g["rel_aa"][keep]
+    w = rng.permutation(len(ei)) + 10                      # distinct match counts
+    vg = sfm.ViewGraph()
+    for i, j, r, c in zip(ei, ej, rel, w):
+        info = sfm.TwoViewInfo()
+        info.rotation_2 = r
+        info.num_verified_matches = int(c)
+        vg.AddEdge(int(i), int(j), info)
+    o = sfm.MapViewIdVector3d()
+    assert sfm.OrientationsFromMaximumSpanningTree(vg, o)
+    A = coo_matrix((np.ones(len(ei)), (ei, ej)), shape=(80, 80))
+    ncomp, label = connected_components(A, directed=False)
+    big = np.argmax(np.bincount(label))
+    members = set(np.flatnonzero(label == big).tolist())
+    assert set(o.keys()) == members and len(members) < 80                      # largest component only
+    T = minimum_spanning_tree(coo_matrix((-w.astype(float), (ei, ej)), shape=(80, 80))).tocoo()
+    tree = {(int(a), int(b)) for a, b in zip(T.row, T.col) if int(a) in members}
+    # independent composition over scipy's tree: R_j = R_ij R_i across an edge (i < j), from the same root
+    rel_of = {(int(i), int(j)): R.from_rotvec(r) for i, j, r in zip(ei, ej, rel)}
+    adj = {}
+    for a, b in tree:
+        adj.setdefault(a, []).append(b)
+        adj.setdefault(b, []).append(a)
+    root = min(members)
+    Rw = {root: R.identity()}
+    stack = [root]
+    while stack:
+        s_ = stack.pop()
+        for n_ in adj.get(s_, []):
+            if n_ in Rw:
+                continue
+            Rw[n_] = rel_of[(s_, n_)] * Rw[s_] if s_ < n_ else rel_of[(n_, s_)].inv() * Rw[s_]
+            stack.append(n_)
+    assert len(Rw) == len(members)
+    for k in members:
+        d = (R.from_rotvec(np.asarray(o[k])) * Rw[k].inv()).magnitude()
+        assert d < 1e-12, (k, d)
