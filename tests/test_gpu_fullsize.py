@@ -55,14 +55,47 @@ def test_c3_anisotropic_covariances_magsac_against_oracle(oracle):
     assert synth.angular_distance(synth.align_rotations(rd, ro), ro).mean() <= 1e-6
 
 
-def test_c4_fourteen_disconnected_scenes_as_one_problem(oracle):
-    # scene sizes after thirdparty/TheiaSfM/docs/source/performance.rst:94-112 (Trafalgar's 5288 left out for time)
-    sizes = [227, 328, 332, 341, 437, 450, 553, 572, 577, 733, 789, 836, 1084, 2152]
+def _madrid_component(golden_dir):
+    """The one real scene in the tree: Madrid_Metropolis' view graph (394 views / 23 784 edges) with synthetic covariances (the dataset's
+    covariance_rot.txt is a missing blob) and the pipeline's spanning-tree initialisation."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(golden_dir), "..", "globalsfmpy_amd"))
+    import GlobalSfMpy as sfm
+    m = np.load(os.path.join(golden_dir, "madrid_graph.npz"))
+    ids = np.sort(m["view_ids"])
+    idx = {int(v): k for k, v in enumerate(ids)}
+    vg = sfm.ViewGraph()
+    for a_, b_, r_ in zip(m["edge_a"], m["edge_b"], m["rel_aa"]):
+        info = sfm.TwoViewInfo()
+        info.rotation_2 = r_
+        info.num_verified_matches = 1
+        vg.AddEdge(int(a_), int(b_), info)
+    init = sfm.MapViewIdVector3d()
+    sfm.OrientationsFromMaximumSpanningTree(vg, init)
+    rng = np.random.default_rng(7)
+    A = rng.standard_normal((len(m["rel_aa"]), 3, 3))
+    S = (A @ np.transpose(A, (0, 2, 1)) + 0.5 * np.eye(3)) * 3e-8
+    return {"n_cams": len(ids), "edge_i": np.array([idx[int(v)] for v in m["edge_a"]]), "edge_j": np.array([idx[int(v)] for v in m["edge_b"]]),
+            "rel_aa": m["rel_aa"], "cov6": np.stack([S[:, 0, 0], S[:, 1, 1], S[:, 2, 2], S[:, 0, 1], S[:, 0, 2], S[:, 1, 2]], axis=1),
+            "init_aa": np.array([init[int(v)] for v in ids]), "gt_aa": None}
+
+
+def test_c4_fourteen_disconnected_scenes_as_one_problem(oracle, golden_dir):
+    """C4: the 14 1DSfM scenes as ONE disconnected graph.  Only Madrid_Metropolis' graph is in the reference checkout, so it enters as it
+    is; the other thirteen are synthetic graphs with the scenes' camera counts (thirdparty/TheiaSfM/docs/source/performance.rst:78-92),
+    Trafalgar's 5288 included.  The reference's own wrappers initialise only the largest component, so the batch enters through the
+    estimator entry point with a per-component initialisation."""
+    sizes = {"Alamo": 577, "Ellis Island": 227, "Montreal N.D.": 450, "Notre Dame": 553, "NYC Library": 332, "Piazza del Popolo": 328,
+             "Piccadilly": 2152, "Roman Forum": 1084, "Tower of London": 572, "Union Square": 789, "Vienna Cathedral": 836,
+             "Yorkminster": 437, "Trafalgar": 5288}
+    scenes = [synth.make_graph(n, 12 * n, seed=400 + k, outlier_frac=0.1) for k, n in enumerate(sizes.values())]
+    scenes.insert(2, _madrid_component(golden_dir))
+    assert len(scenes) == 14
     parts, off = [], 0
-    for k, n in enumerate(sizes):
-        g = synth.make_graph(n, 12 * n, seed=400 + k, outlier_frac=0.1)
+    for g in scenes:
         parts.append((off, g))
-        off += n
+        off += g["n_cams"]
     N = off
     ei = np.concatenate([g["edge_i"] + o for o, g in parts]).astype(np.uint32)
     ej = np.concatenate([g["edge_j"] + o for o, g in parts]).astype(np.uint32)
@@ -77,13 +110,32 @@ def test_c4_fourteen_disconnected_scenes_as_one_problem(oracle):
     ora.set_loss(loss)
     rd, sd = dev.solve(init)
     ro, so = ora.solve(init)
+    print("C4: %d cameras / %d edges in 14 components: device %d it (%.1f ms), oracle %d it" % (N, len(ei), sd["num_iterations"], sd["t_total_ms"], so["num_iterations"]))
     assert sd["num_iterations"] == so["num_iterations"]
-    assert abs(sd["final_cost"] - so["final_cost"]) <= 1e-8 * so["final_cost"]
-    for o, g in parts:   # every component has its own gauge
+    assert abs(sd["final_cost"] - so["final_cost"]) <= 1e-9 * so["final_cost"]
+    # (disconnected problem: the device's PCG runs at 1e-14, see gsfm_rot_options.cg_relative_tolerance -- at 1e-12 the real Madrid
+    # component, long converged while the batch keeps iterating, ended 3e-5 rad from the oracle)
+    # The oracle's own sensitivity, per component, for the record: the same solve on measurements moved by one ulp.
+    from sensitivity import ulp_perturbed
+    spread = np.zeros(len(parts))
+    op = oracle.OracleProblem(N, ei, ej, ulp_perturbed(rel, np.random.default_rng(0)), _abi.ANGLE_AXIS_COVTRACE, cov6=cov)
+    op.set_loss(loss)
+    rp, _ = op.solve(init)
+    for c, (o, g) in enumerate(parts):
         sl = slice(o, o + g["n_cams"])
-        assert synth.angular_distance(synth.align_rotations(rd[sl], ro[sl]), ro[sl]).mean() <= 1e-6
-        err = synth.angular_distance(synth.align_rotations(rd[sl], g["gt_aa"]), g["gt_aa"])
-        assert np.rad2deg(err.mean()) < 3.0   # accuracy sanity only (Huber, sparse scenes, 10 % outliers)
+        spread[c] = synth.angular_distance(synth.align_rotations(rp[sl], ro[sl]), ro[sl]).mean()
+    worst = 0.0
+    for c, (o, g) in enumerate(parts):   # every component has its own gauge
+        sl = slice(o, o + g["n_cams"])
+        d = synth.angular_distance(synth.align_rotations(rd[sl], ro[sl]), ro[sl]).mean()
+        worst = max(worst, d)
+        print("   component %2d: %4d cameras, mean |dR| device vs oracle %.2e rad, oracle vs oracle(1 ulp) %.2e rad" % (c, g["n_cams"], d, spread[c]))
+        assert d <= 1e-6, (o, g["n_cams"], d, spread[c])
+        if g["gt_aa"] is not None:
+            err = synth.angular_distance(synth.align_rotations(rd[sl], g["gt_aa"]), g["gt_aa"])
+            assert np.rad2deg(err.mean()) < 3.0   # accuracy sanity only (Huber, sparse scenes, 10 % outliers)
+    assert spread.max() <= 1e-6                                               # every component of this batch is well-posed
+    print("C4: worst per-component mean |dR| device vs oracle %.2e rad" % worst)
 
 
 @pytest.fixture(scope="module")
