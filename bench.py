@@ -335,7 +335,7 @@ def main():
                                     traffic=pmc_bytes("k_cost_full"), bytes_per_edge=lay_b + 32.0, sweep_rate_edges_per_s=e_local / (variants["full_reweight"] * 1e-3)),
                 "k_cost_s_only": dict(roof(sweep_bytes + 8.0 * e_local, variants["s_only"]),
                                       kernel="K1 s-only mode: s stored per edge (pass 1 of sigma consensus and of host-callback losses), on this problem's whitened residuals",
-                                      bytes_per_edge=lay_b + 8.0, sweep_rate_edges_per_s=e_local / (variants["s_only"] * 1e-3)),
+                                      traffic=pmc_bytes("k_cost_s_only"), bytes_per_edge=lay_b + 8.0, sweep_rate_edges_per_s=e_local / (variants["s_only"] * 1e-3)),
             }
             if sigma_pass is not None:
                 # ANGLE_AXIS problem: idx 8 + q_rel 32 + scalar weight 8 in, s 8 out; then s 8 + w 8 in/out + 2 x (eid 4 + w gather 8 + store 8) per entry
