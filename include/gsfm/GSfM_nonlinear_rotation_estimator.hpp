@@ -46,7 +46,8 @@ class GSfMNonlinearRotationEstimator : public RotationEstimator {
   void SetCommonTrackCounter(gsfm::CommonTrackCounter f) { common_tracks_ = f; }  // feeds the *_INLIERS types
   const gsfm_rot_summary& LastSummary() const { return summary_; }               // the reference drops ceres' summary
   const char* LastError() const { return error_.c_str(); }
-  gsfm_rot_options* MutableOptions() { options_set_ = true; return &options_; }
+  // solver options of include/gsfm_rot.h (Ceres defaults + this build's linear-solver switches); starts from gsfm_rot_options_default
+  gsfm_rot_options* MutableOptions() { if (!options_set_) { gsfm_rot_options_default(&options_); options_set_ = true; } return &options_; }
 
  private:
   bool Run(const GsfmViewPairs& view_pairs, GsfmOrientations* global_orientations, ceres::LossFunction* loss_function,
