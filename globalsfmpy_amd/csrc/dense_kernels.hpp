@@ -21,6 +21,9 @@ namespace gsfm {
 
 #define GSFM_CB 32
 #define GSFM_TILE_ELEMS (GSFM_CB * GSFM_CB)
+#ifndef GSFM_CHOL_BATCH
+#define GSFM_CHOL_BATCH 8
+#endif
 #define GSFM_DENSE_MAX_T 160   // block rows the backward kernel keeps in LDS: 3N <= 5120
 
 __host__ __device__ inline size_t chol_tile_off(uint32_t i, uint32_t j) { return ((size_t)i * (i + 1) / 2 + j) * GSFM_TILE_ELEMS; }
@@ -83,8 +86,16 @@ __global__ void __launch_bounds__(256) k_chol_step(CholArgs a) {
       const double inv = rsqrt(piv);
       r[c0] = (lane == (uint32_t)c0) ? piv * inv : r[c0] * inv;
       // entries above the diagonal of the diagonal rows (lane < c) are never read by anyone, so they may hold anything
+      // multipliers L[c][c0] (held by lane c) in batches: all v_readlane of a batch first, then the FMAs -- one SGPR-hazard wait per
+      // batch instead of one per multiplier
 #pragma unroll
-      for (int c = c0 + 1; c < GSFM_CB; ++c) r[c] -= r[c0] * readlane_f64(r[c0], c);   // readlane: L[c][c0], held by lane c
+      for (int cb = c0 + 1; cb < GSFM_CB; cb += GSFM_CHOL_BATCH) {
+        double m[GSFM_CHOL_BATCH];
+#pragma unroll
+        for (int q = 0; q < GSFM_CHOL_BATCH; ++q) if (cb + q < GSFM_CB) m[q] = readlane_f64(r[c0], cb + q);
+#pragma unroll
+        for (int q = 0; q < GSFM_CHOL_BATCH; ++q) if (cb + q < GSFM_CB) r[cb + q] -= r[c0] * m[q];
+      }
     }
     if (lane >= 32) {
       double (*P)[GSFM_CB + 1] = wave == 0 ? Pi : Pj;
@@ -122,41 +133,51 @@ __global__ void __launch_bounds__(256) k_chol_step(CholArgs a) {
   for (int q = 0; q < 4; ++q) d[q] = own[q] - acc[q];
 }
 
-// x = L^-T y, one workgroup: block rows bottom-up; y stays in LDS.  Per block: a 32-step substitution in one wavefront (the running
-// right-hand side in lane registers, the solved component broadcast with v_readlane), then every lane folds x_k into the
-// right-hand sides of the block rows above (L_kj tiles are contiguous: block row k of L).
+// x = L^-T y, one workgroup: block rows bottom-up; y stays in LDS.  Software-pipelined: while the other 15 wavefronts fold x_k into the
+// right-hand sides of the block rows j <= k - 2 (L_kj tiles are contiguous: block row k of L) and prefetch the next diagonal tile,
+// wavefront 0 folds x_k into block row k - 1 and runs that block's 32-step substitution (running right-hand side in lane registers,
+// solved components broadcast with v_readlane) -- one barrier per block row.
+__device__ __forceinline__ void chol_back_block(const double (*Lk)[GSFM_CB + 1], double v, uint32_t lane, double* xk_out, double* x, uint32_t g0, uint32_t n) {
+  const uint32_t l = lane & 31;
+  const double rinv = 1.0 / Lk[l][l];   // all reciprocals at once, off the dependent chain
+#pragma unroll
+  for (int t = GSFM_CB - 1; t >= 0; --t) {
+    const double xt = readlane_f64(v * rinv, t);
+    if (l < (uint32_t)t) v -= Lk[t][l] * xt;
+  }
+  if (lane < GSFM_CB) { const double mine = v * rinv; xk_out[lane] = mine; if (g0 + lane < n) x[g0 + lane] = mine; }   // lane t was never modified after step t
+}
 __global__ void __launch_bounds__(1024) k_chol_back(const double* __restrict__ L, uint32_t n, uint32_t T, double* __restrict__ x) {
   __shared__ double y[GSFM_DENSE_MAX_T * GSFM_CB];
-  __shared__ double Lk[GSFM_CB][GSFM_CB + 1];
-  __shared__ double xk[GSFM_CB];
-  const uint32_t tid = threadIdx.x;
+  __shared__ double Lk[2][GSFM_CB][GSFM_CB + 1];
+  __shared__ double xk[2][GSFM_CB];
+  const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   for (uint32_t idx = tid; idx < T * GSFM_CB; idx += 1024) y[idx] = L[chol_tile_off(T, idx / GSFM_CB) + idx % GSFM_CB];
+  Lk[(T - 1) & 1][tid / GSFM_CB][tid % GSFM_CB] = L[chol_tile_off(T - 1, T - 1) + tid];
   __syncthreads();
-  double nxt = L[chol_tile_off(T - 1, T - 1) + tid];
-  for (uint32_t k = T; k-- > 0;) {
-    Lk[tid / GSFM_CB][tid % GSFM_CB] = nxt;
-    __syncthreads();
-    if (k > 0) nxt = L[chol_tile_off(k - 1, k - 1) + tid];   // in flight behind the substitution and the update below
-    if (tid < 64) {
-      const uint32_t lane = tid & 31;
-      double v = y[k * GSFM_CB + lane];
-      const double rinv = 1.0 / Lk[lane][lane];   // all reciprocals at once, off the dependent chain
+  if (wave == 0) chol_back_block(Lk[(T - 1) & 1], y[(T - 1) * GSFM_CB + (lane & 31)], lane, xk[(T - 1) & 1], x, (T - 1) * GSFM_CB, n);
+  if (T >= 2) { const uint32_t e = tid; Lk[T & 1][e / GSFM_CB][e % GSFM_CB] = L[chol_tile_off(T - 2, T - 2) + e]; }   // (T-2) & 1 == T & 1; all lanes incl. wave 0 after its solve
+  __syncthreads();
+  for (uint32_t k = T - 1; k >= 1; --k) {
+    const double* xs = xk[k & 1];                     // x_k
+    if (wave == 0) {
+      // y_{k-1} -= L_{k,k-1}^T x_k (lanes 0..31 by column, lanes 32..63 mirror), then the substitution of block k - 1
+      const double* t = L + chol_tile_off(k, k - 1) + (lane & 31);
+      double s2 = 0.0;
 #pragma unroll
-      for (int t = GSFM_CB - 1; t >= 0; --t) {
-        const double xt = readlane_f64(v * rinv, t);
-        if (lane < (uint32_t)t) v -= Lk[t][lane] * xt;
+      for (int r = 0; r < GSFM_CB; ++r) s2 += t[r * GSFM_CB] * xs[r];
+      const double v = y[(k - 1) * GSFM_CB + (lane & 31)] - s2;
+      chol_back_block(Lk[(k - 1) & 1], v, lane, xk[(k - 1) & 1], x, (k - 1) * GSFM_CB, n);
+    } else {
+      for (uint32_t idx = tid - 64; idx + GSFM_CB < k * GSFM_CB; idx += 960) {   // block rows j <= k - 2
+        const uint32_t j = idx / GSFM_CB, c = idx % GSFM_CB;
+        const double* t = L + chol_tile_off(k, j) + c;
+        double s2 = 0.0;
+#pragma unroll
+        for (int r = 0; r < GSFM_CB; ++r) s2 += t[r * GSFM_CB] * xs[r];
+        y[idx] -= s2;
       }
-      // lane t was never modified after step t: v * rinv is x_t
-      if (tid < GSFM_CB) { const double mine = v * rinv; xk[lane] = mine; const uint32_t g = k * GSFM_CB + lane; if (g < n) x[g] = mine; }
-    }
-    __syncthreads();
-    for (uint32_t idx = tid; idx < k * GSFM_CB; idx += 1024) {
-      const uint32_t j = idx / GSFM_CB, c = idx % GSFM_CB;
-      const double* t = L + chol_tile_off(k, j) + c;
-      double s = 0.0;
-#pragma unroll
-      for (int r = 0; r < GSFM_CB; ++r) s += t[r * GSFM_CB] * xk[r];
-      y[idx] -= s;
+      if (k >= 2) for (uint32_t e = tid - 64; e < GSFM_TILE_ELEMS; e += 960) Lk[k & 1][e / GSFM_CB][e % GSFM_CB] = L[chol_tile_off(k - 2, k - 2) + e];   // diag tile k-2 replaces tile k
     }
     __syncthreads();
   }
