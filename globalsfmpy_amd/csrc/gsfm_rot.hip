@@ -351,13 +351,37 @@ void launch_cache(gsfm_rot_problem* P, const double* x, double2* q) {
   hipLaunchKernelGGL(k_cam_cache, dim3(grid_for(P->n_cams)), dim3(GSFM_BLOCK), 0, P->stream, x, P->n_cams, P->param_dim, q);
 }
 
+// s of every edge this rank holds, by rows (sharded problems): see k_row_s
+int launch_row_s(gsfm_rot_problem* P, const double2* q, double* s_out, bool unit_weights) {
+  RowSArgs ra{};
+  ra.n_rows = P->n_rows; ra.row_base = P->own_begin; ra.G = P->G; ra.row_ptr = P->row_ptr.p; ra.col = P->col.p; ra.eid = P->dir.eid.p;
+  ra.qr0 = P->dir.qr0.p; ra.qr1 = P->dir.qr1.p; ra.w0 = P->dir.w0.p; ra.w1 = P->dir.w1.p; ra.w2 = P->dir.w2.p; ra.ws = P->dir.ws.p; ra.q = q; ra.s_out = s_out;
+  const dim3 grid(grid_for((size_t)P->n_rows * P->G)), blk(GSFM_BLOCK);
+  const int f = P->functor, w = P->wmode;
+#define GSFM_ROWS(F, W, U) hipLaunchKernelGGL((k_row_s<F, W, U>), grid, blk, 0, P->stream, ra)
+  if (f == F_AA && w == W_SCALAR && unit_weights) GSFM_ROWS(F_AA, W_SCALAR, true);
+  else if (f == F_AA && w == W_NONE) GSFM_ROWS(F_AA, W_NONE, false);
+  else if (f == F_AA && w == W_SCALAR) GSFM_ROWS(F_AA, W_SCALAR, false);
+  else if (f == F_AA && w == W_MATRIX) GSFM_ROWS(F_AA, W_MATRIX, false);
+  else if (f == F_QCOS) GSFM_ROWS(F_QCOS, W_NONE, false);
+  else if (f == F_QNORM) GSFM_ROWS(F_QNORM, W_NONE, false);
+  else if (f == F_RFNORM) GSFM_ROWS(F_RFNORM, W_NONE, false);
+  else return fail(GSFM_ERR_UNSUPPORTED, "no kernel for this error type");
+#undef GSFM_ROWS
+  return 0;
+}
+
 // host-callback loss: s per original edge -> host -> rho triples -> device
 int refresh_external_rho(gsfm_rot_problem* P, const double2* q) {
-  CostArgs a{};
-  a.tiles = P->cost_tiles.p; a.direct = P->cost_direct; a.n_cams = P->n_cams; a.n = P->cost.n; a.idx = P->cost_idx.p; a.qr0 = P->cost.qr0.p; a.qr1 = P->cost.qr1.p;
-  a.w0 = P->cost.w0.p; a.w1 = P->cost.w1.p; a.w2 = P->cost.w2.p; a.ws = P->cost.ws.p;
-  a.q = q; a.loss = P->d_loss.p; a.eid = P->cost.eid.p; a.partials = P->part_cost.p; a.s_out = P->s_ext.p; a.s_only = 1;
-  if (dispatch<CostArgs, CostLauncher>(P, a, P->nb_cost)) return fail(GSFM_ERR_UNSUPPORTED, "no kernel for this error type");
+  if (P->sharded) {   // the rows of this rank need rho for every edge it holds, not only for the ones it counts in the cost
+    if (int st = launch_row_s(P, q, P->s_ext.p, false)) return st;
+  } else {
+    CostArgs a{};
+    a.tiles = P->cost_tiles.p; a.direct = P->cost_direct; a.n_cams = P->n_cams; a.n = P->cost.n; a.idx = P->cost_idx.p; a.qr0 = P->cost.qr0.p; a.qr1 = P->cost.qr1.p;
+    a.w0 = P->cost.w0.p; a.w1 = P->cost.w1.p; a.w2 = P->cost.w2.p; a.ws = P->cost.ws.p;
+    a.q = q; a.loss = P->d_loss.p; a.eid = P->cost.eid.p; a.partials = P->part_cost.p; a.s_out = P->s_ext.p; a.s_only = 1;
+    if (dispatch<CostArgs, CostLauncher>(P, a, P->nb_cost)) return fail(GSFM_ERR_UNSUPPORTED, "no kernel for this error type");
+  }
   const size_t E = P->n_edges_in;
   P->h_s.resize(E); P->h_rho.resize(3 * E);
   HIPCHK(hipMemcpyAsync(P->h_s.data(), P->s_ext.p, 8 * E, hipMemcpyDeviceToHost, P->stream));
@@ -1194,7 +1218,6 @@ gsfm_status gsfm_rot_set_loss(gsfm_rot_problem* P, const gsfm_loss_node* prog, i
 
 gsfm_status gsfm_rot_set_loss_callback(gsfm_rot_problem* P, gsfm_loss_callback fn, void* user) {
   if (!P || !fn) return (gsfm_status)fail(GSFM_ERR_INVALID_ARG, "NULL argument");
-  if (P->sharded) return (gsfm_status)fail(GSFM_ERR_UNSUPPORTED, "host-callback losses are not supported on a sharded problem");
   DeviceGuard g(P->device);
   if (!P->rho_ext.p) {
     if (P->rho_ext.alloc(3 * P->n_edges_in) != hipSuccess || P->s_ext.alloc(P->n_edges_in) != hipSuccess)
@@ -1279,10 +1302,7 @@ gsfm_status gsfm_rot_solve_sigma_consensus(gsfm_rot_problem* P, double* rot, int
     ++outer;
     if (int st = upload_state(P, rot)) return (gsfm_status)st;
     if (P->sharded) {   // s of every edge this rank holds (its rows' entries), not only of the edges it counts in the cost
-      RowSArgs ra{};
-      ra.n_rows = P->n_rows; ra.row_base = P->own_begin; ra.G = P->G; ra.row_ptr = P->row_ptr.p; ra.col = P->col.p; ra.eid = P->dir.eid.p;
-      ra.qr0 = P->dir.qr0.p; ra.qr1 = P->dir.qr1.p; ra.q = P->q.p; ra.s_out = P->s_ext.p;
-      hipLaunchKernelGGL(k_row_s, dim3(grid_for((size_t)P->n_rows * P->G)), dim3(GSFM_BLOCK), 0, P->stream, ra);
+      if (int st = launch_row_s(P, P->q.p, P->s_ext.p, true)) return (gsfm_status)st;
     } else {  // K6 = K1 in s-only mode with unit weights: s_e = ||log(R_j R_i^T R_ij^T)||^2  (:378-398)
       CostArgs a{};
       a.tiles = P->cost_tiles.p; a.direct = P->cost_direct; a.n_cams = P->n_cams; a.n = P->cost.n; a.idx = P->cost_idx.p; a.qr0 = P->cost.qr0.p; a.qr1 = P->cost.qr1.p; a.ws = P->cost.ws.p;

@@ -418,34 +418,43 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_edge_sweep(EdgeSweepArgs a) {
   }
 }
 
-// sigma consensus on a sharded problem: the unweighted s = |log(R_j R_i^T R_ij^T)|^2 of EVERY edge this rank holds (each touches one of
-// its rows), written per local edge.  Same device routine as K1's s-only mode, so the weights equal the single-GPU ones bit for bit.
+// s = |r_e|^2 of EVERY edge a rank holds (each touches one of its rows), written per local edge, by rows of the block-CSR: on a sharded
+// problem the cost sweep K1 only visits the edges a rank counts in the cost, but sigma consensus (unit weights, UNIT = true) and
+// host-callback losses (the problem's own whitening) need s for both ends' rows.  Same device routine as K1, so two ranks holding the
+// same edge -- and the single-GPU sweep -- produce the same bits.
 struct RowSArgs {
   uint32_t n_rows, row_base, G;
   const uint32_t* row_ptr;
   const uint32_t* col;
   const uint32_t* eid;
   const double2 *qr0, *qr1;
+  const double2 *w0, *w1, *w2;
+  const double* ws;
   const double2* q;
   double* s_out;          // per local edge
 };
+template <int F, int WM, bool UNIT>
 __global__ void __launch_bounds__(GSFM_BLOCK) k_row_s(RowSArgs a) {
+  constexpr int R = ResDim<F>::R;
   const uint32_t t = blockIdx.x * GSFM_BLOCK + threadIdx.x;
   const uint32_t row = t / a.G, lane = t % a.G;
   if (row >= a.n_rows) return;
   const Quat qk = load_q(a.q, a.row_base + row);
-  EdgeW W;
-  W.l00 = 1.0; W.l01 = W.l02 = W.l12 = 0.0; W.l11 = W.l22 = 1.0;
   const uint32_t end = a.row_ptr[row + 1];
   for (uint32_t d = a.row_ptr[row] + lane; d < end; d += a.G) {
     const uint32_t cr = a.col[d];
     const Quat qm = load_q(a.q, cr & 0x7fffffffu);
     const double2 r0 = a.qr0[d], r1 = a.qr1[d];
     const Quat qr{r0.x, r0.y, r1.x, r1.y};
-    double r[3];
-    if (cr >> 31) edge_residual<F_AA, W_SCALAR>(qm, qk, qr, W, r);
-    else edge_residual<F_AA, W_SCALAR>(qk, qm, qr, W, r);
-    a.s_out[a.eid[d]] = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
+    EdgeW W = load_w<WM>(a.w0, a.w1, a.w2, a.ws, d);
+    if (UNIT) W.l00 = 1.0;
+    double r[R];
+    if (cr >> 31) edge_residual<F, WM>(qm, qk, qr, W, r);
+    else edge_residual<F, WM>(qk, qm, qr, W, r);
+    double s = 0.0;
+#pragma unroll
+    for (int c = 0; c < R; ++c) s += r[c] * r[c];
+    a.s_out[a.eid[d]] = s;
   }
 }
 

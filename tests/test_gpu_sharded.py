@@ -86,6 +86,22 @@ def test_sigma_consensus_on_a_sharded_problem(tmp_path, world):
     assert synth.angular_distance(synth.align_rotations(res["rot"], rot), rot).mean() <= 1e-6
 
 
+def test_host_callback_loss_on_a_sharded_problem(tmp_path):
+    """A Python loss without a native descriptor (the reference's trampoline case, bind_src/GlobalSfMpy.cpp:33-65) on two ranks: each rank
+    evaluates it for every edge it holds, from bitwise identical s."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from sharded_worker import python_only_loss
+    from globalsfmpy_amd.solver import RotationProblem
+    g = synth.make_graph(1203, 40000, seed=23, outlier_frac=0.3)
+    p = RotationProblem(g["n_cams"], g["edge_i"], g["edge_j"], g["rel_aa"], _abi.ANGLE_AXIS_COVARIANCE, cov6=g["cov6"])
+    p.set_loss_callback(python_only_loss)
+    rot, s = p.solve(g["init_aa"], max_num_iterations=6, dense_cholesky_max_cams=0)
+    res = _launch(2, "gloo", str(tmp_path / "callback.npz"), case="callback")
+    assert int(res["iters"]) == s["num_iterations"] and int(res["term"]) == s["termination"]
+    assert abs(float(res["cost"]) - s["final_cost"]) <= 1e-9 * s["final_cost"]
+    assert synth.angular_distance(synth.align_rotations(res["rot"], rot), rot).mean() <= 1e-6
+
+
 def test_forced_single_rank_shard_over_rccl(tmp_path):
     res = _launch(1, "nccl", str(tmp_path / "nccl1.npz"), {"GSFM_FORCE_SHARD": "1"})
     _compare(res, _reference())
