@@ -14,33 +14,33 @@ import GlobalSfMpy as sfm  # noqa: E402
 from globalsfmpy_amd.loss_functions import *  # noqa: E402,F401,F403
 
 
-def sfm_pipeline(flagfile, dataset_path, loss_func, rotation_error_type, use1DSfM=True):
-    if use1DSfM:
-        options = sfm.ReconstructionBuilderOptions()
+def sfm_pipeline(flagfile, dataset_dir, robust_loss, error_type, use1DSfM=True):
+    """Rotation-only run.  Returns (reconstruction with the estimated orientations, the estimator for its summary)."""
+    def options():
+        o = sfm.ReconstructionBuilderOptions()
         if flagfile:
-            sfm.load_1DSFM_config(flagfile, options)
-        reconstruction = sfm.Reconstruction()
-        view_graph = sfm.ViewGraph()
-        rot_covariances = sfm.MapEdgesCovariance()
-        sfm.Read1DSFM(dataset_path, reconstruction, view_graph, rot_covariances)
-        reconstruction_builder = sfm.ReconstructionBuilder(options, reconstruction, view_graph)
-    else:  # COLMAP export: two_views.txt + images/ + covariance_rot.txt (sfm_pipeline.py:38-47)
-        database = sfm.FeaturesAndMatchesDatabase(dataset_path + "/database")
-        options = sfm.ReconstructionBuilderOptions()
-        if flagfile:
-            sfm.load_1DSFM_config(flagfile, options)
-        rot_covariances = sfm.MapEdgesCovariance()
-        sfm.ReadCovariance(dataset_path, rot_covariances)
-        reconstruction_builder = sfm.ReconstructionBuilder(options, database)
-        sfm.AddColmapMatchesToReconstructionBuilder(dataset_path + "/two_views.txt", dataset_path + "/images/*.JPG", reconstruction_builder)
-    reconstruction_builder.CheckView()
-    view_graph = reconstruction_builder.get_view_graph()
-    reconstruction = reconstruction_builder.get_reconstruction()
-    estimator = sfm.GlobalReconstructionEstimator(options.reconstruction_estimator_options)
-    estimator.FilterInitialViewGraphAndCalibrateCameras(view_graph, reconstruction)
-    assert estimator.EstimateGlobalRotationsUncertainty(loss_func, rot_covariances, rotation_error_type), estimator.LastError()
-    sfm.SetOrientations(estimator.orientations, reconstruction)
-    return reconstruction, estimator
+            sfm.load_1DSFM_config(flagfile, o)
+        return o
+
+    if use1DSfM:   # EGs.txt + cc.txt (+ tracks) and covariance_rot.txt in one directory
+        opts = options()
+        scene, graph, edge_cov = sfm.Reconstruction(), sfm.ViewGraph(), sfm.MapEdgesCovariance()
+        sfm.Read1DSFM(dataset_dir, scene, graph, edge_cov)
+        builder = sfm.ReconstructionBuilder(opts, scene, graph)
+    else:          # COLMAP export: two_views.txt + images/ + covariance_rot.txt (sfm_pipeline.py:38-47)
+        store = sfm.FeaturesAndMatchesDatabase(dataset_dir + "/database")
+        opts = options()
+        edge_cov = sfm.MapEdgesCovariance()
+        sfm.ReadCovariance(dataset_dir, edge_cov)
+        builder = sfm.ReconstructionBuilder(opts, store)
+        sfm.AddColmapMatchesToReconstructionBuilder(dataset_dir + "/two_views.txt", dataset_dir + "/images/*.JPG", builder)
+    builder.CheckView()
+    graph, scene = builder.get_view_graph(), builder.get_reconstruction()
+    solver = sfm.GlobalReconstructionEstimator(opts.reconstruction_estimator_options)
+    solver.FilterInitialViewGraphAndCalibrateCameras(graph, scene)
+    assert solver.EstimateGlobalRotationsUncertainty(robust_loss, edge_cov, error_type), solver.LastError()
+    sfm.SetOrientations(solver.orientations, scene)
+    return scene, solver
 
 
 if __name__ == "__main__":
@@ -49,7 +49,8 @@ if __name__ == "__main__":
     sfm.InitGlog(0, True, "./log")
     if not os.path.exists(os.path.join(dataset, "covariance_rot.txt")):  # sfm_pipeline.py:136-137
         print("covariance_rot.txt missing: estimating per-edge covariances on the device:", sfm.CalcCovariance(dataset))
-    rec, est = sfm_pipeline(flags, dataset, MAGSACWeightBasedLoss(0.02), sfm.RotationErrorType.ANGLE_AXIS_COVARIANCE)  # noqa: F405
-    print("estimated %d orientations; solver summary: %s" % (len(rec.EstimatedOrientations()), est.LastSummary()))
-    sfm.WriteReconstruction(rec, os.path.join(dataset, "rotations_out.txt"))
+    scene, solver = sfm_pipeline(flags, dataset, MAGSACWeightBasedLoss(0.02), sfm.RotationErrorType.ANGLE_AXIS_COVARIANCE)  # noqa: F405
+    print("estimated %d orientations; solver summary: %s" % (len(scene.EstimatedOrientations()), solver.LastSummary()))
+    sfm.WriteReconstruction(scene, os.path.join(dataset, "rotations_out.txt"))
+    sfm.WritePlyFile(os.path.join(dataset, "rotations_out.ply"), scene, 2)   # sfm_pipeline.py:146
     sfm.StopGlog()
