@@ -82,6 +82,20 @@ def cpu_baseline(args, loss_ctor, error_type):
                   "%d sweeps, %d LM iterations, %.1f s" % (args.cpu_sample_cams, args.cpu_sample_edges, args.outliers,
                                                            s["num_residual_sweeps"], s["num_iterations"], dt),
     }
+    ceres_bin = os.path.join(ROOT, "tools", "bench_ceres", "build", "bench_ceres")
+    if os.path.exists(ceres_bin):   # optional target: only on a box that has Ceres + Eigen; never in this image
+        import subprocess
+        import tempfile
+        try:
+            with tempfile.TemporaryDirectory() as td:
+                gb = os.path.join(td, "graph.bin")
+                subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "bench_ceres", "dump_graph.py"), str(args.cpu_single_cams or 10000),
+                                       str(args.cpu_single_edges or 1000000), gb, str(args.seed + 1), str(args.outliers)], stdout=subprocess.DEVNULL)
+                line = subprocess.run([ceres_bin, gb, str(cores)], capture_output=True, text=True, timeout=1800).stdout.strip().splitlines()[-1]
+                out["ceres"] = json.loads(line)
+                out["ceres"]["sample"] = "this build's own functors on the Ceres API (tools/bench_ceres), SPARSE_NORMAL_CHOLESKY, same generator"
+        except Exception as e:  # noqa: BLE001
+            out["ceres"] = {"error": repr(e)}
     if args.cpu_single_cams > 0:
         r1, s1, dt1 = timed(args.cpu_single_cams, args.cpu_single_edges, 1)
         out["single_thread"] = {"value": r1, "unit": "edge-residuals/s", "cores": 1,
