@@ -39,8 +39,8 @@ def parse():
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
     ap.add_argument("--sweep-reps", type=int, default=20)
     ap.add_argument("--cpu-baseline", type=int, default=1)
-    ap.add_argument("--cpu-sample-cams", type=int, default=50000)
-    ap.add_argument("--cpu-sample-edges", type=int, default=5000000)
+    ap.add_argument("--cpu-sample-cams", type=int, default=0, help="0 = the benchmark graph itself (same cameras, edges and seed)")
+    ap.add_argument("--cpu-sample-edges", type=int, default=0)
     ap.add_argument("--cpu-single-cams", type=int, default=10000, help="1-thread CPU sample (0 = skip)")
     ap.add_argument("--cpu-single-edges", type=int, default=1000000)
     ap.add_argument("--verbose", type=int, default=0)
@@ -49,28 +49,31 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(args, loss_ctor, error_type):
+def cpu_baseline(args, loss_ctor, error_type, device_rot=None, device_summary=None):
     """The CPU oracle (restatement of the reference's Ceres path) timed on this host's cores on a
     bounded sample of the same workload: same generator and mean degree, fewer cameras/edges.  SURVEY 8d asks for
     one thread and for all host cores: the all-cores figure is `value`, the 1-thread one rides along."""
     from globalsfmpy_amd import synth
     from oracle import pyoracle
 
-    def timed(n_cams, n_edges, threads):
-        g = synth.make_graph(n_cams, n_edges, args.seed + 1, outlier_frac=args.outliers)
+    def timed(n_cams, n_edges, threads, seed):
+        g = synth.make_graph(n_cams, n_edges, seed, outlier_frac=args.outliers)
         p = pyoracle.OracleProblem(g["n_cams"], g["edge_i"], g["edge_j"], g["rel_aa"], error_type, cov6=g["cov6"])
         p.set_loss(loss_ctor())
         prev = pyoracle.lib().orc_set_num_threads(threads)
         try:
             t0 = time.perf_counter()
-            _, s = p.solve(g["init_aa"])
+            r, s = p.solve(g["init_aa"])
             dt = time.perf_counter() - t0
         finally:
             pyoracle.lib().orc_set_num_threads(prev)
+        s["rotations"] = r
         return n_edges * s["num_residual_sweeps"] / dt, s, dt
 
     cores = pyoracle.usable_cores()   # affinity mask capped by the cgroup CPU quota
-    rate, s, dt = timed(args.cpu_sample_cams, args.cpu_sample_edges, cores)
+    same = args.cpu_sample_cams <= 0 or args.cpu_sample_edges <= 0
+    sc, se = (args.cams, args.edges) if same else (args.cpu_sample_cams, args.cpu_sample_edges)
+    rate, s, dt = timed(sc, se, cores, args.seed if same else args.seed + 1)
     out = {
         "value": rate,
         "unit": "edge-residuals/s",
@@ -78,10 +81,16 @@ def cpu_baseline(args, loss_ctor, error_type):
         "kind": "port",
         "host": "%d hardware threads visible, %d usable under the cgroup CPU quota" % (os.cpu_count() or 0, cores),
         "sample": "oracle/ (C++ restatement of the reference's Ceres LM path, OpenMP over edges, PCG 1e-14): "
-                  "1 full solve of a %d-camera / %d-edge graph from the same generator (same mean degree, %g outliers), "
-                  "%d sweeps, %d LM iterations, %.1f s" % (args.cpu_sample_cams, args.cpu_sample_edges, args.outliers,
-                                                           s["num_residual_sweeps"], s["num_iterations"], dt),
+                  "1 full solve of %s (%d cameras / %d edges, %g outliers), %d sweeps, %d LM iterations, %.1f s"
+                  % ("THE BENCHMARK GRAPH itself, same seed" if same else "a smaller graph from the same generator (same mean degree)", sc, se, args.outliers,
+                     s["num_residual_sweeps"], s["num_iterations"], dt),
+        "final_cost": s["final_cost"],
     }
+    if same and device_rot is not None:   # the same problem was just solved on the device: the oracle doubles as the full-size parity check
+        d = synth.angular_distance(synth.align_rotations(device_rot, s["rotations"]), s["rotations"])
+        out["device_vs_cpu"] = {"mean_angular_difference_rad": float(d.mean()), "max_angular_difference_rad": float(d.max()),
+                                "final_cost_relative_difference": abs(device_summary["final_cost"] - s["final_cost"]) / s["final_cost"],
+                                "lm_iterations_device": device_summary["num_iterations"], "lm_iterations_cpu": s["num_iterations"]}
     ceres_bin = os.path.join(ROOT, "tools", "bench_ceres", "build", "bench_ceres")
     if os.path.exists(ceres_bin):   # optional target: only on a box that has Ceres + Eigen; never in this image
         import subprocess
@@ -97,7 +106,7 @@ def cpu_baseline(args, loss_ctor, error_type):
         except Exception as e:  # noqa: BLE001
             out["ceres"] = {"error": repr(e)}
     if args.cpu_single_cams > 0:
-        r1, s1, dt1 = timed(args.cpu_single_cams, args.cpu_single_edges, 1)
+        r1, s1, dt1 = timed(args.cpu_single_cams, args.cpu_single_edges, 1, args.seed + 1)
         out["single_thread"] = {"value": r1, "unit": "edge-residuals/s", "cores": 1,
                                 "sample": "same oracle, OpenMP pinned to 1 thread: %d cameras / %d edges, %d sweeps, %.1f s"
                                           % (args.cpu_single_cams, args.cpu_single_edges, s1["num_residual_sweeps"], dt1)}
@@ -362,7 +371,7 @@ def main():
         if small is not None:
             out["small_graph_ms"] = small
         if args.cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(args, loss_ctor, error_type)
+            out["cpu_baseline"] = cpu_baseline(args, loss_ctor, error_type, rot, summ)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -12,7 +12,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <sched.h>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/gsfm_rot.h"
@@ -54,6 +56,45 @@ const char* no_device_reason(const char* who) {
       return (gsfm_status)fail(GSFM_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));  \
     }                                                                                             \
   } while (0)
+
+// Host threads for the one-off structure build of gsfm_rot_problem_create: the affinity mask capped by the cgroup CPU quota (the GPU
+// boxes show 256 hardware threads under a quota of 16; oversubscribing that is far slower than one thread) and by 16.
+int host_threads() {
+  if (const char* e = getenv("GSFM_HOST_THREADS")) { const int v = atoi(e); if (v >= 1) return std::min(v, 64); }
+  long n = (long)std::thread::hardware_concurrency();
+  if (n <= 0) n = 1;
+  cpu_set_t set;
+  if (sched_getaffinity(0, sizeof(set), &set) == 0) n = std::min<long>(n, CPU_COUNT(&set));
+  if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+    char q[64]; long period = 0;
+    if (fscanf(f, "%63s %ld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) n = std::min<long>(n, std::max<long>(1, (atol(q) + period / 2) / period));
+    fclose(f);
+  }
+  return (int)std::max<long>(1, std::min<long>(n, 16));
+}
+// body(t, T) on T threads (T - 1 spawned + the caller)
+template <typename F> void parallel_run(int T, F body) {
+  if (T <= 1) { body(0, 1); return; }
+  std::vector<std::thread> th;
+  for (int t = 1; t < T; ++t) th.emplace_back([&body, t, T] { body(t, T); });
+  body(0, T);
+  for (auto& x : th) x.join();
+}
+
+// counts[k + 1] += number of items with key(u) == k, u in [0, n): per-thread histograms over contiguous item ranges, summed in thread order
+template <typename K> void parallel_count(int T, size_t n, size_t n_keys, K key, uint32_t* counts_plus_one) {
+  if (T <= 1 || n < 200000) { for (size_t u = 0; u < n; ++u) counts_plus_one[key(u)]++; return; }
+  std::vector<std::vector<uint32_t>> h((size_t)T);
+  parallel_run(T, [&](int t, int TT) {
+    h[t].assign(n_keys, 0);
+    const size_t lo = n * t / TT, hi = n * (t + 1) / TT;
+    for (size_t u = lo; u < hi; ++u) h[t][key(u)]++;
+  });
+  parallel_run(T, [&](int t, int TT) {
+    const size_t lo = n_keys * t / TT, hi = n_keys * (t + 1) / TT;
+    for (size_t k = lo; k < hi; ++k) { uint32_t c = 0; for (int w = 0; w < TT; ++w) c += h[w][k]; counts_plus_one[k] += c; }
+  });
+}
 
 double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
@@ -996,10 +1037,22 @@ gsfm_status gsfm_rot_problem_create(uint32_t n_cams, uint64_t n_edges, const uin
   const uint32_t ob = P->own_begin, oe = P->own_end;
   auto owned = [&](uint32_t c) { return c >= ob && c < oe; };
   std::vector<uint32_t> rp, cost_eid, col, deid;
+  const int n_host_threads = host_threads();
   auto build_rows = [&]() -> int {
     rp.assign((size_t)P->n_rows + 1, 0);
     cost_eid.clear();
     cost_eid.reserve(P->sharded ? n_edges / 2 + 16 : n_edges);
+    if (!P->sharded && n_edges >= 200000 && n_host_threads > 1) {   // one GPU: every camera and every edge is owned; count on all threads
+      std::vector<int> bad((size_t)n_host_threads, 0);
+      parallel_run(n_host_threads, [&](int t, int T) {
+        const uint64_t lo = n_edges * t / T, hi = n_edges * (t + 1) / T;
+        for (uint64_t e = lo; e < hi; ++e) if (edge_i[e] >= n_cams || edge_j[e] >= n_cams || edge_i[e] == edge_j[e]) { bad[t] = 1; break; }
+      });
+      for (int b : bad) if (b) return fail(GSFM_ERR_INVALID_ARG, "edge with an out-of-range or repeated camera index");
+      parallel_count(n_host_threads, 2 * n_edges, n_cams, [&](size_t u) { return (u & 1) ? edge_j[u >> 1] : edge_i[u >> 1]; }, rp.data() + 1);
+      cost_eid.resize(n_edges);
+      for (uint64_t e = 0; e < n_edges; ++e) cost_eid[e] = (uint32_t)e;
+    } else
     for (uint64_t e = 0; e < n_edges; ++e) {
       const uint32_t i = edge_i[e], j = edge_j[e];
       if (i >= n_cams || j >= n_cams || i == j) return fail(GSFM_ERR_INVALID_ARG, "edge with an out-of-range or repeated camera index");
@@ -1012,12 +1065,24 @@ gsfm_status gsfm_rot_problem_create(uint32_t n_cams, uint64_t n_edges, const uin
     }
     for (size_t r = 0; r < P->n_rows; ++r) rp[r + 1] += rp[r];
     col.resize(rp[P->n_rows]); deid.resize(rp[P->n_rows]);
+    // Fill: the random writes into col / deid (8 B per directed entry) are what costs.  Every thread streams over all edges and fills only
+    // the rows of its own contiguous range (ranges balanced by entry count), so each row still receives its entries in edge order:
+    // the result is identical to the serial loop for any thread count.
     std::vector<uint32_t> fill(rp.begin(), rp.end() - 1);
-    for (uint64_t e = 0; e < n_edges; ++e) {
-      const uint32_t i = edge_i[e], j = edge_j[e];
-      if (owned(i)) { const uint32_t d = fill[i - ob]++; col[d] = j; deid[d] = (uint32_t)e; }
-      if (owned(j)) { const uint32_t d = fill[j - ob]++; col[d] = i | 0x80000000u; deid[d] = (uint32_t)e; }
-    }
+    const int T = n_edges >= 200000 ? n_host_threads : 1;
+    std::vector<uint32_t> cut((size_t)T + 1, 0);
+    for (int t = 1; t < T; ++t) cut[t] = (uint32_t)(std::lower_bound(rp.begin(), rp.end(), (uint32_t)((uint64_t)rp[P->n_rows] * t / T)) - rp.begin());
+    cut[T] = P->n_rows;
+    for (int t = 1; t <= T; ++t) cut[t] = std::max(cut[t], cut[t - 1]);
+    parallel_run(T, [&](int t, int) {
+      const uint32_t lo = ob + cut[t], hi = ob + cut[t + 1];
+      if (lo >= hi) return;
+      for (uint64_t e = 0; e < n_edges; ++e) {
+        const uint32_t i = edge_i[e], j = edge_j[e];
+        if (i >= lo && i < hi) { const uint32_t d = fill[i - ob]++; col[d] = j; deid[d] = (uint32_t)e; }
+        if (j >= lo && j < hi) { const uint32_t d = fill[j - ob]++; col[d] = i | 0x80000000u; deid[d] = (uint32_t)e; }
+      }
+    });
     return 0;
   };
   if (int st = build_rows()) return bail(st);
@@ -1066,9 +1131,20 @@ gsfm_status gsfm_rot_problem_create(uint32_t n_cams, uint64_t n_edges, const uin
   {
     const size_t Ec = cost_eid.size();
     std::vector<uint32_t> tmp(Ec), cnt((size_t)n_cams + 1, 0);
-    for (size_t t = 0; t < Ec; ++t) cnt[edge_i[cost_eid[t]] + 1]++;
+    parallel_count(n_host_threads, Ec, n_cams, [&](size_t u) { return edge_i[cost_eid[u]]; }, cnt.data() + 1);
     for (size_t c = 0; c < n_cams; ++c) cnt[c + 1] += cnt[c];
-    for (size_t t = 0; t < Ec; ++t) tmp[cnt[edge_i[cost_eid[t]]]++] = cost_eid[t];
+    {  // stable scatter by `first`, threads own contiguous key ranges (balanced by count): same result as the serial loop
+      const int T = Ec >= 200000 ? n_host_threads : 1;
+      std::vector<uint32_t> kc((size_t)T + 1, 0);
+      for (int t = 1; t < T; ++t) kc[t] = (uint32_t)(std::lower_bound(cnt.begin(), cnt.end(), (uint32_t)((uint64_t)Ec * t / T)) - cnt.begin());
+      kc[T] = n_cams;
+      for (int t = 1; t <= T; ++t) kc[t] = std::max(kc[t], kc[t - 1]);
+      parallel_run(T, [&](int t, int) {
+        const uint32_t lo = kc[t], hi = kc[t + 1];
+        if (lo >= hi) return;
+        for (size_t u = 0; u < Ec; ++u) { const uint32_t k = edge_i[cost_eid[u]]; if (k >= lo && k < hi) tmp[cnt[k]++] = cost_eid[u]; }
+      });
+    }
     const uint64_t nblk = ((uint64_t)n_cams + GSFM_CAMBLOCK - 1) / GSFM_CAMBLOCK;
     auto tile_of = [&](uint32_t e) { return (uint64_t)(edge_i[e] / GSFM_CAMBLOCK) * nblk + edge_j[e] / GSFM_CAMBLOCK; };
     // The bucket table has nblk^2 entries: beyond 4096 camera blocks (8.4M cameras) the edges simply stay ordered by
@@ -1077,10 +1153,25 @@ gsfm_status gsfm_rot_problem_create(uint32_t n_cams, uint64_t n_edges, const uin
     std::vector<size_t> tstart(bucketed ? nblk * nblk + 1 : 1, 0);
     size_t populated = 0;
     if (bucketed) {
-      for (size_t t = 0; t < Ec; ++t) tstart[tile_of(tmp[t]) + 1]++;
-      for (uint64_t b = 0; b < nblk * nblk; ++b) tstart[b + 1] += tstart[b];
+      {
+        std::vector<uint32_t> tc(nblk * nblk + 1, 0);
+        parallel_count(n_host_threads, Ec, nblk * nblk, [&](size_t u) { return tile_of(tmp[u]); }, tc.data() + 1);
+        for (uint64_t b = 0; b < nblk * nblk; ++b) tstart[b + 1] = tstart[b] + tc[b + 1];
+      }
       std::vector<size_t> fillt(tstart.begin(), tstart.end() - 1);
-      for (size_t t = 0; t < Ec; ++t) cost_eid[fillt[tile_of(tmp[t])]++] = tmp[t];
+      {  // stable scatter by tile, threads own contiguous tile ranges
+        const int T = Ec >= 200000 ? n_host_threads : 1;
+        const uint64_t nt = nblk * nblk;
+        std::vector<uint64_t> kc((size_t)T + 1, 0);
+        for (int t = 1; t < T; ++t) kc[t] = (uint64_t)(std::lower_bound(tstart.begin(), tstart.end(), (size_t)((uint64_t)Ec * t / T)) - tstart.begin());
+        kc[T] = nt;
+        for (int t = 1; t <= T; ++t) kc[t] = std::min<uint64_t>(nt, std::max(kc[t], kc[t - 1]));
+        parallel_run(T, [&](int t, int) {
+          const uint64_t lo = kc[t], hi = kc[t + 1];
+          if (lo >= hi) return;
+          for (size_t u = 0; u < Ec; ++u) { const uint64_t k = tile_of(tmp[u]); if (k >= lo && k < hi) cost_eid[fillt[k]++] = tmp[u]; }
+        });
+      }
       for (uint64_t b = 0; b < nblk * nblk; ++b) populated += tstart[b + 1] > tstart[b];
     } else {
       cost_eid = tmp;
@@ -1109,8 +1200,11 @@ gsfm_status gsfm_rot_problem_create(uint32_t n_cams, uint64_t n_edges, const uin
   }
   std::vector<uint2> cidx(cost_eid.size());
   const uint32_t idx_mod = P->cost_direct ? 0xffffffffu : (uint32_t)GSFM_CAMBLOCK;   // global or block-local camera indices
-  for (size_t t = 0; t < cost_eid.size(); ++t)
-    cidx[t] = P->cost_direct ? make_uint2(edge_i[cost_eid[t]], edge_j[cost_eid[t]]) : make_uint2(edge_i[cost_eid[t]] % idx_mod, edge_j[cost_eid[t]] % idx_mod);
+  parallel_run(cost_eid.size() >= 200000 ? n_host_threads : 1, [&](int t, int T) {
+    const size_t lo = cost_eid.size() * t / T, hi = cost_eid.size() * (t + 1) / T;
+    for (size_t u = lo; u < hi; ++u)
+      cidx[u] = P->cost_direct ? make_uint2(edge_i[cost_eid[u]], edge_j[cost_eid[u]]) : make_uint2(edge_i[cost_eid[u]] % idx_mod, edge_j[cost_eid[u]] % idx_mod);
+  });
   P->h_cost_eid = cost_eid;
 
   lap("cost tiles");
@@ -1134,8 +1228,11 @@ gsfm_status gsfm_rot_problem_create(uint32_t n_cams, uint64_t n_edges, const uin
   {  // K0 whitening
     DevBuf<double> d_cov, d_inl;
     if (P->wmode != W_NONE) {
-      if (cov6 && need_cov) { std::vector<double> t(cov6, cov6 + 6 * n_edges); if (d_cov.upload(t) != hipSuccess) return bail(fail(GSFM_ERR_HIP, "upload cov6")); }
-      if (inlier_weight && need_inl) { std::vector<double> t(inlier_weight, inlier_weight + n_edges); if (d_inl.upload(t) != hipSuccess) return bail(fail(GSFM_ERR_HIP, "upload inlier weights")); }
+      // straight from the caller's arrays (no staging copy: cov6 is 48 B per edge)
+      if (cov6 && need_cov && (d_cov.alloc(6 * n_edges) != hipSuccess || (n_edges && hipMemcpy(d_cov.p, cov6, 48 * n_edges, hipMemcpyHostToDevice) != hipSuccess)))
+        return bail(fail(GSFM_ERR_HIP, "upload cov6"));
+      if (inlier_weight && need_inl && (d_inl.alloc(n_edges) != hipSuccess || (n_edges && hipMemcpy(d_inl.p, inlier_weight, 8 * n_edges, hipMemcpyHostToDevice) != hipSuccess)))
+        return bail(fail(GSFM_ERR_HIP, "upload inlier weights"));
       run_whiten(P, P->cost, d_cov.p, d_inl.p);
       run_whiten(P, P->dir, d_cov.p, d_inl.p);
       if (hipStreamSynchronize(P->stream) != hipSuccess) return bail(fail(GSFM_ERR_HIP, "whitening kernel failed"));

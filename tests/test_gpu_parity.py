@@ -382,3 +382,21 @@ def test_laplacian_form_equals_the_general_blocks(graph, et, monkeypatch):
     assert s1["num_iterations"] == s0["num_iterations"] and s1["termination"] == s0["termination"]
     assert abs(s1["final_cost"] - s0["final_cost"]) < 1e-9 * s0["final_cost"]
     assert synth.angular_distance(r1, r0).max() < 1e-9
+
+
+def test_threaded_structure_build_is_invisible(monkeypatch):
+    """gsfm_rot_problem_create builds the block-CSR rows and the cost-edge tiles with several host threads on large inputs: every thread
+    owns a contiguous range of rows / keys and fills it in edge order, so the structure -- and every bit of the solve -- equals the
+    single-threaded build."""
+    from globalsfmpy_amd.solver import RotationProblem
+    g = synth.make_graph(5000, 300000, seed=31, outlier_frac=0.2)
+    outs = []
+    for threads in ("1", "7", "16"):
+        monkeypatch.setenv("GSFM_HOST_THREADS", threads)
+        p = RotationProblem(g["n_cams"], g["edge_i"], g["edge_j"], g["rel_aa"], _abi.ANGLE_AXIS_COVARIANCE, cov6=g["cov6"])
+        p.set_loss(LF.MAGSACWeightBasedLoss(0.02))
+        r, s = p.solve(g["init_aa"])
+        outs.append((r, s["final_cost"], s["num_cg_iterations"], p.residuals(g["init_aa"])["s"]))
+        p.close()
+    for r, c, n, sq in outs[1:]:
+        assert np.array_equal(r, outs[0][0]) and c == outs[0][1] and n == outs[0][2] and np.array_equal(sq, outs[0][3])
