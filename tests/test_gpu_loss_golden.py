@@ -100,3 +100,23 @@ def test_star_graph_feeds_the_same_rows_through_the_residual_sweep(golden_dir, o
         # rho' is Lipschitz in s away from the cell edges: 1e-14 in s -> <= 1e-10 here
         assert np.allclose(out["rho"], rows[:, 1:], rtol=1e-9, atol=1e-13 * np.abs(rows[:, 1:]).max()), cls
         assert math.isclose(out["cost"], 0.5 * rows[:, 1].sum(), rel_tol=1e-9)
+
+
+def test_theia_residual_known_answers_through_the_device(golden_dir):
+    """Theia's pairwise_rotation_error_test.cc:87-139 (the only residual-level vectors the reference tree holds), through the device: a
+    two-camera problem per case, residual read back with gsfm_rot_residuals (the scalar weight enters as an ANGLE_AXIS_INLIERS weight),
+    Theia's own tolerance 1e-12.  The squared norm also comes out of the stand-alone edge sweep (gsfm_rot_edge_sq_norms)."""
+    from globalsfmpy_amd import solver
+    kats = json.load(open(os.path.join(golden_dir, "residual_kats.json")))
+    assert len(kats["cases"]) >= 4
+    for c in kats["cases"]:
+        rot = np.array([c["rotation1"], c["rotation2"]], dtype=np.float64)
+        rel = np.array([c["relative_rotation"]], dtype=np.float64)
+        p = RotationProblem(2, [0], [1], rel, _abi.ANGLE_AXIS_INLIERS, inlier_weight=np.array([c["weight"]]))
+        out = p.residuals(rot, want_residuals=True)
+        want = np.asarray(c["expected"], dtype=np.float64)
+        assert np.abs(out["residuals"][0] - want).max() < kats["tolerance"], c["name"]
+        assert abs(out["s"][0] - float(want @ want)) < 1e-12 * max(1.0, float(want @ want)), c["name"]
+        sweep = solver.edge_sq_norms(2, [0], [1], rel, rot)
+        w2 = c["weight"] ** 2
+        assert abs(sweep["s"][0] * w2 - float(want @ want)) < 1e-12 * max(1.0, float(want @ want)), c["name"]
