@@ -79,6 +79,7 @@ LOSS_CALLBACK_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_double, C.POINTER(C.c_doubl
 
 
 SHARD_CAPTURABLE = 1
+SHARD_DISCONNECTED = 2
 
 
 class Shard(C.Structure):
@@ -193,6 +194,7 @@ def load_library():
     lib.gsfm_rot_locality_order.argtypes = [C.c_uint32, C.c_uint64, _U32P, _U32P, _U32P]; lib.gsfm_rot_locality_order.restype = C.c_int32
     lib.gsfm_rot_edge_sq_norms.argtypes = [C.c_uint32, C.c_uint64, _U32P, _U32P, _DP, _DP, _DP, C.c_double, _DP, C.POINTER(C.c_uint8), C.POINTER(C.c_uint64), _DP]
     lib.gsfm_rot_edge_sq_norms.restype = C.c_int
+    lib.gsfm_rot_count_components.argtypes = [C.c_uint32, C.c_uint64, _U32P, _U32P]; lib.gsfm_rot_count_components.restype = C.c_int64
     lib.gsfm_cov_estimate.argtypes = [C.c_uint64, C.POINTER(C.c_uint64), _DP, _DP, _DP, _DP, C.c_int32, _DP, _DP, _DP,
                                       C.POINTER(C.c_int32), C.POINTER(C.c_int32), _DP]
     lib.gsfm_cov_estimate.restype = C.c_int

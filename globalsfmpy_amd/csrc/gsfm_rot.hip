@@ -763,6 +763,22 @@ bool reorder_for_locality(uint32_t n_cams, uint64_t n_edges, const uint32_t* ei,
   return true;
 }
 
+// connected components of the view graph among the cameras that have at least one edge (union-find with path halving)
+uint32_t count_components(uint32_t n_cams, uint64_t n_edges, const uint32_t* edge_i, const uint32_t* edge_j) {
+  std::vector<uint32_t> parent(n_cams);
+  std::vector<uint8_t> touched(n_cams, 0);
+  for (uint32_t c = 0; c < n_cams; ++c) parent[c] = c;
+  auto find = [&](uint32_t v) { while (parent[v] != v) { parent[v] = parent[parent[v]]; v = parent[v]; } return v; };
+  for (uint64_t e = 0; e < n_edges; ++e) {
+    const uint32_t a = find(edge_i[e]), b = find(edge_j[e]);
+    touched[edge_i[e]] = touched[edge_j[e]] = 1;
+    if (a != b) parent[a < b ? b : a] = a < b ? a : b;
+  }
+  uint32_t comps = 0;
+  for (uint32_t c = 0; c < n_cams; ++c) if (touched[c] && find(c) == c) ++comps;
+  return comps;
+}
+
 // Per-camera host arrays (rotations, gradient, mat-vec operands) enter and leave in the caller's numbering.
 const double* to_internal(gsfm_rot_problem* P, const double* ext, int width) {
   if (P->perm.empty()) return ext;
@@ -1106,15 +1122,10 @@ gsfm_status gsfm_rot_problem_create(uint32_t n_cams, uint64_t n_edges, const uin
     }
   }
   lap("locality relabelling");
-  if (!P->sharded) {   // connected components of the view graph (union-find over the edges, cameras without edges not counted)
-    std::vector<uint32_t> parent(n_cams);
-    for (uint32_t c = 0; c < n_cams; ++c) parent[c] = c;
-    auto find = [&](uint32_t v) { while (parent[v] != v) { parent[v] = parent[parent[v]]; v = parent[v]; } return v; };
-    for (uint64_t e = 0; e < n_edges; ++e) { const uint32_t a = find(edge_i[e]), b = find(edge_j[e]); if (a != b) parent[a < b ? b : a] = a < b ? a : b; }
-    uint32_t comps = 0;
-    for (uint32_t r = 0; r < P->n_rows; ++r) if (rp[r + 1] > rp[r] && find(r) == r) ++comps;
-    P->n_components = std::max<uint32_t>(1, comps);
-  }
+  // connected components of the view graph: counted here on one GPU; a rank of a sharded problem sees only its own edges, so the
+  // partitioner passes the verdict in the shard descriptor (GSFM_SHARD_DISCONNECTED)
+  if (!P->sharded) P->n_components = std::max<uint32_t>(1, count_components(n_cams, n_edges, edge_i, edge_j));
+  else P->n_components = (P->shard.flags & GSFM_SHARD_DISCONNECTED) ? 2 : 1;
   lap("connected components");
   const size_t nd = rp[P->n_rows];
   {
@@ -1553,6 +1564,12 @@ gsfm_status gsfm_rot_edge_sq_norms(uint32_t n_cams, uint64_t n_edges, const uint
   HIPCHK_S(hipMemcpy(&cnt, dcount.p, 8, hipMemcpyDeviceToHost));
   if (n_kept) *n_kept = keep_out ? (uint64_t)cnt : n_edges;
   return GSFM_OK;
+}
+
+int64_t gsfm_rot_count_components(uint32_t n_cams, uint64_t n_edges, const uint32_t* edge_i, const uint32_t* edge_j) {
+  if ((n_edges > 0 && (!edge_i || !edge_j)) || n_cams >= 0x7fffffffu) { fail(GSFM_ERR_INVALID_ARG, "bad argument"); return -1; }
+  for (uint64_t e = 0; e < n_edges; ++e) if (edge_i[e] >= n_cams || edge_j[e] >= n_cams) { fail(GSFM_ERR_INVALID_ARG, "edge with an out-of-range camera index"); return -1; }
+  return (int64_t)count_components(n_cams, n_edges, edge_i, edge_j);
 }
 
 int32_t gsfm_rot_locality_order(uint32_t n_cams, uint64_t n_edges, const uint32_t* edge_i, const uint32_t* edge_j, uint32_t* perm_out) {

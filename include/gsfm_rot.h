@@ -203,12 +203,14 @@ typedef struct {
  * (cost, dot products) with a sum all-reduce.  Both callbacks receive DEVICE
  * pointers and must enqueue on `hip_stream` (or make it wait).                 */
 #define GSFM_SHARD_CAPTURABLE 1u
+#define GSFM_SHARD_DISCONNECTED 2u   /* the GLOBAL view graph has more than one connected component (see cg_relative_tolerance) */
 typedef struct {
   int32_t rank;
   int32_t world_size;
   uint32_t slice_width;
   uint32_t flags;       /* GSFM_SHARD_CAPTURABLE: the callbacks only enqueue stream-ordered device work (no host synchronisation, no
-                           host staging), so a chunk of PCG iterations containing them may be captured into a hipGraph (pcg_hip_graph = 2) */
+                           host staging), so a chunk of PCG iterations containing them may be captured into a hipGraph (pcg_hip_graph = 2).
+                           GSFM_SHARD_DISCONNECTED: set by the partitioner when the global graph is disconnected (a rank cannot tell) */
   void* ctx;
   /* buf holds world_size * count doubles; rank r's input already sits at buf + r*count */
   int (*all_gather)(void* ctx, double* buf_dev, size_t count, void* hip_stream);
@@ -308,6 +310,9 @@ gsfm_status gsfm_rot_edge_sq_norms(uint32_t n_cams, uint64_t n_edges, const uint
  * identity was returned, -1 on bad input.  Needs no device.  globalsfmpy_amd/sharding.py cuts the order into per-GPU slices. */
 int32_t gsfm_rot_locality_order(uint32_t n_cams, uint64_t n_edges, const uint32_t* edge_i, const uint32_t* edge_j,
                                 uint32_t* perm_out);
+
+/* Host-only: number of connected components of the view graph among the cameras that carry an edge (-1 on bad input). */
+int64_t gsfm_rot_count_components(uint32_t n_cams, uint64_t n_edges, const uint32_t* edge_i, const uint32_t* edge_j);
 
 /* The problem's current native loss program evaluated ON THE DEVICE at the given squared norms, through the same device
  * routines (and kernel specialisation) the sweeps use: rho3_out[3k..] = (rho, rho', rho'')(s[k]) as K2 and the per-edge

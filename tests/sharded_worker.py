@@ -7,6 +7,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+from globalsfmpy_amd import _abi, sharding, synth  # noqa: E402
 
 
 def python_only_loss(s, out):
@@ -15,6 +16,18 @@ def python_only_loss(s, out):
     out[0] = b * np.log1p(s / b)
     out[1] = 1.0 / (1.0 + s / b)
     out[2] = -(1.0 / b) * out[1] * out[1]
+
+
+def two_component_graph():
+    """Two scenes batched as one disconnected problem (BASELINE C4 in small)."""
+    a = synth.make_graph(700, 20000, seed=41, outlier_frac=0.2)
+    b = synth.make_graph(500, 9000, seed=42, outlier_frac=0.1)
+    g = {"n_cams": 1200}
+    for k in ("rel_aa", "cov6", "inlier_weight", "init_aa", "gt_aa"):
+        g[k] = np.concatenate([a[k], b[k]])
+    g["edge_i"] = np.concatenate([a["edge_i"], b["edge_i"] + 700]).astype(np.uint32)
+    g["edge_j"] = np.concatenate([a["edge_j"], b["edge_j"] + 700]).astype(np.uint32)
+    return g
 
 
 def main():
@@ -26,7 +39,6 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
     else:
         dist.init_process_group("gloo")
-    from globalsfmpy_amd import _abi, sharding, synth
     from globalsfmpy_amd.loss_functions import MAGSACWeightBasedLoss
     case = sys.argv[4] if len(sys.argv) > 4 else "default"
     g = synth.make_graph(1203, 40000, seed=23, outlier_frac=0.3)
@@ -34,6 +46,8 @@ def main():
         keep = (g["edge_i"] < 1100) & (g["edge_j"] < 1100)
         for k in ("edge_i", "edge_j", "rel_aa", "cov6", "inlier_weight"):
             g[k] = g[k][keep]
+    if case == "disconnected":
+        g = two_component_graph()
     prefer_native = len(sys.argv) > 3 and sys.argv[3] == "native"
     world = dist.get_world_size()
     if case == "isolated":   # hand-made partition: ranks 0..world-2 share the 1100 connected cameras, the last rank owns only isolated ones

@@ -102,6 +102,23 @@ def test_host_callback_loss_on_a_sharded_problem(tmp_path):
     assert synth.angular_distance(synth.align_rotations(res["rot"], rot), rot).mean() <= 1e-6
 
 
+def test_disconnected_graph_keeps_its_tighter_pcg_tolerance_when_sharded(tmp_path):
+    """A rank sees only its own edges, so the partitioner tells the library that the global graph is disconnected
+    (GSFM_SHARD_DISCONNECTED): same PCG iteration count as the single-GPU solve, which counts the components itself."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from sharded_worker import two_component_graph
+    from globalsfmpy_amd.solver import RotationProblem
+    g = two_component_graph()
+    p = RotationProblem(g["n_cams"], g["edge_i"], g["edge_j"], g["rel_aa"], _abi.ANGLE_AXIS_COVARIANCE, cov6=g["cov6"])
+    p.set_loss(MAGSACWeightBasedLoss(0.02))
+    rot, s = p.solve(g["init_aa"], pcg_single_reduction=0)
+    _, s12 = p.solve(g["init_aa"], pcg_single_reduction=0, cg_relative_tolerance=1e-12)   # (still solved at 1e-14: the floor applies)
+    assert s12["num_cg_iterations"] == s["num_cg_iterations"]
+    res = _launch(2, "gloo", str(tmp_path / "disc.npz"), case="disconnected")
+    assert int(res["iters"]) == s["num_iterations"] and int(res["cg"]) == s["num_cg_iterations"]
+    assert synth.angular_distance(synth.align_rotations(res["rot"], rot), rot).mean() <= 1e-6
+
+
 def test_forced_single_rank_shard_over_rccl(tmp_path):
     res = _launch(1, "nccl", str(tmp_path / "nccl1.npz"), {"GSFM_FORCE_SHARD": "1"})
     _compare(res, _reference())
