@@ -324,7 +324,7 @@ def test_locality_relabelling_is_adopted_only_when_it_helps(monkeypatch):
     assert out["random"] and not out["local"]
 
 
-@pytest.mark.parametrize("n_cams,n_edges", [(300, 3000), (77, 900), (530, 9000)])
+@pytest.mark.parametrize("n_cams,n_edges", [(300, 3000), (77, 900), (530, 9000), (64, 700)])
 def test_dense_cholesky_step_matches_the_oracles_cholesky(oracle, n_cams, n_edges):
     """`dense_cholesky_max_cams`: the LM step from an exact blocked Cholesky of the damped normal matrix on the device (sizes that
     are and are not multiples of the 32-column block) against the oracle's dense Cholesky -- the reference's own linear solver."""
@@ -400,3 +400,17 @@ def test_threaded_structure_build_is_invisible(monkeypatch):
         p.close()
     for r, c, n, sq in outs[1:]:
         assert np.array_equal(r, outs[0][0]) and c == outs[0][1] and n == outs[0][2] and np.array_equal(sq, outs[0][3])
+
+
+def test_default_linear_solver_by_problem_size():
+    """dense_cholesky_max_cams = 512 by default: exact Cholesky steps up to 512 cameras (3N = 1536 = 48 full tiles), PCG from 513 on; a
+    request beyond the 1706 cameras the backward kernel holds in LDS falls back to PCG instead of failing."""
+    from globalsfmpy_amd.solver import RotationProblem
+    for n, want_dense, kw in ((512, True, {}), (513, False, {}), (2000, False, dict(dense_cholesky_max_cams=5000))):
+        g = synth.make_graph(n, 12 * n, seed=n, outlier_frac=0.1)
+        p = RotationProblem(g["n_cams"], g["edge_i"], g["edge_j"], g["rel_aa"], _abi.ANGLE_AXIS)
+        p.set_loss(LF.SoftLOneLoss(0.1))
+        r, s = p.solve(g["init_aa"], **kw)
+        assert (s["num_dense_solves"] == s["num_iterations"]) == want_dense and (s["num_cg_iterations"] == 0) == want_dense, (n, s)
+        err = synth.angular_distance(synth.align_rotations(r, g["gt_aa"]), g["gt_aa"])
+        assert np.rad2deg(err.mean()) < 1.0
