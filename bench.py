@@ -178,6 +178,11 @@ def small_graph_timings(args):
 
 def main():
     args = parse()
+    # Native libraries print to the C-level stdout (RCCL writes a five-line version banner there when its first communicator is created).
+    # The contract is ONE JSON line on stdout: everything else of this process goes to stderr, the line is written to the saved descriptor.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -193,7 +198,10 @@ def main():
     torch.cuda.set_device(local_rank)
     dist = None
     backend = os.environ.get("GSFM_BENCH_BACKEND", "nccl")  # "nccl" = RCCL over xGMI; "gloo" only for smoke tests
-    if world > 1:
+    # GSFM_FORCE_SHARD=1 under a one-process torchrun: the N > 1 code path (process group, partition, native RCCL communicator, collective
+    # callbacks inside the solve) with a single rank -- the closest a 1-GPU box gets to the 8-GPU launch
+    force_shard = world == 1 and os.environ.get("GSFM_FORCE_SHARD") and "RANK" in os.environ
+    if world > 1 or force_shard:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
@@ -217,7 +225,7 @@ def main():
 
     t_create = time.perf_counter()
     part = None
-    if world > 1:
+    if world > 1 or force_shard:
         prob, part = sharding.make_sharded_problem(g, error_type, loss=loss_ctor())
         comm = prob._comm
         init, gt = part.scatter(g["init_aa"]), part.scatter(g["gt_aa"])
@@ -329,7 +337,7 @@ def main():
                                    % (n_cams, n_edges, args.outliers),
                        "cams": n_cams, "edges": n_edges, "outlier_frac": args.outliers, "seed": args.seed,
                        "parallelism": "camera-slice x%d" % world,
-                       "collectives": (comm.backend if world > 1 else "none")},
+                       "collectives": (comm.backend if part is not None else "none")},
             "iters_to_1e-6": summ["iters_to_1e6"], "lm_iterations": summ["num_iterations"],
             "residual_sweeps_per_solve": summ["num_residual_sweeps"], "cg_iterations_per_solve": summ["num_cg_iterations"],
             "termination": summ["termination_name"], "final_cost": summ["final_cost"],
@@ -371,8 +379,9 @@ def main():
         if small is not None:
             out["small_graph_ms"] = small
         if args.cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(args, loss_ctor, error_type, rot, summ)
-        print(json.dumps(out), flush=True)
+            out["cpu_baseline"] = cpu_baseline(args, loss_ctor, error_type, rot_cmp, summ)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -47,3 +47,19 @@ def test_bench_two_ranks_on_one_gpu_over_gloo():
     one = _json_line(subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + SMALL + ["--sigma-pass", "0"], cwd=ROOT, capture_output=True, text=True, timeout=900).stdout)
     assert out["lm_iterations"] == one["lm_iterations"] and out["residual_sweeps_per_solve"] == one["residual_sweeps_per_solve"]
     assert abs(out["final_cost"] - one["final_cost"]) <= 1e-6 * one["final_cost"]
+
+
+def test_bench_single_rank_over_native_rccl_prints_exactly_one_stdout_line():
+    """GSFM_FORCE_SHARD=1 under a one-process torchrun: the N > 1 code path of bench.py on real RCCL (process group over nccl, partition,
+    the C++ communicator, collectives inside the solve).  RCCL prints a version banner on the C-level stdout when its first communicator is
+    created; the bench line must still be the only thing on stdout."""
+    env = dict(os.environ, GSFM_FORCE_SHARD="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    port = 29990 + os.getpid() % 9
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "1"] + SMALL + ["--sigma-pass", "0"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines[:5]
+    out = json.loads(lines[0])
+    assert out["config"]["collectives"] == "rccl-native" and out["value"] > 0 and out["n_gpus"] == 1
