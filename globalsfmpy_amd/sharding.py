@@ -223,24 +223,29 @@ class NativeComm(object):
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
         self.P = int(width)
-        here = os.path.dirname(os.path.abspath(__file__))
-        lib = C.CDLL(os.path.join(here, "libgsfm_rccl.so"))
-        lib.gsfm_rccl_last_error.restype = C.c_char_p
-        lib.gsfm_rccl_create.restype = C.c_void_p
-        lib.gsfm_rccl_create.argtypes = [C.c_char_p, C.c_int, C.c_int]
-        lib.gsfm_rccl_destroy.argtypes = [C.c_void_p]
-        lib.gsfm_rccl_init.argtypes = [C.c_char_p]
-        # Every step that can fail is agreed on by all ranks before the next collective: a rank that raised alone would leave the
-        # others blocked inside ncclCommInitRank (or inside the broadcast of the unique id).
+        # Every step that can fail is agreed on by all ranks before the next collective: a rank that raised alone (a missing
+        # libgsfm_rccl.so included) would leave the others blocked inside ncclCommInitRank or inside the broadcast of the unique id.
         def all_ok(flag):
             t = torch.tensor([1 if flag else 0], dtype=torch.int32, device="cuda" if dist.get_backend(group) == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
             return bool(t.item())
 
-        bundled = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
-        loaded = lib.gsfm_rccl_init(bundled.encode() if os.path.exists(bundled) else None) == 0
-        if not all_ok(loaded):
-            raise RuntimeError("RCCL not available on every rank: %s" % lib.gsfm_rccl_last_error().decode())
+        here = os.path.dirname(os.path.abspath(__file__))
+        lib, why = None, ""
+        try:
+            lib = C.CDLL(os.path.join(here, "libgsfm_rccl.so"))
+            lib.gsfm_rccl_last_error.restype = C.c_char_p
+            lib.gsfm_rccl_create.restype = C.c_void_p
+            lib.gsfm_rccl_create.argtypes = [C.c_char_p, C.c_int, C.c_int]
+            lib.gsfm_rccl_destroy.argtypes = [C.c_void_p]
+            lib.gsfm_rccl_init.argtypes = [C.c_char_p]
+            bundled = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+            if lib.gsfm_rccl_init(bundled.encode() if os.path.exists(bundled) else None) != 0:
+                why, lib = lib.gsfm_rccl_last_error().decode(), None
+        except OSError as e:
+            why, lib = str(e), None
+        if not all_ok(lib is not None):
+            raise RuntimeError("RCCL not available on every rank%s" % (": " + why if why else " (this rank is fine)"))
         ident = [None]
         if self.rank == 0:
             buf = C.create_string_buffer(128)
