@@ -201,7 +201,15 @@ typedef struct {
  * directed (row) contributions of its owned cameras in full, so per-camera sums
  * need no reduction: slices are exchanged with an in-place all-gather; scalars
  * (cost, dot products) with a sum all-reduce.  Both callbacks receive DEVICE
- * pointers and must enqueue on `hip_stream` (or make it wait).                 */
+ * pointers and must enqueue on `hip_stream` (or make it wait).
+ * Failure handling: gsfm_rot_problem_create agrees on its status across ranks before
+ * returning (one all-reduce: every rank fails if any did, none is left inside a
+ * collective).  Inside a solve every decision (step acceptance, convergence, non-finite
+ * cost, PCG termination) is taken from replicated, bitwise identical scalars, so all
+ * ranks return the same status at the same point; what is NOT agreed on is a HIP
+ * runtime error or a failing callback on one rank only (a lost device, a broken link):
+ * that rank returns GSFM_ERR_HIP / GSFM_ERR_COMM while its peers wait in the next
+ * collective until the communicator's own timeout or abort fires.                   */
 #define GSFM_SHARD_CAPTURABLE 1u
 #define GSFM_SHARD_DISCONNECTED 2u   /* the GLOBAL view graph has more than one connected component (see cg_relative_tolerance) */
 typedef struct {
