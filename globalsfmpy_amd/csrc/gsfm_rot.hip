@@ -227,8 +227,8 @@ struct gsfm_rot_problem {
   DevBuf<double2> q, q_trial;
   DevBuf<double> xcg, r, z, p, Ap, s_dir, part_g2, part_d2;
   DevBuf<Cg2Scalars> cg2sc;
+  void* pin = nullptr;              // 256 B of pinned host memory: staging for the small read-backs of the solve loop (read_back)
   DevBuf<double> denseA, denseL;
-  DevBuf<int> dense_info;
   hipGraphExec_t dense_graph = nullptr;   // zero + assemble + blocked Cholesky + solve, captured once
   bool dense_graph_lap = false;           // form of the blocks the captured assemble kernel expects
   int nb_mv = 1, mv_reps = 1;
@@ -312,6 +312,16 @@ int sync_check(gsfm_rot_problem* P, const char* what) {
   return 0;
 }
 
+// Read `bytes` (<= 256) from the device and wait.  The LM / PCG control reads ~100 bytes two to five times per iteration; a copy into
+// pageable memory costs 22 us per read on this platform, into pinned memory 14 us (tools/bench_sync.hip), which is what small graphs feel.
+int read_back(gsfm_rot_problem* P, void* dst, const void* src_dev, size_t bytes, const char* what) {
+  void* stage = (P->pin && bytes <= 256) ? P->pin : dst;
+  HIPCHK(hipMemcpyAsync(stage, src_dev, bytes, hipMemcpyDeviceToHost, P->stream));
+  if (int st = sync_check(P, what)) return st;
+  if (stage != dst) std::memcpy(dst, stage, bytes);
+  return 0;
+}
+
 // ---- loss preparation ---------------------------------------------------------------------
 int prepare_loss(gsfm_rot_problem* P, const gsfm_loss_node* prog, int n) {
   if (n < 0 || n > GSFM_LOSS_MAX_NODES) return fail(GSFM_ERR_INVALID_ARG, "loss program length out of range");
@@ -385,7 +395,7 @@ int all_reduce(gsfm_rot_problem* P, double* buf, size_t count) {
 }
 
 // ---- launches -----------------------------------------------------------------------------
-enum { SC_COST = 0, SC_GMAX = 1, SC_STEP = 2 /* ..6 */, SC_XNORM2 = 7, SC_TRIAL = 8, SC_N = 16 };
+enum { SC_COST = 0, SC_GMAX = 1, SC_STEP = 2 /* ..6 */, SC_XNORM2 = 7, SC_TRIAL = 8, SC_DENSE_INFO = 15 /* an int: status of the Cholesky factorisation */, SC_N = 16 };
 enum { T_LIN = 0, T_SWEEP = 1, T_CG = 2 };
 
 void launch_cache(gsfm_rot_problem* P, const double* x, double2* q) {
@@ -532,8 +542,7 @@ int run_pcg(gsfm_rot_problem* P, const gsfm_rot_options& o, int* iters_out, doub
       launched += chunk;
     }
     P->timer.end(tk);
-    HIPCHK(hipMemcpyAsync(&h, P->cgsc.p, sizeof(h), hipMemcpyDeviceToHost, P->stream));
-    if (int st = sync_check(P, "pcg")) return st;
+    if (int st = read_back(P, &h, P->cgsc.p, sizeof(h), "pcg")) return st;
     if (h.done || launched >= o.max_cg_iterations + chunk) break;
     // Fewer host round trips: extrapolate the average convergence factor so far to the tolerance and enqueue that many
     // chunks before looking again (kernels past convergence return at their first instruction, so overshoot is cheap).
@@ -613,8 +622,7 @@ int run_pcg2(gsfm_rot_problem* P, const gsfm_rot_options& o, int* iters_out, dou
       launched += chunk;
     }
     P->timer.end(tk);
-    HIPCHK(hipMemcpyAsync(&h, P->cg2sc.p, sizeof(h), hipMemcpyDeviceToHost, P->stream));
-    if (int st = sync_check(P, "pcg")) return st;
+    if (int st = read_back(P, &h, P->cg2sc.p, sizeof(h), "pcg")) return st;
     if (h.done || launched >= o.max_cg_iterations + chunk + 2) break;
     chunks = 1;   // same look-ahead as run_pcg: extrapolate the convergence factor, enqueue that many chunks before looking again
     if (h.iters > 0 && h.last_rel > 0.0 && h.last_rel < 1.0 && c.tol > 0.0 && c.tol < h.last_rel) {
@@ -636,25 +644,27 @@ bool use_single_reduction(const gsfm_rot_problem* P, const gsfm_rot_options& o) 
   return !P->sharded && P->dir.n <= (size_t)2000000;
 }
 
-// Exact step for small graphs: dense Cholesky of (J^T J + Lambda) in the left-tangent space (dense_kernels.hpp). *used = false if the
-// factorisation could not be used (a non-positive pivot, or no memory): the caller falls back to PCG.  Returns 0 or a gsfm_status.
+// Exact step for small graphs: dense Cholesky of (J^T J + Lambda) in the left-tangent space (dense_kernels.hpp).  Enqueues only: the
+// factorisation's status lands in the scalar block (SC_DENSE_INFO) and is read together with the trial cost, one host synchronisation
+// later; a non-positive pivot makes the caller solve the step again by PCG.  *used = false if nothing was enqueued (size, memory).
 int run_dense(gsfm_rot_problem* P, bool* used) {
   *used = false;
   const uint32_t n = 3 * P->n_cams, T = (n + GSFM_CB - 1) / GSFM_CB;
   if (T > GSFM_DENSE_MAX_T) return 0;
   const size_t elems = chol_num_tiles(T) * GSFM_TILE_ELEMS;
   if (!P->denseA.p) {
-    if (P->denseA.alloc(elems) != hipSuccess || P->denseL.alloc(elems, true) != hipSuccess || P->dense_info.alloc(1) != hipSuccess) { P->denseA.release(); return 0; }
+    if (P->denseA.alloc(elems) != hipSuccess || P->denseL.alloc(elems, true) != hipSuccess) { P->denseA.release(); return 0; }
   }
   auto enqueue = [&]() {
     (void)hipMemsetAsync(P->denseA.p, 0, 8 * elems, P->stream);
-    (void)hipMemsetAsync(P->dense_info.p, 0, sizeof(int), P->stream);
+    int* const info = (int*)(P->scal.p + SC_DENSE_INFO);
+    (void)hipMemsetAsync(info, 0, sizeof(double), P->stream);
     DenseArgs a{};
     a.n_rows = P->n_rows; a.row_ptr = P->row_ptr.p; a.col = P->col.p; a.h0 = P->h0.p; a.h1 = P->h1.p; a.h2 = P->h2.p; a.h3 = P->h3.p; a.h4 = P->h4.p;
     a.Mblk = P->Mblk.p; a.b = P->b.p; a.A = P->denseA.p; a.n = n; a.T = T; a.q = P->q_lin; a.lap = P->lin_is_lap;
     hipLaunchKernelGGL(k_dense_assemble, dim3(P->n_rows), dim3(GSFM_BLOCK), 0, P->stream, a);
     for (uint32_t k = 0; k < T; ++k) {
-      CholArgs c{P->denseA.p, P->denseL.p, T, k, P->dense_info.p};
+      CholArgs c{P->denseA.p, P->denseL.p, T, k, info};
       const uint32_t m = T - k;
       hipLaunchKernelGGL(k_chol_step, dim3(1 + m * (m + 1) / 2), dim3(256), 0, P->stream, c);
     }
@@ -677,10 +687,6 @@ int run_dense(gsfm_rot_problem* P, bool* used) {
   if (P->dense_graph) { HIPCHK(hipGraphLaunch(P->dense_graph, P->stream)); P->graph_launches++; }
   else enqueue();
   P->timer.end(tk);
-  int info = -1;
-  HIPCHK(hipMemcpyAsync(&info, P->dense_info.p, sizeof(int), hipMemcpyDeviceToHost, P->stream));
-  if (int e = sync_check(P, "dense cholesky")) return e;
-  if (info != 0) return 0;  // not positive definite to working precision: PCG instead
   *used = true;
   return 0;
 }
@@ -695,8 +701,7 @@ int launch_step(gsfm_rot_problem* P) {
 }
 
 int read_scalars(gsfm_rot_problem* P, double* h) {
-  HIPCHK(hipMemcpyAsync(h, P->scal.p, SC_N * sizeof(double), hipMemcpyDeviceToHost, P->stream));
-  return sync_check(P, "read scalars");
+  return read_back(P, h, P->scal.p, SC_N * sizeof(double), "read scalars");
 }
 
 // Reverse Cuthill-McKee style relabelling (plain BFS from a minimum-degree camera of every component, reversed).  The p[col]
@@ -882,14 +887,22 @@ int lm_solve(gsfm_rot_problem* P, const gsfm_rot_options& o_in, gsfm_rot_summary
     if (!P->sharded && dense_cap > 0 && (int64_t)P->n_cams <= dense_cap && (o.dense_cholesky_max_cams > 0 || pcg_struggles)) {
       if (int st = run_dense(P, &dense_used)) return st;
     }
-    if (dense_used) sum->num_dense_solves++;
-    else if (int st = (use_single_reduction(P, o) ? run_pcg2(P, o, &cg, &cg_rel) : run_pcg(P, o, &cg, &cg_rel))) return st;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+      if (!dense_used) {
+        if (int st = (use_single_reduction(P, o) ? run_pcg2(P, o, &cg, &cg_rel) : run_pcg(P, o, &cg, &cg_rel))) return st;
+      }
+      launch_step(P);
+      if (int st = launch_cost(P, P->q_trial.p, SC_TRIAL)) return st;
+      if (int st = read_scalars(P, h)) return st;
+      if (!dense_used) break;
+      int info = 0;
+      std::memcpy(&info, &h[SC_DENSE_INFO], sizeof(int));
+      if (info == 0) { sum->num_dense_solves++; break; }
+      dense_used = false;   // not positive definite to working precision: the step just evaluated is meaningless, PCG solves it again
+    }
     if (cg > 150) pcg_struggles = true;
     sum->num_cg_iterations += cg;
-    launch_step(P);
-    if (int st = launch_cost(P, P->q_trial.p, SC_TRIAL)) return st;
     sum->num_residual_sweeps++;
-    if (int st = read_scalars(P, h)) return st;
     // model_cost_change = -eta.g - 1/2 eta^T B eta with B eta = -g - r_cg - Lambda eta
     const double eta_g = h[SC_STEP], eta_r = h[SC_STEP + 1], eta_L = h[SC_STEP + 2];
     const double model_cost_change = -0.5 * eta_g + 0.5 * eta_r + 0.5 * eta_L;
@@ -1046,6 +1059,7 @@ gsfm_status gsfm_rot_problem_create(uint32_t n_cams, uint64_t n_edges, const uin
   if (hipStreamCreateWithFlags(&P->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(GSFM_ERR_HIP, "hipStreamCreate failed"));
   P->own_stream = true;
   P->timer.stream = P->stream; P->timer.init();
+  if (hipHostMalloc(&P->pin, 256, hipHostMallocDefault) != hipSuccess) { P->pin = nullptr; (void)hipGetLastError(); }   // (read_back then copies to pageable memory)
 
   // ---- host-side structure: directed entries by row (counting sort), cost-owned edges ----
   const uint32_t *edge_i = edge_i_in, *edge_j = edge_j_in;
@@ -1302,6 +1316,7 @@ void gsfm_rot_problem_destroy(gsfm_rot_problem* P) {
   P->pcg_graph.reset(); P->pcg2_graph.reset();
   if (P->dense_graph) (void)hipGraphExecDestroy(P->dense_graph);
   if (P->own_stream && P->stream) (void)hipStreamDestroy(P->stream);
+  if (P->pin) (void)hipHostFree(P->pin);
   delete P;
 }
 

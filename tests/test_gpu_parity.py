@@ -363,6 +363,23 @@ def test_dense_cholesky_auto_mode_switches_only_when_pcg_struggles(graph):
     assert synth.angular_distance(synth.align_rotations(r1, r0), r0).mean() <= 1e-4
 
 
+def test_a_factorisation_that_breaks_down_is_solved_again_by_pcg():
+    """With a trust region of 1e20 the damping vanishes and the normal matrix keeps its three-dimensional gauge null space: the Cholesky
+    factorisation meets a non-positive pivot (its status is read together with the trial cost, one synchronisation later, so the step
+    evaluated from the failed factor is thrown away) and the step comes from PCG instead, which handles the consistent singular system."""
+    from globalsfmpy_amd.solver import RotationProblem
+    g = synth.make_graph(60, 400, 3, outlier_frac=0.1)
+    p = RotationProblem(g["n_cams"], g["edge_i"], g["edge_j"], g["rel_aa"], _abi.ANGLE_AXIS); p.set_loss(LF.HuberLoss(0.1))
+    kw = dict(initial_trust_region_radius=1e20, max_trust_region_radius=1e20)
+    rd, sd = p.solve(g["init_aa"], **kw)
+    rp, sp = p.solve(g["init_aa"], dense_cholesky_max_cams=0, **kw)
+    assert sd["termination_name"] == sp["termination_name"] == "FUNCTION_TOLERANCE" and not sd["nonfinite"]
+    assert sd["num_dense_solves"] < sd["num_iterations"] and sd["num_cg_iterations"] > 0            # at least one step fell back
+    assert sd["num_residual_sweeps"] == sp["num_residual_sweeps"]                                  # the discarded evaluation is not counted
+    assert abs(sd["final_cost"] - sp["final_cost"]) <= 1e-6 * sp["final_cost"]
+    assert synth.angular_distance(synth.align_rotations(rd, rp), rp).mean() <= 1e-4
+
+
 @pytest.mark.parametrize("et", [_abi.ANGLE_AXIS_COVARIANCE, _abi.QUATERNION_COSINE])
 def test_laplacian_form_equals_the_general_blocks(graph, et, monkeypatch):
     """H_km = -G_k R_k R_m^T (6 stored doubles per directed entry) against the general 9-value blocks: same mat-vec to rounding,
