@@ -146,7 +146,7 @@ typedef struct {
                                           the run has needed more than 150 iterations.  Measured on MI355X (tools/bench_chol.hip, factor +
                                           both substitutions as one graph replay): 0.59 ms at 394 cameras, 1.9 ms at 800, 7.7 ms at 1500;
                                           a PCG iteration of a graph this size costs ~14 us, and real view graphs need 60-570 of them per LM
-                                          step once the damping has vanished.  Madrid (394 cameras, 62 LM iterations, MAGSAC): 45 ms exact vs
+                                          step once the damping has vanished.  Madrid (394 cameras, 62 LM iterations, MAGSAC): 43 ms exact vs
                                           325 ms PCG; SoftL1 32 vs 58 ms; quaternion-Huber 19 vs 26 ms.  PCG remains the fallback when a pivot
                                           is not positive, and the only solver of sharded problems. */
   int32_t pcg_hip_graph;               /* default 1: the chunk of cg_check_interval PCG iterations between two host checks
