@@ -658,10 +658,9 @@ int run_dense(gsfm_rot_problem* P, bool* used) {
   auto enqueue = [&]() {
     (void)hipMemsetAsync(P->denseA.p, 0, 8 * elems, P->stream);
     int* const info = (int*)(P->scal.p + SC_DENSE_INFO);
-    (void)hipMemsetAsync(info, 0, sizeof(double), P->stream);
     DenseArgs a{};
     a.n_rows = P->n_rows; a.row_ptr = P->row_ptr.p; a.col = P->col.p; a.h0 = P->h0.p; a.h1 = P->h1.p; a.h2 = P->h2.p; a.h3 = P->h3.p; a.h4 = P->h4.p;
-    a.Mblk = P->Mblk.p; a.b = P->b.p; a.A = P->denseA.p; a.n = n; a.T = T; a.q = P->q_lin; a.lap = P->lin_is_lap;
+    a.Mblk = P->Mblk.p; a.b = P->b.p; a.A = P->denseA.p; a.n = n; a.T = T; a.q = P->q_lin; a.lap = P->lin_is_lap; a.info_slot = P->scal.p + SC_DENSE_INFO; a.rcg = P->r.p;
     hipLaunchKernelGGL(k_dense_assemble, dim3(P->n_rows), dim3(GSFM_BLOCK), 0, P->stream, a);
     for (uint32_t k = 0; k < T; ++k) {
       CholArgs c{P->denseA.p, P->denseL.p, T, k, info};
@@ -669,7 +668,7 @@ int run_dense(gsfm_rot_problem* P, bool* used) {
       hipLaunchKernelGGL(k_chol_step, dim3(1 + m * (m + 1) / 2), dim3(256), 0, P->stream, c);
     }
     hipLaunchKernelGGL(k_chol_back, dim3(1), dim3(1024), 0, P->stream, (const double*)P->denseL.p, n, T, P->xcg.p);
-    (void)hipMemsetAsync(P->r.p, 0, 8 * (size_t)n, P->stream);  // exact solve: the PCG residual term of the model decrease is zero
+    // (exact solve: the PCG residual term of the model decrease is zero -- k_dense_assemble cleared it)
   };
   const int tk = P->timer.begin(T_CG);
   if (P->dense_graph && P->dense_graph_lap != P->lin_is_lap) { (void)hipGraphExecDestroy(P->dense_graph); P->dense_graph = nullptr; }

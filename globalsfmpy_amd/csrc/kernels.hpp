@@ -1465,6 +1465,8 @@ struct DenseArgs {
   uint32_t n, T;
   const double2* q;    // Laplacian form (lap = 1): planes h0..h2 hold G_k, the block is -G_k R_k R_m^T
   int lap;
+  double* info_slot;   // status word of the factorisation (an int in a double slot of the scalar block) and
+  double* rcg;         // the PCG residual (3 per camera, zero for an exact solve): cleared here instead of by two more memset nodes
 };
 __device__ __forceinline__ double* dense_elem(double* A, uint32_t gr, uint32_t gc) {
   return A + ((size_t)(gr / 32) * (gr / 32 + 1) / 2 + gc / 32) * 1024 + (gr % 32) * 32 + gc % 32;
@@ -1472,6 +1474,8 @@ __device__ __forceinline__ double* dense_elem(double* A, uint32_t gr, uint32_t g
 __global__ void __launch_bounds__(GSFM_BLOCK) k_dense_assemble(DenseArgs a) {
   const uint32_t row = blockIdx.x;
   if (row >= a.n_rows) return;
+  if (threadIdx.x < 3) a.rcg[3 * (size_t)row + threadIdx.x] = 0.0;
+  if (row == 0 && threadIdx.x == 3) *a.info_slot = 0.0;
   if (threadIdx.x == 0) {
     const double* M = a.Mblk + 6 * (size_t)row;
     const double m[9] = {M[0], M[1], M[2], M[1], M[3], M[4], M[2], M[4], M[5]};
