@@ -1,7 +1,7 @@
 """Dev probe: C4 batch (14 components incl. real Madrid), Madrid component's distance to the oracle vs the PCG tolerance."""
 import os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from oracle import pyoracle
 from globalsfmpy_amd import _abi, synth

@@ -1,7 +1,7 @@
 """Round-2 probe (dev tool): Madrid (C1) on the device, exact dense-Cholesky step vs PCG, against the oracle's Cholesky."""
 import os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import pyoracle
 from globalsfmpy_amd import _abi, synth

@@ -1,0 +1,17 @@
+"""A short fixed-seed pass of the randomised differential run (tests/manual/fuzz_differential.py): device against oracle on adversarial
+small graphs -- rotations over all of SO(3), repeated pairs, isolated cameras, zero / pi relative rotations, cameras started on the cut
+locus -- across all error types and losses."""
+import os
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("seed", [11, 12])
+def test_randomised_device_vs_oracle(oracle, seed, monkeypatch):
+    monkeypatch.delenv("FUZZ_ONLY", raising=False)
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "manual"))
+    import fuzz_differential
+    assert fuzz_differential.run(trials=120, seed=seed, quick=True) == 0
