@@ -89,7 +89,9 @@ def run(trials=200, seed=1, quick=False):
         # scales: residual entries that are pure rounding noise (a noise-free graph evaluated at the truth) are compared absolutely
         r_scale = max(1.0, float(np.abs(b["residuals"]).max()))
         jmax = float(np.sqrt(np.abs(np.asarray(lb["diag_blocks"])).max()))
-        g_scale = jmax * max(float(np.sqrt(b["s"].max())), 1e-9) + 1e-300   # ~ |J| |r|, floored where r itself is rounding noise
+        rho1 = np.asarray(b["rho"])[:, 1]
+        sr = float(np.sqrt(max(1.0, np.abs(rho1[np.isfinite(rho1)]).max()))) if np.isfinite(rho1).any() else 1.0   # (the robustified residual is sqrt(rho') r)
+        g_scale = jmax * sr * max(float(np.sqrt(b["s"].max())), 1e-9) + 1e-300   # ~ |J| |r|, floored where r itself is rounding noise
         def scaled(x, y, scale):
             x, y = np.asarray(x, dtype=np.float64), np.asarray(y, dtype=np.float64)
             if not np.array_equal(np.isfinite(x), np.isfinite(y)):
