@@ -130,6 +130,8 @@ __device__ __forceinline__ void pair_evaluate(const CovArgs& a, uint64_t mb, uin
     const double trp = t[0] * rp[0] + t[1] * rp[1] + t[2] * rp[2];
     const double db0[3] = {(trp * R[0] - rp[0] * Rt[0]) / f1, (trp * R[3] - rp[0] * Rt[1]) / f1, (trp * R[6] - rp[0] * Rt[2]) / f1};
     const double db1[3] = {(trp * R[1] - rp[1] * Rt[0]) / f1, (trp * R[4] - rp[1] * Rt[1]) / f1, (trp * R[7] - rp[1] * Rt[2]) / f1};
+    // (sign(num) at num == 0 is taken as +1.  The reference's autodiff of sqrt(num^2 / den) has NO derivative there -- 0.5 / sqrt(0) * 0 = NaN,
+    // and Ceres rejects the evaluation -- which only an exactly noise-free match at the exact pose can hit; the oracle restates the NaN.)
     const double sg = (num < 0.0) ? -isd : isd, q = num / den;
     double jeta[3], jt[3];
 #pragma unroll
@@ -183,6 +185,25 @@ __device__ __forceinline__ bool chol5(const double* Au, const double* diag_add, 
   for (int i = 0; i < 5; ++i) { double s = b[i]; for (int k = 0; k < i; ++k) s -= L[5 * i + k] * y[k]; y[i] = s / L[5 * i + i]; }
   for (int i = 4; i >= 0; --i) { double s = y[i]; for (int k = i + 1; k < 5; ++k) s -= L[5 * k + i] * x[k]; x[i] = s / L[5 * i + i]; }
   return true;
+}
+
+// Is the 3 x 3 information matrix rank deficient to working precision?  Cholesky with diagonal pivoting (the criterion of LAPACK's
+// dpstrf): a pivot below 1e-14 of the first one -- ceres::Covariance's own bound on the reciprocal condition number
+// (Covariance::Options::min_reciprocal_condition_number).  There ceres::Covariance::Compute returns false and the reference
+// CHECK-aborts (src/uncertainty.cpp:157); here the view pair gets status 2 and no covariance, instead of the inverse of rounding noise.
+__host__ __device__ inline bool sym3_rank_deficient(double h00, double h01, double h02, double h11, double h12, double h22) {
+  const double tol = 1e-14;
+  // first pivot: the largest diagonal entry
+  double d1, a, b, ab, a1, b1;   // pivot; the other two diagonal entries, their coupling, and their couplings to the pivot
+  if (h00 >= h11 && h00 >= h22) { d1 = h00; a = h11; b = h22; ab = h12; a1 = h01; b1 = h02; }
+  else if (h11 >= h22) { d1 = h11; a = h00; b = h22; ab = h02; a1 = h01; b1 = h12; }
+  else { d1 = h22; a = h00; b = h11; ab = h01; a1 = h02; b1 = h12; }
+  if (!(d1 > 0.0)) return true;
+  const double saa = a - a1 * a1 / d1, sbb = b - b1 * b1 / d1, sab = ab - a1 * b1 / d1;   // Schur complement
+  const double d2 = saa >= sbb ? saa : sbb, other = saa >= sbb ? sbb : saa;
+  if (!(d2 > tol * d1)) return true;
+  const double d3 = other - sab * sab / d2;
+  return !(d3 > tol * d1);
 }
 
 __global__ void __launch_bounds__(GSFM_BLOCK) k_cov_estimate(CovArgs a) {
@@ -280,7 +301,7 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_cov_estimate(CovArgs a) {
     const double h00 = cur.H[hidx(0, 0)], h01 = cur.H[hidx(0, 1)], h02 = cur.H[hidx(0, 2)], h11 = cur.H[hidx(1, 1)], h12 = cur.H[hidx(1, 2)], h22 = cur.H[hidx(2, 2)];
     const double c00 = h11 * h22 - h12 * h12, c01 = h12 * h02 - h01 * h22, c02 = h01 * h12 - h11 * h02;
     const double det = h00 * c00 + h01 * c01 + h02 * c02;
-    if (!(fabs(det) > 0.0) || !isfinite(det)) status = 2;
+    if (!(fabs(det) > 0.0) || !isfinite(det) || sym3_rank_deficient(h00, h01, h02, h11, h12, h22)) status = 2;
     else {
       cov[0] = c00 / det; cov[1] = c01 / det; cov[2] = c02 / det;
       cov[3] = cov[1]; cov[4] = (h00 * h22 - h02 * h02) / det; cov[5] = (h02 * h01 - h00 * h12) / det;

@@ -14,6 +14,7 @@
 #include <cmath>
 #include <cstring>
 #include <limits>
+#include <utility>
 #include <vector>
 
 #include "oracle_api.h"
@@ -180,6 +181,27 @@ int refine(const PairProblem& P, double* rot, double* t, int max_iterations, int
 
 }  // namespace
 
+// ceres::Covariance::Compute fails on a rank-deficient Jacobian (the reference then CHECK-aborts, uncertainty.cpp:157).  The 3 x 3
+// restatement: Cholesky with diagonal pivoting on a copy of H, rank deficient when a pivot drops below 1e-14 of the first
+// (Covariance::Options::min_reciprocal_condition_number).  Degenerate view pairs (identical or collinear matches) end here.
+static bool information_is_rank_deficient(const double H[9]) {
+  double A[3][3];
+  for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) A[r][c] = H[3 * r + c];
+  int idx[3] = {0, 1, 2};
+  double first = 0.0;
+  for (int k = 0; k < 3; ++k) {
+    int best = k;
+    for (int j = k + 1; j < 3; ++j) if (A[idx[j]][idx[j]] > A[idx[best]][idx[best]]) best = j;
+    std::swap(idx[k], idx[best]);
+    const double piv = A[idx[k]][idx[k]];
+    if (k == 0) { first = piv; if (!(piv > 0.0)) return true; }
+    else if (!(piv > 1e-14 * first)) return true;
+    for (int i = k + 1; i < 3; ++i)
+      for (int j = k + 1; j < 3; ++j) A[idx[i]][idx[j]] -= A[idx[i]][idx[k]] * A[idx[k]][idx[j]] / piv;
+  }
+  return false;
+}
+
 extern "C" {
 
 // One call = store_covariance_rot's loop body for every edge (uncertainty.cpp:164-198).
@@ -206,7 +228,7 @@ int orc_cov_estimate(uint64_t n_edges, const uint64_t* match_ptr, const double* 
       for (int k = 0; k < P.n; ++k) for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) H[3 * a + b] += J[5 * k + a] * J[5 * k + b];
       const double c00 = H[4] * H[8] - H[5] * H[7], c01 = H[5] * H[6] - H[3] * H[8], c02 = H[3] * H[7] - H[4] * H[6];
       const double det = H[0] * c00 + H[1] * c01 + H[2] * c02;
-      if (!(std::fabs(det) > 0) || !std::isfinite(det)) st = 2;
+      if (!(std::fabs(det) > 0) || !std::isfinite(det) || information_is_rank_deficient(H)) st = 2;
       else {
         double* C = cov9_out + 9 * e;
         C[0] = c00 / det; C[1] = (H[2] * H[7] - H[1] * H[8]) / det; C[2] = (H[1] * H[5] - H[2] * H[4]) / det;

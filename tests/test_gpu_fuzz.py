@@ -15,3 +15,12 @@ def test_randomised_device_vs_oracle(oracle, seed, monkeypatch):
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "manual"))
     import fuzz_differential
     assert fuzz_differential.run(trials=120, seed=seed, quick=True) == 0
+
+
+def test_randomised_covariance_estimation_vs_oracle(oracle):
+    """gsfm_cov_estimate on awkward view pairs (5-60 matches, gross outliers, zero / tiny translation, identical or collinear matches,
+    far-off initial rotations): same status, same iteration count and the same covariance as the oracle wherever the refinement is short;
+    rank-deficient information (where the reference's ceres::Covariance::Compute fails) is reported as status 2 by both."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "manual"))
+    import fuzz_covariance
+    assert fuzz_covariance.run(batches=6, seed=5, n_edges=200) == 0
