@@ -369,7 +369,9 @@ gsfm_status gsfm_rot_sweep_bytes(gsfm_rot_problem* p, double* algorithmic_bytes,
  *   intrinsics       6 doubles per edge: f1 u1 v1 f2 u2 v2 (CameraIntrinsicsPrior focal length / principal point, :99-104)
  *   rot_in/trans_in  TwoViewInfo::rotation_2 / position_2 (3 doubles each)
  *   cov9_out         row-major 3x3 per edge (what ceres::Covariance::GetCovarianceBlock returns)
- *   status_out       0 ok, 1 skipped (zero translation, :123, or no matches), 2 singular information matrix
+ *   status_out       0 ok, 1 skipped (zero translation, :123, or no matches), 2 rank-deficient information matrix (a pivot of
+ *                    its pivoted Cholesky below 1e-14 of the first, ceres::Covariance's reciprocal-condition bound: identical or
+ *                    collinear matches; where the reference's CHECK(covariance.Compute(...)) aborts, :157) -- no covariance
  *   iters_out        LM iterations used (may be NULL)                                                                */
 gsfm_status gsfm_cov_estimate(uint64_t n_edges, const uint64_t* match_ptr, const double* matches, const double* intrinsics,
                               const double* rot_in, const double* trans_in, int32_t max_iterations, double* cov9_out,
