@@ -24,3 +24,10 @@ def test_randomised_covariance_estimation_vs_oracle(oracle):
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "manual"))
     import fuzz_covariance
     assert fuzz_covariance.run(batches=6, seed=5, n_edges=200) == 0
+
+
+def test_randomised_nested_loss_programs_three_way(oracle):
+    """ScaledLoss / ComposedLoss trees over all leaf losses, s from 0 to 1e20: device interpreter vs oracle interpreter vs the Python classes."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "manual"))
+    import fuzz_loss
+    assert fuzz_loss.run(programs=150, seed=9) == 0
