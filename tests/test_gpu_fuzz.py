@@ -31,3 +31,11 @@ def test_randomised_nested_loss_programs_three_way(oracle):
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "manual"))
     import fuzz_loss
     assert fuzz_loss.run(programs=150, seed=9) == 0
+
+
+def test_randomised_plugin_surface_vs_flat_path():
+    """GlobalSfMpy module -> estimator class -> C-ABI on random view graphs with sparse shuffled ViewIds, views without an initial orientation and
+    pairs without a covariance: the same edges are used as the reference's skip rules dictate, and the rotations equal the flat-array solve."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "manual"))
+    import fuzz_host_layer
+    assert fuzz_host_layer.run(trials=40, seed=4) == 0
