@@ -1,0 +1,47 @@
+"""Randomised run of EstimateRotationsWithSigmaConsensus (outer IRLS with MAGSAC sigma-consensus weights around inner LM solves,
+estimator.cpp:314-457) on the device against the oracle: random graph sizes, outlier fractions, sigma_max and outer iteration caps;
+repeated pairs and isolated cameras.  usage: fuzz_sigma.py [trials] [seed]"""
+import os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from globalsfmpy_amd import _abi, synth
+from globalsfmpy_amd import loss_functions as LF
+from globalsfmpy_amd.solver import RotationProblem
+from oracle import pyoracle
+
+
+def run(trials=40, seed=1):
+    rng = np.random.default_rng(seed)
+    bad = 0
+    for t in range(trials):
+        n = int(rng.integers(5, 150)); e = int(rng.integers(n - 1, min(n * (n - 1) // 2, 12 * n) + 1))
+        g = synth.make_graph(n, e, int(rng.integers(1 << 30)), outlier_frac=float(rng.uniform(0, 0.4)), init_noise_deg=float(rng.choice([0.5, 2.0, 10.0])))
+        ei, ej, rel = g["edge_i"].copy(), g["edge_j"].copy(), g["rel_aa"].copy()
+        mode = int(rng.integers(0, 3))
+        if mode == 1 and e > 6:
+            k = int(rng.integers(1, 6)); ei = np.concatenate([ei, ej[:k]]); ej = np.concatenate([ej, g["edge_i"][:k]]); rel = np.concatenate([rel, -rel[:k]])
+        init = g["init_aa"]
+        if mode == 2:
+            n += 2; init = np.concatenate([init, 0.1 * rng.standard_normal((2, 3))])
+        iters, smax = int(rng.integers(1, 12)), float(np.exp(rng.uniform(np.log(0.01), np.log(1.0))))
+        dev = RotationProblem(n, ei, ej, rel, _abi.ANGLE_AXIS); ora = pyoracle.OracleProblem(n, ei, ej, rel, _abi.ANGLE_AXIS)
+        for p in (dev, ora):
+            p.set_loss(LF.TrivialLoss())
+        rd, sd = dev.solve_sigma_consensus(init, iters, smax)
+        ro, so = ora.solve_sigma_consensus(init, iters, smax)
+        act = np.zeros(n, bool); act[ei] = True; act[ej] = True
+        d = float(synth.angular_distance(synth.align_rotations(rd[act], ro[act]), ro[act]).mean())
+        its = max(sd["num_iterations"], so["num_iterations"])
+        ok = sd["outer_iterations"] == so["outer_iterations"] and abs(sd["last_weight_change"] - so["last_weight_change"]) < 1e-7 and d <= (1e-6 if its <= 25 else 1e-4 if its <= 40 else 1e-2)   # graded by the length of the solve
+        if not ok:
+            bad += 1
+            print("MISMATCH trial %d n=%d e=%d mode=%d outer cap %d sigma_max %.3g: outer %d vs %d, LM iterations %d vs %d, weight change %.3e vs %.3e, mean dR %.2e" % (
+                t, n, len(ei), mode, iters, smax, sd["outer_iterations"], so["outer_iterations"], sd["num_iterations"], so["num_iterations"], sd["last_weight_change"], so["last_weight_change"], d), flush=True)
+        dev.close(); ora.close()
+    print("sigma-consensus fuzz: %d trials, seed %d: %d mismatches" % (trials, seed, bad))
+    return bad
+
+
+if __name__ == "__main__":
+    sys.exit(min(1, run(int(sys.argv[1]) if len(sys.argv) > 1 else 40, int(sys.argv[2]) if len(sys.argv) > 2 else 1)))

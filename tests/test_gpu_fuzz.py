@@ -39,3 +39,9 @@ def test_randomised_plugin_surface_vs_flat_path():
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "manual"))
     import fuzz_host_layer
     assert fuzz_host_layer.run(trials=40, seed=4) == 0
+
+
+def test_randomised_sigma_consensus_vs_oracle(oracle):
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "manual"))
+    import fuzz_sigma
+    assert fuzz_sigma.run(trials=30, seed=6) == 0
