@@ -83,6 +83,11 @@ def make_local_edges(rng, n_cams, n_edges, window, shuffle=True):
     datasets arrive.  Returns (edge_i, edge_j) with edge_i < edge_j."""
     chain_i = np.arange(0, n_cams - 1, dtype=np.int64)
     need = n_edges - (n_cams - 1)
+    # pairs (a, a + d) with 2 <= d <= window // 2 (d >= 2: the chain holds d = 1) and a + d < n_cams
+    reach = max(2, window // 2)
+    available = sum(max(0, n_cams - d) for d in range(2, reach + 1))
+    if need > available:
+        raise ValueError("a window of %d admits only %d edges beside the chain on %d cameras, %d asked for" % (window, available, n_cams, need))
     keys = np.empty(0, dtype=np.int64)
     while keys.size < need:
         m = int((need - keys.size) * 1.3) + 16

@@ -30,6 +30,42 @@ def two_component_graph():
     return g
 
 
+def random_case(seed, out, prefer_native):
+    """Random graph, error type, loss and a random partition (arbitrary cut points: slices of very different widths, ranks that own no camera at
+    all); rank 0 also solves the same problem unsharded and stores both answers."""
+    import torch.distributed as dist
+    from globalsfmpy_amd import loss_functions as LF
+    from globalsfmpy_amd.solver import RotationProblem
+    rng = np.random.default_rng(seed)          # the same stream on every rank
+    world, rank = dist.get_world_size(), dist.get_rank()
+    n = int(rng.integers(max(8, world), 1500)); window = int(rng.choice([0, 0, 50]))
+    e_max = min(n * (n - 1) // 2, 30 * n) if window == 0 else n - 1 + sum(max(0, n - d) for d in range(2, window // 2 + 1)) // 2
+    e = int(rng.integers(n - 1, e_max + 1))
+    g = synth.make_graph(n, e, int(rng.integers(1 << 30)), outlier_frac=float(rng.uniform(0, 0.3)), local_window=window)
+    et = [_abi.ANGLE_AXIS, _abi.ANGLE_AXIS_COVARIANCE, _abi.QUATERNION_COSINE, _abi.ROTATION_MAT_FNORM, _abi.ANGLE_AXIS_COV_INLIERS][int(rng.integers(5))]
+    loss = [LF.HuberLoss(0.1), LF.SoftLOneLoss(0.1), LF.MAGSACWeightBasedLoss(0.02), LF.GemanMcClureLoss(0.1, 1.0)][int(rng.integers(4))]
+    order = rng.permutation(n) if rng.random() < 0.5 else np.arange(n)
+    cuts = np.sort(rng.integers(0, n + 1, world - 1)) if rng.random() < 0.5 else (np.arange(1, world) * n) // world
+    cuts = [0] + [int(c) for c in cuts] + [n]
+    width = max(1, max(cuts[r + 1] - cuts[r] for r in range(world)))
+    new_id = np.empty(n, dtype=np.int64)
+    for r in range(world):
+        members = order[cuts[r]:cuts[r + 1]]
+        new_id[members] = r * width + np.arange(members.size)
+    part = sharding.Partition(n, world, width, new_id, [0] * world)
+    prob, part = sharding.make_sharded_problem(g, et, loss=loss, prefer_native=prefer_native, part=part)
+    opts = dict(max_num_iterations=12, pcg_single_reduction=int(rng.integers(0, 2)))
+    rot, summ = prob.solve(part.scatter(g["init_aa"]), **opts)
+    res = prob.residuals(rot) if False else None
+    if rank == 0:
+        ref = RotationProblem(n, g["edge_i"], g["edge_j"], g["rel_aa"], et, cov6=g["cov6"], inlier_weight=g["inlier_weight"]); ref.set_loss(loss)
+        r1, s1 = ref.solve(g["init_aa"], dense_cholesky_max_cams=0, **opts)
+        np.savez(out, rot=part.gather(rot), ref_rot=r1, cost=summ["final_cost"], ref_cost=s1["final_cost"], iters=summ["num_iterations"], ref_iters=s1["num_iterations"],
+                 cg=summ["num_cg_iterations"], ref_cg=s1["num_cg_iterations"], n=n, e=e, et=et, widths=np.diff(cuts), loss=type(loss).__name__)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     backend, out = sys.argv[1], sys.argv[2]
     import torch
@@ -41,6 +77,8 @@ def main():
         dist.init_process_group("gloo")
     from globalsfmpy_amd.loss_functions import MAGSACWeightBasedLoss
     case = sys.argv[4] if len(sys.argv) > 4 else "default"
+    if case.startswith("random"):
+        return random_case(int(case.split(":")[1]), out, len(sys.argv) > 3 and sys.argv[3] == "native")
     g = synth.make_graph(1203, 40000, seed=23, outlier_frac=0.3)
     if case == "isolated":   # the last cameras carry no edge at all: with 8 ranks the last slice holds nothing but isolated cameras
         keep = (g["edge_i"] < 1100) & (g["edge_j"] < 1100)

@@ -145,3 +145,14 @@ def test_host_staged_collectives_fall_back_to_plain_launches_when_capture_is_req
     res = _launch(2, "gloo", str(tmp_path / "gloo_graph.npz"), {"GSFM_TEST_PCG_GRAPH": "2"})
     _compare(res, _reference())
     assert int(res["graph_launches"]) == 0
+
+
+@pytest.mark.parametrize("world,seed", [(3, 102), (5, 103), (8, 104), (6, 106), (8, 108)])
+def test_random_graph_random_partition_equals_the_single_gpu_solve(tmp_path, world, seed):
+    """Random size, error type (the non-Laplacian 9-residual functor included), loss, PCG variant and a random partition -- arbitrary cut points,
+    so slices of very different widths and ranks that own no camera at all: same LM and PCG iteration counts, same cost, same rotations."""
+    res = _launch(world, "gloo", str(tmp_path / ("rand%d.npz" % seed)), case="random:%d" % seed)
+    info = "n=%d e=%d et=%d %s slice sizes %s" % (int(res["n"]), int(res["e"]), int(res["et"]), str(res["loss"]), res["widths"].tolist())
+    assert int(res["iters"]) == int(res["ref_iters"]) and int(res["cg"]) == int(res["ref_cg"]), info
+    assert abs(float(res["cost"]) - float(res["ref_cost"])) <= 1e-12 * float(res["ref_cost"]), info
+    assert synth.angular_distance(res["rot"], res["ref_rot"]).max() < 1e-9, info
