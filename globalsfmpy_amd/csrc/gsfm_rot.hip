@@ -199,7 +199,7 @@ struct gsfm_rot_problem {
   // replayable chunk of PCG iterations (hipGraph), keyed on the by-value kernel arguments it froze
   struct PcgGraph {
     hipGraphExec_t exec = nullptr;
-    double tol = 0; int max_iters = 0, stall = 0, chunk = 0;
+    double tol = 0; int max_iters = 0, stall = 0, chunk = 0; uint32_t coarse = 0;
     bool unusable = false, lap = false;
     void reset() { if (exec) (void)hipGraphExecDestroy(exec); exec = nullptr; }
   } pcg_graph, pcg2_graph;
@@ -227,6 +227,10 @@ struct gsfm_rot_problem {
   DevBuf<double2> q, q_trial;
   DevBuf<double> xcg, r, z, p, Ap, s_dir, part_g2, part_d2;
   DevBuf<Cg2Scalars> cg2sc;
+  // two-level preconditioner (kernels.hpp, k_coarse_*): aggregates wanted (0 = off, decided at create) / in use for the current LM step
+  uint32_t coarse_want = 0, coarse_n = 0, coarse_chunk = 0;
+  DevBuf<double> coarseA, coarseAinv, coarse_rc, coarse_xc;
+  std::vector<double> h_coarse, h_coarse_inv;
   void* pin = nullptr;              // 256 B of pinned host memory: staging for the small read-backs of the solve loop (read_back)
   DevBuf<double> denseA, denseL;
   hipGraphExec_t dense_graph = nullptr;   // zero + assemble + blocked Cholesky + solve, captured once
@@ -493,6 +497,76 @@ int launch_matvec(gsfm_rot_problem* P, const double* Mblk, const double* p, doub
   return all_gather(P, y, (size_t)P->shard.slice_width * 3);
 }
 
+// Inverse of a symmetric positive definite n x n matrix (row-major) through its Cholesky factor; false if a pivot is not positive.
+bool spd_inverse(std::vector<double>& A, size_t n, std::vector<double>& inv) {
+  for (size_t j = 0; j < n; ++j) {          // A <- L (lower), column by column
+    double d = A[j * n + j];
+    for (size_t k = 0; k < j; ++k) d -= A[j * n + k] * A[j * n + k];
+    if (!(d > 0.0) || !std::isfinite(d)) return false;
+    const double l = std::sqrt(d);
+    A[j * n + j] = l;
+    for (size_t i = j + 1; i < n; ++i) {
+      double v = A[i * n + j];
+      for (size_t k = 0; k < j; ++k) v -= A[i * n + k] * A[j * n + k];
+      A[i * n + j] = v / l;
+    }
+  }
+  std::vector<double> Li(n * n, 0.0);       // L^-1 (lower), row by row: row_i = (e_i - sum_{k<i} L[i][k] row_k) / L[i][i]  (contiguous rows only)
+  for (size_t i = 0; i < n; ++i) {
+    double* ri = &Li[i * n];
+    ri[i] = 1.0;
+    for (size_t k = 0; k < i; ++k) {
+      const double l = A[i * n + k];
+      const double* rk = &Li[k * n];
+      for (size_t c = 0; c <= k; ++c) ri[c] -= l * rk[c];
+    }
+    const double d = 1.0 / A[i * n + i];
+    for (size_t c = 0; c <= i; ++c) ri[c] *= d;
+  }
+  inv.assign(n * n, 0.0);                   // A^-1 = L^-T L^-1 as a sum of rank-one updates of the lower triangle, then mirrored
+  for (size_t k = 0; k < n; ++k) {
+    const double* rk = &Li[k * n];
+    for (size_t i = 0; i <= k; ++i) {
+      const double a = rk[i];
+      double* oi = &inv[i * n];
+      for (size_t j = 0; j <= i; ++j) oi[j] += a * rk[j];
+    }
+  }
+  for (size_t i = 0; i < n; ++i) for (size_t j = 0; j < i; ++j) inv[j * n + i] = inv[i * n + j];
+  return true;
+}
+
+// Coarse matrix of the two-level preconditioner for the current linearisation and damping: assembled on the device, inverted on the host
+// (3 n_agg <= 384 unknowns).  Leaves P->coarse_n = 0 (plain block-Jacobi for this step) if the matrix is not positive definite.
+int coarse_build(gsfm_rot_problem* P) {
+  P->coarse_n = 0;
+  if (!P->coarse_want || P->sharded || !P->lin_is_lap) return 0;
+  const uint32_t na = P->coarse_want, nc = 3 * na;
+  if (!P->coarseA.p) {
+    if (P->coarseA.alloc((size_t)nc * nc) != hipSuccess || P->coarseAinv.alloc((size_t)nc * nc) != hipSuccess || P->coarse_rc.alloc(nc, true) != hipSuccess ||
+        P->coarse_xc.alloc(nc + 1, true) != hipSuccess) { P->coarseA.release(); P->coarse_want = 0; (void)hipGetLastError(); return 0; }
+  }
+  const int tk = P->timer.begin(T_CG);
+  HIPCHK(hipMemsetAsync(P->coarseA.p, 0, 8 * (size_t)nc * nc, P->stream));
+  CoarseAsmArgs a{};
+  a.n_rows = P->n_rows; a.G = P->G; a.n_agg = na; a.chunk = P->coarse_chunk; a.row_ptr = P->row_ptr.p; a.col = P->col.p;
+  a.h0 = P->h0.p; a.h1 = P->h1.p; a.h2 = P->h2.p; a.Mblk = P->Mblk.p; a.q = P->q_lin; a.Ac = P->coarseA.p;
+  hipLaunchKernelGGL(k_coarse_assemble, dim3(grid_for((size_t)P->n_rows * P->G)), dim3(GSFM_BLOCK), 0, P->stream, a);
+  P->timer.end(tk);
+  P->h_coarse.resize((size_t)nc * nc);
+  HIPCHK(hipMemcpyAsync(P->h_coarse.data(), P->coarseA.p, 8 * (size_t)nc * nc, hipMemcpyDeviceToHost, P->stream));
+  const double t_a = now_ms();
+  if (int st = sync_check(P, "coarse matrix")) return st;
+  const double t_b = now_ms();
+  auto& A = P->h_coarse;
+  for (size_t i = 0; i < nc; ++i) for (size_t j = 0; j < i; ++j) { const double v = 0.5 * (A[i * nc + j] + A[j * nc + i]); A[i * nc + j] = A[j * nc + i] = v; }
+  if (!spd_inverse(A, nc, P->h_coarse_inv)) return 0;
+  if (getenv("GSFM_COARSE_TIMING")) fprintf(stderr, "gsfm coarse: assemble + download (wait) %.2f ms, host inverse of %u unknowns %.2f ms\n", t_b - t_a, nc, now_ms() - t_b);
+  HIPCHK(hipMemcpyAsync(P->coarseAinv.p, P->h_coarse_inv.data(), 8 * (size_t)nc * nc, hipMemcpyHostToDevice, P->stream));
+  P->coarse_n = na;
+  return 0;
+}
+
 // block-Jacobi PCG on (J^T J + Lambda) eta = -g; returns iterations
 int run_pcg(gsfm_rot_problem* P, const gsfm_rot_options& o, int* iters_out, double* rel_out) {
   CgArgs a{};
@@ -500,10 +574,21 @@ int run_pcg(gsfm_rot_problem* P, const gsfm_rot_options& o, int* iters_out, doub
   a.Minv = P->Minv.p; a.b = P->b.p; a.xcg = P->xcg.p; a.r = P->r.p; a.z = P->z.p; a.p = P->p.p; a.Ap = P->Ap.p;
   a.part_a = P->part_a.p; a.part_b = P->part_b.p; a.sc = P->cgsc.p;
   a.q = P->q_lin; a.u = P->lin_is_lap ? P->u_rot.p : nullptr;
+  a.coarse_n = P->coarse_n; a.coarse_chunk = P->coarse_chunk; a.xc = P->coarse_xc.p;
+  CoarseArgs ca{};
+  ca.n = P->n_cams; ca.n_agg = P->coarse_n; ca.chunk = P->coarse_chunk; ca.q = P->q_lin; ca.r = P->r.p; ca.rc = P->coarse_rc.p; ca.Ainv = P->coarseAinv.p;
+  ca.xc = P->coarse_xc.p; ca.done = nullptr;
   const dim3 g(P->nb_cam), blk(GSFM_BLOCK);
   const int tk0 = P->timer.begin(T_CG);
   hipLaunchKernelGGL(k_cg_init, g, blk, 0, P->stream, a);
   hipLaunchKernelGGL(k_cg_init_fin, dim3(1), blk, 0, P->stream, a);
+  if (a.coarse_n) {   // z_0 = Minv r_0 + P Ac^-1 P^T r_0
+    hipLaunchKernelGGL(k_coarse_restrict, dim3(a.coarse_n), blk, 0, P->stream, ca);
+    hipLaunchKernelGGL(k_coarse_apply, dim3(1), dim3(1024), 0, P->stream, ca);
+    hipLaunchKernelGGL(k_cg_init_coarse, g, blk, 0, P->stream, a);
+    hipLaunchKernelGGL(k_cg_init_coarse_fin, dim3(1), dim3(1), 0, P->stream, a);
+  }
+  ca.done = &P->cgsc.p->done;
   P->timer.end(tk0);
   CgScalars h{};
   const int chunk = std::max(1, o.cg_check_interval);
@@ -512,6 +597,10 @@ int run_pcg(gsfm_rot_problem* P, const gsfm_rot_options& o, int* iters_out, doub
       if (int st = launch_matvec(P, P->Mblk.p, P->p.p, P->Ap.p, &P->cgsc.p->done)) return st;
       hipLaunchKernelGGL(k_cg_dot, g, blk, 0, P->stream, a);
       hipLaunchKernelGGL(k_cg_update, g, blk, 0, P->stream, a);
+      if (a.coarse_n) {
+        hipLaunchKernelGGL(k_coarse_restrict, dim3(a.coarse_n), blk, 0, P->stream, ca);
+        hipLaunchKernelGGL(k_coarse_apply, dim3(1), dim3(1024), 0, P->stream, ca);
+      }
       hipLaunchKernelGGL(k_cg_pupdate, g, blk, 0, P->stream, a);
       a.par ^= 1;
     }
@@ -520,14 +609,14 @@ int run_pcg(gsfm_rot_problem* P, const gsfm_rot_options& o, int* iters_out, doub
   // The chunk between two host checks as one hipGraph launch: 4 * chunk dependent kernels whose arguments never change.
   auto& G = P->pcg_graph;
   bool graph = o.pcg_hip_graph && (!P->sharded || (o.pcg_hip_graph >= 2 && (P->shard.flags & GSFM_SHARD_CAPTURABLE))) && chunk % 2 == 0 && !G.unusable;
-  if (graph && (!G.exec || G.tol != a.tol || G.max_iters != a.max_iters || G.stall != a.stall_limit || G.chunk != chunk || G.lap != P->lin_is_lap)) {
+  if (graph && (!G.exec || G.tol != a.tol || G.max_iters != a.max_iters || G.stall != a.stall_limit || G.chunk != chunk || G.lap != P->lin_is_lap || G.coarse != a.coarse_n)) {
     G.reset();
     hipGraph_t captured = nullptr;
     if (hipStreamBeginCapture(P->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
       const int st = enqueue_chunk();
       const hipError_t e = hipStreamEndCapture(P->stream, &captured);
       if (st == 0 && e == hipSuccess && captured && hipGraphInstantiate(&G.exec, captured, nullptr, nullptr, 0) == hipSuccess) {
-        G.tol = a.tol; G.max_iters = a.max_iters; G.stall = a.stall_limit; G.chunk = chunk; G.lap = P->lin_is_lap;
+        G.tol = a.tol; G.max_iters = a.max_iters; G.stall = a.stall_limit; G.chunk = chunk; G.lap = P->lin_is_lap; G.coarse = a.coarse_n;
       } else { G.exec = nullptr; }
       if (captured) (void)hipGraphDestroy(captured);
     }
@@ -888,7 +977,8 @@ int lm_solve(gsfm_rot_problem* P, const gsfm_rot_options& o_in, gsfm_rot_summary
     }
     for (int attempt = 0; attempt < 2; ++attempt) {
       if (!dense_used) {
-        if (int st = (use_single_reduction(P, o) ? run_pcg2(P, o, &cg, &cg_rel) : run_pcg(P, o, &cg, &cg_rel))) return st;
+        if (int st = coarse_build(P)) return st;
+        if (int st = ((P->coarse_n == 0 && use_single_reduction(P, o)) ? run_pcg2(P, o, &cg, &cg_rel) : run_pcg(P, o, &cg, &cg_rel))) return st;
       }
       launch_step(P);
       if (int st = launch_cost(P, P->q_trial.p, SC_TRIAL)) return st;
@@ -1135,6 +1225,25 @@ gsfm_status gsfm_rot_problem_create(uint32_t n_cams, uint64_t n_edges, const uin
     }
   }
   lap("locality relabelling");
+  {  // two-level preconditioner: aggregates = contiguous chunks of the camera order, which only mean something if that order is the
+     // locality order (adopted above) -- GSFM_PCG_COARSE=n forces n aggregates, =0 switches it off
+    const char* env = getenv("GSFM_PCG_COARSE");
+    int want = env && *env ? atoi(env) : -1;
+    if (want < 0 && !P->sharded && n_cams >= 8192) {
+      // spatially coherent in the numbering the rows now have (relabelled above, or coherent as given)?  Mean index distance over a
+      // sample of the edges: n/3 for a uniformly random graph, the neighbourhood radius for a coherent one
+      double sum = 0.0; uint64_t cnt = 0;
+      for (uint64_t e = 0; e < n_edges; e += 61) { sum += std::fabs((double)edge_i[e] - (double)edge_j[e]); ++cnt; }
+      want = (cnt && sum / (double)cnt <= (double)n_cams / 32.0) ? 64 : 0;
+    }
+    if (want < 0) want = 0;
+    want = std::min(want, 128);
+    if (P->sharded || want < 2 || n_cams < 4u * (uint32_t)want) want = 0;
+    if (want) {
+      P->coarse_chunk = (n_cams + want - 1) / want;
+      P->coarse_want = (n_cams + P->coarse_chunk - 1) / P->coarse_chunk;   // no empty aggregate
+    }
+  }
   // connected components of the view graph: counted here on one GPU; a rank of a sharded problem sees only its own edges, so the
   // partitioner passes the verdict in the shard descriptor (GSFM_SHARD_DISCONNECTED)
   if (!P->sharded) P->n_components = std::max<uint32_t>(1, count_components(n_cams, n_edges, edge_i, edge_j));

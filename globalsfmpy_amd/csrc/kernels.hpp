@@ -1096,7 +1096,19 @@ struct CgArgs {
   CgScalars* sc;
   const double2* q;  // Laplacian form: camera quaternions and
   double* u;         //   u_k = R_k^T p_k, written wherever p is (null otherwise)
+  // two-level preconditioner (see k_coarse_*): z = Minv r + P xc, with xc the coarse correction of this iteration; 0 aggregates = off
+  uint32_t coarse_n, coarse_chunk;
+  const double* xc;  // [3 coarse_n + 1]: correction per aggregate (body frame), then rc . xc
 };
+// (P xc)_k = R_k xc[aggregate of k]
+__device__ __forceinline__ void coarse_prolong(const CgArgs& a, uint32_t k, double* out) {
+  const uint32_t I = min(k / a.coarse_chunk, a.coarse_n - 1);
+  const Quat qq{a.q[2 * (size_t)k].x, a.q[2 * (size_t)k].y, a.q[2 * (size_t)k + 1].x, a.q[2 * (size_t)k + 1].y};
+  double R[9];
+  qmat(qq, R);
+  const double x0 = a.xc[3 * I], x1 = a.xc[3 * I + 1], x2 = a.xc[3 * I + 2];
+  out[0] = R[0] * x0 + R[1] * x1 + R[2] * x2; out[1] = R[3] * x0 + R[4] * x1 + R[5] * x2; out[2] = R[6] * x0 + R[7] * x1 + R[8] * x2;
+}
 
 // x = 0, r = b, z = Minv r, p = z, partial r.z
 __global__ void __launch_bounds__(GSFM_BLOCK) k_cg_init(CgArgs a) {
@@ -1165,15 +1177,17 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_cg_update(CgArgs a) {
 __global__ void __launch_bounds__(GSFM_BLOCK) k_cg_pupdate(CgArgs a) {
   if (a.sc->done) return;
   __shared__ double lds[8];
-  const double rz_new = sum_partials_bcast(a.part_b, a.nb, lds);
+  double rz_new = sum_partials_bcast(a.part_b, a.nb, lds);
+  if (a.coarse_n) rz_new += a.xc[3 * a.coarse_n];   // r . (Minv r + P xc) = r . Minv r + (P^T r) . xc
   const double rz_old = a.sc->rz[a.par];
   const double beta = rz_new / rz_old;
   const uint32_t k = blockIdx.x * GSFM_BLOCK + threadIdx.x;
   if (k < a.n) {
     const size_t k3 = 3 * (size_t)k;
-    double pn[3];
+    double pn[3], zc[3] = {0.0, 0.0, 0.0};
+    if (a.coarse_n) coarse_prolong(a, k, zc);
 #pragma unroll
-    for (int c = 0; c < 3; ++c) { pn[c] = a.z[k3 + c] + beta * a.p[k3 + c]; a.p[k3 + c] = pn[c]; }
+    for (int c = 0; c < 3; ++c) { pn[c] = (a.z[k3 + c] + zc[c]) + beta * a.p[k3 + c]; a.p[k3 + c] = pn[c]; }
     if (a.u) {
       const Quat qq{a.q[2 * (size_t)k].x, a.q[2 * (size_t)k].y, a.q[2 * (size_t)k + 1].x, a.q[2 * (size_t)k + 1].y};
       double uu[3];
@@ -1194,6 +1208,175 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_cg_pupdate(CgArgs a) {
       if (rel < 0.5 * a.sc->best_rel) { a.sc->best_rel = rel; a.sc->stall = 0; }
       else if (++a.sc->stall >= a.stall_limit) { a.sc->done = 1; a.sc->stalled = 1; }
     }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Two-level preconditioner for spatially coherent graphs (block-Jacobi alone needs hundreds of PCG iterations per step there: the
+// condition number grows with the square of the graph's diameter).  In the body frame u_k = R_k^T eta_k the normal matrix of the
+// Laplacian form is a graph Laplacian with one symmetric 3 x 3 weight per edge, whose near-null vectors are the constants (the global
+// gauge rotation), so the coarse space is one 3-vector per aggregate = contiguous chunk of the locality ordering, rotated by R_k:
+//   z = Minv r + P Ac^-1 P^T r,   (P v)_k = R_k v[agg(k)],   Ac = P^T A P  (3 n_agg square, assembled per LM step, inverted on the host).
+// Additive, symmetric positive definite: PCG's answer does not depend on it, only its iteration count does.
+// ------------------------------------------------------------------------------------------
+struct CoarseArgs {
+  uint32_t n, n_agg, chunk;     // cameras, aggregates, cameras per aggregate
+  const double2* q;
+  const double* r;              // residual, 3 per camera
+  double* rc;                   // [3 n_agg]  P^T r
+  const double* Ainv;           // [nc x nc], symmetric
+  double* xc;                   // [nc + 1]   Ainv rc, then rc . xc
+  const int* done;
+};
+__global__ void __launch_bounds__(GSFM_BLOCK) k_coarse_restrict(CoarseArgs a) {
+  if (a.done && *a.done) return;
+  __shared__ double lds[8];
+  const uint32_t I = blockIdx.x, lo = I * a.chunk, hi = (I + 1 == a.n_agg) ? a.n : min(a.n, lo + a.chunk);
+  double acc[3] = {0.0, 0.0, 0.0};
+  for (uint32_t k = lo + threadIdx.x; k < hi; k += GSFM_BLOCK) {
+    const Quat qq{a.q[2 * (size_t)k].x, a.q[2 * (size_t)k].y, a.q[2 * (size_t)k + 1].x, a.q[2 * (size_t)k + 1].y};
+    double uu[3];
+    rot_transpose_apply(qq, a.r + 3 * (size_t)k, uu);
+    acc[0] += uu[0]; acc[1] += uu[1]; acc[2] += uu[2];
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const double t = block_sum_bcast(acc[c], lds);
+    if (threadIdx.x == 0) a.rc[3 * I + c] = t;
+  }
+}
+// xc = Ainv rc and rc . xc: one workgroup of 1024 lanes; lane (row, g) sums the columns g, g + groups, ... of its row (Ainv is symmetric, so
+// column `row` is read as a row: coalesced over the lanes), the groups are combined through LDS.  3 n_agg <= 384.
+#define GSFM_COARSE_MAX_NC 384
+__global__ void __launch_bounds__(1024) k_coarse_apply(CoarseArgs a) {
+  if (a.done && *a.done) return;
+  __shared__ double rcs[GSFM_COARSE_MAX_NC];
+  __shared__ double part[1024];
+  __shared__ double lds[20];
+  const uint32_t nc = 3 * a.n_agg, tid = threadIdx.x, groups = 1024 / nc, row = tid % nc, g = tid / nc;
+  for (uint32_t c = tid; c < nc; c += 1024) rcs[c] = a.rc[c];
+  __syncthreads();
+  double sum = 0.0;
+  if (g < groups) {
+#pragma unroll 8
+    for (uint32_t c = g; c < nc; c += groups) sum += a.Ainv[(size_t)c * nc + row] * rcs[c];
+  }
+  part[tid] = sum;
+  __syncthreads();
+  double dot = 0.0;
+  if (tid < nc) {
+    double x = 0.0;
+    for (uint32_t gg = 0; gg < groups; ++gg) x += part[gg * nc + tid];
+    a.xc[tid] = x;
+    dot = x * rcs[tid];
+  }
+  // block sum over 1024 lanes
+  dot = wave_sum(dot);
+  if ((tid & 63) == 0) lds[tid >> 6] = dot;
+  __syncthreads();
+  if (tid == 0) { double t = 0.0; for (int w = 0; w < 16; ++w) t += lds[w]; a.xc[nc] = t; }
+}
+// after k_cg_init / k_cg_init_fin: p = z + P xc (and u = R^T p), r.z += rc . xc
+__global__ void __launch_bounds__(GSFM_BLOCK) k_cg_init_coarse(CgArgs a) {
+  const uint32_t k = blockIdx.x * GSFM_BLOCK + threadIdx.x;
+  if (k < a.n) {
+    const size_t k3 = 3 * (size_t)k;
+    double zc[3], pn[3];
+    coarse_prolong(a, k, zc);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { pn[c] = a.z[k3 + c] + zc[c]; a.p[k3 + c] = pn[c]; }
+    if (a.u) {
+      const Quat qq{a.q[2 * (size_t)k].x, a.q[2 * (size_t)k].y, a.q[2 * (size_t)k + 1].x, a.q[2 * (size_t)k + 1].y};
+      double uu[3];
+      rot_transpose_apply(qq, pn, uu);
+      a.u[k3] = uu[0]; a.u[k3 + 1] = uu[1]; a.u[k3 + 2] = uu[2];
+    }
+  }
+}
+__global__ void k_cg_init_coarse_fin(CgArgs a) {
+  const double rz = a.sc->rz[0] + a.xc[3 * a.coarse_n];
+  a.sc->rz[0] = rz; a.sc->rz[1] = rz; a.sc->rz0 = rz; a.sc->done = !(rz > 0.0);
+}
+// Ac = P^T A P from the stored blocks of the Laplacian form: off-diagonal entry (k -> m) contributes -R_k^T G_k R_k to block (agg k, agg m),
+// the diagonal block R_k^T M_k R_k to (agg k, agg k).  G lanes per row; a lane sums its consecutive entries that fall into the same
+// aggregate before touching memory (rows are sorted by neighbour, so that is most of them), then adds with hardware fp64 atomics:
+// the order of those additions varies from run to run, i.e. the PRECONDITIONER is reproducible to rounding only (the solution it
+// leads to is the same to the PCG tolerance either way).  Ac is zero-filled before the launch.
+struct CoarseAsmArgs {
+  uint32_t n_rows, G, n_agg, chunk;
+  const uint32_t* row_ptr;
+  const uint32_t* col;
+  const double2 *h0, *h1, *h2;
+  const double* Mblk;
+  const double2* q;
+  double* Ac;
+};
+__device__ __forceinline__ void coarse_flush(double* Ac, uint32_t nc, uint32_t I, uint32_t J, const double* S /* sym 6: 00 01 02 11 12 22 */) {
+  double* o = Ac + (size_t)(3 * I) * nc + 3 * J;
+  unsafeAtomicAdd(o, S[0]); unsafeAtomicAdd(o + 1, S[1]); unsafeAtomicAdd(o + 2, S[2]);
+  unsafeAtomicAdd(o + nc, S[1]); unsafeAtomicAdd(o + nc + 1, S[3]); unsafeAtomicAdd(o + nc + 2, S[4]);
+  unsafeAtomicAdd(o + 2 * nc, S[2]); unsafeAtomicAdd(o + 2 * nc + 1, S[4]); unsafeAtomicAdd(o + 2 * nc + 2, S[5]);
+}
+// S = R^T Sym R for a symmetric 3 x 3 given as (00 01 02 11 12 22)
+__device__ __forceinline__ void sym3_congruence_T(const double* R, const double* M, double* S) {
+  const double m[9] = {M[0], M[1], M[2], M[1], M[3], M[4], M[2], M[4], M[5]};
+  double t[9];   // t = M R
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) t[3 * r + c] = m[3 * r] * R[c] + m[3 * r + 1] * R[3 + c] + m[3 * r + 2] * R[6 + c];
+  // S = R^T t
+  S[0] = R[0] * t[0] + R[3] * t[3] + R[6] * t[6]; S[1] = R[0] * t[1] + R[3] * t[4] + R[6] * t[7]; S[2] = R[0] * t[2] + R[3] * t[5] + R[6] * t[8];
+  S[3] = R[1] * t[1] + R[4] * t[4] + R[7] * t[7]; S[4] = R[1] * t[2] + R[4] * t[5] + R[7] * t[8]; S[5] = R[2] * t[2] + R[5] * t[5] + R[8] * t[8];
+}
+__global__ void __launch_bounds__(GSFM_BLOCK) k_coarse_assemble(CoarseAsmArgs a) {
+  const uint32_t t = blockIdx.x * GSFM_BLOCK + threadIdx.x;
+  const uint32_t row = t / a.G, lane = t % a.G;
+  const bool valid = row < a.n_rows;
+  const uint32_t nc = 3 * a.n_agg, I = min((valid ? row : a.n_rows - 1) / a.chunk, a.n_agg - 1);
+  double own[6] = {0, 0, 0, 0, 0, 0};   // contributions to the aggregate's own diagonal block (I, I): by far the most, summed over the wavefront below
+  if (valid) {
+    double R[9];
+    qmat(load_q(a.q, row), R);
+    uint32_t curJ = 0xffffffffu;
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    const uint32_t end = a.row_ptr[row + 1];
+    for (uint32_t d = a.row_ptr[row] + lane; d < end; d += a.G) {
+      const uint32_t m = a.col[d] & 0x7fffffffu, J = min(m / a.chunk, a.n_agg - 1);
+      const double2 A = a.h0[d], B = a.h1[d], C = a.h2[d];
+      const double Gs[6] = {A.x, A.y, B.x, B.y, C.x, C.y};
+      double S[6];
+      sym3_congruence_T(R, Gs, S);
+      if (J == I) {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) own[c] -= S[c];
+        continue;
+      }
+      if (J != curJ) {
+        if (curJ != 0xffffffffu) coarse_flush(a.Ac, nc, I, curJ, acc);
+        curJ = J;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) acc[c] = 0.0;
+      }
+#pragma unroll
+      for (int c = 0; c < 6; ++c) acc[c] -= S[c];
+    }
+    if (curJ != 0xffffffffu) coarse_flush(a.Ac, nc, I, curJ, acc);
+    if (lane == 0) {
+      double S[6];
+      sym3_congruence_T(R, a.Mblk + 6 * (size_t)row, S);
+#pragma unroll
+      for (int c = 0; c < 6; ++c) own[c] += S[c];
+    }
+  }
+  // one set of atomics per wavefront when all its rows belong to the same aggregate (they do, except at the 63 chunk boundaries)
+  const uint32_t I0 = __shfl(I, 0);
+  if (__all(I == I0)) {
+#pragma unroll
+    for (int c = 0; c < 6; ++c) own[c] = wave_sum(own[c]);
+    if ((threadIdx.x & 63) == 0) coarse_flush(a.Ac, nc, I0, I0, own);
+  } else if (valid) {
+    coarse_flush(a.Ac, nc, I, I, own);
   }
 }
 

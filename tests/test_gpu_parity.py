@@ -380,6 +380,52 @@ def test_a_factorisation_that_breaks_down_is_solved_again_by_pcg():
     assert synth.angular_distance(synth.align_rotations(rd, rp), rp).mean() <= 1e-4
 
 
+@pytest.mark.parametrize("et,loss", [(_abi.ANGLE_AXIS, LF.HuberLoss(0.1)), (_abi.ANGLE_AXIS_COVARIANCE, LF.MAGSACWeightBasedLoss(0.02))])
+def test_two_level_preconditioner_on_a_coherent_graph(oracle, et, loss, monkeypatch):
+    """Spatially coherent 12k-camera graph with shuffled ids: block-Jacobi PCG needs ~1000 iterations per solve; with the aggregates of the
+    locality ordering as a coarse space (chosen automatically: >= 8192 cameras, coherent numbering) a fraction of that -- and the SAME
+    answer, because PCG's result does not depend on its preconditioner: against the plain path and against the oracle."""
+    from globalsfmpy_amd.solver import RotationProblem
+    g = synth.make_graph(12000, 240000, 17, outlier_frac=0.1, local_window=400)
+    kw = {"cov6": g["cov6"]} if et == _abi.ANGLE_AXIS_COVARIANCE else {}
+    out = {}
+    for mode in ("0", None, "32"):
+        if mode is None:
+            monkeypatch.delenv("GSFM_PCG_COARSE", raising=False)
+        else:
+            monkeypatch.setenv("GSFM_PCG_COARSE", mode)
+        p = RotationProblem(g["n_cams"], g["edge_i"], g["edge_j"], g["rel_aa"], et, **kw); p.set_loss(loss)
+        out[mode] = p.solve(g["init_aa"])
+        p.close()
+    (r0, s0), (r1, s1), (r2, s2) = out["0"], out[None], out["32"]
+    print("PCG iterations: block-Jacobi %d, two-level (auto) %d, 32 aggregates %d" % (s0["num_cg_iterations"], s1["num_cg_iterations"], s2["num_cg_iterations"]))
+    assert s1["num_cg_iterations"] * 3 <= s0["num_cg_iterations"] and s2["num_cg_iterations"] * 2 <= s0["num_cg_iterations"]
+    for r, s in ((r1, s1), (r2, s2)):
+        assert s["num_iterations"] == s0["num_iterations"] and s["termination"] == s0["termination"]
+        assert abs(s["final_cost"] - s0["final_cost"]) <= 1e-10 * s0["final_cost"]
+        assert synth.angular_distance(synth.align_rotations(r, r0), r0).max() <= 1e-9
+    ora = oracle.OracleProblem(g["n_cams"], g["edge_i"], g["edge_j"], g["rel_aa"], et, **kw); ora.set_loss(loss)
+    ro, so = ora.solve(g["init_aa"])
+    assert s1["num_iterations"] == so["num_iterations"]
+    assert synth.angular_distance(synth.align_rotations(r1, ro), ro).mean() <= 1e-6
+
+
+def test_two_level_preconditioner_leaves_random_graphs_alone(monkeypatch):
+    """A uniformly random graph has no coherent numbering: the automatic choice is block-Jacobi, bit for bit the same solve as with the switch off."""
+    from globalsfmpy_amd.solver import RotationProblem
+    g = synth.make_graph(9000, 180000, 19, outlier_frac=0.2)
+    res = []
+    for mode in ("0", None):
+        if mode is None:
+            monkeypatch.delenv("GSFM_PCG_COARSE", raising=False)
+        else:
+            monkeypatch.setenv("GSFM_PCG_COARSE", mode)
+        p = RotationProblem(g["n_cams"], g["edge_i"], g["edge_j"], g["rel_aa"], _abi.ANGLE_AXIS); p.set_loss(LF.HuberLoss(0.1))
+        res.append(p.solve(g["init_aa"]))
+        p.close()
+    assert np.array_equal(res[0][0], res[1][0]) and res[0][1]["num_cg_iterations"] == res[1][1]["num_cg_iterations"]
+
+
 @pytest.mark.parametrize("et", [_abi.ANGLE_AXIS_COVARIANCE, _abi.QUATERNION_COSINE])
 def test_laplacian_form_equals_the_general_blocks(graph, et, monkeypatch):
     """H_km = -G_k R_k R_m^T (6 stored doubles per directed entry) against the general 9-value blocks: same mat-vec to rounding,
