@@ -140,6 +140,19 @@ def small_graph_timings(args):
     p.set_loss(LF.MAGSACWeightBasedLoss(0.02))
     out["C2_10k_cams_200k_edges_cov_magsac"] = best(p, g["init_aa"])
     p.close()
+    # a spatially coherent graph (what real large view graphs look like, unlike the uniformly random C5): neighbours within +-500 of a hidden
+    # ordering, ids shuffled.  Block-Jacobi PCG against the two-level preconditioner the library chooses for such graphs (same answer).
+    gc = synth.make_graph(100000, 2000000, 7, outlier_frac=0.1, local_window=1000)
+    for label, env in (("two_level_auto", None), ("block_jacobi_only", "0")):
+        if env is None:
+            os.environ.pop("GSFM_PCG_COARSE", None)
+        else:
+            os.environ["GSFM_PCG_COARSE"] = env
+        p = RotationProblem(gc["n_cams"], gc["edge_i"], gc["edge_j"], gc["rel_aa"], _abi.ANGLE_AXIS_COVARIANCE, cov6=gc["cov6"])
+        p.set_loss(LF.MAGSACWeightBasedLoss(0.02))
+        out["coherent_100k_cams_2M_edges_cov_magsac_" + label] = best(p, gc["init_aa"])
+        p.close()
+    os.environ.pop("GSFM_PCG_COARSE", None)
     path = os.path.join(ROOT, "tests", "golden", "madrid_graph.npz")
     if os.path.exists(path):
         try:

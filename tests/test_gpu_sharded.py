@@ -147,7 +147,7 @@ def test_host_staged_collectives_fall_back_to_plain_launches_when_capture_is_req
     assert int(res["graph_launches"]) == 0
 
 
-@pytest.mark.parametrize("world,seed", [(3, 102), (5, 103), (8, 104), (6, 106), (8, 108)])
+@pytest.mark.parametrize("world,seed", [(3, 102), (5, 103), (8, 104), (6, 106), (7, 222)])
 def test_random_graph_random_partition_equals_the_single_gpu_solve(tmp_path, world, seed):
     """Random size, error type (the non-Laplacian 9-residual functor included), loss, PCG variant and a random partition -- arbitrary cut points,
     so slices of very different widths and ranks that own no camera at all: same LM and PCG iteration counts, same cost, same rotations."""
