@@ -560,6 +560,7 @@ int coarse_build(gsfm_rot_problem* P) {
   const double t_b = now_ms();
   auto& A = P->h_coarse;
   for (size_t i = 0; i < nc; ++i) for (size_t j = 0; j < i; ++j) { const double v = 0.5 * (A[i * nc + j] + A[j * nc + i]); A[i * nc + j] = A[j * nc + i] = v; }
+  for (size_t i = 0; i < nc; ++i) if (A[i * nc + i] == 0.0) A[i * nc + i] = 1.0;   // an aggregate of cameras without edges: decoupled, its correction stays zero
   if (!spd_inverse(A, nc, P->h_coarse_inv)) return 0;
   if (getenv("GSFM_COARSE_TIMING")) fprintf(stderr, "gsfm coarse: assemble + download (wait) %.2f ms, host inverse of %u unknowns %.2f ms\n", t_b - t_a, nc, now_ms() - t_b);
   HIPCHK(hipMemcpyAsync(P->coarseAinv.p, P->h_coarse_inv.data(), 8 * (size_t)nc * nc, hipMemcpyHostToDevice, P->stream));
@@ -574,10 +575,10 @@ int run_pcg(gsfm_rot_problem* P, const gsfm_rot_options& o, int* iters_out, doub
   a.Minv = P->Minv.p; a.b = P->b.p; a.xcg = P->xcg.p; a.r = P->r.p; a.z = P->z.p; a.p = P->p.p; a.Ap = P->Ap.p;
   a.part_a = P->part_a.p; a.part_b = P->part_b.p; a.sc = P->cgsc.p;
   a.q = P->q_lin; a.u = P->lin_is_lap ? P->u_rot.p : nullptr;
-  a.coarse_n = P->coarse_n; a.coarse_chunk = P->coarse_chunk; a.xc = P->coarse_xc.p;
+  a.coarse_n = P->coarse_n; a.coarse_chunk = P->coarse_chunk; a.xc = P->coarse_xc.p; a.active = P->active.p;
   CoarseArgs ca{};
   ca.n = P->n_cams; ca.n_agg = P->coarse_n; ca.chunk = P->coarse_chunk; ca.q = P->q_lin; ca.r = P->r.p; ca.rc = P->coarse_rc.p; ca.Ainv = P->coarseAinv.p;
-  ca.xc = P->coarse_xc.p; ca.done = nullptr;
+  ca.xc = P->coarse_xc.p; ca.done = nullptr; ca.active = P->active.p;
   const dim3 g(P->nb_cam), blk(GSFM_BLOCK);
   const int tk0 = P->timer.begin(T_CG);
   hipLaunchKernelGGL(k_cg_init, g, blk, 0, P->stream, a);

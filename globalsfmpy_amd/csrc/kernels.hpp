@@ -1099,9 +1099,11 @@ struct CgArgs {
   // two-level preconditioner (see k_coarse_*): z = Minv r + P xc, with xc the coarse correction of this iteration; 0 aggregates = off
   uint32_t coarse_n, coarse_chunk;
   const double* xc;  // [3 coarse_n + 1]: correction per aggregate (body frame), then rc . xc
+  const double* active;  // 1 / 0 per camera: cameras without an edge take no part in the coarse space either (they must not move)
 };
 // (P xc)_k = R_k xc[aggregate of k]
 __device__ __forceinline__ void coarse_prolong(const CgArgs& a, uint32_t k, double* out) {
+  if (a.active[k] == 0.0) { out[0] = out[1] = out[2] = 0.0; return; }
   const uint32_t I = min(k / a.coarse_chunk, a.coarse_n - 1);
   const Quat qq{a.q[2 * (size_t)k].x, a.q[2 * (size_t)k].y, a.q[2 * (size_t)k + 1].x, a.q[2 * (size_t)k + 1].y};
   double R[9];
@@ -1227,6 +1229,7 @@ struct CoarseArgs {
   const double* Ainv;           // [nc x nc], symmetric
   double* xc;                   // [nc + 1]   Ainv rc, then rc . xc
   const int* done;
+  const double* active;
 };
 __global__ void __launch_bounds__(GSFM_BLOCK) k_coarse_restrict(CoarseArgs a) {
   if (a.done && *a.done) return;
@@ -1234,6 +1237,7 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_coarse_restrict(CoarseArgs a) {
   const uint32_t I = blockIdx.x, lo = I * a.chunk, hi = (I + 1 == a.n_agg) ? a.n : min(a.n, lo + a.chunk);
   double acc[3] = {0.0, 0.0, 0.0};
   for (uint32_t k = lo + threadIdx.x; k < hi; k += GSFM_BLOCK) {
+    if (a.active[k] == 0.0) continue;
     const Quat qq{a.q[2 * (size_t)k].x, a.q[2 * (size_t)k].y, a.q[2 * (size_t)k + 1].x, a.q[2 * (size_t)k + 1].y};
     double uu[3];
     rot_transpose_apply(qq, a.r + 3 * (size_t)k, uu);
@@ -1362,7 +1366,7 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_coarse_assemble(CoarseAsmArgs a)
       for (int c = 0; c < 6; ++c) acc[c] -= S[c];
     }
     if (curJ != 0xffffffffu) coarse_flush(a.Ac, nc, I, curJ, acc);
-    if (lane == 0) {
+    if (lane == 0 && end > a.row_ptr[row]) {   // (a camera without edges is not part of the coarse space)
       double S[6];
       sym3_congruence_T(R, a.Mblk + 6 * (size_t)row, S);
 #pragma unroll

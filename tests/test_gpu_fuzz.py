@@ -45,3 +45,11 @@ def test_randomised_sigma_consensus_vs_oracle(oracle):
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "manual"))
     import fuzz_sigma
     assert fuzz_sigma.run(trials=30, seed=6) == 0
+
+
+def test_two_level_preconditioner_awkward_cases():
+    """Every Laplacian-form error type, aggregates made of cameras without edges (which must not move), two disconnected components, a coarse
+    space forced onto a random graph, sigma consensus: each against the block-Jacobi solve of the same problem."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "manual"))
+    import coarse_cases
+    assert coarse_cases.run() == 0
