@@ -1235,7 +1235,9 @@ gsfm_status gsfm_rot_problem_create(uint32_t n_cams, uint64_t n_edges, const uin
       // sample of the edges: n/3 for a uniformly random graph, the neighbourhood radius for a coherent one
       double sum = 0.0; uint64_t cnt = 0;
       for (uint64_t e = 0; e < n_edges; e += 61) { sum += std::fabs((double)edge_i[e] - (double)edge_j[e]); ++cnt; }
-      want = (cnt && sum / (double)cnt <= (double)n_cams / 32.0) ? 64 : 0;
+      // one aggregate per ~256 cameras, 32 to 64 of them: more aggregates need fewer iterations but a larger dense inverse per LM step
+      // (measured on coherent graphs: 6000 cameras 16 > 64 aggregates, 100k cameras 64 > 16 and > 128)
+      want = (cnt && sum / (double)cnt <= (double)n_cams / 32.0) ? (int)std::min<uint32_t>(64, std::max<uint32_t>(32, n_cams / 256)) : 0;
     }
     if (want < 0) want = 0;
     want = std::min(want, 128);
