@@ -1338,7 +1338,8 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_coarse_assemble(CoarseAsmArgs a)
   const uint32_t row = t / a.G, lane = t % a.G;
   const bool valid = row < a.n_rows;
   const uint32_t nc = 3 * a.n_agg, I = min((valid ? row : a.n_rows - 1) / a.chunk, a.n_agg - 1);
-  double own[6] = {0, 0, 0, 0, 0, 0};   // contributions to the aggregate's own diagonal block (I, I): by far the most, summed over the wavefront below
+  // blocks (I, I-1), (I, I), (I, I+1): in a coherent graph nearly every entry; summed over the wavefront below, one set of atomics each
+  double near[3][6] = {{0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0}};
   if (valid) {
     double R[9];
     qmat(load_q(a.q, row), R);
@@ -1351,9 +1352,14 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_coarse_assemble(CoarseAsmArgs a)
       const double Gs[6] = {A.x, A.y, B.x, B.y, C.x, C.y};
       double S[6];
       sym3_congruence_T(R, Gs, S);
-      if (J == I) {
+      const uint32_t rel = J + 1 - I;   // 0, 1, 2 for the three near blocks (unsigned wrap-around puts everything else above 2)
+      if (rel <= 2) {
 #pragma unroll
-        for (int c = 0; c < 6; ++c) own[c] -= S[c];
+        for (int w = 0; w < 3; ++w)
+          if (rel == (uint32_t)w) {
+#pragma unroll
+            for (int c = 0; c < 6; ++c) near[w][c] -= S[c];
+          }
         continue;
       }
       if (J != curJ) {
@@ -1370,17 +1376,24 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_coarse_assemble(CoarseAsmArgs a)
       double S[6];
       sym3_congruence_T(R, a.Mblk + 6 * (size_t)row, S);
 #pragma unroll
-      for (int c = 0; c < 6; ++c) own[c] += S[c];
+      for (int c = 0; c < 6; ++c) near[1][c] += S[c];
     }
   }
-  // one set of atomics per wavefront when all its rows belong to the same aggregate (they do, except at the 63 chunk boundaries)
+  // one set of atomics per wavefront and block when all its rows belong to the same aggregate (they do, except at the chunk boundaries)
   const uint32_t I0 = __shfl(I, 0);
-  if (__all(I == I0)) {
+  const bool uniform = __all(I == I0);
 #pragma unroll
-    for (int c = 0; c < 6; ++c) own[c] = wave_sum(own[c]);
-    if ((threadIdx.x & 63) == 0) coarse_flush(a.Ac, nc, I0, I0, own);
-  } else if (valid) {
-    coarse_flush(a.Ac, nc, I, I, own);
+  for (int w = 0; w < 3; ++w) {
+    const uint32_t J = I + (uint32_t)w - 1u;
+    if (J >= a.n_agg) continue;          // (I - 1 of the first aggregate wraps around; I + 1 of the last does not exist)
+    if (uniform) {
+      double sum6[6];
+#pragma unroll
+      for (int c = 0; c < 6; ++c) sum6[c] = wave_sum(near[w][c]);
+      if ((threadIdx.x & 63) == 0) coarse_flush(a.Ac, nc, I0, J, sum6);
+    } else if (valid) {
+      coarse_flush(a.Ac, nc, I, J, near[w]);
+    }
   }
 }
 

@@ -130,7 +130,7 @@ typedef struct {
                                           Preconditioner: block-Jacobi (the 3x3 diagonal blocks), plus -- chosen automatically for unsharded
                                           problems of >= 8192 cameras whose numbering keeps neighbours close (as given, or after the locality
                                           relabelling) -- a coarse space of 64 aggregates of the camera order in the body frame, where the gauge
-                                          rotation is the constant vector: 10-15x fewer iterations on spatially coherent graphs (431 -> 48 ms on
+                                          rotation is the constant vector: 10-15x fewer iterations on spatially coherent graphs (431 -> 43 ms on
                                           100k cameras / 2M edges), the same answer to this tolerance.  Environment GSFM_PCG_COARSE=n forces n
                                           aggregates, =0 switches it off.  Its coarse matrix is summed with fp64 atomics: with it, results are
                                           reproducible to rounding (1e-12 rad), not bit for bit. */
