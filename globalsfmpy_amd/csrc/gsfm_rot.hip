@@ -540,7 +540,7 @@ bool spd_inverse(std::vector<double>& A, size_t n, std::vector<double>& inv) {
 // (3 n_agg <= 384 unknowns).  Leaves P->coarse_n = 0 (plain block-Jacobi for this step) if the matrix is not positive definite.
 int coarse_build(gsfm_rot_problem* P) {
   P->coarse_n = 0;
-  if (!P->coarse_want || P->sharded || !P->lin_is_lap) return 0;
+  if (!P->coarse_want || !P->lin_is_lap) return 0;
   const uint32_t na = P->coarse_want, nc = 3 * na;
   if (!P->coarseA.p) {
     if (P->coarseA.alloc((size_t)nc * nc) != hipSuccess || P->coarseAinv.alloc((size_t)nc * nc) != hipSuccess || P->coarse_rc.alloc(nc, true) != hipSuccess ||
@@ -551,8 +551,12 @@ int coarse_build(gsfm_rot_problem* P) {
   CoarseAsmArgs a{};
   a.n_rows = P->n_rows; a.G = P->G; a.n_agg = na; a.chunk = P->coarse_chunk; a.row_ptr = P->row_ptr.p; a.col = P->col.p;
   a.h0 = P->h0.p; a.h1 = P->h1.p; a.h2 = P->h2.p; a.Mblk = P->Mblk.p; a.q = P->q_lin; a.Ac = P->coarseA.p;
-  hipLaunchKernelGGL(k_coarse_assemble, dim3(grid_for((size_t)P->n_rows * P->G)), dim3(GSFM_BLOCK), 0, P->stream, a);
+  a.row_base = P->own_begin;
+  if (P->n_rows) hipLaunchKernelGGL(k_coarse_assemble, dim3(grid_for((size_t)P->n_rows * P->G)), dim3(GSFM_BLOCK), 0, P->stream, a);
   P->timer.end(tk);
+  // sharded: every rank summed the rows it owns; the vector side (restriction, coarse solve, prolongation) then runs replicated on the
+  // replicated PCG vectors like every other O(N) step, so this all-reduce per LM step is the only collective the preconditioner adds
+  if (int st = all_reduce(P, P->coarseA.p, (size_t)nc * nc)) return st;
   P->h_coarse.resize((size_t)nc * nc);
   HIPCHK(hipMemcpyAsync(P->h_coarse.data(), P->coarseA.p, 8 * (size_t)nc * nc, hipMemcpyDeviceToHost, P->stream));
   const double t_a = now_ms();
@@ -1230,18 +1234,19 @@ gsfm_status gsfm_rot_problem_create(uint32_t n_cams, uint64_t n_edges, const uin
      // locality order (adopted above) -- GSFM_PCG_COARSE=n forces n aggregates, =0 switches it off
     const char* env = getenv("GSFM_PCG_COARSE");
     int want = env && *env ? atoi(env) : -1;
-    if (want < 0 && !P->sharded && n_cams >= 8192) {
+    if (want < 0 && n_cams >= 8192) {   // (sharded: n_cams is the padded index space of the partition's locality order, the edges this rank's share)
       // spatially coherent in the numbering the rows now have (relabelled above, or coherent as given)?  Mean index distance over a
       // sample of the edges: n/3 for a uniformly random graph, the neighbourhood radius for a coherent one
       double sum = 0.0; uint64_t cnt = 0;
       for (uint64_t e = 0; e < n_edges; e += 61) { sum += std::fabs((double)edge_i[e] - (double)edge_j[e]); ++cnt; }
+      if (cnt == 0) { cnt = 1; sum = 0.0; }   // a rank without edges has no objection
       // one aggregate per ~256 cameras, 32 to 64 of them: more aggregates need fewer iterations but a larger dense inverse per LM step
       // (measured on coherent graphs: 6000 cameras 16 > 64 aggregates, 100k cameras 64 > 16 and > 128)
       want = (cnt && sum / (double)cnt <= (double)n_cams / 32.0) ? (int)std::min<uint32_t>(64, std::max<uint32_t>(32, n_cams / 256)) : 0;
     }
     if (want < 0) want = 0;
     want = std::min(want, 128);
-    if (P->sharded || want < 2 || n_cams < 4u * (uint32_t)want) want = 0;
+    if (want < 2 || n_cams < 4u * (uint32_t)want) want = 0;
     if (want) {
       P->coarse_chunk = (n_cams + want - 1) / want;
       P->coarse_want = (n_cams + P->coarse_chunk - 1) / P->coarse_chunk;   // no empty aggregate
@@ -1413,6 +1418,13 @@ gsfm_status gsfm_rot_problem_create(uint32_t n_cams, uint64_t n_edges, const uin
     }
     if (int st = all_gather(P, P->active.p, P->shard.slice_width)) return bail(st);
     if (P->sharded && hipStreamSynchronize(P->stream) != hipSuccess) return bail(fail(GSFM_ERR_HIP, "active mask all-gather failed"));
+    if (P->sharded) {   // the two-level preconditioner is used only if every rank chose it (each judged the coherence of its own edges)
+      double vote = P->coarse_want ? 0.0 : 1.0;   // number of ranks against
+      if (agree_buf.alloc(1) != hipSuccess || hipMemcpy(agree_buf.p, &vote, 8, hipMemcpyHostToDevice) != hipSuccess) return bail(fail(GSFM_ERR_HIP, "coarse-space vote"));
+      if (int st = all_reduce(P, agree_buf.p, 1)) return bail(st);
+      if (hipStreamSynchronize(P->stream) != hipSuccess || hipMemcpy(&vote, agree_buf.p, 8, hipMemcpyDeviceToHost) != hipSuccess) return bail(fail(GSFM_ERR_HIP, "coarse-space vote"));
+      if (vote > 0.5) P->coarse_want = 0;
+    }
   }
   if (int st = prepare_loss(P, nullptr, 0)) return bail(st);
   lap("camera buffers");

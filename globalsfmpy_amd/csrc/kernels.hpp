@@ -1307,7 +1307,7 @@ __global__ void k_cg_init_coarse_fin(CgArgs a) {
 // the order of those additions varies from run to run, i.e. the PRECONDITIONER is reproducible to rounding only (the solution it
 // leads to is the same to the PCG tolerance either way).  Ac is zero-filled before the launch.
 struct CoarseAsmArgs {
-  uint32_t n_rows, G, n_agg, chunk;
+  uint32_t n_rows, row_base, G, n_agg, chunk;   // owned rows; global camera index of row 0
   const uint32_t* row_ptr;
   const uint32_t* col;
   const double2 *h0, *h1, *h2;
@@ -1337,12 +1337,13 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_coarse_assemble(CoarseAsmArgs a)
   const uint32_t t = blockIdx.x * GSFM_BLOCK + threadIdx.x;
   const uint32_t row = t / a.G, lane = t % a.G;
   const bool valid = row < a.n_rows;
-  const uint32_t nc = 3 * a.n_agg, I = min((valid ? row : a.n_rows - 1) / a.chunk, a.n_agg - 1);
+  const uint32_t cam = a.row_base + (valid ? row : a.n_rows - 1);
+  const uint32_t nc = 3 * a.n_agg, I = min(cam / a.chunk, a.n_agg - 1);
   // blocks (I, I-1), (I, I), (I, I+1): in a coherent graph nearly every entry; summed over the wavefront below, one set of atomics each
   double near[3][6] = {{0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0}};
   if (valid) {
     double R[9];
-    qmat(load_q(a.q, row), R);
+    qmat(load_q(a.q, cam), R);
     uint32_t curJ = 0xffffffffu;
     double acc[6] = {0, 0, 0, 0, 0, 0};
     const uint32_t end = a.row_ptr[row + 1];
@@ -1374,7 +1375,7 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_coarse_assemble(CoarseAsmArgs a)
     if (curJ != 0xffffffffu) coarse_flush(a.Ac, nc, I, curJ, acc);
     if (lane == 0 && end > a.row_ptr[row]) {   // (a camera without edges is not part of the coarse space)
       double S[6];
-      sym3_congruence_T(R, a.Mblk + 6 * (size_t)row, S);
+      sym3_congruence_T(R, a.Mblk + 6 * (size_t)cam, S);
 #pragma unroll
       for (int c = 0; c < 6; ++c) near[1][c] += S[c];
     }

@@ -127,7 +127,7 @@ typedef struct {
                                           1e-14: the residual norm is global, and a component that has already converged would otherwise be
                                           left with an error that is large against its own right-hand side (measured: 3e-5 rad on the real
                                           Madrid component of the 14-scene batch at 1e-12, 4e-9 rad at 1e-14, for 9 % more iterations).
-                                          Preconditioner: block-Jacobi (the 3x3 diagonal blocks), plus -- chosen automatically for unsharded
+                                          Preconditioner: block-Jacobi (the 3x3 diagonal blocks), plus -- chosen automatically for
                                           problems of >= 8192 cameras whose numbering keeps neighbours close (as given, or after the locality
                                           relabelling) -- a coarse space of 64 aggregates of the camera order in the body frame, where the gauge
                                           rotation is the constant vector: 10-15x fewer iterations on spatially coherent graphs (431 -> 43 ms on

@@ -30,6 +30,30 @@ def two_component_graph():
     return g
 
 
+def coarse_case(out, prefer_native):
+    """A spatially coherent 10k-camera graph with shuffled ids: the partitioner's locality order makes every rank's share coherent, all ranks vote
+    for the two-level preconditioner, its coarse matrix is all-reduced once per LM step."""
+    import torch.distributed as dist
+    from globalsfmpy_amd import loss_functions as LF
+    from globalsfmpy_amd.solver import RotationProblem
+    g = synth.make_graph(10000, 150000, 3, outlier_frac=0.1, local_window=300)
+    loss = LF.MAGSACWeightBasedLoss(0.02)
+    prob, part = sharding.make_sharded_problem(g, _abi.ANGLE_AXIS_COVARIANCE, loss=loss, prefer_native=prefer_native)
+    rot, summ = prob.solve(part.scatter(g["init_aa"]))
+    n_ar = prob._comm.n_all_reduce
+    os.environ["GSFM_PCG_COARSE"] = "0"
+    plain, _ = sharding.make_sharded_problem(g, _abi.ANGLE_AXIS_COVARIANCE, loss=loss, prefer_native=prefer_native, part=part)
+    _, s_plain = plain.solve(part.scatter(g["init_aa"]))
+    os.environ.pop("GSFM_PCG_COARSE")
+    if dist.get_rank() == 0:
+        ref = RotationProblem(g["n_cams"], g["edge_i"], g["edge_j"], g["rel_aa"], _abi.ANGLE_AXIS_COVARIANCE, cov6=g["cov6"]); ref.set_loss(loss)
+        r1, s1 = ref.solve(g["init_aa"])
+        np.savez(out, rot=part.gather(rot), ref_rot=r1, cost=summ["final_cost"], ref_cost=s1["final_cost"], iters=summ["num_iterations"], ref_iters=s1["num_iterations"],
+                 cg=summ["num_cg_iterations"], ref_cg=s1["num_cg_iterations"], plain_cg=s_plain["num_cg_iterations"], n_ar=n_ar)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def random_case(seed, out, prefer_native):
     """Random graph, error type, loss and a random partition (arbitrary cut points: slices of very different widths, ranks that own no camera at
     all); rank 0 also solves the same problem unsharded and stores both answers."""
@@ -77,6 +101,8 @@ def main():
         dist.init_process_group("gloo")
     from globalsfmpy_amd.loss_functions import MAGSACWeightBasedLoss
     case = sys.argv[4] if len(sys.argv) > 4 else "default"
+    if case == "coarse":
+        return coarse_case(out, len(sys.argv) > 3 and sys.argv[3] == "native")
     if case.startswith("random"):
         return random_case(int(case.split(":")[1]), out, len(sys.argv) > 3 and sys.argv[3] == "native")
     g = synth.make_graph(1203, 40000, seed=23, outlier_frac=0.3)

@@ -158,3 +158,14 @@ def test_random_graph_random_partition_equals_the_single_gpu_solve(tmp_path, wor
     assert int(res["iters"]) == int(res["ref_iters"]) and abs(int(res["cg"]) - int(res["ref_cg"])) <= 0.02 * int(res["ref_cg"]) + 2, info
     assert abs(float(res["cost"]) - float(res["ref_cost"])) <= 1e-8 * float(res["ref_cost"]), info
     assert synth.angular_distance(res["rot"], res["ref_rot"]).max() < (1e-4 if "MAGSAC" in str(res["loss"]) else 1e-6), info
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_two_level_preconditioner_on_a_sharded_coherent_graph(tmp_path, world):
+    """Every rank judges its own share coherent, the vote at creation is unanimous, the coarse matrix is summed over the ranks once per LM step
+    and everything else of the preconditioner runs replicated: a fraction of the block-Jacobi iterations, the single-GPU answer."""
+    res = _launch(world, "gloo", str(tmp_path / ("coarse%d.npz" % world)), case="coarse")
+    assert int(res["cg"]) * 3 <= int(res["plain_cg"]), (int(res["cg"]), int(res["plain_cg"]))
+    assert int(res["iters"]) == int(res["ref_iters"]) and abs(int(res["cg"]) - int(res["ref_cg"])) <= 0.05 * int(res["ref_cg"]) + 2
+    assert abs(float(res["cost"]) - float(res["ref_cost"])) <= 1e-9 * float(res["ref_cost"])
+    assert synth.angular_distance(res["rot"], res["ref_rot"]).max() < 1e-8
