@@ -229,7 +229,7 @@ struct gsfm_rot_problem {
   DevBuf<Cg2Scalars> cg2sc;
   // two-level preconditioner (kernels.hpp, k_coarse_*): aggregates wanted (0 = off, decided at create) / in use for the current LM step
   uint32_t coarse_want = 0, coarse_n = 0, coarse_chunk = 0;
-  DevBuf<double> coarseA, coarseAinv, coarse_rc, coarse_xc;
+  DevBuf<double> coarseA, coarseAinv, coarse_rc, coarse_xc, coarse_scale;
   std::vector<double> h_coarse, h_coarse_inv;
   void* pin = nullptr;              // 256 B of pinned host memory: staging for the small read-backs of the solve loop (read_back)
   DevBuf<double> denseA, denseL;
@@ -544,15 +544,21 @@ int coarse_build(gsfm_rot_problem* P) {
   const uint32_t na = P->coarse_want, nc = 3 * na;
   if (!P->coarseA.p) {
     if (P->coarseA.alloc((size_t)nc * nc) != hipSuccess || P->coarseAinv.alloc((size_t)nc * nc) != hipSuccess || P->coarse_rc.alloc(nc, true) != hipSuccess ||
-        P->coarse_xc.alloc(nc + 1, true) != hipSuccess) { P->coarseA.release(); P->coarse_want = 0; (void)hipGetLastError(); return 0; }
+        P->coarse_xc.alloc(nc + 1, true) != hipSuccess || P->coarse_scale.alloc(2, true) != hipSuccess) { P->coarseA.release(); P->coarse_want = 0; (void)hipGetLastError(); return 0; }
   }
   const int tk = P->timer.begin(T_CG);
   HIPCHK(hipMemsetAsync(P->coarseA.p, 0, 8 * (size_t)nc * nc, P->stream));
   CoarseAsmArgs a{};
   a.n_rows = P->n_rows; a.G = P->G; a.n_agg = na; a.chunk = P->coarse_chunk; a.row_ptr = P->row_ptr.p; a.col = P->col.p;
   a.h0 = P->h0.p; a.h1 = P->h1.p; a.h2 = P->h2.p; a.Mblk = P->Mblk.p; a.q = P->q_lin; a.Ac = P->coarseA.p;
-  a.row_base = P->own_begin;
+  a.row_base = P->own_begin; a.scale = P->coarse_scale.p;
+  {  // the fixed-point scale must be the same on every rank: the largest diagonal entry over ALL cameras (Mblk is complete everywhere)
+    const uint32_t nb = (uint32_t)grid_for(P->n_cams);
+    hipLaunchKernelGGL(k_coarse_scale, dim3(nb), dim3(GSFM_BLOCK), 0, P->stream, (const double*)P->Mblk.p, P->n_cams, 0u, P->part_a.p, P->coarse_scale.p, 0);
+    hipLaunchKernelGGL(k_coarse_scale, dim3(1), dim3(GSFM_BLOCK), 0, P->stream, (const double*)P->Mblk.p, nb, 0u, P->part_a.p, P->coarse_scale.p, 1);
+  }
   if (P->n_rows) hipLaunchKernelGGL(k_coarse_assemble, dim3(grid_for((size_t)P->n_rows * P->G)), dim3(GSFM_BLOCK), 0, P->stream, a);
+  hipLaunchKernelGGL(k_coarse_unscale, dim3(grid_for((size_t)nc * nc)), dim3(GSFM_BLOCK), 0, P->stream, P->coarseA.p, (size_t)nc * nc, (const double*)P->coarse_scale.p);
   P->timer.end(tk);
   // sharded: every rank summed the rows it owns; the vector side (restriction, coarse solve, prolongation) then runs replicated on the
   // replicated PCG vectors like every other O(N) step, so this all-reduce per LM step is the only collective the preconditioner adds

@@ -1303,9 +1303,8 @@ __global__ void k_cg_init_coarse_fin(CgArgs a) {
 }
 // Ac = P^T A P from the stored blocks of the Laplacian form: off-diagonal entry (k -> m) contributes -R_k^T G_k R_k to block (agg k, agg m),
 // the diagonal block R_k^T M_k R_k to (agg k, agg k).  G lanes per row; a lane sums its consecutive entries that fall into the same
-// aggregate before touching memory (rows are sorted by neighbour, so that is most of them), then adds with hardware fp64 atomics:
-// the order of those additions varies from run to run, i.e. the PRECONDITIONER is reproducible to rounding only (the solution it
-// leads to is the same to the PCG tolerance either way).  Ac is zero-filled before the launch.
+// aggregate before touching memory (rows are sorted by neighbour, so that is most of them), then adds with 64-bit integer atomics on a
+// fixed-point image of the matrix (coarse_flush): bit-identical from run to run.  Ac is zero-filled before the launch.
 struct CoarseAsmArgs {
   uint32_t n_rows, row_base, G, n_agg, chunk;   // owned rows; global camera index of row 0
   const uint32_t* row_ptr;
@@ -1313,13 +1312,46 @@ struct CoarseAsmArgs {
   const double2 *h0, *h1, *h2;
   const double* Mblk;
   const double2* q;
-  double* Ac;
+  double* Ac;          // fixed point while being summed (coarse_flush), doubles after k_coarse_unscale
+  const double* scale;
 };
-__device__ __forceinline__ void coarse_flush(double* Ac, uint32_t nc, uint32_t I, uint32_t J, const double* S /* sym 6: 00 01 02 11 12 22 */) {
-  double* o = Ac + (size_t)(3 * I) * nc + 3 * J;
-  unsafeAtomicAdd(o, S[0]); unsafeAtomicAdd(o + 1, S[1]); unsafeAtomicAdd(o + 2, S[2]);
-  unsafeAtomicAdd(o + nc, S[1]); unsafeAtomicAdd(o + nc + 1, S[3]); unsafeAtomicAdd(o + nc + 2, S[4]);
-  unsafeAtomicAdd(o + 2 * nc, S[2]); unsafeAtomicAdd(o + 2 * nc + 1, S[4]); unsafeAtomicAdd(o + 2 * nc + 2, S[5]);
+// Sums in 64-bit FIXED POINT: integer addition is associative, so the atomics may land in any order and Ac is still the same bits on every
+// run (floating-point atomics would make the preconditioner, and through it the PCG path, reproducible to rounding only).  `scale` = 2^e with
+// e chosen by k_coarse_scale so that the largest single contribution is below 2^40: 2^22 of them fit before an int64 overflows (an aggregate
+// sums <= chunk x degree ~ 2^19), and the resolution of 2^-40 of the largest diagonal entry is far finer than a preconditioner needs.
+__device__ __forceinline__ void coarse_flush(double* Ac, uint32_t nc, uint32_t I, uint32_t J, const double* S /* sym 6: 00 01 02 11 12 22 */, double scale) {
+  unsigned long long* o = (unsigned long long*)(Ac + (size_t)(3 * I) * nc + 3 * J);
+  long long q[6];
+#pragma unroll
+  for (int c = 0; c < 6; ++c) q[c] = __double2ll_rn(S[c] * scale);
+  atomicAdd(o, (unsigned long long)q[0]); atomicAdd(o + 1, (unsigned long long)q[1]); atomicAdd(o + 2, (unsigned long long)q[2]);
+  atomicAdd(o + nc, (unsigned long long)q[1]); atomicAdd(o + nc + 1, (unsigned long long)q[3]); atomicAdd(o + nc + 2, (unsigned long long)q[4]);
+  atomicAdd(o + 2 * nc, (unsigned long long)q[2]); atomicAdd(o + 2 * nc + 1, (unsigned long long)q[4]); atomicAdd(o + 2 * nc + 2, (unsigned long long)q[5]);
+}
+// scale[0] = 2^e, scale[1] = 2^-e from the largest diagonal entry of the damped diagonal blocks (every |G_ab| of an edge is below it: G is
+// positive semi-definite and M_k sums the G of camera k's edges)
+__global__ void __launch_bounds__(GSFM_BLOCK) k_coarse_scale(const double* __restrict__ Mblk, uint32_t n_rows, uint32_t row_base, double* partials, double* scale, int pass) {
+  __shared__ double lds[8];
+  double v = 0.0;
+  if (pass == 0) {
+    const uint32_t r = blockIdx.x * GSFM_BLOCK + threadIdx.x;
+    if (r < n_rows) { const double* M = Mblk + 6 * (size_t)(row_base + r); v = fmax(fabs(M[0]), fmax(fabs(M[3]), fabs(M[5]))); }
+    v = block_max_bcast(v, lds);
+    if (threadIdx.x == 0) partials[blockIdx.x] = v;
+  } else {   // one block: partials -> the power of two
+    for (uint32_t k = threadIdx.x; k < n_rows /* = number of partials */; k += GSFM_BLOCK) v = fmax(v, partials[k]);
+    v = block_max_bcast(v, lds);
+    if (threadIdx.x == 0) {
+      int e = 0;
+      if (v > 0.0 && isfinite(v)) { (void)frexp(v, &e); e = 40 - e; }   // v < 2^(40 - e')... v * 2^e < 2^40
+      scale[0] = ldexp(1.0, e); scale[1] = ldexp(1.0, -e);
+    }
+  }
+}
+// fixed point -> double, in place
+__global__ void __launch_bounds__(GSFM_BLOCK) k_coarse_unscale(double* Ac, size_t n, const double* scale) {
+  const size_t t = (size_t)blockIdx.x * GSFM_BLOCK + threadIdx.x;
+  if (t < n) { const long long q = ((const long long*)Ac)[t]; Ac[t] = (double)q * scale[1]; }
 }
 // S = R^T Sym R for a symmetric 3 x 3 given as (00 01 02 11 12 22)
 __device__ __forceinline__ void sym3_congruence_T(const double* R, const double* M, double* S) {
@@ -1337,6 +1369,7 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_coarse_assemble(CoarseAsmArgs a)
   const uint32_t t = blockIdx.x * GSFM_BLOCK + threadIdx.x;
   const uint32_t row = t / a.G, lane = t % a.G;
   const bool valid = row < a.n_rows;
+  const double scale = a.scale[0];
   const uint32_t cam = a.row_base + (valid ? row : a.n_rows - 1);
   const uint32_t nc = 3 * a.n_agg, I = min(cam / a.chunk, a.n_agg - 1);
   // blocks (I, I-1), (I, I), (I, I+1): in a coherent graph nearly every entry; summed over the wavefront below, one set of atomics each
@@ -1364,7 +1397,7 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_coarse_assemble(CoarseAsmArgs a)
         continue;
       }
       if (J != curJ) {
-        if (curJ != 0xffffffffu) coarse_flush(a.Ac, nc, I, curJ, acc);
+        if (curJ != 0xffffffffu) coarse_flush(a.Ac, nc, I, curJ, acc, scale);
         curJ = J;
 #pragma unroll
         for (int c = 0; c < 6; ++c) acc[c] = 0.0;
@@ -1372,7 +1405,7 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_coarse_assemble(CoarseAsmArgs a)
 #pragma unroll
       for (int c = 0; c < 6; ++c) acc[c] -= S[c];
     }
-    if (curJ != 0xffffffffu) coarse_flush(a.Ac, nc, I, curJ, acc);
+    if (curJ != 0xffffffffu) coarse_flush(a.Ac, nc, I, curJ, acc, scale);
     if (lane == 0 && end > a.row_ptr[row]) {   // (a camera without edges is not part of the coarse space)
       double S[6];
       sym3_congruence_T(R, a.Mblk + 6 * (size_t)cam, S);
@@ -1391,9 +1424,9 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_coarse_assemble(CoarseAsmArgs a)
       double sum6[6];
 #pragma unroll
       for (int c = 0; c < 6; ++c) sum6[c] = wave_sum(near[w][c]);
-      if ((threadIdx.x & 63) == 0) coarse_flush(a.Ac, nc, I0, J, sum6);
+      if ((threadIdx.x & 63) == 0) coarse_flush(a.Ac, nc, I0, J, sum6, scale);
     } else if (valid) {
-      coarse_flush(a.Ac, nc, I, J, near[w]);
+      coarse_flush(a.Ac, nc, I, J, near[w], scale);
     }
   }
 }

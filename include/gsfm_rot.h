@@ -132,8 +132,8 @@ typedef struct {
                                           relabelling) -- a coarse space of 64 aggregates of the camera order in the body frame, where the gauge
                                           rotation is the constant vector: 10-15x fewer iterations on spatially coherent graphs (431 -> 43 ms on
                                           100k cameras / 2M edges), the same answer to this tolerance.  Environment GSFM_PCG_COARSE=n forces n
-                                          aggregates, =0 switches it off.  Its coarse matrix is summed with fp64 atomics: with it, results are
-                                          reproducible to rounding (1e-12 rad), not bit for bit. */
+                                          aggregates, =0 switches it off.  Its coarse matrix is summed with integer atomics on a fixed-point
+                                          image: results stay bit-identical from run to run. */
   int32_t cg_check_interval;           /* CG iterations enqueued between host checks (default 8) */
   int32_t verbose;                     /* 1: print one line per LM iteration to stderr */
   int32_t pcg_single_reduction;        /* 0: textbook PCG, 4 dependent kernels per iteration; 1: Chronopoulos-Gear single-reduction PCG, 2 kernels

@@ -47,6 +47,12 @@ def run():
         bad += not ok
         print("%-28s LM %2d/%2d  PCG %5d -> %5d  cost rel %.1e  max dR %.1e  %s" % (name, s0["num_iterations"], s1["num_iterations"], s0["num_cg_iterations"], s1["num_cg_iterations"],
               abs(s0["final_cost"] - s1["final_cost"]) / abs(s0["final_cost"]), d, "ok" if ok else "MISMATCH"), flush=True)
+    # the coarse matrix is summed in fixed point: the same bits on every run
+    ra, sa = solve(g["n_cams"], g["edge_i"], g["edge_j"], g["rel_aa"], _abi.ANGLE_AXIS_COVARIANCE, LF.MAGSACWeightBasedLoss(0.02), g["init_aa"], None, cov6=g["cov6"])
+    rb, sb = solve(g["n_cams"], g["edge_i"], g["edge_j"], g["rel_aa"], _abi.ANGLE_AXIS_COVARIANCE, LF.MAGSACWeightBasedLoss(0.02), g["init_aa"], None, cov6=g["cov6"])
+    same = np.array_equal(ra, rb) and sa["num_cg_iterations"] == sb["num_cg_iterations"] and sa["final_cost"] == sb["final_cost"]
+    bad += not same
+    print("two runs bit-identical: %s (PCG %d / %d)" % (same, sa["num_cg_iterations"], sb["num_cg_iterations"]))
     os.environ.pop("GSFM_PCG_COARSE", None)
     print("coarse cases: %d mismatches" % bad)
     return bad
