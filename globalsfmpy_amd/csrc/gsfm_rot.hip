@@ -229,6 +229,7 @@ struct gsfm_rot_problem {
   DevBuf<Cg2Scalars> cg2sc;
   // two-level preconditioner (kernels.hpp, k_coarse_*): aggregates wanted (0 = off, decided at create) / in use for the current LM step
   uint32_t coarse_want = 0, coarse_n = 0, coarse_chunk = 0;
+  bool coarse_adaptive = false;     // use it only once a block-Jacobi PCG solve of the run has needed more than 150 iterations
   DevBuf<double> coarseA, coarseAinv, coarse_rc, coarse_xc, coarse_scale;
   std::vector<double> h_coarse, h_coarse_inv;
   void* pin = nullptr;              // 256 B of pinned host memory: staging for the small read-backs of the solve loop (read_back)
@@ -538,9 +539,9 @@ bool spd_inverse(std::vector<double>& A, size_t n, std::vector<double>& inv) {
 
 // Coarse matrix of the two-level preconditioner for the current linearisation and damping: assembled on the device, inverted on the host
 // (3 n_agg <= 384 unknowns).  Leaves P->coarse_n = 0 (plain block-Jacobi for this step) if the matrix is not positive definite.
-int coarse_build(gsfm_rot_problem* P) {
+int coarse_build(gsfm_rot_problem* P, bool pcg_struggles) {
   P->coarse_n = 0;
-  if (!P->coarse_want || !P->lin_is_lap) return 0;
+  if (!P->coarse_want || !P->lin_is_lap || (P->coarse_adaptive && !pcg_struggles)) return 0;
   const uint32_t na = P->coarse_want, nc = 3 * na;
   if (!P->coarseA.p) {
     if (P->coarseA.alloc((size_t)nc * nc) != hipSuccess || P->coarseAinv.alloc((size_t)nc * nc) != hipSuccess || P->coarse_rc.alloc(nc, true) != hipSuccess ||
@@ -988,7 +989,7 @@ int lm_solve(gsfm_rot_problem* P, const gsfm_rot_options& o_in, gsfm_rot_summary
     }
     for (int attempt = 0; attempt < 2; ++attempt) {
       if (!dense_used) {
-        if (int st = coarse_build(P)) return st;
+        if (int st = coarse_build(P, pcg_struggles)) return st;
         if (int st = ((P->coarse_n == 0 && use_single_reduction(P, o)) ? run_pcg2(P, o, &cg, &cg_rel) : run_pcg(P, o, &cg, &cg_rel))) return st;
       }
       launch_step(P);
@@ -1240,15 +1241,21 @@ gsfm_status gsfm_rot_problem_create(uint32_t n_cams, uint64_t n_edges, const uin
      // locality order (adopted above) -- GSFM_PCG_COARSE=n forces n aggregates, =0 switches it off
     const char* env = getenv("GSFM_PCG_COARSE");
     int want = env && *env ? atoi(env) : -1;
-    if (want < 0 && n_cams >= 8192) {   // (sharded: n_cams is the padded index space of the partition's locality order, the edges this rank's share)
+    if (want < 0 && n_cams >= 4096) {   // (sharded: n_cams is the padded index space of the partition's locality order, the edges this rank's share)
       // spatially coherent in the numbering the rows now have (relabelled above, or coherent as given)?  Mean index distance over a
       // sample of the edges: n/3 for a uniformly random graph, the neighbourhood radius for a coherent one
       double sum = 0.0; uint64_t cnt = 0;
       for (uint64_t e = 0; e < n_edges; e += 61) { sum += std::fabs((double)edge_i[e] - (double)edge_j[e]); ++cnt; }
       if (cnt == 0) { cnt = 1; sum = 0.0; }   // a rank without edges has no objection
-      // one aggregate per ~256 cameras, 32 to 64 of them: more aggregates need fewer iterations but a larger dense inverse per LM step
-      // (measured on coherent graphs: 6000 cameras 16 > 64 aggregates, 100k cameras 64 > 16 and > 128)
-      want = (cnt && sum / (double)cnt <= (double)n_cams / 32.0) ? (int)std::min<uint32_t>(64, std::max<uint32_t>(32, n_cams / 256)) : 0;
+      // What block-Jacobi cannot cope with is the DIAMETER of the graph, ~ cameras / neighbourhood radius.  Measured on coherent graphs: from a
+      // ratio of ~100 the coarse space cuts the iterations 5-15x (12k cameras / radius 100: 120; 100k / 250: 400); between 32 and 100 it
+      // depends on the degree (6000 cameras / 100, degree 40: 1.4x faster; 5000 / 100, degree 240: no fewer iterations, slower), so there it
+      // is switched on only after a PCG solve has struggled; below, never.
+      const double ratio = (double)n_cams / std::max(1.0, sum / (double)cnt);
+      // one aggregate per ~256 cameras, 16 to 64 of them: more aggregates need fewer iterations but a larger dense inverse per LM step
+      // (measured: 6000 cameras 16 > 64 aggregates, 100k cameras 64 > 16 and > 128)
+      want = ratio >= 32.0 ? (int)std::min<uint32_t>(64, std::max<uint32_t>(16, n_cams / 256)) : 0;
+      P->coarse_adaptive = ratio < 100.0;
     }
     if (want < 0) want = 0;
     want = std::min(want, 128);
@@ -1425,7 +1432,7 @@ gsfm_status gsfm_rot_problem_create(uint32_t n_cams, uint64_t n_edges, const uin
     if (int st = all_gather(P, P->active.p, P->shard.slice_width)) return bail(st);
     if (P->sharded && hipStreamSynchronize(P->stream) != hipSuccess) return bail(fail(GSFM_ERR_HIP, "active mask all-gather failed"));
     if (P->sharded) {   // the two-level preconditioner is used only if every rank chose it (each judged the coherence of its own edges)
-      double vote = P->coarse_want ? 0.0 : 1.0;   // number of ranks against
+      double vote = (P->coarse_want && !P->coarse_adaptive) ? 0.0 : 1.0;   // number of ranks against (the wait-and-see mode is single-GPU only)
       if (agree_buf.alloc(1) != hipSuccess || hipMemcpy(agree_buf.p, &vote, 8, hipMemcpyHostToDevice) != hipSuccess) return bail(fail(GSFM_ERR_HIP, "coarse-space vote"));
       if (int st = all_reduce(P, agree_buf.p, 1)) return bail(st);
       if (hipStreamSynchronize(P->stream) != hipSuccess || hipMemcpy(&vote, agree_buf.p, 8, hipMemcpyDeviceToHost) != hipSuccess) return bail(fail(GSFM_ERR_HIP, "coarse-space vote"));

@@ -383,7 +383,7 @@ def test_a_factorisation_that_breaks_down_is_solved_again_by_pcg():
 @pytest.mark.parametrize("et,loss", [(_abi.ANGLE_AXIS, LF.HuberLoss(0.1)), (_abi.ANGLE_AXIS_COVARIANCE, LF.MAGSACWeightBasedLoss(0.02))])
 def test_two_level_preconditioner_on_a_coherent_graph(oracle, et, loss, monkeypatch):
     """Spatially coherent 12k-camera graph with shuffled ids: block-Jacobi PCG needs ~1000 iterations per solve; with the aggregates of the
-    locality ordering as a coarse space (chosen automatically: >= 8192 cameras, coherent numbering) a fraction of that -- and the SAME
+    locality ordering as a coarse space (chosen automatically: >= 4096 cameras, coherent numbering) a fraction of that -- and the SAME
     answer, because PCG's result does not depend on its preconditioner: against the plain path and against the oracle."""
     from globalsfmpy_amd.solver import RotationProblem
     g = synth.make_graph(12000, 240000, 17, outlier_frac=0.1, local_window=400)

@@ -13,8 +13,9 @@ for cams, edges, win in cases:
     g = synth.make_graph(cams, edges, 7, outlier_frac=0.1, local_window=win)
     for name, et, loss, kw in (("Huber", _abi.ANGLE_AXIS, LF.HuberLoss(0.1), {}), ("cov+MAGSAC", _abi.ANGLE_AXIS_COVARIANCE, LF.MAGSACWeightBasedLoss(0.02), dict(cov6=g["cov6"]))):
         ref = None
-        for coarse in ("0", "16", "64", "128"):
-            os.environ["GSFM_PCG_COARSE"] = coarse
+        for coarse in ("0", "auto", "16", "64"):
+            if coarse == "auto": os.environ.pop("GSFM_PCG_COARSE", None)
+            else: os.environ["GSFM_PCG_COARSE"] = coarse
             p = RotationProblem(g["n_cams"], g["edge_i"], g["edge_j"], g["rel_aa"], et, **kw); p.set_loss(loss)
             p.solve(g["init_aa"], max_num_iterations=2)
             t = time.perf_counter(); r, s = p.solve(g["init_aa"]); dt = time.perf_counter() - t
