@@ -542,11 +542,7 @@ bool spd_inverse(std::vector<double>& A, size_t n, std::vector<double>& inv) {
 int coarse_build(gsfm_rot_problem* P, bool pcg_struggles) {
   P->coarse_n = 0;
   if (!P->coarse_want || !P->lin_is_lap || (P->coarse_adaptive && !pcg_struggles)) return 0;
-  const uint32_t na = P->coarse_want, nc = 3 * na;
-  if (!P->coarseA.p) {
-    if (P->coarseA.alloc((size_t)nc * nc) != hipSuccess || P->coarseAinv.alloc((size_t)nc * nc) != hipSuccess || P->coarse_rc.alloc(nc, true) != hipSuccess ||
-        P->coarse_xc.alloc(nc + 1, true) != hipSuccess || P->coarse_scale.alloc(2, true) != hipSuccess) { P->coarseA.release(); P->coarse_want = 0; (void)hipGetLastError(); return 0; }
-  }
+  const uint32_t na = P->coarse_want, nc = 3 * na;   // (buffers: allocated at creation, before the ranks of a sharded problem vote)
   const int tk = P->timer.begin(T_CG);
   HIPCHK(hipMemsetAsync(P->coarseA.p, 0, 8 * (size_t)nc * nc, P->stream));
   CoarseAsmArgs a{};
@@ -1263,6 +1259,11 @@ gsfm_status gsfm_rot_problem_create(uint32_t n_cams, uint64_t n_edges, const uin
     if (want) {
       P->coarse_chunk = (n_cams + want - 1) / want;
       P->coarse_want = (n_cams + P->coarse_chunk - 1) / P->coarse_chunk;   // no empty aggregate
+      const size_t nc = 3 * (size_t)P->coarse_want;
+      if (P->coarseA.alloc(nc * nc) != hipSuccess || P->coarseAinv.alloc(nc * nc) != hipSuccess || P->coarse_rc.alloc(nc, true) != hipSuccess ||
+          P->coarse_xc.alloc(nc + 1, true) != hipSuccess || P->coarse_scale.alloc(2, true) != hipSuccess) {
+        P->coarseA.release(); P->coarse_want = 0; (void)hipGetLastError();   // (a sharded rank then votes against below: all ranks stay on block-Jacobi)
+      }
     }
   }
   // connected components of the view graph: counted here on one GPU; a rank of a sharded problem sees only its own edges, so the
