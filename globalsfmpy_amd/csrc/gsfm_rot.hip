@@ -1250,7 +1250,8 @@ gsfm_status gsfm_rot_problem_create(uint32_t n_cams, uint64_t n_edges, const uin
       const double ratio = (double)n_cams / std::max(1.0, sum / (double)cnt);
       // one aggregate per ~256 cameras, 16 to 64 of them: more aggregates need fewer iterations but a larger dense inverse per LM step
       // (measured: 6000 cameras 16 > 64 aggregates, 100k cameras 64 > 16 and > 128)
-      want = ratio >= 32.0 ? (int)std::min<uint32_t>(64, std::max<uint32_t>(16, n_cams / 256)) : 0;
+      // (from 400k cameras a PCG iteration costs more than the 5 ms the host needs for the 384-unknown inverse: 128 aggregates there)
+      want = ratio >= 32.0 ? (int)std::min<uint32_t>(n_cams >= 400000 ? 128 : 64, std::max<uint32_t>(16, n_cams / 256)) : 0;
       P->coarse_adaptive = ratio < 100.0;
     }
     if (want < 0) want = 0;
