@@ -230,7 +230,7 @@ struct gsfm_rot_problem {
   // two-level preconditioner (kernels.hpp, k_coarse_*): aggregates wanted (0 = off, decided at create) / in use for the current LM step
   uint32_t coarse_want = 0, coarse_n = 0, coarse_chunk = 0;
   bool coarse_adaptive = false;     // use it only once a block-Jacobi PCG solve of the run has needed more than 150 iterations
-  DevBuf<double> coarseA, coarseAinv, coarse_rc, coarse_xc, coarse_scale;
+  DevBuf<double> coarseA, coarseAinv, coarse_rc, coarse_xc, coarse_scale, coarse_part;
   std::vector<double> h_coarse, h_coarse_inv;
   void* pin = nullptr;              // 256 B of pinned host memory: staging for the small read-backs of the solve loop (read_back)
   DevBuf<double> denseA, denseL;
@@ -583,9 +583,12 @@ int run_pcg(gsfm_rot_problem* P, const gsfm_rot_options& o, int* iters_out, doub
   a.part_a = P->part_a.p; a.part_b = P->part_b.p; a.sc = P->cgsc.p;
   a.q = P->q_lin; a.u = P->lin_is_lap ? P->u_rot.p : nullptr;
   a.coarse_n = P->coarse_n; a.coarse_chunk = P->coarse_chunk; a.xc = P->coarse_xc.p; a.active = P->active.p;
+  // aggregates at least as wide as a block of the camera kernels (always, unless forced narrower): the restriction rides along in k_cg_update
+  const bool fused_restrict = P->coarse_n && P->coarse_chunk >= GSFM_BLOCK;
+  a.rc_part = fused_restrict ? P->coarse_part.p : nullptr;
   CoarseArgs ca{};
   ca.n = P->n_cams; ca.n_agg = P->coarse_n; ca.chunk = P->coarse_chunk; ca.q = P->q_lin; ca.r = P->r.p; ca.rc = P->coarse_rc.p; ca.Ainv = P->coarseAinv.p;
-  ca.xc = P->coarse_xc.p; ca.done = nullptr; ca.active = P->active.p;
+  ca.xc = P->coarse_xc.p; ca.done = nullptr; ca.active = P->active.p; ca.rc_part = nullptr; ca.nb = (uint32_t)P->nb_cam;
   const dim3 g(P->nb_cam), blk(GSFM_BLOCK);
   const int tk0 = P->timer.begin(T_CG);
   hipLaunchKernelGGL(k_cg_init, g, blk, 0, P->stream, a);
@@ -596,7 +599,7 @@ int run_pcg(gsfm_rot_problem* P, const gsfm_rot_options& o, int* iters_out, doub
     hipLaunchKernelGGL(k_cg_init_coarse, g, blk, 0, P->stream, a);
     hipLaunchKernelGGL(k_cg_init_coarse_fin, dim3(1), dim3(1), 0, P->stream, a);
   }
-  ca.done = &P->cgsc.p->done;
+  ca.done = &P->cgsc.p->done; ca.rc_part = a.rc_part;
   P->timer.end(tk0);
   CgScalars h{};
   const int chunk = std::max(1, o.cg_check_interval);
@@ -606,7 +609,7 @@ int run_pcg(gsfm_rot_problem* P, const gsfm_rot_options& o, int* iters_out, doub
       hipLaunchKernelGGL(k_cg_dot, g, blk, 0, P->stream, a);
       hipLaunchKernelGGL(k_cg_update, g, blk, 0, P->stream, a);
       if (a.coarse_n) {
-        hipLaunchKernelGGL(k_coarse_restrict, dim3(a.coarse_n), blk, 0, P->stream, ca);
+        if (!fused_restrict) hipLaunchKernelGGL(k_coarse_restrict, dim3(a.coarse_n), blk, 0, P->stream, ca);
         hipLaunchKernelGGL(k_coarse_apply, dim3(1), dim3(1024), 0, P->stream, ca);
       }
       hipLaunchKernelGGL(k_cg_pupdate, g, blk, 0, P->stream, a);
@@ -1262,7 +1265,7 @@ gsfm_status gsfm_rot_problem_create(uint32_t n_cams, uint64_t n_edges, const uin
       P->coarse_want = (n_cams + P->coarse_chunk - 1) / P->coarse_chunk;   // no empty aggregate
       const size_t nc = 3 * (size_t)P->coarse_want;
       if (P->coarseA.alloc(nc * nc) != hipSuccess || P->coarseAinv.alloc(nc * nc) != hipSuccess || P->coarse_rc.alloc(nc, true) != hipSuccess ||
-          P->coarse_xc.alloc(nc + 1, true) != hipSuccess || P->coarse_scale.alloc(2, true) != hipSuccess) {
+          P->coarse_xc.alloc(nc + 1, true) != hipSuccess || P->coarse_scale.alloc(2, true) != hipSuccess || P->coarse_part.alloc(6 * (size_t)grid_for(n_cams), true) != hipSuccess) {
         P->coarseA.release(); P->coarse_want = 0; (void)hipGetLastError();   // (a sharded rank then votes against below: all ranks stay on block-Jacobi)
       }
     }

@@ -1100,6 +1100,8 @@ struct CgArgs {
   uint32_t coarse_n, coarse_chunk;
   const double* xc;  // [3 coarse_n + 1]: correction per aggregate (body frame), then rc . xc
   const double* active;  // 1 / 0 per camera: cameras without an edge take no part in the coarse space either (they must not move)
+  double* rc_part;       // [nb][2][3]: this kernel block's share of P^T r for the (at most two) aggregates its 256 cameras belong to; null = the
+                         // restriction runs as its own kernel (aggregates narrower than a block)
 };
 // (P xc)_k = R_k xc[aggregate of k]
 __device__ __forceinline__ void coarse_prolong(const CgArgs& a, uint32_t k, double* out) {
@@ -1161,7 +1163,7 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_cg_update(CgArgs a) {
   __shared__ double lds[8];
   const double pAp = sum_partials_bcast(a.part_a, a.nb, lds);
   const double alpha = a.sc->rz[a.par] / pAp;
-  double v = 0.0;
+  double v = 0.0, rc6[6] = {0, 0, 0, 0, 0, 0};
   const uint32_t k = blockIdx.x * GSFM_BLOCK + threadIdx.x;
   if (k < a.n) {
     const size_t k3 = 3 * (size_t)k;
@@ -1171,9 +1173,29 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_cg_update(CgArgs a) {
     sym3_mulvec(a.Minv + 6 * (size_t)k, r, z);
 #pragma unroll
     for (int c = 0; c < 3; ++c) { a.z[k3 + c] = z[c]; v += r[c] * z[c]; }
+    if (a.rc_part && a.active[k] != 0.0) {   // two-level preconditioner: this camera's term of P^T r, for the first or the second aggregate of the block
+      const Quat qq{a.q[2 * (size_t)k].x, a.q[2 * (size_t)k].y, a.q[2 * (size_t)k + 1].x, a.q[2 * (size_t)k + 1].y};
+      double uu[3];
+      rot_transpose_apply(qq, r, uu);
+      const uint32_t I = min(k / a.coarse_chunk, a.coarse_n - 1), I0 = min((blockIdx.x * GSFM_BLOCK) / a.coarse_chunk, a.coarse_n - 1);
+      const int sel = I != I0;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { rc6[c] = sel ? 0.0 : uu[c]; rc6[3 + c] = sel ? uu[c] : 0.0; }
+    }
   }
   const double t = block_sum_bcast(v, lds);
   if (threadIdx.x == 0) a.part_b[blockIdx.x] = t;
+  if (a.rc_part) {
+    __shared__ double l6[GSFM_BLOCK / 64][6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) { const double w = wave_sum(rc6[c]); if ((threadIdx.x & 63) == 0) l6[threadIdx.x >> 6][c] = w; }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+      double sum = 0.0;
+      for (int w = 0; w < GSFM_BLOCK / 64; ++w) sum += l6[w][threadIdx.x];
+      a.rc_part[6 * (size_t)blockIdx.x + threadIdx.x] = sum;
+    }
+  }
 }
 // beta = rz_new / rz; p = z + beta p; convergence test
 __global__ void __launch_bounds__(GSFM_BLOCK) k_cg_pupdate(CgArgs a) {
@@ -1230,6 +1252,8 @@ struct CoarseArgs {
   double* xc;                   // [nc + 1]   Ainv rc, then rc . xc
   const int* done;
   const double* active;
+  const double* rc_part;        // non-null: rc is the fixed-order sum of the camera blocks' shares written by k_cg_update ([nb][2][3])
+  uint32_t nb;
 };
 __global__ void __launch_bounds__(GSFM_BLOCK) k_coarse_restrict(CoarseArgs a) {
   if (a.done && *a.done) return;
@@ -1258,7 +1282,20 @@ __global__ void __launch_bounds__(1024) k_coarse_apply(CoarseArgs a) {
   __shared__ double part[1024];
   __shared__ double lds[20];
   const uint32_t nc = 3 * a.n_agg, tid = threadIdx.x, groups = 1024 / nc, row = tid % nc, g = tid / nc;
-  for (uint32_t c = tid; c < nc; c += 1024) rcs[c] = a.rc[c];
+  for (uint32_t c = tid; c < nc; c += 1024) {
+    if (a.rc_part) {   // aggregate I = cameras [I chunk, (I + 1) chunk): the blocks of 256 cameras that overlap it, in order
+      const uint32_t I = c / 3, comp = c % 3, lo = I * a.chunk, hi = (I + 1 == a.n_agg) ? a.n : min(a.n, lo + a.chunk);
+      double sum = 0.0;
+      if (hi > lo) {
+        for (uint32_t w = lo / GSFM_BLOCK; w <= (hi - 1) / GSFM_BLOCK && w < a.nb; ++w) {
+          const uint32_t I0 = min((w * GSFM_BLOCK) / a.chunk, a.n_agg - 1);
+          if (I == I0) sum += a.rc_part[6 * (size_t)w + comp];
+          else if (I == I0 + 1) sum += a.rc_part[6 * (size_t)w + 3 + comp];
+        }
+      }
+      rcs[c] = sum;
+    } else rcs[c] = a.rc[c];
+  }
   __syncthreads();
   double sum = 0.0;
   if (g < groups) {
