@@ -130,7 +130,7 @@ typedef struct {
                                           Preconditioner: block-Jacobi (the 3x3 diagonal blocks), plus -- chosen automatically for
                                           problems of >= 4096 cameras whose numbering keeps neighbours close (as given, or after the locality
                                           relabelling; judged by cameras / mean index distance of the edges) -- a coarse space of 16-64 aggregates of the camera order in the body frame, where the gauge
-                                          rotation is the constant vector: 10-15x fewer iterations on spatially coherent graphs (431 -> 43 ms on
+                                          rotation is the constant vector: 10-15x fewer iterations on spatially coherent graphs (430 -> 40 ms on
                                           100k cameras / 2M edges), the same answer to this tolerance.  Environment GSFM_PCG_COARSE=n forces n
                                           aggregates, =0 switches it off.  Its coarse matrix is summed with integer atomics on a fixed-point
                                           image: results stay bit-identical from run to run. */
