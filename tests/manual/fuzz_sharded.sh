@@ -1,13 +1,14 @@
 #!/bin/bash
 # Random sharded cases (tests/sharded_worker.py "random:<seed>") over gloo on one GPU: usage fuzz_sharded.sh <first seed> <last seed>
-# each seed runs with 2..8 ranks (seed mod 7 + 2); prints one verdict line per seed.
+# each seed runs with 2..8 ranks (seed mod 7 + 2); prints one verdict line per seed.  FUZZ_CASE=randomcoarse: 5-9k-camera coherent graphs
+# (the two-level preconditioner is voted in by the ranks).
 cd "$(dirname "$0")/../.."
 export HSA_ENABLE_IPC_MODE_LEGACY=0
 for seed in $(seq $1 $2); do
   world=$(( seed % 7 + 2 ))
   out=/tmp/fz_sharded_$seed.npz
   timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node $world --master-addr 127.0.0.1 --master-port $((29800 + seed % 150)) \
-      tests/sharded_worker.py gloo $out torch random:$seed > /tmp/fz_sharded_$seed.log 2>&1
+      tests/sharded_worker.py gloo $out torch ${FUZZ_CASE:-random}:$seed > /tmp/fz_sharded_$seed.log 2>&1
   rc=$?
   python - "$out" "$seed" "$world" "$rc" <<'PY'
 import sys, numpy as np

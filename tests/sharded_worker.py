@@ -54,7 +54,7 @@ def coarse_case(out, prefer_native):
     dist.destroy_process_group()
 
 
-def random_case(seed, out, prefer_native):
+def random_case(seed, out, prefer_native, big=False):
     """Random graph, error type, loss and a random partition (arbitrary cut points: slices of very different widths, ranks that own no camera at
     all); rank 0 also solves the same problem unsharded and stores both answers."""
     import torch.distributed as dist
@@ -63,6 +63,8 @@ def random_case(seed, out, prefer_native):
     rng = np.random.default_rng(seed)          # the same stream on every rank
     world, rank = dist.get_world_size(), dist.get_rank()
     n = int(rng.integers(max(8, world), 1500)); window = int(rng.choice([0, 0, 50]))
+    if big:   # large enough and coherent enough for the two-level preconditioner to be voted in
+        n = int(rng.integers(5000, 9000)); window = int(rng.choice([60, 100, 160]))
     e_max = min(n * (n - 1) // 2, 30 * n) if window == 0 else n - 1 + sum(max(0, n - d) for d in range(2, window // 2 + 1)) // 2
     e = int(rng.integers(n - 1, e_max + 1))
     g = synth.make_graph(n, e, int(rng.integers(1 << 30)), outlier_frac=float(rng.uniform(0, 0.3)), local_window=window)
@@ -104,7 +106,7 @@ def main():
     if case == "coarse":
         return coarse_case(out, len(sys.argv) > 3 and sys.argv[3] == "native")
     if case.startswith("random"):
-        return random_case(int(case.split(":")[1]), out, len(sys.argv) > 3 and sys.argv[3] == "native")
+        return random_case(int(case.split(":")[1]), out, len(sys.argv) > 3 and sys.argv[3] == "native", big=case.startswith("randomcoarse"))
     g = synth.make_graph(1203, 40000, seed=23, outlier_frac=0.3)
     if case == "isolated":   # the last cameras carry no edge at all: with 8 ranks the last slice holds nothing but isolated cameras
         keep = (g["edge_i"] < 1100) & (g["edge_j"] < 1100)
