@@ -1001,6 +1001,8 @@ int lm_solve(gsfm_rot_problem* P, const gsfm_rot_options& o_in, gsfm_rot_summary
       dense_used = false;   // not positive definite to working precision: the step just evaluated is meaningless, PCG solves it again
     }
     if (cg > 150) pcg_struggles = true;
+    if (o.verbose && !dense_used && cg >= o.max_cg_iterations && cg_rel > o.cg_relative_tolerance)
+      fprintf(stderr, "[gsfm] it %3d: PCG stopped at its cap of %d iterations with a relative residual of %.1e (tolerance %.1e): this step is inexact\n", iteration, o.max_cg_iterations, cg_rel, o.cg_relative_tolerance);
     sum->num_cg_iterations += cg;
     sum->num_residual_sweeps++;
     // model_cost_change = -eta.g - 1/2 eta^T B eta with B eta = -g - r_cg - Lambda eta
