@@ -45,14 +45,27 @@ def parse():
     ap.add_argument("--cpu-single-edges", type=int, default=1000000)
     ap.add_argument("--verbose", type=int, default=0)
     ap.add_argument("--sigma-pass", type=int, default=1, help="time the sigma-consensus weight pass on an ANGLE_AXIS problem of the same graph")
-    ap.add_argument("--small-graphs", type=int, default=1, help="also time the latency-regime configurations (C1 Madrid, C2)")
+    ap.add_argument("--small-graphs", type=int, default=1, help="also time the latency-regime configurations (C1 Madrid, C2), each beside the CPU oracle")
+    ap.add_argument("--coherent", type=int, default=0, help="also time the spatially coherent 100k / 2M graph with and without the two-level preconditioner (not a BASELINE config)")
+    ap.add_argument("--tree-init", type=int, default=1, help="also solve from the maximum-spanning-tree initialisation of SURVEY 8(d)")
     return ap.parse_args()
 
 
+def kernel_source_sha16():
+    """Identity of the device code a committed PMC measurement belongs to: bench.py reports `traffic` only if it still matches."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "globalsfmpy_amd", "csrc")
+    for f in ("kernels.hpp", "loss_dev.hpp", "so3_dev.hpp"):
+        h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def cpu_baseline(args, loss_ctor, error_type, device_rot=None, device_summary=None):
-    """The CPU oracle (restatement of the reference's Ceres path) timed on this host's cores on a
-    bounded sample of the same workload: same generator and mean degree, fewer cameras/edges.  SURVEY 8d asks for
-    one thread and for all host cores: the all-cores figure is `value`, the 1-thread one rides along."""
+    """The CPU oracle (restatement of the reference's Ceres path) timed on this host's cores: by default one full solve of THE
+    BENCHMARK GRAPH itself (about 17 s on 16 cores; --cpu-sample-cams/-edges select a smaller graph of the same generator instead),
+    which doubles as a full-size parity check.  SURVEY 8d asks for one thread and for all host cores: the all-cores figure is
+    `value`, the 1-thread one (a smaller sample) rides along."""
     from globalsfmpy_amd import synth
     from oracle import pyoracle
 
@@ -120,30 +133,43 @@ def small_graph_timings(args):
     from globalsfmpy_amd import _abi, synth
     from globalsfmpy_amd import loss_functions as LF
     from globalsfmpy_amd.solver import RotationProblem
+    from oracle import pyoracle
     out = {}
+    cores = pyoracle.usable_cores()
 
-    def best(p, x0):
+    def best(p, x0, oracle_args=None):
         ts, s = [], None
-        p.solve(x0)
+        rd, _ = p.solve(x0)
         for _ in range(3):
             t = time.perf_counter()
-            _, s = p.solve(x0)
+            rd, s = p.solve(x0)
             ts.append(time.perf_counter() - t)
-        return {"ms": 1e3 * min(ts), "lm_iterations": s["num_iterations"], "cg_iterations": s["num_cg_iterations"], "dense_cholesky_steps": s["num_dense_solves"]}
+        r = {"ms": 1e3 * min(ts), "lm_iterations": s["num_iterations"], "cg_iterations": s["num_cg_iterations"], "dense_cholesky_steps": s["num_dense_solves"]}
+        if oracle_args is not None and args.cpu_baseline:   # the same solve by the CPU oracle on all usable cores, beside it
+            n, ei, ej, rel, et, c6, loss = oracle_args
+            o = pyoracle.OracleProblem(n, ei, ej, rel, et, cov6=c6)
+            o.set_loss(loss)
+            t = time.perf_counter()
+            ro, so = o.solve(x0)
+            r["cpu_oracle_ms"] = 1e3 * (time.perf_counter() - t)
+            r["cpu_oracle_cores"] = cores
+            r["cpu_oracle_lm_iterations"] = so["num_iterations"]
+            r["device_vs_cpu_mean_rad"] = float(synth.angular_distance(synth.align_rotations(rd, ro), ro).mean())
+        return r
 
     g = synth.make_graph(10000, 200000, 11, outlier_frac=0.1)
     p = RotationProblem(g["n_cams"], g["edge_i"], g["edge_j"], g["rel_aa"], _abi.ANGLE_AXIS)
     p.set_loss(LF.GemanMcClureLoss(0.1, 1.0))
-    out["C2_10k_cams_200k_edges_geman_mcclure"] = best(p, g["init_aa"])
+    out["C2_10k_cams_200k_edges_geman_mcclure"] = best(p, g["init_aa"], (g["n_cams"], g["edge_i"], g["edge_j"], g["rel_aa"], _abi.ANGLE_AXIS, None, LF.GemanMcClureLoss(0.1, 1.0)))
     p.close()
     p = RotationProblem(g["n_cams"], g["edge_i"], g["edge_j"], g["rel_aa"], _abi.ANGLE_AXIS_COVARIANCE, cov6=g["cov6"])
     p.set_loss(LF.MAGSACWeightBasedLoss(0.02))
-    out["C2_10k_cams_200k_edges_cov_magsac"] = best(p, g["init_aa"])
+    out["C2_10k_cams_200k_edges_cov_magsac"] = best(p, g["init_aa"], (g["n_cams"], g["edge_i"], g["edge_j"], g["rel_aa"], _abi.ANGLE_AXIS_COVARIANCE, g["cov6"], LF.MAGSACWeightBasedLoss(0.02)))
     p.close()
     # a spatially coherent graph (what real large view graphs look like, unlike the uniformly random C5): neighbours within +-500 of a hidden
     # ordering, ids shuffled.  Block-Jacobi PCG against the two-level preconditioner the library chooses for such graphs (same answer).
-    gc = synth.make_graph(100000, 2000000, 7, outlier_frac=0.1, local_window=1000)
-    for label, env in (("two_level_auto", None), ("block_jacobi_only", "0")):
+    gc = synth.make_graph(100000, 2000000, 7, outlier_frac=0.1, local_window=1000) if args.coherent else None
+    for label, env in ((("two_level_auto", None), ("block_jacobi_only", "0")) if args.coherent else ()):
         if env is None:
             os.environ.pop("GSFM_PCG_COARSE", None)
         else:
@@ -178,11 +204,11 @@ def small_graph_timings(args):
             c6 = np.stack([S[:, 0, 0], S[:, 1, 1], S[:, 2, 2], S[:, 0, 1], S[:, 0, 2], S[:, 1, 2]], axis=1)
             p = RotationProblem(len(ids), ei, ej, m["rel_aa"], _abi.ANGLE_AXIS_COVARIANCE, cov6=c6)
             p.set_loss(LF.MAGSACWeightBasedLoss(0.02))
-            out["C1_madrid_394_views_23784_edges_cov_magsac"] = best(p, x0)
+            out["C1_madrid_394_views_23784_edges_cov_magsac"] = best(p, x0, (len(ids), ei, ej, m["rel_aa"], _abi.ANGLE_AXIS_COVARIANCE, c6, LF.MAGSACWeightBasedLoss(0.02)))
             p.close()
             p = RotationProblem(len(ids), ei, ej, m["rel_aa"], _abi.ANGLE_AXIS)
             p.set_loss(LF.SoftLOneLoss(0.1))
-            out["C1_madrid_softl1_EstimateRotations_default"] = best(p, x0)
+            out["C1_madrid_softl1_EstimateRotations_default"] = best(p, x0, (len(ids), ei, ej, m["rel_aa"], _abi.ANGLE_AXIS, None, LF.SoftLOneLoss(0.1)))
             p.close()
         except Exception as e:  # noqa: BLE001  (the extra keys never take the headline down with them)
             out["C1_madrid_error"] = repr(e)
@@ -283,11 +309,33 @@ def main():
                 "lm_iterations": sf["num_iterations"], "cg_iterations": sf["num_cg_iterations"],
                 "mean_rotation_change_vs_default_rad": float(dev.mean()), "max_rotation_change_vs_default_rad": float(dev.max())}
 
+    # SURVEY 8(d)'s initialisation: rotations composed along a maximum spanning tree of the view graph (what the reference pipeline feeds
+    # the solver, OrientationsFromMaximumSpanningTree), instead of ground truth + 2 degrees of noise.  Same graph, same kernels; a harder start.
+    tree = None
+    if world == 1 and args.tree_init:
+        t_tree = time.perf_counter()
+        init_tree, _ = synth.spanning_tree_init(g, args.seed)
+        t_tree = time.perf_counter() - t_tree
+        e0 = synth.angular_distance(synth.align_rotations(init_tree, g["gt_aa"]), g["gt_aa"])
+        prob.solve(init_tree)
+        t1 = time.perf_counter()
+        rot_t, st = prob.solve(init_tree)
+        dt_tree = time.perf_counter() - t1
+        e1 = synth.angular_distance(synth.align_rotations(rot_t, g["gt_aa"]), g["gt_aa"])
+        dd = synth.angular_distance(synth.align_rotations(rot_t, rot), rot)
+        tree = {"init": "maximum spanning tree by match count (inlier pairs 150-1500 matches, outlier pairs 16-150), composed from camera 0",
+                "init_mean_error_deg": float(np.rad2deg(e0.mean())), "ms_per_solve": 1e3 * dt_tree, "value": n_edges * st["num_residual_sweeps"] / dt_tree,
+                "iters_to_1e-6": st["iters_to_1e6"], "lm_iterations": st["num_iterations"], "cg_iterations": st["num_cg_iterations"],
+                "residual_sweeps": st["num_residual_sweeps"], "termination": st["termination_name"], "final_cost": st["final_cost"],
+                "mean_angular_error_vs_ground_truth_deg": float(np.rad2deg(e1.mean())),
+                "mean_difference_to_the_noise_init_solution_rad": float(dd.mean()), "host_tree_build_s": t_tree}
+
     # ---- kernels, timed live with HIP events on the solver's stream (this rank's share of the problem) ----
     e_local = summ["num_edges_used"]
     kt = prob.time_kernels(init, reps=10)   # k_cost (trial cost), k_lin, k_matvec; contains collectives when sharded: every rank must call it
     variants = prob.time_sweep_variants(init, reps=args.sweep_reps) if world == 1 else None
     alg_b, lay_b = prob.sweep_bytes()
+    mv_layout_bytes, mv_form = prob.matvec_bytes()
 
     sigma_pass = None
     if world == 1 and args.sigma_pass:
@@ -297,22 +345,22 @@ def main():
         p6.set_loss(TrivialLoss())
         p6.set_edge_weights(np.ones(n_edges))
         v6 = p6.time_sweep_variants(init, reps=args.sweep_reps)
-        sigma_pass = {"s_only_sweep_ms": v6["s_only"], "weight_pass_ms": v6["sigma_weight_pass"]}
+        sigma_pass = {k: v6[k] for k in ("k1_sigma_fused", "k1_sigma_plain", "k2_sigma_fused", "k2_sigma_plain")}
         p6.close()
 
     small = None
     if world == 1 and args.small_graphs:
         small = small_graph_timings(args)
 
-    pmc = None
-    try:  # committed PMC measurement of the same kernels on the same workload (bench.py cannot run rocprofv3 on itself)
-        for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
-            path = os.path.join(ROOT, "profiles", name)
-            if os.path.exists(path):
-                pm = json.load(open(path))
-                if world == 1 and pm["workload"] == {"cams": n_cams, "edges": n_edges}:
-                    pmc = (pm, "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH x2 gfx950 correction)" % name)
-                break
+    pmc, pmc_note = None, None
+    try:  # committed PMC measurement (bench.py cannot run rocprofv3 on itself): used only if it was taken on THESE kernel sources and this workload
+        path = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+        if os.path.exists(path):
+            pm = json.load(open(path))
+            if world == 1 and pm["workload"] == {"cams": n_cams, "edges": n_edges} and pm.get("kernel_source_sha16") == kernel_source_sha16():
+                pmc = (pm, "profiles/r03_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH x2 gfx950 correction; kernel sources %s)" % pm["kernel_source_sha16"])
+            else:
+                pmc_note = "profiles/r03_pmc_traffic.json is for other kernel sources or another workload: not reported"
     except Exception:
         pass
 
@@ -329,7 +377,9 @@ def main():
         lap = os.environ.get("GSFM_LAPLACIAN", "1") != "0"     # angle-axis / quaternion-cosine problems: 6 doubles per directed entry instead of 9
         blk = 48.0 if lap else 72.0
         nd = 2.0 * e_local if part is None else float(part.entries_per_rank[rank])   # (sharded: rank 0's rows)
-        mv_bytes = nd * (blk + 4.0) + 2 * 24.0 * n_cams
+        mv_bytes = mv_layout_bytes      # this rank's mat-vec as laid out (gsfm_rot_matvec_bytes): row-major 52 B per directed entry, column-sorted 54 B per position + ...
+        mv_kernel = {0: "k_matvec<false> (K3: general 9-value blocks, row-major)", 1: "k_matvec<LAP> (K3: Laplacian form, row-major, 52 B per directed entry)",
+                     2: "k_mv_col + k_mv_col_finish (K3c: Laplacian form, column-sorted row blocks, 54 B per position; csrc/colsort_kernels.hpp)"}[mv_form]
         lin_bytes = nd * (84.0 + blk) + 72.0 * n_cams
         sweep_bytes = e_local * lay_b + 32.0 * n_cams          # as laid out: idx 8 + q_rel 32 + Lt 48 per edge, the quaternions once
 
@@ -359,35 +409,45 @@ def main():
             "setup_s": {"generate": t_gen, "create_problem": t_create},
             # the time-dominant kernel: one launch per PCG iteration
             "roofline": dict(roof(mv_bytes, kt["k_matvec"]), bound="hbm",
-                             kernel="k_matvec<LAP> (K3: normal-equation mat-vec of the Laplacian form, one launch per PCG iteration, %.0f %% of the solve's GPU time)%s"
-                                    % (100.0 * mv_share, "" if world == 1 else "; rank 0's rows, kernel_ms includes the all-gather of A.p that follows every launch"),
-                             traffic=pmc_bytes("k_matvec"), traffic_unit="bytes per launch", traffic_source=(pmc[1] if pmc else None),
-                             bytes_per_directed_entry=blk + 4.0, directed_entries_per_launch=int(nd), launches_per_solve=summ["num_cg_iterations"]),
+                             kernel="%s: the normal-equation mat-vec, one per PCG iteration, %.0f %% of the solve's GPU time%s"
+                                    % (mv_kernel, 100.0 * mv_share, "" if world == 1 else "; rank 0's rows, kernel_ms includes the all-gather of A.p that follows every launch"),
+                             frac_on_survey_8d_bytes=((80.0 * e_local + 2 * 24.0 * n_cams) / (kt["k_matvec"] * 1e-3) / 1e9 / HBM_PEAK_GBPS) if part is None else None,
+                             traffic=pmc_bytes("k_matvec"), traffic_unit="bytes per launch", traffic_source=(pmc[1] if pmc else pmc_note),
+                             directed_entries_per_launch=int(nd), launches_per_solve=summ["num_cg_iterations"]),
         }
         if fast is not None:
             out["inexact_pcg_option"] = fast
+        if tree is not None:
+            out["spanning_tree_init"] = tree
         out["kernels_us"] = {k: 1e3 * v for k, v in kt.items()}
         if world == 1:
+            def k1_entry(ms, out_bytes, what, pmc_key):
+                d = dict(roof(sweep_bytes + out_bytes * e_local, ms), kernel=what, traffic=pmc_bytes(pmc_key), bytes_per_edge=lay_b + out_bytes,
+                         sweep_rate_edges_per_s=e_local / (ms * 1e-3))
+                # the same launch priced on SURVEY 8(d)'s own accounting (88 B per edge in covariance mode + 24 B per camera), whatever it stores
+                d["frac_on_survey_8d_bytes"] = (e_local * alg_b + 24.0 * n_cams) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS
+                return d
             other = {
-                "k_lin": dict(roof(lin_bytes, kt["k_lin"]), kernel="K2: residual, Jacobians, robust weights (rho', rho''), gradient, diagonal blocks, edge blocks; once per accepted LM step",
+                "k_lin": dict(roof(lin_bytes, kt["k_lin"]), kernel="K2: residual, row Jacobian, robust weight rho', gradient, diagonal blocks, edge blocks; once per accepted LM step "
+                                                                   "(fast path: losses with rho'' <= 0, see kernels.hpp lin_rows_fast)",
                               traffic=pmc_bytes("k_lin"), bytes_per_directed_entry=84.0 + blk),
-                "k_cost_trial": dict(roof(sweep_bytes, variants["trial_cost"]), kernel="K1 k_cost<FULL=false>: residual + rho VALUE, block-reduced; the solver's trial-cost sweep (no rho', no per-edge store)",
-                                     traffic=pmc_bytes("k_cost"), bytes_per_edge=lay_b, survey_8d_bytes_per_edge=alg_b,
-                                     sweep_rate_edges_per_s=e_local / (variants["trial_cost"] * 1e-3)),
-                "k_cost_full": dict(roof(sweep_bytes + 32.0 * e_local, variants["full_reweight"]),
-                                    kernel="K1 k_cost<FULL=true>: residual, s, (rho, rho', rho'') stored per edge in the caller's edge order (gsfm_rot_residuals)",
-                                    traffic=pmc_bytes("k_cost_full"), bytes_per_edge=lay_b + 32.0, sweep_rate_edges_per_s=e_local / (variants["full_reweight"] * 1e-3)),
-                "k_cost_s_only": dict(roof(sweep_bytes + 8.0 * e_local, variants["s_only"]),
-                                      kernel="K1 s-only mode: s stored per edge (pass 1 of sigma consensus and of host-callback losses), on this problem's whitened residuals",
-                                      traffic=pmc_bytes("k_cost_s_only"), bytes_per_edge=lay_b + 8.0, sweep_rate_edges_per_s=e_local / (variants["s_only"] * 1e-3)),
+                "k_cost_trial": k1_entry(variants["trial_cost"], 0.0, "K1 k_cost<FULL=false>: residual + rho VALUE, block-reduced; the solver's trial-cost sweep (no rho', no per-edge store)", "k_cost"),
+                "k_cost_reweight": k1_entry(variants["rho1_only"], 8.0, "K1 k_cost<FULL=true>, the reweight sweep as SURVEY 8(d) defines it: residual, loss, rho' stored per edge "
+                                                                        "(problem edge order, coalesced non-temporal stores)", "k_cost_reweight"),
+                "k_cost_full": k1_entry(variants["full_reweight"], 32.0, "K1 k_cost<FULL=true>: residual, s, (rho, rho', rho'') stored per edge in the problem's edge order "
+                                                                         "(what gsfm_rot_residuals runs; the caller's order is restored at the C-ABI boundary)", "k_cost_full"),
+                "k_cost_s_only": k1_entry(variants["s_only"], 8.0, "K1 s-only mode: s stored per edge (pass 1 of host-callback losses)", "k_cost_s_only"),
             }
             if sigma_pass is not None:
-                # ANGLE_AXIS problem: idx 8 + q_rel 32 + scalar weight 8 in, s 8 out; then s 8 + w 8 in/out + 2 x (eid 4 + w gather 8 + store 8) per entry
+                # ANGLE_AXIS problem with scalar weights: K1 streams idx 8 + q_rel 32 + weight 8 per edge, K2 col 4 + q_rel 32 + weight 8 in, block 48 out per
+                # directed entry; the fused forms add one 8-byte weight store per edge / entry.  There is no separate weight pass any more.
+                e6, nd6 = float(e_local), 2.0 * e_local
                 other["sigma_consensus_K6"] = {
-                    "kernel": "K6 on an ANGLE_AXIS problem of the same graph: K1 s-only sweep (unit weights), then k_sigma_weights + the gathers into the cost and directed weight planes",
-                    "s_only_sweep": roof(e_local * (48.0 + 8.0) + 32.0 * n_cams, sigma_pass["s_only_sweep_ms"]),
-                    "weight_pass": roof(e_local * 24.0 + 3.0 * e_local * 20.0, sigma_pass["weight_pass_ms"]),
-                    "edges_per_s": e_local / ((sigma_pass["s_only_sweep_ms"] + sigma_pass["weight_pass_ms"]) * 1e-3)}
+                    "kernel": "sigma consensus on an ANGLE_AXIS problem of the same graph: the weights are computed inside the inner solve's first cost sweep (K1) and first "
+                              "linearisation (K2), stored to each kernel's own weight plane; `plain` = the same kernels without the weight computation",
+                    "k1_fused": roof(e6 * (48.0 + 8.0) + 32.0 * n_cams, sigma_pass["k1_sigma_fused"]), "k1_plain": roof(e6 * 48.0 + 32.0 * n_cams, sigma_pass["k1_sigma_plain"]),
+                    "k2_fused": roof(nd6 * (44.0 + 48.0 + 8.0) + 72.0 * n_cams, sigma_pass["k2_sigma_fused"]), "k2_plain": roof(nd6 * (44.0 + 48.0) + 72.0 * n_cams, sigma_pass["k2_sigma_plain"]),
+                    "added_ms_per_outer_iteration": (sigma_pass["k1_sigma_fused"] - sigma_pass["k1_sigma_plain"]) + (sigma_pass["k2_sigma_fused"] - sigma_pass["k2_sigma_plain"])}
             out["roofline_other"] = other
         if small is not None:
             out["small_graph_ms"] = small

@@ -176,7 +176,7 @@ def load_library():
             "globalsfmpy_amd: %s not found. The HIP extension is the product and has no CPU fallback; "
             "build it with `python -c 'import __graft_entry__ as g; g.build()'`." % LIB_PATH)
     lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
-    if lib.gsfm_rot_abi_version() != 1:
+    if lib.gsfm_rot_abi_version() != 2:
         raise ImportError("globalsfmpy_amd: ABI version mismatch in %s" % LIB_PATH)
     lib.gsfm_last_error.restype = C.c_char_p
     lib.gsfm_rot_options_default.argtypes = [C.POINTER(Options)]
@@ -189,8 +189,10 @@ def load_library():
     lib.gsfm_rot_time_sweep.argtypes = [C.c_void_p, _DP, C.c_int32, _DP]; lib.gsfm_rot_time_sweep.restype = C.c_int
     lib.gsfm_rot_time_kernels.argtypes = [C.c_void_p, _DP, C.c_int32, _DP]; lib.gsfm_rot_time_kernels.restype = C.c_int
     lib.gsfm_rot_time_sweep_variants.argtypes = [C.c_void_p, _DP, C.c_int32, _DP]; lib.gsfm_rot_time_sweep_variants.restype = C.c_int
+    lib.gsfm_rot_matvec_bytes.argtypes = [C.c_void_p, _DP, _DP, C.POINTER(C.c_int32)]; lib.gsfm_rot_matvec_bytes.restype = C.c_int
     lib.gsfm_rot_sweep_bytes.argtypes = [C.c_void_p, _DP, _DP]; lib.gsfm_rot_sweep_bytes.restype = C.c_int
-    lib.gsfm_rot_loss_eval.argtypes = [C.c_void_p, _DP, C.c_uint64, _DP, _DP]; lib.gsfm_rot_loss_eval.restype = C.c_int
+    lib.gsfm_rot_loss_eval.argtypes = [C.c_void_p, _DP, C.c_uint64, _DP, _DP, _DP]; lib.gsfm_rot_loss_eval.restype = C.c_int
+    lib.gsfm_rot_edge_order.argtypes = [C.c_void_p, _U32P, C.c_uint64]; lib.gsfm_rot_edge_order.restype = C.c_int64
     lib.gsfm_rot_locality_order.argtypes = [C.c_uint32, C.c_uint64, _U32P, _U32P, _U32P]; lib.gsfm_rot_locality_order.restype = C.c_int32
     lib.gsfm_rot_edge_sq_norms.argtypes = [C.c_uint32, C.c_uint64, _U32P, _U32P, _DP, _DP, _DP, C.c_double, _DP, C.POINTER(C.c_uint8), C.POINTER(C.c_uint64), _DP]
     lib.gsfm_rot_edge_sq_norms.restype = C.c_int

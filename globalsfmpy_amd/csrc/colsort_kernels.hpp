@@ -1,0 +1,222 @@
+// K2c / K3c: linearisation and normal-equation mat-vec on the COLUMN-SORTED layout of the directed entries, for large graphs WITHOUT
+// locality (the C5 benchmark graph is a uniformly random expander).
+//
+// Why: counters on the row-major K3 (profiles/r03_k3_ceiling.md) show that every u[col] gather is its own L1 -> L2 request (32.1 M
+// requests per product for 20 M entries + 8 M stream lines, no line shared between lanes), and that the vector L1 sustains only ~100
+// requests in flight at a ~555-cycle loaded L2 latency: one 128-byte line per ~5.5 cycles per CU, 295 us for those 32 M lines whatever
+// else the kernel does.  The only way below that is fewer lines.
+//
+// How: rows are grouped into blocks of RB = 512 and the entries of a block are sorted by COLUMN; this order replaces the row-major one
+// for all per-entry planes of the problem (measurements, whitening, blocks).  A wavefront then touches 64 neighbouring cameras -- at the C5
+// shape 100k cameras / 102k entries per block, ~5 lanes per 128-byte line -- and the gather's L2 requests drop about fivefold; the
+// mat-vec becomes a stream of its own 54 B per entry.  Per-row sums stay deterministic and atomic-free: a sub-chunk of SUB entries is
+// evaluated entry-parallel, each entry's contribution is written to its slot of a ROW-sorted LDS staging area (2-byte permutation index
+// per entry), and after a barrier the lane that owns row r adds the slots of row r, in slot order, to the sums it keeps in registers
+// (seg[] = 2-byte slot offsets per row and sub-chunk).  The sub-chunks of a block are dealt to NCH workgroups; a finishing kernel adds
+// the NCH partials of a row in fixed order.  K2c stores the edge blocks in the BODY frame, B = R_k^T G R_k (it has R_k at hand), so K3c
+// applies R_k once per row, in its finish, instead of once per entry.
+//   measured at C5 (tools/bench_matvec6.hip, random data): row-major mat-vec 322 us -> 193 + 3 us.
+#pragma once
+#include "kernels.hpp"
+
+namespace gsfm {
+
+#define GSFM_COL_RB 512    // rows per block = positions per sub-chunk = lanes of a K3c workgroup
+#define GSFM_COL_SUB GSFM_COL_RB
+#define GSFM_COL_EPL 2     // K3c: sub-chunks in flight per iteration (entries per lane)
+#define GSFM_COL_PAD 0xffffffffu   // column value of a padding position (zero block, reads camera 0)
+
+struct ColWg { uint32_t first_sub, n_sub, row0, pad; };   // sub-chunk range; first row of the block (local to the owned rows)
+struct ColLayoutDev {
+  const ColWg* wg;
+  const uint32_t* col;      // per position: neighbour camera | role << 31; GSFM_COL_PAD = padding
+  const uint16_t* rowl;     // per position: row inside its block
+  const uint16_t* perm;     // per position: slot in the row-sorted staging area of its sub-chunk
+  const uint16_t* seg;      // per sub-chunk: RB + 1 slot offsets
+  uint32_t n_wg, nch;
+};
+
+// ---- K3c ----------------------------------------------------------------------------------------------------------------
+struct ColMatvecArgs {
+  ColLayoutDev L;
+  const double2 *b0, *b1, *b2;   // body-frame blocks (b00 b01) (b02 b11) (b12 b22); zero at padding positions
+  const double* u;          // u_m = R_m^T p_m, 3 per camera
+  double* part;             // 3 planes of [n_wg * RB]
+  const int* done;          // PCG convergence flag (may be null)
+};
+__global__ void __launch_bounds__(GSFM_COL_RB) k_mv_col(ColMatvecArgs a) {
+  if (a.done && *a.done) return;
+  constexpr int RB = GSFM_COL_RB, EPL = GSFM_COL_EPL;
+  // plane-major: the slot-contiguous reads of one row are conflict-free; two buffers, so one barrier per iteration suffices (a buffer is
+  // written again two iterations later, after the barrier every lane passes once it has finished reading it)
+  __shared__ double slots[2][EPL][3][RB];
+  const ColWg w = a.L.wg[blockIdx.x];
+  const uint32_t r = threadIdx.x;
+  double y0 = 0.0, y1 = 0.0, y2 = 0.0;
+  uint32_t m[EPL]; double2 A[EPL], B[EPL], C[EPL]; uint16_t pm[EPL];
+  auto request = [&](uint32_t s) {   // the streams of sub-chunks s .. s + EPL - 1 of this workgroup (past its end: the last one again, discarded)
+#pragma unroll
+    for (int k = 0; k < EPL; ++k) {
+      const uint32_t sc = w.first_sub + min(s + (uint32_t)k, w.n_sub - 1);
+      const size_t e = (size_t)sc * RB + r;
+      m[k] = __builtin_nontemporal_load(a.L.col + e);
+      A[k] = nt_load2(a.b0 + e); B[k] = nt_load2(a.b1 + e); C[k] = nt_load2(a.b2 + e);
+      pm[k] = __builtin_nontemporal_load(a.L.perm + e);
+    }
+  };
+  if (w.n_sub) request(0);
+  int buf = 0;
+  for (uint32_t s = 0; s < w.n_sub; s += EPL, buf ^= 1) {
+#pragma unroll
+    for (int k = 0; k < EPL; ++k) {
+      const uint32_t cam = m[k] == GSFM_COL_PAD ? 0u : (m[k] & 0x7fffffffu);
+      const double* um = a.u + 3 * (size_t)cam;
+      const double u0 = um[0], u1 = um[1], u2 = um[2];
+      slots[buf][k][0][pm[k]] = A[k].x * u0 + A[k].y * u1 + B[k].x * u2;
+      slots[buf][k][1][pm[k]] = A[k].y * u0 + B[k].y * u1 + C[k].x * u2;
+      slots[buf][k][2][pm[k]] = B[k].x * u0 + C[k].x * u1 + C[k].y * u2;
+    }
+    uint32_t s0[EPL], s1[EPL];
+#pragma unroll
+    for (int k = 0; k < EPL; ++k) {
+      const bool live = s + (uint32_t)k < w.n_sub;
+      const uint16_t* sg = a.L.seg + (size_t)(w.first_sub + (live ? s + (uint32_t)k : s)) * (RB + 1);
+      s0[k] = sg[r]; s1[k] = live ? (uint32_t)sg[r + 1] : s0[k];
+    }
+    if (s + EPL < w.n_sub) request(s + EPL);   // the next iteration's streams are in flight across the barrier and the row phase
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < EPL; ++k)
+      for (uint32_t t = s0[k]; t < s1[k]; ++t) { y0 += slots[buf][k][0][t]; y1 += slots[buf][k][1][t]; y2 += slots[buf][k][2][t]; }
+  }
+  const size_t o = (size_t)blockIdx.x * RB + r, plane = (size_t)a.L.n_wg * RB;
+  a.part[o] = y0; a.part[plane + o] = y1; a.part[2 * plane + o] = y2;
+}
+// y_k = M_k p_k - R_k sum_{c < NCH} part[block(k) * NCH + c][k mod RB]
+struct ColFinishArgs {
+  uint32_t n_rows, row_base, nch, n_wg;
+  const double* part; const double* Mblk; const double* p; const double2* q; double* y; const int* done;
+};
+__global__ void __launch_bounds__(GSFM_BLOCK) k_mv_col_finish(ColFinishArgs a) {
+  if (a.done && *a.done) return;
+  const uint32_t row = blockIdx.x * GSFM_BLOCK + threadIdx.x;
+  if (row >= a.n_rows) return;
+  const uint32_t blk = row / GSFM_COL_RB, r = row % GSFM_COL_RB;
+  const size_t plane = (size_t)a.n_wg * GSFM_COL_RB;
+  double t0 = 0.0, t1 = 0.0, t2 = 0.0;
+  for (uint32_t c = 0; c < a.nch; ++c) { const size_t o = ((size_t)blk * a.nch + c) * GSFM_COL_RB + r; t0 += a.part[o]; t1 += a.part[plane + o]; t2 += a.part[2 * plane + o]; }
+  const size_t k = a.row_base + row;
+  double R[9], mp[3];
+  qmat(load_q(a.q, (uint32_t)k), R);
+  sym3_mulvec(a.Mblk + 6 * k, a.p + 3 * k, mp);
+  a.y[3 * k] = mp[0] - (R[0] * t0 + R[1] * t1 + R[2] * t2);
+  a.y[3 * k + 1] = mp[1] - (R[3] * t0 + R[4] * t1 + R[5] * t2);
+  a.y[3 * k + 2] = mp[2] - (R[6] * t0 + R[7] * t1 + R[8] * t2);
+}
+
+// ---- K2c ----------------------------------------------------------------------------------------------------------------
+// The linearisation in the same order: one entry per lane and trip, 256 lanes work through a sub-chunk of GSFM_COL_SUB positions in two
+// trips; the nine per-entry contributions to (g, D) of the row camera go through the LDS slots, lanes t and t + 256 own rows t and t + 256
+// of the block (37 KB of slots + 16 KB of row quaternions per workgroup: three workgroups, i.e. three waves per SIMD, per CU).  The row cameras' quaternions are staged in LDS once per workgroup (a lane's row is arbitrary inside the block); the
+// neighbour's quaternion is gathered -- line-sharing, like u in K3c.  a.h0..h2 receive the BODY-frame block at the entry's position.
+#define GSFM_COLLIN_THREADS 256
+struct ColLinArgs {
+  LinArgs lin;              // streams (qr, w, col, eid: all in position order), q, loss, rho_ext, sigma, h0..h2 (out); row_base
+  ColLayoutDev L;
+  double* part;             // 9 planes of [n_wg * RB]
+};
+template <int F, int WM, int LM, bool FAST>
+__device__ __forceinline__ void lin_col_body(const ColLinArgs& a) {
+  constexpr int RB = GSFM_COL_RB, SUB = GSFM_COL_SUB, T = GSFM_COLLIN_THREADS, RPL = RB / T;
+  __shared__ double slots[9][SUB];
+  __shared__ double2 qrow[2][RB];
+  const ColWg w = a.L.wg[blockIdx.x];
+  const uint32_t t = threadIdx.x;
+  for (uint32_t r = t; r < RB; r += T) {
+    const uint32_t k = min(a.lin.row_base + w.row0 + r, a.lin.row_base + a.lin.n_rows - 1);   // (a ragged last block re-reads its last row)
+    qrow[0][r] = a.lin.q[2 * (size_t)k]; qrow[1][r] = a.lin.q[2 * (size_t)k + 1];
+  }
+  double acc[RPL][9];
+#pragma unroll
+  for (int j = 0; j < RPL; ++j)
+#pragma unroll
+    for (int c = 0; c < 9; ++c) acc[j][c] = 0.0;
+  __syncthreads();
+  for (uint32_t s = 0; s < w.n_sub; ++s) {
+    const uint32_t sc = w.first_sub + s;
+    for (uint32_t k = 0; k < SUB / T; ++k) {
+      const uint32_t d = sc * SUB + k * T + t;
+      const uint32_t cr = __builtin_nontemporal_load(a.L.col + d);
+      const uint32_t pm = __builtin_nontemporal_load(a.L.perm + d);
+      double g3[3] = {0, 0, 0}, G6[6] = {0, 0, 0, 0, 0, 0}, B6[6] = {0, 0, 0, 0, 0, 0};
+      if (cr != GSFM_COL_PAD) {
+        const uint32_t rl = __builtin_nontemporal_load(a.L.rowl + d);
+        const LinStreams S = lin_load_streams<WM>(a.lin, d);
+        const Quat qm = load_q(a.lin.q, cr & 0x7fffffffu);
+        const double2 k0 = qrow[0][rl], k1 = qrow[1][rl];
+        const Quat qk{k0.x, k0.y, k1.x, k1.y};
+        lin_entry_eval<F, WM, LM, FAST>(a.lin, d, cr, qk, qm, S, g3, G6);
+        // body frame: B = R_k^T G R_k
+        double R[9], Tm[9];
+        qmat(qk, R);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          Tm[c] = G6[0] * R[c] + G6[1] * R[3 + c] + G6[2] * R[6 + c];
+          Tm[3 + c] = G6[1] * R[c] + G6[3] * R[3 + c] + G6[4] * R[6 + c];
+          Tm[6 + c] = G6[2] * R[c] + G6[4] * R[3 + c] + G6[5] * R[6 + c];
+        }
+        B6[0] = R[0] * Tm[0] + R[3] * Tm[3] + R[6] * Tm[6]; B6[1] = R[0] * Tm[1] + R[3] * Tm[4] + R[6] * Tm[7]; B6[2] = R[0] * Tm[2] + R[3] * Tm[5] + R[6] * Tm[8];
+        B6[3] = R[1] * Tm[1] + R[4] * Tm[4] + R[7] * Tm[7]; B6[4] = R[1] * Tm[2] + R[4] * Tm[5] + R[7] * Tm[8]; B6[5] = R[2] * Tm[2] + R[5] * Tm[5] + R[8] * Tm[8];
+      }
+      nt_store2(a.lin.h0 + d, B6[0], B6[1]);
+      nt_store2(a.lin.h1 + d, B6[2], B6[3]);
+      nt_store2(a.lin.h2 + d, B6[4], B6[5]);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) slots[c][pm] = g3[c];
+#pragma unroll
+      for (int c = 0; c < 6; ++c) slots[3 + c][pm] = G6[c];
+    }
+    const uint16_t* sg = a.L.seg + (size_t)sc * (RB + 1);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < RPL; ++j) {
+      const uint32_t r = t + j * T;
+      const uint32_t s0 = sg[r], s1 = sg[r + 1];
+      for (uint32_t u = s0; u < s1; ++u) {
+#pragma unroll
+        for (int c = 0; c < 9; ++c) acc[j][c] += slots[c][u];
+      }
+    }
+    __syncthreads();
+  }
+  const size_t plane = (size_t)a.L.n_wg * RB;
+#pragma unroll
+  for (int j = 0; j < RPL; ++j) {
+    const size_t o = (size_t)blockIdx.x * RB + t + j * T;
+#pragma unroll
+    for (int c = 0; c < 9; ++c) a.part[(size_t)c * plane + o] = acc[j][c];
+  }
+}
+template <int F, int WM, int LM, bool FAST>
+__global__ void __launch_bounds__(GSFM_COLLIN_THREADS) GSFM_K2_ATTR k_lin_col(ColLinArgs a) { lin_col_body<F, WM, LM, FAST>(a); }
+template <int F, int WM, int LM, bool FAST>
+__global__ void __launch_bounds__(GSFM_COLLIN_THREADS) k_lin_col_free(ColLinArgs a) { lin_col_body<F, WM, LM, FAST>(a); }
+
+// gD[k] = sum_{c < NCH} part[block(k) * NCH + c][k mod RB]  (nine values per camera)
+__global__ void __launch_bounds__(GSFM_BLOCK) k_lin_col_finish(uint32_t n_rows, uint32_t row_base, uint32_t nch, uint32_t n_wg, const double* __restrict__ part, double* __restrict__ gD) {
+  const uint32_t row = blockIdx.x * GSFM_BLOCK + threadIdx.x;
+  if (row >= n_rows) return;
+  const uint32_t blk = row / GSFM_COL_RB, r = row % GSFM_COL_RB;
+  const size_t plane = (size_t)n_wg * GSFM_COL_RB;
+  double v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (uint32_t c = 0; c < nch; ++c) {
+    const size_t o = ((size_t)blk * nch + c) * GSFM_COL_RB + r;
+#pragma unroll
+    for (int x = 0; x < 9; ++x) v[x] += part[(size_t)x * plane + o];
+  }
+  double* out = gD + 9 * (size_t)(row_base + row);
+#pragma unroll
+  for (int x = 0; x < 9; ++x) out[x] = v[x];
+}
+
+}  // namespace gsfm

@@ -21,6 +21,7 @@
 #include "kernels.hpp"
 #include "cov_kernels.hpp"
 #include "dense_kernels.hpp"
+#include "colsort_kernels.hpp"
 
 using namespace gsfm;
 
@@ -251,6 +252,23 @@ struct gsfm_rot_problem {
   DevBuf<double> rho_ext, s_ext, w_orig;
   std::vector<double> h_s, h_rho;
 
+  // Column-sorted layout of the directed entries for large graphs without locality (colsort_kernels.hpp): when active it IS the order of
+  // every per-entry plane (dir.*, col, h0..h2), and K2c / K3c replace the row-major K2 / K3
+  struct ColSort {
+    bool active = false;
+    uint32_t nch = 0, n_wg = 0;
+    size_t n_pos = 0;
+    DevBuf<ColWg> wg;
+    DevBuf<uint16_t> rowl, perm, seg;
+    DevBuf<double> part;      // 9 planes of [n_wg * RB] (K2c; K3c uses the first three)
+    ColLayoutDev dev(const uint32_t* col) const { return ColLayoutDev{wg.p, col, rowl.p, perm.p, seg.p, n_wg, nch}; }
+  } cs;
+
+  // sigma consensus (gsfm_rot_solve_sigma_consensus): the weights are computed inside the first cost sweep / linearisation of a solve
+  SigmaDev sigma{};
+  bool sigma_pending_cost = false, sigma_pending_lin = false;
+  DevBuf<double> sigma_table, sigma_sum;   // nu = 3 table; [0] = sum |w - w_old| over this rank's cost edges
+
   bool have_lin = false;
   int graph_launches = 0;
   std::vector<double> trace;
@@ -266,7 +284,7 @@ int loss_mode(const gsfm_rot_problem* P) {
   if (L.n == 0) return LM_SIMPLE;
   if (L.n == 1) {
     const int k = L.nodes[0].kind;
-    if (k == GSFM_LOSS_MAGSAC) return LM_MAGSAC;
+    if (k == GSFM_LOSS_MAGSAC) return (L.nodes[0].nu == 3 && !L.nodes[0].inverse) ? LM_MAGSAC : LM_PROGRAM;
     if (k == GSFM_LOSS_TRIVIAL || k == GSFM_LOSS_HUBER || k == GSFM_LOSS_SOFT_L1 || k == GSFM_LOSS_TUKEY || k == GSFM_LOSS_GEMAN_MCCLURE) return LM_SIMPLE;
   }
   return LM_PROGRAM;
@@ -284,7 +302,7 @@ int dispatch(const gsfm_rot_problem* P, const ArgsT& args, int grid) {
 }
 template <int F, int W, int L> struct CostLauncher {
   static void go(const CostArgs& a, int grid, hipStream_t s) {
-    const bool full = a.s_only || a.rho_ext || a.s_out;
+    const bool full = a.s_only || a.rho_ext || a.s_out || a.rho01_out || a.rho2_out || a.rho1_out || a.r_out || a.sigma.on;
     if (a.direct) {
       if (full) hipLaunchKernelGGL((k_cost_direct<F, W, L, true>), dim3(grid), dim3(GSFM_BLOCK), 0, s, a);
       else hipLaunchKernelGGL((k_cost_direct<F, W, L, false>), dim3(grid), dim3(GSFM_BLOCK), 0, s, a);
@@ -294,17 +312,36 @@ template <int F, int W, int L> struct CostLauncher {
     else hipLaunchKernelGGL((k_cost<F, W, L, false>), dim3(grid), dim3(GSFM_TILE_THREADS), 0, s, a);
   }
 };
+// K2: GSFM_K2_FAST=0 switches the fast path (losses with rho'' <= 0) off, for A/B measurements.  Read at every launch.
+bool k2_fast_enabled() {
+  const char* e = getenv("GSFM_K2_FAST");
+  return !(e && *e && atoi(e) <= 0);
+}
 template <int F, int W, int L> struct LinLauncher {
   static void go(const LinArgs& a, int grid, hipStream_t s) {
     if constexpr (F == F_AA || F == F_QCOS) {   // functors of R_j R_i^T only: the Laplacian form exists (lin_rows)
       if (a.lap) {
-        if constexpr (L != LM_PROGRAM) hipLaunchKernelGGL((k_lin3<F, W, L, true>), dim3(grid), dim3(GSFM_BLOCK), 0, s, a);
-        else hipLaunchKernelGGL((k_lin<F, W, L, true>), dim3(grid), dim3(GSFM_BLOCK), 0, s, a);
+        if constexpr (L != LM_PROGRAM) {
+          // (a host-callback loss may have rho'' > 0: the general path applies the Corrector in full)
+          if (!a.rho_ext && k2_fast_enabled()) hipLaunchKernelGGL((k_lin_fast<F, W, L>), dim3(grid), dim3(GSFM_BLOCK), 0, s, a);
+          else hipLaunchKernelGGL((k_lin3<F, W, L, true>), dim3(grid), dim3(GSFM_BLOCK), 0, s, a);
+        } else hipLaunchKernelGGL((k_lin<F, W, L, true>), dim3(grid), dim3(GSFM_BLOCK), 0, s, a);
         return;
       }
     }
     if constexpr (L != LM_PROGRAM && F != F_RFNORM) hipLaunchKernelGGL((k_lin3<F, W, L, false>), dim3(grid), dim3(GSFM_BLOCK), 0, s, a);
     else hipLaunchKernelGGL((k_lin<F, W, L, false>), dim3(grid), dim3(GSFM_BLOCK), 0, s, a);
+  }
+};
+template <int F, int W, int L> struct ColLinLauncher {   // K2c (column-sorted layout: Laplacian-capable functors only)
+  static void go(const ColLinArgs& a, int grid, hipStream_t s) {
+    if constexpr (F == F_AA || F == F_QCOS) {
+      const dim3 g(grid), b(GSFM_COLLIN_THREADS);
+      if constexpr (L != LM_PROGRAM) {
+        if (!a.lin.rho_ext && k2_fast_enabled()) hipLaunchKernelGGL((k_lin_col<F, W, L, true>), g, b, 0, s, a);
+        else hipLaunchKernelGGL((k_lin_col<F, W, L, false>), g, b, 0, s, a);
+      } else hipLaunchKernelGGL((k_lin_col_free<F, W, L, false>), g, b, 0, s, a);
+    }
   }
 };
 
@@ -371,6 +408,7 @@ int prepare_loss(gsfm_rot_problem* P, const gsfm_loss_node* prog, int n) {
         d.aux[0] = squared_sigma; d.aux[1] = 2.0 * squared_sigma; d.aux[2] = squared_sigma * sigma;
         d.aux[3] = C_times_two_ad_dof; d.aux[4] = one_over_sigma; d.aux[5] = one_over_sigma * gamma_difference;
         d.aux[6] = c.q * c.q * squared_sigma; d.aux[7] = c.gk;
+        d.rho1_scale = C_times_two_ad_dof / (2.0 * squared_sigma * sigma);   // rho' = rho1_scale * exp(-x / 1000) for nu = 3 (loss_functions.py:311)
         const int ti = nu == 3 ? 0 : nu == 4 ? 1 : 2;
         if (!P->tables[ti].p) {
           if (P->tables[ti].upload(magsac_table(nu)) != hipSuccess) return fail(GSFM_ERR_HIP, "uploading MAGSAC table failed");
@@ -427,38 +465,68 @@ int launch_row_s(gsfm_rot_problem* P, const double2* q, double* s_out, bool unit
   return 0;
 }
 
-// host-callback loss: s per original edge -> host -> rho triples -> device
+CostArgs cost_args(gsfm_rot_problem* P, const double2* q) {
+  CostArgs a{};
+  a.tiles = P->cost_tiles.p; a.direct = P->cost_direct; a.n_cams = P->n_cams; a.n = P->cost.n; a.idx = P->cost_idx.p; a.qr0 = P->cost.qr0.p; a.qr1 = P->cost.qr1.p;
+  a.w0 = P->cost.w0.p; a.w1 = P->cost.w1.p; a.w2 = P->cost.w2.p; a.ws = P->cost.ws.p; a.ws_rw = P->cost.ws.p;
+  a.q = q; a.loss = P->d_loss.p; a.eid = P->cost.eid.p; a.partials = P->part_cost.p;
+  return a;
+}
+
+// host-callback loss: s per edge -> host -> rho triples per ORIGINAL edge -> device
 int refresh_external_rho(gsfm_rot_problem* P, const double2* q) {
-  if (P->sharded) {   // the rows of this rank need rho for every edge it holds, not only for the ones it counts in the cost
-    if (int st = launch_row_s(P, q, P->s_ext.p, false)) return st;
-  } else {
-    CostArgs a{};
-    a.tiles = P->cost_tiles.p; a.direct = P->cost_direct; a.n_cams = P->n_cams; a.n = P->cost.n; a.idx = P->cost_idx.p; a.qr0 = P->cost.qr0.p; a.qr1 = P->cost.qr1.p;
-    a.w0 = P->cost.w0.p; a.w1 = P->cost.w1.p; a.w2 = P->cost.w2.p; a.ws = P->cost.ws.p;
-    a.q = q; a.loss = P->d_loss.p; a.eid = P->cost.eid.p; a.partials = P->part_cost.p; a.s_out = P->s_ext.p; a.s_only = 1;
-    if (dispatch<CostArgs, CostLauncher>(P, a, P->nb_cost)) return fail(GSFM_ERR_UNSUPPORTED, "no kernel for this error type");
-  }
   const size_t E = P->n_edges_in;
   P->h_s.resize(E); P->h_rho.resize(3 * E);
-  HIPCHK(hipMemcpyAsync(P->h_s.data(), P->s_ext.p, 8 * E, hipMemcpyDeviceToHost, P->stream));
-  if (int st = sync_check(P, "callback loss: read s")) return st;
-  for (size_t e = 0; e < E; ++e) P->cb(P->cb_user, P->h_s[e], &P->h_rho[3 * e]);
+  if (P->sharded) {   // the rows of this rank need rho for every edge it holds, not only for the ones it counts in the cost
+    if (int st = launch_row_s(P, q, P->s_ext.p, false)) return st;
+    HIPCHK(hipMemcpyAsync(P->h_s.data(), P->s_ext.p, 8 * E, hipMemcpyDeviceToHost, P->stream));
+    if (int st = sync_check(P, "callback loss: read s")) return st;
+    for (size_t e = 0; e < E; ++e) P->cb(P->cb_user, P->h_s[e], &P->h_rho[3 * e]);
+  } else {            // K1's s-only mode writes in the problem's edge order; the callback's answers go back to the original numbering
+    CostArgs a = cost_args(P, q);
+    a.s_out = P->s_ext.p; a.s_only = 1;
+    if (dispatch<CostArgs, CostLauncher>(P, a, P->nb_cost)) return fail(GSFM_ERR_UNSUPPORTED, "no kernel for this error type");
+    HIPCHK(hipMemcpyAsync(P->h_s.data(), P->s_ext.p, 8 * P->cost.n, hipMemcpyDeviceToHost, P->stream));
+    if (int st = sync_check(P, "callback loss: read s")) return st;
+    for (size_t u = 0; u < P->cost.n; ++u) P->cb(P->cb_user, P->h_s[u], &P->h_rho[3 * (size_t)P->h_cost_eid[u]]);
+  }
   HIPCHK(hipMemcpyAsync(P->rho_ext.p, P->h_rho.data(), 24 * E, hipMemcpyHostToDevice, P->stream));
   return 0;
 }
 
+// optional per-edge outputs of K1 (device pointers, problem edge order)
+struct CostOutputs { double* s = nullptr; double2* rho01 = nullptr; double* rho2 = nullptr; double* rho1 = nullptr; double* r = nullptr; };
+
+int launch_lin(gsfm_rot_problem* P, const double2* q);
+
 // K1: cost at quaternion cache q -> scal[slot] (all-reduced when sharded)
-int launch_cost(gsfm_rot_problem* P, const double2* q, int slot, double* s_out = nullptr, double* rho_out = nullptr, double* r_out = nullptr) {
-  if (P->cb) { if (int st = refresh_external_rho(P, q)) return st; }
-  CostArgs a{};
-  a.tiles = P->cost_tiles.p; a.direct = P->cost_direct; a.n_cams = P->n_cams; a.n = P->cost.n; a.idx = P->cost_idx.p; a.qr0 = P->cost.qr0.p; a.qr1 = P->cost.qr1.p;
-  a.w0 = P->cost.w0.p; a.w1 = P->cost.w1.p; a.w2 = P->cost.w2.p; a.ws = P->cost.ws.p;
-  a.q = q; a.loss = P->d_loss.p; a.rho_ext = P->cb ? P->rho_ext.p : nullptr; a.eid = P->cost.eid.p;
-  a.partials = P->part_cost.p; a.s_out = s_out; a.rho_out = rho_out; a.r_out = r_out; a.s_only = 0;
+int launch_cost(gsfm_rot_problem* P, const double2* q, int slot, const CostOutputs& out = CostOutputs()) {
+  const bool sig = P->sigma_pending_cost;
+  P->sigma_pending_cost = false;
+  if (P->cb) {
+    if (sig) {   // the callback's s must already carry the new weights: weight-only passes of K1 and K2 first (rare path: the host loop dominates it)
+      CostArgs a = cost_args(P, q);
+      a.s_out = P->s_ext.p; a.s_only = 1; a.sigma = P->sigma; a.sigma.on = 1;
+      if (dispatch<CostArgs, CostLauncher>(P, a, P->nb_cost)) return fail(GSFM_ERR_UNSUPPORTED, "no kernel for this error type");
+      hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(GSFM_BLOCK), 0, P->stream, P->part_cost.p + P->nb_cost, P->nb_cost, P->sigma_sum.p);
+      gsfm_loss_callback keep = P->cb;
+      P->cb = nullptr;                       // (one linearisation with the in-kernel loss slot: only its weight stores matter)
+      P->sigma_pending_lin = true;
+      const int st = launch_lin(P, q);
+      P->cb = keep;
+      if (st) return st;
+    }
+    if (int st = refresh_external_rho(P, q)) return st;
+  }
+  CostArgs a = cost_args(P, q);
+  a.rho_ext = P->cb ? P->rho_ext.p : nullptr;
+  a.s_out = out.s; a.rho01_out = out.rho01; a.rho2_out = out.rho2; a.rho1_out = out.rho1; a.r_out = out.r; a.s_only = 0;
+  if (sig && !P->cb) { a.sigma = P->sigma; a.sigma.on = 1; }
   const int tk = P->timer.begin(T_SWEEP);
   if (dispatch<CostArgs, CostLauncher>(P, a, P->nb_cost)) return fail(GSFM_ERR_UNSUPPORTED, "no kernel for this error type");
   P->timer.end(tk);
   hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(GSFM_BLOCK), 0, P->stream, P->part_cost.p, P->nb_cost, P->scal.p + slot);
+  if (sig && !P->cb) hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(GSFM_BLOCK), 0, P->stream, P->part_cost.p + P->nb_cost, P->nb_cost, P->sigma_sum.p);
   return all_reduce(P, P->scal.p + slot, 1);
 }
 
@@ -467,13 +535,19 @@ int launch_lin(gsfm_rot_problem* P, const double2* q) {
   if (P->cb) { if (int st = refresh_external_rho(P, q)) return st; }
   LinArgs a{};
   a.n_rows = P->n_rows; a.row_base = P->own_begin; a.G = P->G; a.row_ptr = P->row_ptr.p; a.col = P->col.p; a.eid = P->dir.eid.p;
-  a.qr0 = P->dir.qr0.p; a.qr1 = P->dir.qr1.p; a.w0 = P->dir.w0.p; a.w1 = P->dir.w1.p; a.w2 = P->dir.w2.p; a.ws = P->dir.ws.p;
+  a.qr0 = P->dir.qr0.p; a.qr1 = P->dir.qr1.p; a.w0 = P->dir.w0.p; a.w1 = P->dir.w1.p; a.w2 = P->dir.w2.p; a.ws = P->dir.ws.p; a.ws_rw = P->dir.ws.p;
   a.q = q; a.loss = P->d_loss.p; a.rho_ext = P->cb ? P->rho_ext.p : nullptr;
+  if (P->sigma_pending_lin) { a.sigma = P->sigma; a.sigma.on = 1; P->sigma_pending_lin = false; }
   if (!P->lap && !P->h3.p && (P->h3.alloc(P->dir.n) != hipSuccess || P->h4.alloc(P->dir.n) != hipSuccess)) return fail(GSFM_ERR_HIP, "allocating the general normal-equation blocks failed");
   a.h0 = P->h0.p; a.h1 = P->h1.p; a.h2 = P->h2.p; a.h3 = P->h3.p; a.h4 = P->h4.p; a.gD = P->gD.p; a.lap = P->lap;
   P->lin_is_lap = P->lap; P->q_lin = q;
   const int tk = P->timer.begin(T_LIN);
-  if (dispatch<LinArgs, LinLauncher>(P, a, grid_for((size_t)P->n_rows * P->G))) return fail(GSFM_ERR_UNSUPPORTED, "no kernel for this error type");
+  if (P->cs.active) {
+    ColLinArgs ca{};
+    ca.lin = a; ca.L = P->cs.dev(P->col.p); ca.part = P->cs.part.p;
+    if (dispatch<ColLinArgs, ColLinLauncher>(P, ca, (int)P->cs.n_wg)) return fail(GSFM_ERR_UNSUPPORTED, "no kernel for this error type");
+    hipLaunchKernelGGL(k_lin_col_finish, dim3(grid_for(P->n_rows)), dim3(GSFM_BLOCK), 0, P->stream, P->n_rows, P->own_begin, P->cs.nch, P->cs.n_wg, (const double*)P->cs.part.p, P->gD.p);
+  } else if (dispatch<LinArgs, LinLauncher>(P, a, grid_for((size_t)P->n_rows * P->G))) return fail(GSFM_ERR_UNSUPPORTED, "no kernel for this error type");
   P->timer.end(tk);
   P->have_lin = true;
   return all_gather(P, P->gD.p, (size_t)P->shard.slice_width * 9);
@@ -493,6 +567,16 @@ int launch_matvec(gsfm_rot_problem* P, const double* Mblk, const double* p, doub
   a.n_rows = P->n_rows; a.row_base = P->own_begin; a.G = P->G; a.row_ptr = P->row_ptr.p; a.col = P->col.p;
   a.h0 = P->h0.p; a.h1 = P->h1.p; a.h2 = P->h2.p; a.h3 = P->h3.p; a.h4 = P->h4.p; a.Mblk = Mblk; a.p = p; a.y = y; a.done = done;
   a.q = P->q_lin; a.u = P->u_rot.p;   // Laplacian form: the caller keeps u_rot = R^T p (PCG vector kernels, or k_cam_rotT)
+  if (P->cs.active) {   // graphs without locality: the column-sorted form (always Laplacian)
+    auto& c = P->cs;
+    ColMatvecArgs m{};
+    m.L = c.dev(P->col.p); m.b0 = P->h0.p; m.b1 = P->h1.p; m.b2 = P->h2.p; m.u = P->u_rot.p; m.part = c.part.p; m.done = done;
+    hipLaunchKernelGGL(k_mv_col, dim3(c.n_wg), dim3(GSFM_COL_RB), 0, P->stream, m);
+    ColFinishArgs f{};
+    f.n_rows = P->n_rows; f.row_base = P->own_begin; f.nch = c.nch; f.n_wg = c.n_wg; f.part = c.part.p; f.Mblk = Mblk; f.p = p; f.q = P->q_lin; f.y = y; f.done = done;
+    hipLaunchKernelGGL(k_mv_col_finish, dim3(grid_for(P->n_rows)), dim3(GSFM_BLOCK), 0, P->stream, f);
+    return all_gather(P, y, (size_t)P->shard.slice_width * 3);
+  }
   if (P->lin_is_lap) hipLaunchKernelGGL(k_matvec<true>, dim3(grid_for((size_t)P->n_rows * P->G)), dim3(GSFM_BLOCK), 0, P->stream, a);
   else hipLaunchKernelGGL(k_matvec<false>, dim3(grid_for((size_t)P->n_rows * P->G)), dim3(GSFM_BLOCK), 0, P->stream, a);
   return all_gather(P, y, (size_t)P->shard.slice_width * 3);
@@ -743,6 +827,8 @@ bool use_single_reduction(const gsfm_rot_problem* P, const gsfm_rot_options& o) 
   if (o.cg_stall_iterations > 0) return false;   // stagnation detection lives in the textbook variant's scalar kernel
   return !P->sharded && P->dir.n <= (size_t)2000000;
 }
+bool single_reduction_possible(const gsfm_rot_problem* P) { return !P->cs.active;   // (its fused mat-vec is the row-major one)
+}
 
 // Exact step for small graphs: dense Cholesky of (J^T J + Lambda) in the left-tangent space (dense_kernels.hpp).  Enqueues only: the
 // factorisation's status lands in the scalar block (SC_DENSE_INFO) and is read together with the trial cost, one host synchronisation
@@ -750,7 +836,7 @@ bool use_single_reduction(const gsfm_rot_problem* P, const gsfm_rot_options& o) 
 int run_dense(gsfm_rot_problem* P, bool* used) {
   *used = false;
   const uint32_t n = 3 * P->n_cams, T = (n + GSFM_CB - 1) / GSFM_CB;
-  if (T > GSFM_DENSE_MAX_T) return 0;
+  if (T > GSFM_DENSE_MAX_T || P->cs.active) return 0;   // (the assembly walks the row-major entry order)
   const size_t elems = chol_num_tiles(T) * GSFM_TILE_ELEMS;
   if (!P->denseA.p) {
     if (P->denseA.alloc(elems) != hipSuccess || P->denseL.alloc(elems, true) != hipSuccess) { P->denseA.release(); return 0; }
@@ -989,7 +1075,7 @@ int lm_solve(gsfm_rot_problem* P, const gsfm_rot_options& o_in, gsfm_rot_summary
     for (int attempt = 0; attempt < 2; ++attempt) {
       if (!dense_used) {
         if (int st = coarse_build(P, pcg_struggles)) return st;
-        if (int st = ((P->coarse_n == 0 && use_single_reduction(P, o)) ? run_pcg2(P, o, &cg, &cg_rel) : run_pcg(P, o, &cg, &cg_rel))) return st;
+        if (int st = ((P->coarse_n == 0 && single_reduction_possible(P) && use_single_reduction(P, o)) ? run_pcg2(P, o, &cg, &cg_rel) : run_pcg(P, o, &cg, &cg_rel))) return st;
       }
       launch_step(P);
       if (int st = launch_cost(P, P->q_trial.p, SC_TRIAL)) return st;
@@ -1070,6 +1156,70 @@ int upload_planes(gsfm_rot_problem* P, EdgePlanes& pl, const std::vector<uint32_
   }
   return 0;
 }
+// Column-sorted layout of the directed entries (colsort_kernels.hpp): positions grouped by row block, sorted by column inside a block,
+// cut into sub-chunks of GSFM_COL_SUB (each with its row-sorted slot permutation and per-row slot offsets), the sub-chunks of a block
+// dealt to `nch` workgroups.  Host, once per problem, blocks in parallel.  In: the row-major CSR (rp, col with the role bit, deid = edge of
+// every entry).  Out: col / deid REPLACED by their position-ordered forms (padding: GSFM_COL_PAD / edge 0), the layout arrays on the device.
+int build_colsort(gsfm_rot_problem* P, const std::vector<uint32_t>& rp, std::vector<uint32_t>& col, std::vector<uint32_t>& deid, int n_threads) {
+  constexpr uint32_t RB = GSFM_COL_RB, SUB = GSFM_COL_SUB;
+  auto& C = P->cs;
+  const uint32_t n_rows = P->n_rows, nblk = (n_rows + RB - 1) / RB;
+  if (nblk == 0) return 0;
+  C.nch = std::min<uint32_t>(16, std::max<uint32_t>(1, (1536 + nblk - 1) / nblk));
+  std::vector<size_t> sub_off((size_t)nblk + 1, 0);
+  for (uint32_t b = 0; b < nblk; ++b) {
+    const size_t ne = rp[std::min(n_rows, (b + 1) * RB)] - rp[b * RB];
+    sub_off[b + 1] = sub_off[b] + (ne + SUB - 1) / SUB;
+  }
+  const size_t n_sub = sub_off[nblk], n_pos = n_sub * SUB;
+  if (n_pos == 0 || n_pos >= 0x7fffffffull) return 0;   // (positions are 32-bit in the kernels: stay on the row-major form)
+  std::vector<uint32_t> h_col(n_pos), h_eid(n_pos);
+  std::vector<uint16_t> h_rowl(n_pos), h_perm(n_pos), h_seg(n_sub * (RB + 1));
+  std::vector<ColWg> h_wg((size_t)nblk * C.nch);
+  parallel_run(std::max(1, std::min<int>(n_threads, (int)nblk)), [&](int t, int T) {
+    std::vector<std::pair<uint64_t, uint32_t>> ent;   // (camera << 16 | local row, d): a repeated camera pair is ordered by d
+    std::vector<uint32_t> cnt(RB + 1), fill(RB);
+    for (uint32_t b = (uint32_t)t; b < nblk; b += (uint32_t)T) {
+      const uint32_t r0 = b * RB, r1 = std::min(n_rows, r0 + RB);
+      ent.clear();
+      for (uint32_t r = r0; r < r1; ++r) for (uint32_t d = rp[r]; d < rp[r + 1]; ++d) ent.emplace_back(((uint64_t)(col[d] & 0x7fffffffu) << 16) | (r - r0), d);
+      std::sort(ent.begin(), ent.end());
+      const size_t ne = ent.size(), ns = sub_off[b + 1] - sub_off[b];
+      for (uint32_t c = 0; c < C.nch; ++c) {
+        const size_t lo = ns * c / C.nch, hi = ns * (c + 1) / C.nch;
+        h_wg[(size_t)b * C.nch + c] = ColWg{(uint32_t)(sub_off[b] + lo), (uint32_t)(hi - lo), r0, 0};
+      }
+      for (size_t s = 0; s < ns; ++s) {
+        const size_t lo = s * SUB, hi = std::min(ne, lo + SUB), base = (sub_off[b] + s) * SUB;
+        std::fill(cnt.begin(), cnt.end(), 0u);
+        for (size_t e = lo; e < hi; ++e) cnt[(ent[e].first & 0xffff) + 1]++;
+        for (uint32_t r = 0; r < RB; ++r) cnt[r + 1] += cnt[r];
+        uint16_t* sg = &h_seg[(sub_off[b] + s) * (RB + 1)];
+        for (uint32_t r = 0; r <= RB; ++r) sg[r] = (uint16_t)cnt[r];
+        std::copy(cnt.begin(), cnt.end() - 1, fill.begin());
+        uint32_t pad_slot = (uint32_t)(hi - lo);
+        for (size_t e = lo; e < lo + SUB; ++e) {
+          const size_t o = base + (e - lo);
+          if (e < hi) {
+            const uint32_t rl = (uint32_t)(ent[e].first & 0xffff), d = ent[e].second;
+            h_col[o] = col[d]; h_eid[o] = deid[d]; h_rowl[o] = (uint16_t)rl; h_perm[o] = (uint16_t)fill[rl]++;
+          } else { h_col[o] = GSFM_COL_PAD; h_eid[o] = 0; h_rowl[o] = 0; h_perm[o] = (uint16_t)pad_slot++; }   // zero block, a slot no row reads
+        }
+      }
+    }
+  });
+  C.n_wg = (uint32_t)h_wg.size(); C.n_pos = n_pos;
+  if (C.wg.upload(h_wg) != hipSuccess || C.rowl.upload(h_rowl) != hipSuccess || C.perm.upload(h_perm) != hipSuccess || C.seg.upload(h_seg) != hipSuccess ||
+      C.part.alloc((size_t)9 * C.n_wg * RB) != hipSuccess) {
+    (void)hipGetLastError();
+    C = gsfm_rot_problem::ColSort();   // out of memory: the row-major form needs none of this
+    return 0;
+  }
+  col.swap(h_col); deid.swap(h_eid);
+  C.active = true;
+  return 0;
+}
+
 void run_whiten(gsfm_rot_problem* P, EdgePlanes& pl, const double* d_cov6, const double* d_inl) {
   if (P->wmode == W_NONE || pl.n == 0) return;
   WhitenArgs a{};
@@ -1369,6 +1519,18 @@ gsfm_status gsfm_rot_problem_create(uint32_t n_cams, uint64_t n_edges, const uin
   P->h_cost_eid = cost_eid;
 
   lap("cost tiles");
+  {  // K2c / K3c, the column-sorted layout of the directed entries: for large graphs whose rows offer the gathers no locality -- i.e. where
+     // neither the relabelling nor the two-level preconditioner (both for spatially coherent graphs) applies.  GSFM_K3_COLSORT=0/1 overrides.
+    const char* env = getenv("GSFM_K3_COLSORT");
+    const int mode = env && *env ? atoi(env) : -1;
+    const bool lap_ok = (P->functor == F_AA || P->functor == F_QCOS) && !(getenv("GSFM_LAPLACIAN") && atoi(getenv("GSFM_LAPLACIAN")) == 0);
+    if (lap_ok && !P->sharded && nd > 0 && (mode > 0 || (mode < 0 && nd >= (size_t)4000000 && P->coarse_want == 0 && P->perm.empty()))) {
+      if (int st = build_colsort(P, rp, col, deid, n_host_threads)) return bail(st);
+      if (P->cs.active) { P->coarse_want = 0; P->coarse_adaptive = false; }
+    }
+  }
+  lap("column-sorted layout");
+  const size_t nd_planes = P->cs.active ? P->cs.n_pos : nd;   // per-entry planes: one per position (padded sub-chunks) in the column-sorted layout
   // ---- uploads ----
   {
     DevBuf<double> d_rel;   // the measurements go up once; both sets of planes are gathered from them on the device
@@ -1383,9 +1545,10 @@ gsfm_status gsfm_rot_problem_create(uint32_t n_cams, uint64_t n_edges, const uin
   if (P->cost_idx.upload(cidx) != hipSuccess || P->row_ptr.upload(rp) != hipSuccess || P->col.upload(col) != hipSuccess)
     return bail(fail(GSFM_ERR_HIP, "uploading graph structure failed"));
   // planes h3, h4 (the last three of the nine values of a general block) are allocated on first use: the Laplacian form needs six
-  if (P->h0.alloc(nd) != hipSuccess || P->h1.alloc(nd) != hipSuccess || P->h2.alloc(nd) != hipSuccess)
+  if (P->h0.alloc(nd_planes) != hipSuccess || P->h1.alloc(nd_planes) != hipSuccess || P->h2.alloc(nd_planes) != hipSuccess)
     return bail(fail(GSFM_ERR_HIP, "allocating normal-equation blocks failed"));
   lap("edge planes -> device");
+
   {  // K0 whitening
     DevBuf<double> d_cov, d_inl;
     if (P->wmode != W_NONE) {
@@ -1418,7 +1581,7 @@ gsfm_status gsfm_rot_problem_create(uint32_t n_cams, uint64_t n_edges, const uin
     P->lap = P->lap_capable;
   }
   ok &= P->part_a.alloc(P->nb_cam) == hipSuccess; ok &= P->part_b.alloc(P->nb_cam) == hipSuccess;
-  ok &= P->part_cam.alloc((size_t)5 * P->nb_cam) == hipSuccess; ok &= P->part_cost.alloc(P->nb_cost) == hipSuccess;
+  ok &= P->part_cam.alloc((size_t)5 * P->nb_cam) == hipSuccess; ok &= P->part_cost.alloc((size_t)2 * P->nb_cost) == hipSuccess;
   ok &= P->scal.alloc(SC_N, true) == hipSuccess; ok &= P->cgsc.alloc(1, true) == hipSuccess;
   {  // fused mat-vec of the single-reduction PCG: one row group (256 / G rows) per workgroup unless that leaves too many partials
     const size_t rows_per_group = GSFM_BLOCK / P->G, groups = (P->n_rows + rows_per_group - 1) / rows_per_group;
@@ -1532,62 +1695,46 @@ gsfm_status gsfm_rot_solve_sigma_consensus(gsfm_rot_problem* P, double* rot, int
   std::memset(&total, 0, sizeof(total));
   const double t0 = now_ms();
   const MagsacConst c = magsac_const(3);
-  const std::vector<double>& table = magsac_table(3);
   const double squared_sigma_max_2 = sigma_max * sigma_max * 2.0;
   const double dof_minus_one_per_two = (c.nu - 1.0) / 2.0;
   const double one_over_sigma = c.C * std::pow(2.0, dof_minus_one_per_two) / sigma_max;
   const double weight_zero = one_over_sigma * (std::tgamma(dof_minus_one_per_two) - c.gk);
-  const size_t E = P->n_edges_in;
-  if (!P->s_ext.p && P->s_ext.alloc(E) != hipSuccess) return (gsfm_status)fail(GSFM_ERR_HIP, "alloc");
-  // scalar-weight planes and the per-edge weight vector live on the device for the whole loop; the first comparison is
-  // against zero weights, like the reference's zero-initialised last_weights (:352-353)
+  // The scalar-weight planes live on the device for the whole loop, each in its kernel's own order.  There is no weight pass: the first
+  // cost sweep and the first linearisation of every inner solve start from exactly the rotations the reference computes the weights at
+  // (:378-416), so they compute, store and use them (kernels.hpp, SigmaDev).  The first comparison is against zero weights, like the
+  // reference's zero-initialised last_weights (:352-353).
   if (P->wmode == W_NONE) {
     if (P->cost.ws.alloc(P->cost.n) != hipSuccess || P->dir.ws.alloc(P->dir.n) != hipSuccess) return (gsfm_status)fail(GSFM_ERR_HIP, "alloc weight planes");
     P->wmode = W_SCALAR;
   }
-  if (!P->w_orig.p && P->w_orig.alloc(E) != hipSuccess) return (gsfm_status)fail(GSFM_ERR_HIP, "alloc weights");
-  if (hipMemsetAsync(P->w_orig.p, 0, 8 * E, P->stream) != hipSuccess) return (gsfm_status)fail(GSFM_ERR_HIP, "clear weights");
-  DevBuf<double> d_table, d_part, d_sum;
-  DevBuf<uint8_t> d_counted;
-  const int nb_sig = std::max(1, grid_for(E));
-  if (d_table.upload(table) != hipSuccess || d_part.alloc(nb_sig, true) != hipSuccess || d_sum.alloc(2, true) != hipSuccess) return (gsfm_status)fail(GSFM_ERR_HIP, "alloc sigma consensus buffers");
-  double global_edges = (double)E;
+  if (P->cost.n) HIPCHK_S(hipMemsetAsync(P->cost.ws.p, 0, 8 * P->cost.n, P->stream));
+  if (!P->sigma_table.p && P->sigma_table.upload(magsac_table(3)) != hipSuccess) return (gsfm_status)fail(GSFM_ERR_HIP, "alloc sigma consensus buffers");
+  if (!P->sigma_sum.p && P->sigma_sum.alloc(2, true) != hipSuccess) return (gsfm_status)fail(GSFM_ERR_HIP, "alloc sigma consensus buffers");
+  P->sigma.table = P->sigma_table.p; P->sigma.table_len = c.n; P->sigma.on = 0; P->sigma.ssm2 = squared_sigma_max_2;
+  P->sigma.one_over_sigma = one_over_sigma; P->sigma.gk = c.gk; P->sigma.weight_zero = weight_zero;
+  double global_edges = (double)P->n_edges_in;
   if (P->sharded) {
     // every edge is counted in mean |w - w_old| by exactly one rank: its cost owner
-    std::vector<uint8_t> counted(E, 0);
-    for (uint32_t e : P->h_cost_eid) counted[e] = 1;
-    if (d_counted.upload(counted) != hipSuccess) return (gsfm_status)fail(GSFM_ERR_HIP, "alloc sigma consensus buffers");
-    const double mine = (double)P->h_cost_eid.size();
-    HIPCHK_S(hipMemcpyAsync(d_sum.p + 1, &mine, 8, hipMemcpyHostToDevice, P->stream));
-    if (int st = all_reduce(P, d_sum.p + 1, 1)) return (gsfm_status)st;
-    HIPCHK_S(hipMemcpyAsync(&global_edges, d_sum.p + 1, 8, hipMemcpyDeviceToHost, P->stream));
+    const double mine = (double)P->cost.n;
+    HIPCHK_S(hipMemcpyAsync(P->sigma_sum.p + 1, &mine, 8, hipMemcpyHostToDevice, P->stream));
+    if (int st = all_reduce(P, P->sigma_sum.p + 1, 1)) return (gsfm_status)st;
+    HIPCHK_S(hipMemcpyAsync(&global_edges, P->sigma_sum.p + 1, 8, hipMemcpyDeviceToHost, P->stream));
     if (int st = sync_check(P, "sigma consensus: edge count")) return (gsfm_status)st;
   }
   int outer = 0;
   for (int it = 0; it < iters_num; ++it) {
     ++outer;
-    if (int st = upload_state(P, rot)) return (gsfm_status)st;
-    if (P->sharded) {   // s of every edge this rank holds (its rows' entries), not only of the edges it counts in the cost
-      if (int st = launch_row_s(P, P->q.p, P->s_ext.p, true)) return (gsfm_status)st;
-    } else {  // K6 = K1 in s-only mode with unit weights: s_e = ||log(R_j R_i^T R_ij^T)||^2  (:378-398)
-      CostArgs a{};
-      a.tiles = P->cost_tiles.p; a.direct = P->cost_direct; a.n_cams = P->n_cams; a.n = P->cost.n; a.idx = P->cost_idx.p; a.qr0 = P->cost.qr0.p; a.qr1 = P->cost.qr1.p; a.ws = P->cost.ws.p;
-      a.q = P->q.p; a.loss = P->d_loss.p; a.eid = P->cost.eid.p; a.partials = P->part_cost.p; a.s_out = P->s_ext.p; a.s_only = 1; a.unit_w = 1;
-      if (dispatch<CostArgs, CostLauncher>(P, a, P->nb_cost)) return (gsfm_status)fail(GSFM_ERR_UNSUPPORTED, "dispatch");
-    }
-    SigmaArgs sa{};
-    sa.s = P->s_ext.p; sa.w = P->w_orig.p; sa.n = E; sa.table = d_table.p; sa.table_len = c.n; sa.ssm2 = squared_sigma_max_2;
-    sa.one_over_sigma = one_over_sigma; sa.gk = c.gk; sa.weight_zero = weight_zero; sa.partials = d_part.p; sa.counted = d_counted.p;
-    hipLaunchKernelGGL(k_sigma_weights, dim3(nb_sig), dim3(GSFM_BLOCK), 0, P->stream, sa);
-    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(GSFM_BLOCK), 0, P->stream, d_part.p, nb_sig, d_sum.p);
-    if (int st = all_reduce(P, d_sum.p, 1)) return (gsfm_status)st;
-    if (P->cost.n) hipLaunchKernelGGL(k_gather_weights, dim3(grid_for(P->cost.n)), dim3(GSFM_BLOCK), 0, P->stream, P->w_orig.p, P->cost.eid.p, P->cost.n, P->cost.ws.p);
-    if (P->dir.n) hipLaunchKernelGGL(k_gather_weights, dim3(grid_for(P->dir.n)), dim3(GSFM_BLOCK), 0, P->stream, P->w_orig.p, P->dir.eid.p, P->dir.n, P->dir.ws.p);
+    P->sigma_pending_cost = P->sigma_pending_lin = true;   // consumed by the solve's first K1 / K2
+    const gsfm_status sst = gsfm_rot_solve(P, rot, &o, summary);
+    P->sigma_pending_cost = P->sigma_pending_lin = false;
+    if (sst) return sst;
+    // sum |w - w_old| was left on the device by that first sweep: read it now, after the solve (the decision it feeds comes after the
+    // solve in the reference too, :448)
+    if (int st = all_reduce(P, P->sigma_sum.p, 1)) return (gsfm_status)st;
     double avg = 0.0;
-    if (hipMemcpyAsync(&avg, d_sum.p, 8, hipMemcpyDeviceToHost, P->stream) != hipSuccess) return (gsfm_status)fail(GSFM_ERR_HIP, "read weight change");
+    if (hipMemcpyAsync(&avg, P->sigma_sum.p, 8, hipMemcpyDeviceToHost, P->stream) != hipSuccess) return (gsfm_status)fail(GSFM_ERR_HIP, "read weight change");
     if (int st = sync_check(P, "sigma consensus weights")) return (gsfm_status)st;
     avg /= global_edges;
-    if (gsfm_status st = gsfm_rot_solve(P, rot, &o, summary)) return st;
     if (it == 0) total = *summary;
     else {
       total.num_iterations += summary->num_iterations; total.num_successful_steps += summary->num_successful_steps;
@@ -1598,7 +1745,6 @@ gsfm_status gsfm_rot_solve_sigma_consensus(gsfm_rot_problem* P, double* rot, int
       total.num_dense_solves += summary->num_dense_solves; total.num_graph_launches += summary->num_graph_launches;
       total.t_linearize_ms += summary->t_linearize_ms; total.t_sweep_ms += summary->t_sweep_ms; total.t_cg_ms += summary->t_cg_ms;
     }
-    total.num_residual_sweeps += 1;  // the weight sweep
     total.last_weight_change = avg;
     if (avg <= 1e-7) break;  // :448
   }
@@ -1610,19 +1756,48 @@ gsfm_status gsfm_rot_solve_sigma_consensus(gsfm_rot_problem* P, double* rot, int
 gsfm_status gsfm_rot_residuals(gsfm_rot_problem* P, const double* rot, double* s_out, double* rho_out, double* r_out, double* cost) {
   if (!P || !rot) return (gsfm_status)fail(GSFM_ERR_INVALID_ARG, "NULL argument");
   DeviceGuard g(P->device);
-  const size_t E = P->n_edges_in;
+  const size_t E = P->n_edges_in, Ec = P->cost.n, R = (size_t)P->res_dim;
   if (int st = upload_state(P, rot)) return (gsfm_status)st;
-  DevBuf<double> ds, drho, dr;
-  if (ds.alloc(E, true) != hipSuccess || drho.alloc(3 * E, true) != hipSuccess || dr.alloc((size_t)P->res_dim * E, true) != hipSuccess)
+  // The sweep writes in the problem's own edge order (coalesced); the caller's order is restored here, at the C-ABI edge, on the host:
+  // out[edge_order[u]] = device[u].  Edges this rank does not count in the cost (sharded problems) stay zero.
+  DevBuf<double> ds, dr2, dr; DevBuf<double2> dr01;
+  if ((s_out && ds.alloc(Ec) != hipSuccess) || (rho_out && (dr01.alloc(Ec) != hipSuccess || dr2.alloc(Ec) != hipSuccess)) || (r_out && dr.alloc(R * Ec) != hipSuccess))
     return (gsfm_status)fail(GSFM_ERR_HIP, "alloc outputs");
-  if (int st = launch_cost(P, P->q.p, SC_COST, ds.p, drho.p, dr.p)) return (gsfm_status)st;
+  CostOutputs out;
+  out.s = ds.p; out.rho01 = dr01.p; out.rho2 = dr2.p; out.r = dr.p;
+  if (int st = launch_cost(P, P->q.p, SC_COST, out)) return (gsfm_status)st;
   double h[SC_N];
   if (int st = read_scalars(P, h)) return (gsfm_status)st;
   if (cost) *cost = h[SC_COST];
-  if (s_out && hipMemcpy(s_out, ds.p, 8 * E, hipMemcpyDeviceToHost) != hipSuccess) return (gsfm_status)fail(GSFM_ERR_HIP, "copy s");
-  if (rho_out && hipMemcpy(rho_out, drho.p, 24 * E, hipMemcpyDeviceToHost) != hipSuccess) return (gsfm_status)fail(GSFM_ERR_HIP, "copy rho");
-  if (r_out && hipMemcpy(r_out, dr.p, 8 * (size_t)P->res_dim * E, hipMemcpyDeviceToHost) != hipSuccess) return (gsfm_status)fail(GSFM_ERR_HIP, "copy r");
+  const std::vector<uint32_t>& ord = P->h_cost_eid;
+  std::vector<double> stage;
+  if (s_out) {
+    stage.resize(Ec);
+    if (Ec && hipMemcpy(stage.data(), ds.p, 8 * Ec, hipMemcpyDeviceToHost) != hipSuccess) return (gsfm_status)fail(GSFM_ERR_HIP, "copy s");
+    std::memset(s_out, 0, 8 * E);
+    for (size_t u = 0; u < Ec; ++u) s_out[ord[u]] = stage[u];
+  }
+  if (rho_out) {
+    stage.resize(3 * Ec);
+    if (Ec && (hipMemcpy(stage.data(), dr01.p, 16 * Ec, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(stage.data() + 2 * Ec, dr2.p, 8 * Ec, hipMemcpyDeviceToHost) != hipSuccess))
+      return (gsfm_status)fail(GSFM_ERR_HIP, "copy rho");
+    std::memset(rho_out, 0, 24 * E);
+    for (size_t u = 0; u < Ec; ++u) { double* o = rho_out + 3 * (size_t)ord[u]; o[0] = stage[2 * u]; o[1] = stage[2 * u + 1]; o[2] = stage[2 * Ec + u]; }
+  }
+  if (r_out) {
+    stage.resize(R * Ec);
+    if (Ec && hipMemcpy(stage.data(), dr.p, 8 * R * Ec, hipMemcpyDeviceToHost) != hipSuccess) return (gsfm_status)fail(GSFM_ERR_HIP, "copy r");
+    std::memset(r_out, 0, 8 * R * E);
+    for (size_t u = 0; u < Ec; ++u) for (size_t k = 0; k < R; ++k) r_out[R * (size_t)ord[u] + k] = stage[k * Ec + u];
+  }
   return GSFM_OK;
+}
+
+int64_t gsfm_rot_edge_order(gsfm_rot_problem* P, uint32_t* order_out, uint64_t cap) {
+  if (!P) { fail(GSFM_ERR_INVALID_ARG, "NULL problem"); return -1; }
+  const size_t n = P->h_cost_eid.size();
+  if (order_out) std::memcpy(order_out, P->h_cost_eid.data(), 4 * std::min<size_t>(n, cap));
+  return (int64_t)n;
 }
 
 gsfm_status gsfm_rot_linearize(gsfm_rot_problem* P, const double* rot, double* gradient, double* diag_blocks, double* cost) {
@@ -1670,20 +1845,23 @@ gsfm_status gsfm_rot_normal_matvec(gsfm_rot_problem* P, const double* v, double*
   return GSFM_OK;
 }
 
-gsfm_status gsfm_rot_loss_eval(gsfm_rot_problem* P, const double* s, uint64_t n, double* rho3_out, double* value_out) {
+gsfm_status gsfm_rot_loss_eval(gsfm_rot_problem* P, const double* s, uint64_t n, double* rho3_out, double* value_out, double* rho1_fast_out) {
   if (!P || (n > 0 && !s)) return (gsfm_status)fail(GSFM_ERR_INVALID_ARG, "NULL argument");
   if (P->cb) return (gsfm_status)fail(GSFM_ERR_UNSUPPORTED, "loss_eval needs a native loss program (a host-callback loss runs on the host)");
   if (n == 0) return GSFM_OK;
   DeviceGuard g(P->device);
-  DevBuf<double> ds, d3, dv;
-  if (ds.alloc(n) != hipSuccess || (rho3_out && d3.alloc(3 * n) != hipSuccess) || (value_out && dv.alloc(n) != hipSuccess)) return (gsfm_status)fail(GSFM_ERR_HIP, "alloc");
+  DevBuf<double> ds, d3, dv, d1;
+  const int lm = loss_mode(P);
+  if (rho1_fast_out && lm == LM_PROGRAM) { for (uint64_t k = 0; k < n; ++k) rho1_fast_out[k] = std::numeric_limits<double>::quiet_NaN(); rho1_fast_out = nullptr; }   // K2 has no fast path for this program
+  if (ds.alloc(n) != hipSuccess || (rho3_out && d3.alloc(3 * n) != hipSuccess) || (value_out && dv.alloc(n) != hipSuccess) || (rho1_fast_out && d1.alloc(n) != hipSuccess)) return (gsfm_status)fail(GSFM_ERR_HIP, "alloc");
   HIPCHK_S(hipMemcpyAsync(ds.p, s, 8 * n, hipMemcpyHostToDevice, P->stream));
   const dim3 grid(grid_for(n)), blk(GSFM_BLOCK);
-  switch (loss_mode(P)) {   // the specialisation K1 / K2 are dispatched on for this program
-    case LM_SIMPLE: hipLaunchKernelGGL(k_loss_eval<LM_SIMPLE>, grid, blk, 0, P->stream, (const DevLoss*)P->d_loss.p, (const double*)ds.p, (size_t)n, d3.p, dv.p); break;
-    case LM_MAGSAC: hipLaunchKernelGGL(k_loss_eval<LM_MAGSAC>, grid, blk, 0, P->stream, (const DevLoss*)P->d_loss.p, (const double*)ds.p, (size_t)n, d3.p, dv.p); break;
-    default: hipLaunchKernelGGL(k_loss_eval<LM_PROGRAM>, grid, blk, 0, P->stream, (const DevLoss*)P->d_loss.p, (const double*)ds.p, (size_t)n, d3.p, dv.p); break;
+  switch (lm) {   // the specialisation K1 / K2 are dispatched on for this program
+    case LM_SIMPLE: hipLaunchKernelGGL(k_loss_eval<LM_SIMPLE>, grid, blk, 0, P->stream, (const DevLoss*)P->d_loss.p, (const double*)ds.p, (size_t)n, d3.p, dv.p, d1.p); break;
+    case LM_MAGSAC: hipLaunchKernelGGL(k_loss_eval<LM_MAGSAC>, grid, blk, 0, P->stream, (const DevLoss*)P->d_loss.p, (const double*)ds.p, (size_t)n, d3.p, dv.p, d1.p); break;
+    default: hipLaunchKernelGGL(k_loss_eval<LM_PROGRAM>, grid, blk, 0, P->stream, (const DevLoss*)P->d_loss.p, (const double*)ds.p, (size_t)n, d3.p, dv.p, d1.p); break;
   }
+  if (rho1_fast_out) HIPCHK_S(hipMemcpyAsync(rho1_fast_out, d1.p, 8 * n, hipMemcpyDeviceToHost, P->stream));
   if (rho3_out) HIPCHK_S(hipMemcpyAsync(rho3_out, d3.p, 24 * n, hipMemcpyDeviceToHost, P->stream));
   if (value_out) HIPCHK_S(hipMemcpyAsync(value_out, dv.p, 8 * n, hipMemcpyDeviceToHost, P->stream));
   return (gsfm_status)sync_check(P, "loss_eval");
@@ -1761,10 +1939,7 @@ gsfm_status gsfm_rot_time_sweep(gsfm_rot_problem* P, const double* rot, int32_t 
   if (P->cb) return (gsfm_status)fail(GSFM_ERR_UNSUPPORTED, "time_sweep needs a native loss");
   DeviceGuard g(P->device);
   if (int st = upload_state(P, rot)) return (gsfm_status)st;
-  CostArgs a{};
-  a.tiles = P->cost_tiles.p; a.direct = P->cost_direct; a.n_cams = P->n_cams; a.n = P->cost.n; a.idx = P->cost_idx.p; a.qr0 = P->cost.qr0.p; a.qr1 = P->cost.qr1.p;
-  a.w0 = P->cost.w0.p; a.w1 = P->cost.w1.p; a.w2 = P->cost.w2.p; a.ws = P->cost.ws.p;
-  a.q = P->q.p; a.loss = P->d_loss.p; a.eid = P->cost.eid.p; a.partials = P->part_cost.p;
+  const CostArgs a = cost_args(P, P->q.p);
   for (int k = 0; k < 3; ++k) if (dispatch<CostArgs, CostLauncher>(P, a, P->nb_cost)) return (gsfm_status)fail(GSFM_ERR_UNSUPPORTED, "dispatch");
   hipEvent_t e0, e1;
   if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return (gsfm_status)fail(GSFM_ERR_HIP, "event create");
@@ -1779,18 +1954,15 @@ gsfm_status gsfm_rot_time_sweep(gsfm_rot_problem* P, const double* rot, int32_t 
   return (gsfm_status)st;
 }
 
-gsfm_status gsfm_rot_time_sweep_variants(gsfm_rot_problem* P, const double* rot, int32_t reps, double* out_ms4) {
-  if (!P || !rot || !out_ms4 || reps <= 0) return (gsfm_status)fail(GSFM_ERR_INVALID_ARG, "bad argument");
+gsfm_status gsfm_rot_time_sweep_variants(gsfm_rot_problem* P, const double* rot, int32_t reps, double* out_ms8) {
+  if (!P || !rot || !out_ms8 || reps <= 0) return (gsfm_status)fail(GSFM_ERR_INVALID_ARG, "bad argument");
   if (P->cb) return (gsfm_status)fail(GSFM_ERR_UNSUPPORTED, "time_sweep_variants needs a native loss");
   DeviceGuard g(P->device);
-  const size_t E = P->n_edges_in;
+  const size_t Ec = P->cost.n;
   if (int st = upload_state(P, rot)) return (gsfm_status)st;
-  DevBuf<double> ds, drho, dw, dpart, dsum;
-  if (ds.alloc(E, true) != hipSuccess || drho.alloc(3 * E, true) != hipSuccess) return (gsfm_status)fail(GSFM_ERR_HIP, "alloc outputs");
-  CostArgs base{};
-  base.tiles = P->cost_tiles.p; base.direct = P->cost_direct; base.n_cams = P->n_cams; base.n = P->cost.n; base.idx = P->cost_idx.p; base.qr0 = P->cost.qr0.p; base.qr1 = P->cost.qr1.p;
-  base.w0 = P->cost.w0.p; base.w1 = P->cost.w1.p; base.w2 = P->cost.w2.p; base.ws = P->cost.ws.p;
-  base.q = P->q.p; base.loss = P->d_loss.p; base.eid = P->cost.eid.p; base.partials = P->part_cost.p;
+  DevBuf<double> ds, dr2; DevBuf<double2> dr01;
+  if (ds.alloc(Ec, true) != hipSuccess || dr01.alloc(Ec, true) != hipSuccess || dr2.alloc(Ec, true) != hipSuccess) return (gsfm_status)fail(GSFM_ERR_HIP, "alloc outputs");
+  const CostArgs base = cost_args(P, P->q.p);
   hipEvent_t e0, e1;
   if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return (gsfm_status)fail(GSFM_ERR_HIP, "event create");
   auto timed = [&](auto&& launch, double* out) -> int {
@@ -1800,44 +1972,44 @@ gsfm_status gsfm_rot_time_sweep_variants(gsfm_rot_problem* P, const double* rot,
     float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1); *out = ms / reps; return 0;
   };
   int st = 0;
-  out_ms4[0] = out_ms4[1] = out_ms4[2] = out_ms4[3] = 0.0;
-  { CostArgs a = base; st = timed([&] { dispatch<CostArgs, CostLauncher>(P, a, P->nb_cost); }, &out_ms4[0]); }                                   // trial cost: rho value only
-  if (!st) { CostArgs a = base; a.s_out = ds.p; a.rho_out = drho.p; st = timed([&] { dispatch<CostArgs, CostLauncher>(P, a, P->nb_cost); }, &out_ms4[1]); }  // full reweight sweep with per-edge stores
-  if (!st) { CostArgs a = base; a.s_out = ds.p; a.s_only = 1; a.unit_w = 1; st = timed([&] { dispatch<CostArgs, CostLauncher>(P, a, P->nb_cost); }, &out_ms4[2]); }
-  if (!st && P->functor == F_AA && P->wmode == W_SCALAR && P->cost.ws.p && P->dir.ws.p) {   // sigma-consensus weight pass (estimator.cpp:400-416) on the s just written
+  for (int k = 0; k < 8; ++k) out_ms8[k] = 0.0;
+  { CostArgs a = base; st = timed([&] { dispatch<CostArgs, CostLauncher>(P, a, P->nb_cost); }, &out_ms8[0]); }                                   // trial cost: rho value only
+  if (!st) { CostArgs a = base; a.s_out = ds.p; a.rho01_out = dr01.p; a.rho2_out = dr2.p; st = timed([&] { dispatch<CostArgs, CostLauncher>(P, a, P->nb_cost); }, &out_ms8[1]); }  // s + rho triple
+  if (!st) { CostArgs a = base; a.s_out = ds.p; a.s_only = 1; st = timed([&] { dispatch<CostArgs, CostLauncher>(P, a, P->nb_cost); }, &out_ms8[2]); }   // s only (callback pass 1)
+  if (!st) { CostArgs a = base; a.rho1_out = ds.p; st = timed([&] { dispatch<CostArgs, CostLauncher>(P, a, P->nb_cost); }, &out_ms8[3]); }             // the reweight sweep of SURVEY 8(d): rho' out
+  if (!st && P->functor == F_AA && P->wmode == W_SCALAR && P->cost.ws.p && P->dir.ws.p) {
+    // sigma consensus: the first cost sweep / linearisation of an inner solve with the weight computation fused in (estimator.cpp:400-416),
+    // against the same kernels without it.  The sweeps overwrite the problem's own weight planes: save and restore them.
     const MagsacConst c = magsac_const(3);
-    DevBuf<double> d_table;
-    const int nb_sig = std::max(1, grid_for(E));
-    if (d_table.upload(magsac_table(3)) != hipSuccess || dw.alloc(E, true) != hipSuccess || dpart.alloc(nb_sig, true) != hipSuccess || dsum.alloc(1, true) != hipSuccess) st = fail(GSFM_ERR_HIP, "alloc");
+    if (!P->sigma_table.p && P->sigma_table.upload(magsac_table(3)) != hipSuccess) st = fail(GSFM_ERR_HIP, "alloc");
+    if (!st && !P->sigma_sum.p && P->sigma_sum.alloc(2, true) != hipSuccess) st = fail(GSFM_ERR_HIP, "alloc");
+    DevBuf<double> keep_c, keep_d;
+    if (!st && (keep_c.alloc(P->cost.n) != hipSuccess || keep_d.alloc(P->dir.n) != hipSuccess)) st = fail(GSFM_ERR_HIP, "alloc");
     if (!st) {
       const double sigma_max = 0.02, one_over_sigma = c.C * std::pow(2.0, (c.nu - 1.0) / 2.0) / sigma_max;
-      SigmaArgs sa{};
-      sa.s = ds.p; sa.w = dw.p; sa.n = E; sa.table = d_table.p; sa.table_len = c.n; sa.ssm2 = 2.0 * sigma_max * sigma_max; sa.one_over_sigma = one_over_sigma;
-      sa.gk = c.gk; sa.weight_zero = one_over_sigma * (std::tgamma((c.nu - 1.0) / 2.0) - c.gk); sa.partials = dpart.p;
-      // the gathers write the problem's own weight planes: save and restore them around the timing
-      DevBuf<double> keep_c, keep_d;
-      if (keep_c.alloc(P->cost.n) != hipSuccess || keep_d.alloc(P->dir.n) != hipSuccess) st = fail(GSFM_ERR_HIP, "alloc");
-      if (!st) {
-        (void)hipMemcpyAsync(keep_c.p, P->cost.ws.p, 8 * P->cost.n, hipMemcpyDeviceToDevice, P->stream);
-        (void)hipMemcpyAsync(keep_d.p, P->dir.ws.p, 8 * P->dir.n, hipMemcpyDeviceToDevice, P->stream);
-        st = timed([&] {
-          hipLaunchKernelGGL(k_sigma_weights, dim3(nb_sig), dim3(GSFM_BLOCK), 0, P->stream, sa);
-          hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(GSFM_BLOCK), 0, P->stream, dpart.p, nb_sig, dsum.p);
-          if (P->cost.n) hipLaunchKernelGGL(k_gather_weights, dim3(grid_for(P->cost.n)), dim3(GSFM_BLOCK), 0, P->stream, dw.p, P->cost.eid.p, P->cost.n, P->cost.ws.p);
-          if (P->dir.n) hipLaunchKernelGGL(k_gather_weights, dim3(grid_for(P->dir.n)), dim3(GSFM_BLOCK), 0, P->stream, dw.p, P->dir.eid.p, P->dir.n, P->dir.ws.p);
-        }, &out_ms4[3]);
-        (void)hipMemcpyAsync(P->cost.ws.p, keep_c.p, 8 * P->cost.n, hipMemcpyDeviceToDevice, P->stream);
-        (void)hipMemcpyAsync(P->dir.ws.p, keep_d.p, 8 * P->dir.n, hipMemcpyDeviceToDevice, P->stream);
-        if (int s2 = sync_check(P, "time_sweep_variants restore")) st = st ? st : s2;
-      }
+      SigmaDev sg{};
+      sg.table = P->sigma_table.p; sg.table_len = c.n; sg.on = 1; sg.ssm2 = 2.0 * sigma_max * sigma_max; sg.one_over_sigma = one_over_sigma;
+      sg.gk = c.gk; sg.weight_zero = one_over_sigma * (std::tgamma((c.nu - 1.0) / 2.0) - c.gk);
+      (void)hipMemcpyAsync(keep_c.p, P->cost.ws.p, 8 * P->cost.n, hipMemcpyDeviceToDevice, P->stream);
+      (void)hipMemcpyAsync(keep_d.p, P->dir.ws.p, 8 * P->dir.n, hipMemcpyDeviceToDevice, P->stream);
+      const SigmaDev keep_sigma = P->sigma;
+      P->sigma = sg;
+      st = timed([&] { P->sigma_pending_cost = true; (void)launch_cost(P, P->q.p, SC_COST); }, &out_ms8[4]);    // K1 with the weights fused in (+ the two scalar reductions)
+      if (!st) st = timed([&] { (void)launch_cost(P, P->q.p, SC_COST); }, &out_ms8[5]);                          // the same sweep without
+      if (!st) st = timed([&] { P->sigma_pending_lin = true; (void)launch_lin(P, P->q.p); }, &out_ms8[6]);       // K2 with the weights fused in
+      if (!st) st = timed([&] { (void)launch_lin(P, P->q.p); }, &out_ms8[7]);                                    // K2 without
+      P->sigma = keep_sigma; P->sigma_pending_cost = P->sigma_pending_lin = false;
+      (void)hipMemcpyAsync(P->cost.ws.p, keep_c.p, 8 * P->cost.n, hipMemcpyDeviceToDevice, P->stream);
+      (void)hipMemcpyAsync(P->dir.ws.p, keep_d.p, 8 * P->dir.n, hipMemcpyDeviceToDevice, P->stream);
+      if (int s2 = sync_check(P, "time_sweep_variants restore")) st = st ? st : s2;
     }
   }
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   return (gsfm_status)st;
 }
 
-gsfm_status gsfm_rot_time_kernels(gsfm_rot_problem* P, const double* rot, int32_t reps, double* out_ms3) {
-  if (!P || !rot || !out_ms3 || reps <= 0) return (gsfm_status)fail(GSFM_ERR_INVALID_ARG, "bad argument");
+gsfm_status gsfm_rot_time_kernels(gsfm_rot_problem* P, const double* rot, int32_t reps, double* out_ms4) {
+  if (!P || !rot || !out_ms4 || reps <= 0) return (gsfm_status)fail(GSFM_ERR_INVALID_ARG, "bad argument");
   if (P->cb) return (gsfm_status)fail(GSFM_ERR_UNSUPPORTED, "time_kernels needs a native loss");
   DeviceGuard g(P->device);
   const gsfm_rot_options o = default_options();
@@ -1847,20 +2019,43 @@ gsfm_status gsfm_rot_time_kernels(gsfm_rot_problem* P, const double* rot, int32_
   if (int st = sync_check(P, "time_kernels setup")) return (gsfm_status)st;
   hipEvent_t e0, e1;
   if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return (gsfm_status)fail(GSFM_ERR_HIP, "event create");
-  for (int which = 0; which < 3; ++which) {
+  for (int which = 0; which < 4; ++which) {
+    out_ms4[which] = 0.0;
+    if (which == 3) continue;   // (reserved)
     for (int k = -2; k < reps; ++k) {  // two warm-up launches
       if (k == 0) (void)hipEventRecord(e0, P->stream);
       if (which == 0) { if (int st = launch_cost(P, P->q.p, SC_COST)) return (gsfm_status)st; }
       else if (which == 1) { if (int st = launch_lin(P, P->q.p)) return (gsfm_status)st; }
-      else { if (int st = launch_matvec(P, P->Mblk.p, P->b.p, P->Ap.p, nullptr)) return (gsfm_status)st; }
+      else if (which == 2) { if (int st = launch_matvec(P, P->Mblk.p, P->b.p, P->Ap.p, nullptr)) return (gsfm_status)st; }
     }
     (void)hipEventRecord(e1, P->stream);
     if (int st = sync_check(P, "time_kernels")) return (gsfm_status)st;
     float ms = 0;
     (void)hipEventElapsedTime(&ms, e0, e1);
-    out_ms3[which] = ms / reps;
+    out_ms4[which] = ms / reps;
   }
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  return GSFM_OK;
+}
+
+gsfm_status gsfm_rot_matvec_bytes(gsfm_rot_problem* P, double* layout_bytes, double* lin_bytes, int32_t* form) {
+  if (!P) return (gsfm_status)fail(GSFM_ERR_INVALID_ARG, "NULL problem");
+  const double N = (double)P->n_rows;
+  const bool lap = P->lap_capable;
+  if (lap && P->cs.active) {
+    // mat-vec, per position: column 4 + body-frame block 48 + slot permutation 2; per sub-chunk the row offsets; partial sums written and
+    // read once; the gathered vector, the diagonal blocks, p, q in, y out once per camera.  Linearisation, per position: column 4 + local
+    // row 2 + slot 2 + q_rel 32 + whitening 48 in, block 48 out; nine partial sums per row and workgroup
+    const double n_sub = (double)(P->cs.n_pos / GSFM_COL_SUB);
+    if (layout_bytes) *layout_bytes = 54.0 * (double)P->cs.n_pos + 2.0 * (GSFM_COL_RB + 1) * n_sub + 2.0 * 24.0 * P->cs.n_wg * GSFM_COL_RB + (24.0 + 48.0 + 24.0 + 32.0 + 24.0) * N;
+    if (lin_bytes) *lin_bytes = (88.0 + 48.0) * (double)P->cs.n_pos + 2.0 * (GSFM_COL_RB + 1) * n_sub + 2.0 * 72.0 * P->cs.n_wg * GSFM_COL_RB + (32.0 + 72.0) * N;
+    if (form) *form = 2;
+  } else {
+    if (layout_bytes) *layout_bytes = (double)P->dir.n * (lap ? 52.0 : 76.0) + 2.0 * 24.0 * N;
+    const double w = P->wmode == W_MATRIX ? 48.0 : P->wmode == W_SCALAR ? 8.0 : 0.0;
+    if (lin_bytes) *lin_bytes = (double)P->dir.n * (4.0 + 32.0 + w + (lap ? 48.0 : 72.0)) + (32.0 + 72.0) * N;
+    if (form) *form = lap ? 1 : 0;
+  }
   return GSFM_OK;
 }
 

@@ -343,37 +343,25 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_whiten(WhitenArgs a) {
   }
 }
 
-// sigma-consensus weights (src/GSfM_nonlinear_rotation_estimator.cpp:400-416) from the unweighted s = |e|^2 of every original edge,
-// in place of a device -> host -> device round trip of 3 x 8 B per edge per outer iteration; block partials of |w - w_old|
-struct SigmaArgs {
-  const double* s;        // per original edge
-  double* w;              // in: previous weights, out: new weights
-  const uint8_t* counted; // sharded: 1 where this rank counts the edge in sum |w - w_old| (its cost-owned edges); null = all
-  size_t n;
+// sigma-consensus weights (src/GSfM_nonlinear_rotation_estimator.cpp:400-416).  The weight of an edge depends only on its UNWEIGHTED
+// residual at the rotations an outer iteration starts from -- exactly the point the inner solve's first cost sweep (K1) and first
+// linearisation (K2) evaluate anyway.  So there is no weight pass: in `sigma` mode K1 and K2 compute the weight from the unit-weight
+// residual they have in registers, store it into their own scalar-weight plane in their own order (8 B per edge / directed entry,
+// coalesced) and use it at once; K1 also sums |w - w_old| against the plane's previous content.  Later sweeps of the solve read the
+// planes as usual.  (Round 2: an s-only sweep, a weight kernel over the original edge order and two scattered gathers, 478 us at C5.)
+struct SigmaDev {
   const double* table;    // Gamma(1, x / 1000), nu = 3
   int table_len;
+  int on;                 // 1: this launch computes and stores the weights
   double ssm2, one_over_sigma, gk, weight_zero;
-  double* partials;       // [gridDim.x]
 };
-__global__ void __launch_bounds__(GSFM_BLOCK) k_sigma_weights(SigmaArgs a) {
-  __shared__ double lds[8];
-  const size_t e = (size_t)blockIdx.x * GSFM_BLOCK + threadIdx.x;
-  double change = 0.0;
-  if (e < a.n) {
-    const double residual = sqrt(a.s[e]);
-    double weight;
-    if (residual < 2.220446049250313e-16) weight = a.weight_zero;
-    else {
-      const double squared_residual = residual * residual;                 // as written in the reference, not s itself
-      double xf = round(1000.0 * squared_residual / a.ssm2);               // std::round: halves away from zero
-      if (!(xf < (double)(a.table_len - 1))) xf = (double)(a.table_len - 1);  // last stored entry (the reference reads one past it)
-      weight = a.one_over_sigma * (a.table[(int)xf] - a.gk);
-    }
-    change = (!a.counted || a.counted[e]) ? fabs(weight - a.w[e]) : 0.0;
-    a.w[e] = weight;
-  }
-  const double t = block_sum_bcast(change, lds);
-  if (threadIdx.x == 0) a.partials[blockIdx.x] = t;
+__device__ __forceinline__ double sigma_weight(const SigmaDev& g, double s_unit) {
+  const double residual = sqrt(s_unit);
+  if (residual < 2.220446049250313e-16) return g.weight_zero;
+  const double squared_residual = residual * residual;                 // as written in the reference, not s itself
+  double xf = round(1000.0 * squared_residual / g.ssm2);               // std::round: halves away from zero
+  if (!(xf < (double)(g.table_len - 1))) xf = (double)(g.table_len - 1);  // last stored entry (the reference reads one past it)
+  return g.one_over_sigma * (g.table[(int)xf] - g.gk);
 }
 
 // The step after the solve and the evaluation statistic as one edge sweep with K1's device routines, without a problem object:
@@ -481,44 +469,59 @@ struct CostArgs {
   const double2* q;          // camera quaternions
   const DevLoss* loss;
   const double* rho_ext;     // external rho triples per ORIGINAL edge (callback path) or null
-  const uint32_t* eid;       // entry -> original edge (for outputs / rho_ext)
-  double* partials;          // [gridDim.x] sum of 1/2 rho
-  // optional per-edge outputs in ORIGINAL edge order (null in the solver loop)
-  double* s_out;
-  double* rho_out;
-  double* r_out;
+  const uint32_t* eid;       // entry -> original edge (rho_ext only)
+  double* partials;          // [gridDim.x] sum of 1/2 rho; FULL kernels: [2 * gridDim.x], second half = sum |w - w_old| (sigma mode)
+  // optional per-edge outputs (null in the solver loop), in the PROBLEM's edge order (= the order of the streamed planes; position u holds
+  // original edge gsfm_rot_edge_order()[u]): every store is a coalesced non-temporal 8 / 16 B per lane.  (Round 2 stored through `eid`
+  // into the caller's order: 438 MB written for 320 MB of payload, 0.43 of the HBM roofline.)
+  double* s_out;             // s
+  double2* rho01_out;        // (rho, rho')
+  double* rho2_out;          // rho''
+  double* rho1_out;          // rho' alone: the reweight sweep of SURVEY 8(d) (8 B out per edge)
+  double* r_out;             // residuals, R planes of n
   int s_only;                // 1: write s_out only, skip the loss (callback path, phase 1)
   int direct;                // 1: k_cost_direct (idx = global camera indices, tiles = plain chunks)
-  int unit_w;                // 1: ignore the scalar weight plane (sigma consensus evaluates the UNWEIGHTED residual norm)
+  int unit_w;                // 1: ignore the scalar weight plane
+  SigmaDev sigma;            // sigma consensus: compute, store (ws_rw) and use the weights
+  double* ws_rw;             // = ws, writable
 };
 
 // K1.  FULL = false: the solver's trial-cost sweep (cost only: for MAGSAC the value needs no exp and no division
-// by constants).  FULL = true: per-edge outputs / external rho / s-only modes of the C-ABI (gsfm_rot_residuals,
-// host-callback losses, sigma consensus).  One edge per lane; the seven streamed planes are 16-byte coalesced,
-// non-temporal loads; both camera quaternions come from LDS.  Measured (tools/bench_cost*.hip, C5): streams only
+// by constants).  FULL = true: per-edge outputs / external rho / s-only / sigma modes.  One edge per lane; the seven streamed planes
+// are 16-byte coalesced, non-temporal loads; both camera quaternions come from LDS.  Measured (tools/bench_cost*.hip, C5): streams only
 // 137 us; + all arithmetic 138-152 us (hidden); direct global gathers 181 us; these 2-D LDS tiles 160 us.
 // One edge of K1: residual, s, loss, optional per-edge outputs; returns the edge's 1/2 rho (0 in s_only mode).
 template <int F, int WM, int LM, bool FULL>
-__device__ __forceinline__ double cost_edge(const CostArgs& a, uint32_t e, const Quat& qi, const Quat& qj, const Quat& qr, const EdgeW& W) {
+__device__ __forceinline__ double cost_edge(const CostArgs& a, uint32_t e, const Quat& qi, const Quat& qj, const Quat& qr, EdgeW W, double& dw_acc) {
   constexpr int R = ResDim<F>::R;
   double r[R];
-  edge_residual<F, WM>(qi, qj, qr, W, r);
+  if (FULL && F == F_AA && WM == W_SCALAR && a.sigma.on) {
+    const double w_old = W.l00;
+    W.l00 = 1.0;
+    edge_residual<F, WM>(qi, qj, qr, W, r);
+    const double w = sigma_weight(a.sigma, r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+    dw_acc += fabs(w - w_old);
+    __builtin_nontemporal_store(w, a.ws_rw + e);
+#pragma unroll
+    for (int k = 0; k < R; ++k) r[k] *= w;
+  } else {
+    edge_residual<F, WM>(qi, qj, qr, W, r);
+  }
   double s = 0.0;
 #pragma unroll
   for (int k = 0; k < R; ++k) s += r[k] * r[k];
   if (!FULL) return 0.5 * loss_value<LM>(a.loss, s);
-  if (a.s_only) { a.s_out[a.eid[e]] = s; return 0.0; }
+  if (a.s_only) { __builtin_nontemporal_store(s, a.s_out + e); return 0.0; }
   Rho3 rho;
   if (a.rho_ext) { const size_t o = 3 * (size_t)a.eid[e]; rho.r0 = a.rho_ext[o]; rho.r1 = a.rho_ext[o + 1]; rho.r2 = a.rho_ext[o + 2]; }
   else rho = loss_eval<LM>(a.loss, s);
-  if (a.s_out) {
-    const size_t o = a.eid[e];
-    a.s_out[o] = s;
-    if (a.rho_out) { a.rho_out[3 * o] = rho.r0; a.rho_out[3 * o + 1] = rho.r1; a.rho_out[3 * o + 2] = rho.r2; }
-    if (a.r_out) {
+  if (a.s_out) __builtin_nontemporal_store(s, a.s_out + e);
+  if (a.rho01_out) nt_store2(a.rho01_out + e, rho.r0, rho.r1);
+  if (a.rho2_out) __builtin_nontemporal_store(rho.r2, a.rho2_out + e);
+  if (a.rho1_out) __builtin_nontemporal_store(rho.r1, a.rho1_out + e);
+  if (a.r_out) {
 #pragma unroll
-      for (int k = 0; k < R; ++k) a.r_out[R * o + k] = r[k];
-    }
+    for (int k = 0; k < R; ++k) __builtin_nontemporal_store(r[k], a.r_out + (size_t)k * a.n + e);
   }
   return 0.5 * rho.r0;
 }
@@ -535,7 +538,7 @@ __global__ void __launch_bounds__(GSFM_TILE_THREADS) k_cost(CostArgs a) {
     for (uint32_t c = threadIdx.x; c < cj; c += GSFM_TILE_THREADS) { qj_xy[c] = a.q[2 * (size_t)(bj + c)]; qj_zw[c] = a.q[2 * (size_t)(bj + c) + 1]; }
   }
   __syncthreads();
-  double acc = 0.0;
+  double acc = 0.0, dw = 0.0;
   constexpr int U = GSFM_K1_UNROLL;
   for (uint32_t e0 = tile.begin + threadIdx.x; e0 < tile.end; e0 += U * GSFM_TILE_THREADS) {
     // request phase: the streams of U edges are in flight before the first residual is evaluated
@@ -558,7 +561,7 @@ __global__ void __launch_bounds__(GSFM_TILE_THREADS) k_cost(CostArgs a) {
       const Quat qr{r0[u].x, r0[u].y, r1[u].x, r1[u].y};
       const double2 i0 = qi_xy[ij[u].x], i1 = qi_zw[ij[u].x], j0 = qj_xy[ij[u].y], j1 = qj_zw[ij[u].y];
       const Quat qi{i0.x, i0.y, i1.x, i1.y}, qj{j0.x, j0.y, j1.x, j1.y};
-      acc += cost_edge<F, WM, LM, FULL>(a, e, qi, qj, qr, Wm[u]);
+      acc += cost_edge<F, WM, LM, FULL>(a, e, qi, qj, qr, Wm[u], dw);
     }
   }
   // deterministic block reduction (fixed tree per wave, fixed order over the 16 waves)
@@ -570,6 +573,17 @@ __global__ void __launch_bounds__(GSFM_TILE_THREADS) k_cost(CostArgs a) {
     for (int k = 0; k < GSFM_TILE_THREADS / 64; ++k) t += lds[k];
     a.partials[blockIdx.x] = t;
   }
+  if (FULL) {   // sum |w - w_old| of the sigma mode (zero otherwise)
+    dw = wave_sum(dw);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = dw;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double t = 0.0;
+      for (int k = 0; k < GSFM_TILE_THREADS / 64; ++k) t += lds[k];
+      a.partials[gridDim.x + blockIdx.x] = t;
+    }
+  }
 }
 
 // K1 without LDS staging, for sweeps whose (first block, second block) tiles are too thinly populated to amortise the
@@ -580,14 +594,14 @@ template <int F, int WM, int LM, bool FULL>
 __global__ void __launch_bounds__(GSFM_BLOCK) k_cost_direct(CostArgs a) {
   __shared__ double lds[GSFM_BLOCK / 64 + 1];
   const CostTile tile = a.tiles[blockIdx.x];
-  double acc = 0.0;
+  double acc = 0.0, dw = 0.0;
   for (uint32_t e = tile.begin + threadIdx.x; e < tile.end; e += GSFM_BLOCK) {
     const uint2 ij = a.idx[e];
     const double2 r0 = nt_load2(a.qr0 + e), r1 = nt_load2(a.qr1 + e);
     EdgeW W = load_w<WM>(a.w0, a.w1, a.w2, a.ws, e);
     if (WM == W_SCALAR && a.unit_w) W.l00 = 1.0;
     const Quat qi = load_q(a.q, ij.x), qj = load_q(a.q, ij.y);
-    acc += cost_edge<F, WM, LM, FULL>(a, e, qi, qj, Quat{r0.x, r0.y, r1.x, r1.y}, W);
+    acc += cost_edge<F, WM, LM, FULL>(a, e, qi, qj, Quat{r0.x, r0.y, r1.x, r1.y}, W, dw);
   }
   acc = wave_sum(acc);
   if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = acc;
@@ -597,18 +611,31 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_cost_direct(CostArgs a) {
     for (int k = 0; k < GSFM_BLOCK / 64; ++k) t += lds[k];
     a.partials[blockIdx.x] = t;
   }
+  if (FULL) {
+    dw = wave_sum(dw);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = dw;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double t = 0.0;
+      for (int k = 0; k < GSFM_BLOCK / 64; ++k) t += lds[k];
+      a.partials[gridDim.x + blockIdx.x] = t;
+    }
+  }
 }
 
 // The loss program on given squared norms, through the very routines the sweeps use (device-level pin against the reference's
-// recorded (s, rho, rho', rho'') vectors): rho3 = loss_eval<LM> (K2 and the FULL sweep), val = loss_value<LM> (the cost-only sweep).
+// recorded (s, rho, rho', rho'') vectors): rho3 = loss_eval<LM> (K2's general path and the FULL sweep), val = loss_value<LM> (the
+// cost-only sweep), rho1 = loss_rho1<LM> (K2's fast path; LM_SIMPLE / LM_MAGSAC only).
 template <int LM>
 __global__ void __launch_bounds__(GSFM_BLOCK) k_loss_eval(const DevLoss* __restrict__ loss, const double* __restrict__ s, size_t n,
-                                                          double* __restrict__ rho3, double* __restrict__ val) {
+                                                          double* __restrict__ rho3, double* __restrict__ val, double* __restrict__ rho1) {
   const size_t t = (size_t)blockIdx.x * GSFM_BLOCK + threadIdx.x;
   if (t >= n) return;
   const double sq = s[t];
   if (rho3) { const Rho3 r = loss_eval<LM>(loss, sq); rho3[3 * t] = r.r0; rho3[3 * t + 1] = r.r1; rho3[3 * t + 2] = r.r2; }
   if (val) val[t] = loss_value<LM>(loss, sq);
+  if (LM != LM_PROGRAM && rho1) rho1[t] = loss_rho1<LM>(loss, sq);
 }
 
 // out[0] = sum partials (single block, fixed order)
@@ -638,6 +665,8 @@ struct LinArgs {
   double* h4;                  // H22
   double* gD;                  // 9 per camera: g(3), D sym(6: d00 d01 d02 d11 d12 d22)
   int lap;                     // 1: Laplacian form, planes h0..h2 hold the symmetric edge weight B (see lin_rows)
+  SigmaDev sigma;              // sigma consensus: compute the weight of every directed entry from its unit-weight residual, store it
+  double* ws_rw;               //   into the weight plane (= ws, writable) and use it
 };
 
 // LAP = true ("Laplacian form", functors that depend on R_j R_i^T only: angle-axis and quaternion-cosine): for those
@@ -666,11 +695,24 @@ __device__ __forceinline__ void lin_rows(const LinArgs& a) {
       const bool row_is_second = (cr >> 31) != 0;
       const double2 r0 = nt_load2(a.qr0 + d), r1 = nt_load2(a.qr1 + d);
       const Quat qr{r0.x, r0.y, r1.x, r1.y};
-      const EdgeW W = load_w<WM>(a.w0, a.w1, a.w2, a.ws, d);
+      EdgeW W = load_w<WM>(a.w0, a.w1, a.w2, a.ws, d);
+      const bool sig = F == F_AA && WM == W_SCALAR && a.sigma.on;
+      if (sig) W.l00 = 1.0;
       const Quat qm = load_q(a.q, m);
       double r[R], Ai[3 * R], Aj[3 * R];
       if (row_is_second) edge_linearize<F, WM>(qm, qk, qr, W, r, Ai, Aj);
       else edge_linearize<F, WM>(qk, qm, qr, W, r, Ai, Aj);
+      if (sig) {   // r, Ai, Aj are unweighted here: the weight comes from |e|^2 and multiplies all three
+        double su = 0.0;
+#pragma unroll
+        for (int c = 0; c < R; ++c) su += r[c] * r[c];
+        const double w = sigma_weight(a.sigma, su);
+        __builtin_nontemporal_store(w, a.ws_rw + d);
+#pragma unroll
+        for (int c = 0; c < R; ++c) r[c] *= w;
+#pragma unroll
+        for (int c = 0; c < 3 * R; ++c) { Ai[c] *= w; Aj[c] *= w; }
+      }
       double s = 0.0;
 #pragma unroll
       for (int c = 0; c < R; ++c) s += r[c] * r[c];
@@ -732,6 +774,163 @@ __device__ __forceinline__ void lin_rows(const LinArgs& a) {
     for (int c = 0; c < 9; ++c) o[c] = acc[c];
   }
 }
+// K2, fast path: Laplacian form + a loss whose rho'' is never positive (every LM_SIMPLE leaf, nu = 3 MAGSAC) + no host callback.
+// Ceres' Corrector then takes its alpha = 0 branch for EVERY edge (corrector.cc: `if ((sq_norm == 0.0) || (rho[2] <= 0.0))`): residual and
+// Jacobians are scaled by sqrt(rho') and nothing else.  So this path evaluates, per directed entry, only what the row needs:
+//   * the row camera's Jacobian alone (the neighbour's is never formed; the general path computes both and discards one),
+//   * rho' alone (loss_rho1: for MAGSAC one exp and one exact division instead of two exp, a table gather and nine divisions),
+//   * g and G = J^T J from the unscaled Jacobian, multiplied by rho' at the end (no sqrt).
+// About a third fewer VALU instructions per entry than the general path (round 2: 891, 22 of them IEEE divisions); C5: 914 -> 710 us.
+// Same values as lin_rows up to the rounding of sqrt(rho')^2 vs rho'.
+struct LinStreams { double2 r0, r1; EdgeW W; };
+template <int WM>
+__device__ __forceinline__ LinStreams lin_load_streams(const LinArgs& a, uint32_t d) {
+  LinStreams S;
+  S.r0 = nt_load2(a.qr0 + d); S.r1 = nt_load2(a.qr1 + d);
+  S.W = load_w<WM>(a.w0, a.w1, a.w2, a.ws, d);
+  return S;
+}
+// one directed entry: residual r, row-camera Jacobian Ar (3x3 row-major); returns nothing else
+template <int F, int WM>
+__device__ __forceinline__ void edge_lin_row(const Quat& qk, const Quat& qm, const Quat& qr, EdgeW& W, bool row_is_second,
+                                             const SigmaDev& sg, double* ws_slot, double* r, double* Ar) {
+  const Quat qi = row_is_second ? qm : qk, qj = row_is_second ? qk : qm;
+  if (F == F_AA) {
+    const Quat qe = qmul(qmul(qj, qconj(qi)), qconj(qr));
+    double e[3], s, th;
+    quat_log(qe, e, &s, &th);
+    if (WM == W_SCALAR && sg.on) {   // sigma consensus: e is the unit-weight residual
+      W.l00 = sigma_weight(sg, e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
+      __builtin_nontemporal_store(W.l00, ws_slot);
+    }
+    apply_w_vec<WM>(W, e, r);
+    const double c = jlinv_coeff(th, s, fabs(qe.w));
+    double B[9], Mx[9];
+    jlinv_matrix(e, c, B);                 // de/d eta_j = J_l^-1(e)
+    if (row_is_second) {
+#pragma unroll
+      for (int k = 0; k < 9; ++k) Mx[k] = B[k];
+    } else {                               // de/d eta_i = -J_l^-1(e)^T R_ij
+      double Rij[9], T[9];
+      qmat(qr, Rij);
+      mat3_tmul(B, Rij, T);
+#pragma unroll
+      for (int k = 0; k < 9; ++k) Mx[k] = -T[k];
+    }
+    apply_w_mat<WM>(W, Mx, Ar);
+  } else {  // F_QCOS
+    const Quat a = qmul(qr, qconj(qmul(qj, qconj(qi))));
+    r[0] = 2.0 * a.x; r[1] = 2.0 * a.y; r[2] = 2.0 * a.z;
+    if (row_is_second) {
+      Ar[0] = -a.w; Ar[1] = a.z;  Ar[2] = -a.y;
+      Ar[3] = -a.z; Ar[4] = -a.w; Ar[5] = a.x;
+      Ar[6] = a.y;  Ar[7] = -a.x; Ar[8] = -a.w;
+    } else {
+      const double K[9] = {a.w, a.z, -a.y, -a.z, a.w, a.x, a.y, -a.x, a.w};
+      double Rij[9];
+      qmat(qr, Rij);
+      mat3_mul(K, Rij, Ar);
+    }
+  }
+}
+// g (3) and G = J_k^T J_k (6: 00 01 02 11 12 22) of one directed entry, Corrector applied.  FAST: the rho'' <= 0 path above; otherwise the
+// general one (both Jacobians, full Corrector, host-callback rho) restricted to the row camera's block -- the Laplacian form needs no more.
+template <int F, int WM, int LM, bool FAST>
+__device__ __forceinline__ void lin_entry_eval(const LinArgs& a, uint32_t d, uint32_t cr, const Quat& qk, const Quat& qm, LinStreams S, double* g3, double* G6) {
+  const Quat qr{S.r0.x, S.r0.y, S.r1.x, S.r1.y};
+  const bool row_is_second = (cr >> 31) != 0;
+  if (FAST) {
+    double r[3], Ar[9];
+    edge_lin_row<F, WM>(qk, qm, qr, S.W, row_is_second, a.sigma, a.ws_rw + d, r, Ar);
+    const double rho1 = loss_rho1<LM>(a.loss, r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+#pragma unroll
+    for (int x = 0; x < 3; ++x) g3[x] = rho1 * (Ar[x] * r[0] + Ar[3 + x] * r[1] + Ar[6 + x] * r[2]);
+    G6[0] = rho1 * (Ar[0] * Ar[0] + Ar[3] * Ar[3] + Ar[6] * Ar[6]); G6[1] = rho1 * (Ar[0] * Ar[1] + Ar[3] * Ar[4] + Ar[6] * Ar[7]);
+    G6[2] = rho1 * (Ar[0] * Ar[2] + Ar[3] * Ar[5] + Ar[6] * Ar[8]); G6[3] = rho1 * (Ar[1] * Ar[1] + Ar[4] * Ar[4] + Ar[7] * Ar[7]);
+    G6[4] = rho1 * (Ar[1] * Ar[2] + Ar[4] * Ar[5] + Ar[7] * Ar[8]); G6[5] = rho1 * (Ar[2] * Ar[2] + Ar[5] * Ar[5] + Ar[8] * Ar[8]);
+  } else {
+    constexpr int R = ResDim<F>::R;
+    EdgeW W = S.W;
+    const bool sig = F == F_AA && WM == W_SCALAR && a.sigma.on;
+    if (sig) W.l00 = 1.0;
+    double r[R], Ai[3 * R], Aj[3 * R];
+    if (row_is_second) edge_linearize<F, WM>(qm, qk, qr, W, r, Ai, Aj);
+    else edge_linearize<F, WM>(qk, qm, qr, W, r, Ai, Aj);
+    if (sig) {
+      double su = 0.0;
+#pragma unroll
+      for (int c = 0; c < R; ++c) su += r[c] * r[c];
+      const double w = sigma_weight(a.sigma, su);
+      __builtin_nontemporal_store(w, a.ws_rw + d);
+#pragma unroll
+      for (int c = 0; c < R; ++c) r[c] *= w;
+#pragma unroll
+      for (int c = 0; c < 3 * R; ++c) { Ai[c] *= w; Aj[c] *= w; }
+    }
+    double s = 0.0;
+#pragma unroll
+    for (int c = 0; c < R; ++c) s += r[c] * r[c];
+    Rho3 rho;
+    if (a.rho_ext) { const size_t o = 3 * (size_t)a.eid[d]; rho.r0 = a.rho_ext[o]; rho.r1 = a.rho_ext[o + 1]; rho.r2 = a.rho_ext[o + 2]; }
+    else rho = loss_eval<LM>(a.loss, s);
+    robustify<R>(rho, s, r, Ai, Aj);
+    const double* Ar = row_is_second ? Aj : Ai;
+#pragma unroll
+    for (int x = 0; x < 3; ++x) {
+      double g = 0.0;
+#pragma unroll
+      for (int c = 0; c < R; ++c) g += Ar[3 * c + x] * r[c];
+      g3[x] = g;
+    }
+    double d00 = 0, d01 = 0, d02 = 0, d11 = 0, d12 = 0, d22 = 0;
+#pragma unroll
+    for (int c = 0; c < R; ++c) {
+      const double x0 = Ar[3 * c], x1 = Ar[3 * c + 1], x2 = Ar[3 * c + 2];
+      d00 += x0 * x0; d01 += x0 * x1; d02 += x0 * x2; d11 += x1 * x1; d12 += x1 * x2; d22 += x2 * x2;
+    }
+    G6[0] = d00; G6[1] = d01; G6[2] = d02; G6[3] = d11; G6[4] = d12; G6[5] = d22;
+  }
+}
+template <int F, int WM, int LM>
+__device__ __forceinline__ void lin_rows_fast(const LinArgs& a) {
+  const uint32_t G = a.G;
+  const uint32_t t = blockIdx.x * GSFM_BLOCK + threadIdx.x;
+  const uint32_t row = t / G, lane = t % G;
+  const bool live = row < a.n_rows;
+  double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  if (live) {
+    const Quat qk = load_q(a.q, a.row_base + row);
+    const uint32_t end = a.row_ptr[row + 1];
+    // (a software-pipelined form of this loop -- next trip's streams and gather in flight during the evaluation -- was measured and dropped:
+    // 705-719 us against 710 at C5; at three waves per SIMD it spills and takes 1430)
+    for (uint32_t d = a.row_ptr[row] + lane; d < end; d += G) {
+      const uint32_t cr = __builtin_nontemporal_load(a.col + d);
+      const LinStreams S = lin_load_streams<WM>(a, d);
+      const Quat qm = load_q(a.q, cr & 0x7fffffffu);
+      double g3[3], G6[6];
+      lin_entry_eval<F, WM, LM, true>(a, d, cr, qk, qm, S, g3, G6);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) acc[c] += g3[c];
+#pragma unroll
+      for (int c = 0; c < 6; ++c) acc[3 + c] += G6[c];
+      nt_store2(a.h0 + d, G6[0], G6[1]);
+      nt_store2(a.h1 + d, G6[2], G6[3]);
+      nt_store2(a.h2 + d, G6[4], G6[5]);
+    }
+  }
+  for (uint32_t off = G >> 1; off > 0; off >>= 1) {
+#pragma unroll
+    for (int c = 0; c < 9; ++c) acc[c] += __shfl_down(acc[c], off, G);
+  }
+  if (live && lane == 0) {
+    double* o = a.gD + 9 * (size_t)(a.row_base + row);
+#pragma unroll
+    for (int c = 0; c < 9; ++c) o[c] = acc[c];
+  }
+}
+template <int F, int WM, int LM>
+__global__ void __launch_bounds__(GSFM_BLOCK) GSFM_K2_ATTR k_lin_fast(LinArgs a) { lin_rows_fast<F, WM, LM>(a); }
+
 // Two entry points over the same body: `k_lin3` asks for at least three waves per SIMD, which is free (no spill) for the
 // instantiations that matter and would spill for the general loss program and the 9-residual functor; the launcher picks.
 template <int F, int WM, int LM, bool LAP>

@@ -16,6 +16,7 @@ struct DevLossNode {
   // MAGSAC aux: 0 squared_sigma, 1 squared_sigma_max_2, 2 cubed_sigma_max, 3 C_times_two_ad_dof,
   //             4 one_over_sigma, 5 weight_zero, 6 cut (= q^2 sigma^2), 7 upper_incomplete_gamma_of_k
   double aux[8];
+  double rho1_scale;    // MAGSAC: C 2^((nu-1)/2) / (2 sigma^3), the constant factor of rho' = -weight'(s) (host-precomputed reciprocal)
   const double* table;  // device pointer, Gamma((nu-1)/2, x/1000)
   int32_t table_len;
   int32_t inverse;
@@ -170,7 +171,21 @@ __device__ __forceinline__ double loss_magsac_value(const DevLossNode& n, double
   return n.inverse ? 1.0 / weight : n.aux[5] - weight;
 }
 
-enum { LM_PROGRAM = 0, LM_SIMPLE = 1, LM_MAGSAC = 2 };  // kernel specialisations
+// Kernel specialisations.  LM_MAGSAC = ONE MAGSACWeightBasedLoss leaf with nu = 3, not inverted (the pipeline's default,
+// scripts/sfm_pipeline.py:136); the nu = 4 / 9 and inverse variants run through the general program.
+enum { LM_PROGRAM = 0, LM_SIMPLE = 1, LM_MAGSAC = 2 };
+
+// rho' alone, for the linearisation (K2) of losses whose rho'' is never positive -- every LM_SIMPLE leaf and the nu = 3 MAGSAC
+// weight loss (rho'' = -C / (8 sigma^5) exp(-u) < 0) -- so that Ceres' Corrector takes its alpha = 0 branch for every edge and
+// needs nothing but sqrt(rho').  nu = 3: weight'(s) = -C 2 exp(-s / 2 sigma^2) / (2 sigma^3) on the quantised s (loss_functions.py:
+// 304-321): the table cell x comes from the same exact division as in loss_magsac, exp(-x / 1000) IS the table value
+// Gamma(1, x / 1000), and the constant factor is one host-precomputed product instead of a division per edge.
+__device__ __forceinline__ double loss_magsac3_rho1(const DevLossNode& n, double sq) {
+  if (sq > n.aux[6]) return 0.00001;
+  const long x = (long)rint(1000.0 * sq / n.aux[1]);
+  const double r1 = n.rho1_scale * exp(-1e-3 * (double)x);
+  return r1 == 0.0 ? 0.00001 : r1;
+}
 
 // Evaluate the program. `loss` is a wave-uniform global pointer (scalar loads).
 __device__ __forceinline__ Rho3 loss_eval_program(const DevLoss* __restrict__ loss, double s) {
@@ -212,6 +227,13 @@ template <int LM>
 __device__ __forceinline__ double loss_value(const DevLoss* __restrict__ loss, double s) {
   if (LM == LM_MAGSAC) return loss_magsac_value(loss->nodes[0], s);
   return loss_eval<LM>(loss, s).r0;  // the unused derivatives are dead code for the simple leaves
+}
+
+// K2's fast path (see lin_rows_fast): only for LM_SIMPLE / LM_MAGSAC
+template <int LM>
+__device__ __forceinline__ double loss_rho1(const DevLoss* __restrict__ loss, double s) {
+  if (LM == LM_MAGSAC) return loss_magsac3_rho1(loss->nodes[0], s);
+  return loss_leaf_simple(loss->nodes[0], s).r1;
 }
 
 // Ceres Corrector (corrector.cc 1.14): residual scaling and the alpha term.

@@ -212,25 +212,48 @@ class RotationProblem(ProblemBase):
         return ms.value
 
     def time_kernels(self, rot_aa, reps=10):
-        """Mean HIP-event time (ms) of k_cost, k_lin, k_matvec."""
+        """Mean HIP-event time (ms) of k_cost, the linearisation and one mat-vec (row-major or column-sorted forms, incl. their finish kernels)."""
         rot = np.ascontiguousarray(rot_aa, dtype=np.float64).reshape(self.n_cams, 3)
-        out = np.zeros(3)
+        out = np.zeros(4)
         self._check(self._lib.gsfm_rot_time_kernels(self._h, _dp(rot), int(reps), _dp(out)), "time_kernels")
         return {"k_cost": out[0], "k_lin": out[1], "k_matvec": out[2]}
 
-    def loss_eval(self, s):
-        """(rho, rho', rho'')(s) and the cost-only rho(s) of the current native loss, evaluated by the device routines."""
+    def matvec_bytes(self):
+        """(bytes one mat-vec streams as laid out, form: 0 general blocks, 1 Laplacian row-major, 2 Laplacian column-sorted)."""
+        b, l, f = C.c_double(0), C.c_double(0), C.c_int32(0)
+        self._check(self._lib.gsfm_rot_matvec_bytes(self._h, C.byref(b), C.byref(l), C.byref(f)), "matvec_bytes")
+        return b.value, int(f.value)
+
+    def linearize_bytes(self):
+        b, l, f = C.c_double(0), C.c_double(0), C.c_int32(0)
+        self._check(self._lib.gsfm_rot_matvec_bytes(self._h, C.byref(b), C.byref(l), C.byref(f)), "matvec_bytes")
+        return l.value
+
+    def loss_eval(self, s, with_fast_rho1=False):
+        """(rho, rho', rho'')(s) and the cost-only rho(s) of the current native loss, evaluated by the device routines; with_fast_rho1 adds
+        rho'(s) as the fast path of the linearisation K2 computes it (NaN for loss programs that have no fast path)."""
         s = np.ascontiguousarray(s, dtype=np.float64).ravel()
         rho3, val = np.empty((s.size, 3)), np.empty(s.size)
-        self._check(self._lib.gsfm_rot_loss_eval(self._h, _dp(s), s.size, _dp(rho3), _dp(val)), "loss_eval")
-        return rho3, val
+        fast = np.empty(s.size) if with_fast_rho1 else None
+        self._check(self._lib.gsfm_rot_loss_eval(self._h, _dp(s), s.size, _dp(rho3), _dp(val), _dp(fast)), "loss_eval")
+        return (rho3, val, fast) if with_fast_rho1 else (rho3, val)
+
+    def edge_order(self):
+        """order[u] = index (in the arrays given at creation) of the edge at position u of the device-side per-edge planes."""
+        n = self._lib.gsfm_rot_edge_order(self._h, None, 0)
+        out = np.empty(max(n, 0), dtype=np.uint32)
+        if n > 0:
+            self._lib.gsfm_rot_edge_order(self._h, out.ctypes.data_as(C.POINTER(C.c_uint32)), n)
+        return out
 
     def time_sweep_variants(self, rot_aa, reps=10):
-        """Mean HIP-event time (ms) of the K1 variants: trial-cost, full reweight sweep with per-edge stores, s-only, sigma-consensus weight pass."""
+        """Mean HIP-event time (ms) of the K1 variants (trial cost; s + rho triple stored; s only; rho' only) and of the sigma-consensus
+        forms of K1 / K2 against their plain forms (zeros unless the problem is an ANGLE_AXIS one carrying scalar weights)."""
         rot = np.ascontiguousarray(rot_aa, dtype=np.float64).reshape(self.n_cams, 3)
-        out = np.zeros(4)
+        out = np.zeros(8)
         self._check(self._lib.gsfm_rot_time_sweep_variants(self._h, _dp(rot), int(reps), _dp(out)), "time_sweep_variants")
-        return {"trial_cost": out[0], "full_reweight": out[1], "s_only": out[2], "sigma_weight_pass": out[3]}
+        return {"trial_cost": out[0], "full_reweight": out[1], "s_only": out[2], "rho1_only": out[3],
+                "k1_sigma_fused": out[4], "k1_sigma_plain": out[5], "k2_sigma_fused": out[6], "k2_sigma_plain": out[7]}
 
     def sweep_bytes(self):
         a, b = C.c_double(0), C.c_double(0)

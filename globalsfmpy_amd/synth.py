@@ -157,6 +157,40 @@ def make_graph(n_cams, n_edges, seed, outlier_frac=0.0, scale=0.2, full_so3=Fals
             "init_aa": np.ascontiguousarray(quat_to_aa(init_q)), "is_outlier": is_out}
 
 
+def spanning_tree_init(g, seed=0, inlier_matches=(150, 1500), outlier_matches=(16, 150)):
+    """The initialisation the reference pipeline feeds the solver (OrientationsFromMaximumSpanningTree, Theia
+    orientations_from_maximum_spanning_tree.cc:62-181): a maximum spanning tree of the view graph weighted by the number of verified
+    matches, rotations composed from the root along the tree (R_j = R_ij R_i going up in id, R_i = R_ij^T R_j going down).  Match
+    counts are drawn so that inlier edges dominate the tree, as they do in real view graphs (an outlier pair has few verified matches).
+    Returns (init_aa, num_matches).  SURVEY 8(d): "Init = chain composition or BFS-tree composition"."""
+    import scipy.sparse as sp
+    from scipy.sparse.csgraph import breadth_first_order, minimum_spanning_tree
+    rng = np.random.Generator(np.random.PCG64(seed + 77))
+    n, ei, ej = g["n_cams"], g["edge_i"].astype(np.int64), g["edge_j"].astype(np.int64)
+    E = ei.size
+    m = rng.integers(inlier_matches[0], inlier_matches[1], E)
+    out = g["is_outlier"]
+    m[out] = rng.integers(outlier_matches[0], outlier_matches[1], int(out.sum()))
+    tree = minimum_spanning_tree(sp.coo_matrix((-m.astype(np.float64), (ei, ej)), shape=(n, n)).tocsr())
+    order, pred = breadth_first_order(tree + tree.T, 0, directed=False)
+    keys = ei * n + ej
+    srt = np.argsort(keys, kind="stable")
+    q_rel = aa_to_quat(g["rel_aa"])
+    q = np.tile(np.array([0.0, 0.0, 0.0, 1.0]), (n, 1))      # cameras outside the root's component keep the identity
+    depth = np.zeros(n, dtype=np.int64)
+    nodes = order[1:]
+    for v in nodes:                                            # (BFS order: a parent's depth is final before its children are visited)
+        depth[v] = depth[pred[v]] + 1
+    for d in range(1, int(depth.max()) + 1 if nodes.size else 1):
+        v = nodes[depth[nodes] == d]
+        p = pred[v]
+        lo, hi = np.minimum(p, v), np.maximum(p, v)
+        e = srt[np.searchsorted(keys, lo * n + hi, sorter=srt)]
+        up = p < v                                             # the parent is `first`: R_v = R_ij R_p; else R_v = R_ij^T R_p
+        q[v] = np.where(up[:, None], quat_mul(q_rel[e], q[p]), quat_mul(quat_conj(q_rel[e]), q[p]))
+    return np.ascontiguousarray(quat_to_aa(q)), m
+
+
 def angular_distance(aa_a, aa_b):
     """Per-camera geodesic distance (rad) between two sets of rotations, no alignment."""
     q = quat_mul(aa_to_quat(aa_a), quat_conj(aa_to_quat(aa_b)))

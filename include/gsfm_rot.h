@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define GSFM_ROT_ABI_VERSION 1
+#define GSFM_ROT_ABI_VERSION 2
 
 typedef enum {
   GSFM_OK = 0,
@@ -290,11 +290,17 @@ gsfm_status gsfm_rot_solve_sigma_consensus(gsfm_rot_problem* p, double* rot_aa_i
  * may be NULL.  s_out[e] = ||r_e||^2, rho_out[3e..] = (rho, rho', rho''),
  * residual_out[stride*e..] = the raw residual (3, 4 or 9 values, see
  * gsfm_rot_residual_dim), *cost = sum 1/2 rho.  Outputs follow the edge order
- * given at create time.                                                         */
+ * given at create time (on the device the sweep stores in the problem's own edge
+ * order, coalesced; the caller's order is restored at this boundary).           */
 gsfm_status gsfm_rot_residuals(gsfm_rot_problem* p, const double* rot_aa,
                                double* s_out, double* rho_out, double* residual_out,
                                double* cost);
 int32_t gsfm_rot_residual_dim(int32_t error_type);
+/* The problem's own edge order: order_out[u] = index (in the arrays given at create time) of the edge at position u of the
+ * device-side per-edge planes -- cost edges bucketed by (camera block of `first`, camera block of `second`).  Per-edge quantities
+ * of the sweep K1 live on the device in THIS order; on a sharded problem only the edges this rank counts in the cost appear.
+ * Copies min(cap, count) entries (order_out may be NULL) and returns the count, -1 on a NULL problem.                          */
+int64_t gsfm_rot_edge_order(gsfm_rot_problem* p, uint32_t* order_out, uint64_t cap);
 
 /* Linearise at rot_aa (kernel K2): gradient J~^T r~ (3 per camera) and the
  * diagonal 3x3 blocks of J~^T J~ (9 per camera, row-major), both with respect to
@@ -330,10 +336,13 @@ int32_t gsfm_rot_locality_order(uint32_t n_cams, uint64_t n_edges, const uint32_
 int64_t gsfm_rot_count_components(uint32_t n_cams, uint64_t n_edges, const uint32_t* edge_i, const uint32_t* edge_j);
 
 /* The problem's current native loss program evaluated ON THE DEVICE at the given squared norms, through the same device
- * routines (and kernel specialisation) the sweeps use: rho3_out[3k..] = (rho, rho', rho'')(s[k]) as K2 and the per-edge
- * sweep compute them, value_out[k] = rho(s[k]) as the solver's cost-only sweep computes it.  Either output may be NULL.
+ * routines (and kernel specialisation) the sweeps use: rho3_out[3k..] = (rho, rho', rho'')(s[k]) as K2's general path and the
+ * per-edge sweep compute them, value_out[k] = rho(s[k]) as the solver's cost-only sweep computes it, rho1_fast_out[k] = rho'(s[k])
+ * as K2's fast path computes it (losses with rho'' <= 0 everywhere: the single cheap leaves and the nu = 3 MAGSAC weight loss; NaN
+ * for programs that have no fast path).  Any output may be NULL.
  * This is how the device is pinned directly against vectors recorded from scripts/loss_functions.py:47-458.              */
-gsfm_status gsfm_rot_loss_eval(gsfm_rot_problem* p, const double* s, uint64_t n, double* rho3_out, double* value_out);
+gsfm_status gsfm_rot_loss_eval(gsfm_rot_problem* p, const double* s, uint64_t n, double* rho3_out, double* value_out,
+                               double* rho1_fast_out);
 
 /* Per-iteration trace of the last solve: rows of GSFM_ROT_TRACE_COLS doubles
  * [iteration, cost, cost_change, gradient_max_norm, step_norm, relative_decrease,
@@ -346,18 +355,27 @@ int32_t gsfm_rot_get_trace(gsfm_rot_problem* p, double* out, int32_t cap_rows);
 gsfm_status gsfm_rot_time_sweep(gsfm_rot_problem* p, const double* rot_aa, int32_t reps,
                                 double* mean_kernel_ms);
 
-/* The variants of the edge sweep K1, each as the mean of `reps` launches (HIP events on the problem's stream, operands resident):
+/* The variants of the edge sweep K1 (and the sigma-consensus forms of K1 / K2), each as the mean of `reps` launches (HIP events on
+ * the problem's stream, operands resident); per-edge outputs are stored in the problem's own edge order (gsfm_rot_edge_order):
  *   out_ms[0]  trial-cost sweep, as the solver launches it after every step: residual + rho VALUE, block-reduced, no per-edge store
- *   out_ms[1]  full reweight sweep: residual, s and (rho, rho', rho'') stored per edge in the caller's edge order (gsfm_rot_residuals)
- *   out_ms[2]  s-only sweep with unit weights: pass 1 of the sigma-consensus weight update and of host-callback losses
- *   out_ms[3]  sigma-consensus weight pass on that s: weights, their mean change, and the gathers into both entry-ordered weight
- *              planes (0 unless the problem is an ANGLE_AXIS one that carries scalar weights, i.e. sigma consensus / set_edge_weights ran)
- * (In the solver the robust weights rho', rho'' of an accepted point are evaluated inside K2, the linearisation; see time_kernels.) */
-gsfm_status gsfm_rot_time_sweep_variants(gsfm_rot_problem* p, const double* rot_aa, int32_t reps, double* out_ms4);
+ *   out_ms[1]  full sweep: residual, s and (rho, rho', rho'') stored per edge (32 B out per edge; what gsfm_rot_residuals runs)
+ *   out_ms[2]  s-only sweep: pass 1 of host-callback losses (8 B out per edge)
+ *   out_ms[3]  reweight sweep as SURVEY 8(d) defines it: residual, loss, rho' stored per edge (8 B out per edge)
+ *   out_ms[4..7]  sigma consensus (0 unless the problem is an ANGLE_AXIS one that carries scalar weights): [4] the first cost sweep of an
+ *              inner solve with the weight computation fused in (weights stored to the sweep's own plane, mean change reduced),
+ *              [5] the same sweep without it, [6] the first linearisation K2 with the weights fused in, [7] K2 without
+ * (In the solver the robust weights of an accepted point are evaluated inside K2, the linearisation; see time_kernels.) */
+gsfm_status gsfm_rot_time_sweep_variants(gsfm_rot_problem* p, const double* rot_aa, int32_t reps, double* out_ms8);
 
-/* Same for the three hot kernels: out_ms[0] = K1 k_cost, [1] = K2 k_lin, [2] = K3 k_matvec (mean of `reps`
- * launches each, HIP events on the problem's stream, operands resident in HBM).                      */
-gsfm_status gsfm_rot_time_kernels(gsfm_rot_problem* p, const double* rot_aa, int32_t reps, double* out_ms3);
+/* Same for the hot kernels: out_ms[0] = K1 k_cost, [1] = the linearisation (K2, row-major or column-sorted form + its finish),
+ * [2] = one normal-equation mat-vec (K3, likewise), [3] = reserved (0).  Mean of `reps` launches each, HIP events on the problem's
+ * stream, operands resident in HBM.                                                                                       */
+gsfm_status gsfm_rot_time_kernels(gsfm_rot_problem* p, const double* rot_aa, int32_t reps, double* out_ms4);
+
+/* Bytes one mat-vec / one linearisation streams as laid out in HBM, and which form the problem uses: 0 = general 9-value blocks (76 B per
+ * directed entry in the mat-vec), 1 = Laplacian form, row-major (52 B), 2 = Laplacian form, column-sorted row blocks (54 B per position
+ * + slot offsets + partial sums; large graphs without locality, csrc/colsort_kernels.hpp).  Any output may be NULL.  For roofline reporting. */
+gsfm_status gsfm_rot_matvec_bytes(gsfm_rot_problem* p, double* matvec_bytes, double* linearize_bytes, int32_t* form);
 
 /* Bytes moved per edge by one K1 sweep as laid out in HBM / as counted
  * algorithmically: for roofline reporting.                          */

@@ -154,7 +154,6 @@ def test_madrid_graph_through_the_reference_pipeline_call_sequence(tmp_path, gol
     x0 = np.array([init[int(v)] for v in ids])
     got = np.array([o[int(v)] for v in ids])
     from globalsfmpy_amd.solver import RotationProblem
-    from sensitivity import oracle_spread
     magsac = LF.MAGSACWeightBasedLoss(0.02)
     dev = RotationProblem(len(ids), ei, ej, rr, _abi.ANGLE_AXIS_COVARIANCE, cov6=c6)
     dev.set_loss(magsac)
@@ -176,18 +175,22 @@ def test_madrid_graph_through_the_reference_pipeline_call_sequence(tmp_path, gol
         d15 = synth.angular_distance(synth.align_rotations(rd15, ro15), ro15)
         print("madrid@15 %s: mean dR %.3e max %.3e rad" % ("pcg" if kw else "cholesky", d15.mean(), d15.max()))
         assert d15.mean() <= 1e-6
-    # (2) MAGSAC to convergence (62-63 iterations).  Beyond iteration ~20 the staircase loss (table cell = 2 sigma^2 / 1000) makes the
-    #     trajectory sensitive to the last bit of its inputs: the ORACLE'S OWN Cholesky run moves by 2e-4 rad (mean) and one
-    #     iteration when the measurements move by 1 ulp (tests/sensitivity.py; CPU evidence in test_oracle_solver.py).  The device
-    #     has to land inside that spread -- closer agreement than the reference has with itself cannot be asked of anyone.
-    ro, so = ora.solve(x0)
-    diff = synth.angular_distance(synth.align_rotations(got, ro), ro)
-    means, maxs, iters = oracle_spread(make_oracle, rr, x0, ro, n_runs=2)
-    print("madrid MAGSAC: device %d it cost %.9e | oracle %d it cost %.9e | mean dR %.3e max %.3e rad | 1-ulp oracle runs: %s it, mean dR %s"
-          % (s["num_iterations"], s["final_cost"], so["num_iterations"], so["final_cost"], diff.mean(), diff.max(), iters, ["%.2e" % m for m in means]))
-    assert min(iters + [so["num_iterations"]]) - 2 <= s["num_iterations"] <= max(iters + [so["num_iterations"]]) + 2
-    assert abs(s["final_cost"] - so["final_cost"]) <= 3e-6 * so["final_cost"]
-    assert diff.mean() <= max(1e-6, 3.0 * max(means))
+    # (2) MAGSAC to convergence (62-63 iterations) -- the pipeline's default configuration (scripts/sfm_pipeline.py:136-141).  Beyond
+    #     iteration ~20 the staircase loss (table cell = 2 sigma^2 / 1000) makes the trajectory sensitive to the last bit of its inputs,
+    #     and the ORACLE'S OWN Cholesky outcomes under 1-ulp changes of the measurements are bimodal, not diffuse (CPU, 13 runs: two
+    #     clusters 2.0e-4 rad apart, one per final iteration count 62 / 63, each 4e-7..5e-6 rad wide).  The device has to
+    #     land IN one of those clusters: nearest ensemble member within 1e-6 rad -- or, where the cluster itself is coarser, no further
+    #     than its members are from each other -- with that member's iteration count, and a cost inside the ensemble's range.
+    from sensitivity import ensemble_verdict, oracle_ensemble
+    ens = oracle_ensemble(make_oracle, rr, x0, n_runs=6)
+    so = ens[0][1]
+    v = ensemble_verdict(got, ens)
+    print("madrid MAGSAC: device %d it cost %.9e | ensemble iterations %s | device -> nearest member #%d (%d it): %.2e rad | all members: %s | members' own nearest neighbours: %s"
+          % (s["num_iterations"], s["final_cost"], v["iters"], v["nearest"], v["nearest_iters"], v["nearest_dist"], ["%.1e" % x for x in v["dists"]],
+             ["%.1e" % x for x in v["member_nn"]]))
+    assert v["nearest_dist"] <= max(1e-6, max(v["member_nn"])), v
+    assert s["num_iterations"] == v["nearest_iters"], v
+    assert min(v["costs"]) * (1 - 1e-6) <= s["final_cost"] <= max(v["costs"]) * (1 + 1e-6), v
     # (3) The same real graph with the reference's other defaults -- EstimateRotations' SoftL1(0.1) on angle-axis residuals and
     #     Huber(0.1) on the quaternion residual (sfm_pipeline.py:131) -- is well-posed, and there the north-star bar holds to
     #     convergence with identical iteration counts, for the Cholesky step and for PCG.

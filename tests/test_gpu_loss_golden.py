@@ -40,21 +40,32 @@ def _assert_rows(got, rows, rtol, what):
 
 def test_every_reference_loss_row_through_the_device_loss_program(golden_dir):
     dev = _tiny_problem()
-    n_rows, modes = 0, set()
+    n_rows, modes, n_fast = 0, set(), 0
     for case in _cases(golden_dir):
         obj = _build(case["program"]) if case["program"] else getattr(LF, case["class"])(*case["args"])
         dev.set_loss(obj)                                   # native descriptor -> prepare_loss -> device program
         rows = np.asarray(case["rows"], dtype=np.float64)
-        rho3, val = dev.loss_eval(rows[:, 0])
+        rho3, val, fast = dev.loss_eval(rows[:, 0], with_fast_rho1=True)
         rtol = 1e-9 if getattr(obj, "use_weight_inverse", False) else 1e-12   # same bars as the oracle's test
         what = (case["class"], case["args"])
         _assert_rows(rho3, rows, rtol, what)
+        # K2's fast path (losses whose rho'' is never positive: the cheap single leaves and the nu = 3 MAGSAC weight loss) evaluates
+        # rho' alone, with a host-precomputed constant factor: the same recorded rows, the same bar.  It must exist exactly for the
+        # losses that can never need the Corrector's alpha term, i.e. never for a recorded row with rho'' > 0.
+        if np.isfinite(fast).all():
+            n_fast += 1
+            assert not (rows[:, 3] > 0).any(), what
+            want1 = np.stack([rows[:, 0], rows[:, 2]], axis=1)
+            _assert_rows(fast[:, None], want1, rtol, what + ("fast rho'",))
+        else:
+            assert np.isnan(fast).all(), what
         # the solver's cost-only specialisation (trial-cost sweeps): rho alone; for MAGSAC nu = 3 it evaluates the table entry
         # as exp(-x / 1000) of the same quantised cell
         _assert_rows(val[:, None], rows[:, :2], rtol, what + ("value",))
         n_rows += len(rows)
         modes.add(case["class"])
     assert n_rows > 2000 and {"MAGSACWeightBasedLoss", "MAGSACWeightBasedLoss4", "MAGSACWeightBasedLoss9", "HuberLoss", "TolerantLoss"} <= modes
+    assert n_fast >= 5
 
 
 def test_magsac_tie_rounding_rows_hit_the_reference_cell(golden_dir):
@@ -68,12 +79,13 @@ def test_magsac_tie_rounding_rows_hit_the_reference_cell(golden_dir):
     ties = np.array([(k + 0.5) * ssm2 / 1000.0 for k in range(0, 4000, 7)])
     ties = ties[np.abs(1000.0 * ties / ssm2 - np.floor(1000.0 * ties / ssm2) - 0.5) == 0.0]   # exact .5 in double arithmetic
     assert len(ties) > 100
-    rho3, _ = dev.loss_eval(ties)
+    rho3, _, fast = dev.loss_eval(ties, with_fast_rho1=True)
     ref = LF.MAGSACWeightBasedLoss(sigma)
-    for s, got in zip(ties, rho3):
+    for s, got, f1 in zip(ties, rho3, fast):
         out = [0.0, 0.0, 0.0]
         ref.Evaluate(float(s), out)                          # pinned to the reference by test_oracle_golden.py
         assert np.allclose(got, out, rtol=1e-12, atol=0.0), (s, got, out)
+        assert math.isclose(f1, out[1], rel_tol=1e-12), (s, f1, out)   # K2's fast rho' lands in the same cell
         x = round(1000.0 * float(s) / ssm2)
         assert x % 2 == 0                                    # the tie went to the even cell
 

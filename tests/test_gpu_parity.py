@@ -117,21 +117,24 @@ def test_solve_matches_oracle(oracle, graph, et):
     o12, t12 = ora.solve(graph["init_aa"], max_num_iterations=12)
     assert abs(s12["final_cost"] - t12["final_cost"]) <= 1e-9 * t12["final_cost"]
     assert synth.angular_distance(synth.align_rotations(r12, o12), o12).mean() <= 1e-6
-    # (2) To convergence (40+ iterations, trust radius up to 1e11, then a run of rejected steps on the staircase) the oracle's own
-    # answer moves by ~1e-5 rad and +-3 iterations under a 1-ulp change of its inputs (tests/sensitivity.py): the device must sit
-    # inside that spread.
-    from sensitivity import oracle_spread
+    # (2) To convergence (35-48 iterations, trust radius up to 1e11, then a run of rejected steps on the staircase) the trajectory is
+    # sensitive to the last bit of its inputs: the oracle's own exact-Cholesky answer moves when the measurements move by 1 ulp.  So the
+    # device is held against the oracle's outcome ENSEMBLE (the given measurements + 12 one-ulp perturbations), at the north-star bar:
+    # within 1e-6 rad (mean, after gauge alignment) of its NEAREST member -- or, should the ensemble itself be coarser than that, no
+    # further from it than its perturbed members are from each other -- with an iteration count and a cost the ensemble shows too.
+    from sensitivity import ensemble_verdict, oracle_ensemble
 
     def make(rel):
         o = oracle.OracleProblem(graph["n_cams"], graph["edge_i"], graph["edge_j"], rel, et, cov6=graph["cov6"], inlier_weight=graph["inlier_weight"])
         o.set_loss(loss)
         return o
-    means, maxs, iters = oracle_spread(make, graph["rel_aa"], graph["init_aa"], ro, n_runs=4)
-    print("et %d: device %d it, oracle %d it, 1-ulp oracle runs %s it; mean dR device %.2e, 1-ulp oracle %s" % (
-        et, sd["num_iterations"], so["num_iterations"], iters, dist.mean(), ["%.2e" % m for m in means]))
-    assert min(iters + [so["num_iterations"]]) - 2 <= sd["num_iterations"] <= max(iters + [so["num_iterations"]]) + 2
-    assert dist.mean() <= max(1e-6, 3.0 * max(means))
-    assert abs(sd["final_cost"] - so["final_cost"]) <= 1e-5 * so["final_cost"]
+    ens = oracle_ensemble(make, graph["rel_aa"], graph["init_aa"], n_runs=12)
+    v = ensemble_verdict(rd, ens)
+    print("et %d: device %d it; ensemble iterations %s; device -> nearest member #%d (%d it): %.2e rad; members' own nearest-neighbour distances %s"
+          % (et, sd["num_iterations"], v["iters"], v["nearest"], v["nearest_iters"], v["nearest_dist"], ["%.1e" % x for x in v["member_nn"]]))
+    assert v["nearest_dist"] <= max(1e-6, max(v["member_nn"][1:])), v
+    assert min(v["iters"]) - 1 <= sd["num_iterations"] <= max(v["iters"]) + 1, v
+    assert min(v["costs"]) * (1 - 1e-6) <= sd["final_cost"] <= max(v["costs"]) * (1 + 1e-6), v
 
 
 @pytest.mark.parametrize("et", [_abi.QUATERNION_NORM, _abi.ROTATION_MAT_FNORM, _abi.QUATERNION_COSINE, _abi.ANGLE_AXIS, _abi.ANGLE_AXIS_COVTRACE])
