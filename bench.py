@@ -336,6 +336,7 @@ def main():
     variants = prob.time_sweep_variants(init, reps=args.sweep_reps) if world == 1 else None
     alg_b, lay_b = prob.sweep_bytes()
     mv_layout_bytes, mv_form = prob.matvec_bytes()
+    lin_layout_bytes = prob.linearize_bytes()
 
     sigma_pass = None
     if world == 1 and args.sigma_pass:
@@ -379,8 +380,8 @@ def main():
         nd = 2.0 * e_local if part is None else float(part.entries_per_rank[rank])   # (sharded: rank 0's rows)
         mv_bytes = mv_layout_bytes      # this rank's mat-vec as laid out (gsfm_rot_matvec_bytes): row-major 52 B per directed entry, column-sorted 54 B per position + ...
         mv_kernel = {0: "k_matvec<false> (K3: general 9-value blocks, row-major)", 1: "k_matvec<LAP> (K3: Laplacian form, row-major, 52 B per directed entry)",
-                     2: "k_mv_col + k_mv_col_finish (K3c: Laplacian form, column-sorted row blocks, 54 B per position; csrc/colsort_kernels.hpp)"}[mv_form]
-        lin_bytes = nd * (84.0 + blk) + 72.0 * n_cams
+                     2: "k_mv_col + k_mv_col_finish (K3c: Laplacian form, column-sorted row blocks, 56 B per position; csrc/colsort_kernels.hpp)"}[mv_form]
+        lin_bytes = lin_layout_bytes    # the linearisation as laid out (row-major: col 4 + q_rel 32 + whitening + block per directed entry; column-sorted: 8 + 32 + whitening + 48 per position)
         sweep_bytes = e_local * lay_b + 32.0 * n_cams          # as laid out: idx 8 + q_rel 32 + Lt 48 per edge, the quaternions once
 
         def roof(bytes_per_launch, ms, **extra):
@@ -428,9 +429,10 @@ def main():
                 d["frac_on_survey_8d_bytes"] = (e_local * alg_b + 24.0 * n_cams) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS
                 return d
             other = {
-                "k_lin": dict(roof(lin_bytes, kt["k_lin"]), kernel="K2: residual, row Jacobian, robust weight rho', gradient, diagonal blocks, edge blocks; once per accepted LM step "
-                                                                   "(fast path: losses with rho'' <= 0, see kernels.hpp lin_rows_fast)",
-                              traffic=pmc_bytes("k_lin"), bytes_per_directed_entry=84.0 + blk),
+                "k_lin": dict(roof(lin_bytes, kt["k_lin"]), kernel=("K2c k_lin_col + finish (column-sorted layout)" if mv_form == 2 else "K2 k_lin_fast (row-major)") +
+                                                                   ": residual, row Jacobian, robust weight rho', gradient, diagonal blocks, edge blocks; once per accepted LM step "
+                                                                   "(fast path: losses with rho'' <= 0, see kernels.hpp lin_entry_eval)",
+                              traffic=pmc_bytes("k_lin"), frac_on_survey_8d_bytes=(168.0 * e_local + 72.0 * n_cams) / (kt["k_lin"] * 1e-3) / 1e9 / HBM_PEAK_GBPS),
                 "k_cost_trial": k1_entry(variants["trial_cost"], 0.0, "K1 k_cost<FULL=false>: residual + rho VALUE, block-reduced; the solver's trial-cost sweep (no rho', no per-edge store)", "k_cost"),
                 "k_cost_reweight": k1_entry(variants["rho1_only"], 8.0, "K1 k_cost<FULL=true>, the reweight sweep as SURVEY 8(d) defines it: residual, loss, rho' stored per edge "
                                                                         "(problem edge order, coalesced non-temporal stores)", "k_cost_reweight"),

@@ -12,7 +12,7 @@
 // mat-vec becomes a stream of its own 54 B per entry.  Per-row sums stay deterministic and atomic-free: a sub-chunk of SUB entries is
 // evaluated entry-parallel, each entry's contribution is written to its slot of a ROW-sorted LDS staging area (2-byte permutation index
 // per entry), and after a barrier the lane that owns row r adds the slots of row r, in slot order, to the sums it keeps in registers
-// (seg[] = 2-byte slot offsets per row and sub-chunk).  The sub-chunks of a block are dealt to NCH workgroups; a finishing kernel adds
+// (seg[] = slot range per row and sub-chunk).  The sub-chunks of a block are dealt to NCH workgroups; a finishing kernel adds
 // the NCH partials of a row in fixed order.  K2c stores the edge blocks in the BODY frame, B = R_k^T G R_k (it has R_k at hand), so K3c
 // applies R_k once per row, in its finish, instead of once per entry.
 //   measured at C5 (tools/bench_matvec6.hip, random data): row-major mat-vec 322 us -> 193 + 3 us.
@@ -29,12 +29,16 @@ namespace gsfm {
 struct ColWg { uint32_t first_sub, n_sub, row0, pad; };   // sub-chunk range; first row of the block (local to the owned rows)
 struct ColLayoutDev {
   const ColWg* wg;
-  const uint32_t* col;      // per position: neighbour camera | role << 31; GSFM_COL_PAD = padding
-  const uint16_t* rowl;     // per position: row inside its block
-  const uint16_t* perm;     // per position: slot in the row-sorted staging area of its sub-chunk
-  const uint16_t* seg;      // per sub-chunk: RB + 1 slot offsets
+  const uint2* meta;        // per position: .x = neighbour camera | role << 31 (GSFM_COL_PAD = padding), .y = slot in the row-sorted staging area
+                            //   of its sub-chunk | row inside its block << 16  -- one 8-byte load per entry
+  const uint32_t* seg;      // per sub-chunk and row: first slot | one-past-last slot << 16  -- one 4-byte load per row
   uint32_t n_wg, nch;
 };
+__device__ __forceinline__ uint2 col_load_meta(const uint2* p) {
+  uint2 v;
+  v.x = __builtin_nontemporal_load(&p->x); v.y = __builtin_nontemporal_load(&p->y);
+  return v;
+}
 
 // ---- K3c ----------------------------------------------------------------------------------------------------------------
 struct ColMatvecArgs {
@@ -53,15 +57,15 @@ __global__ void __launch_bounds__(GSFM_COL_RB) k_mv_col(ColMatvecArgs a) {
   const ColWg w = a.L.wg[blockIdx.x];
   const uint32_t r = threadIdx.x;
   double y0 = 0.0, y1 = 0.0, y2 = 0.0;
-  uint32_t m[EPL]; double2 A[EPL], B[EPL], C[EPL]; uint16_t pm[EPL];
+  uint32_t m[EPL], pm[EPL]; double2 A[EPL], B[EPL], C[EPL];
   auto request = [&](uint32_t s) {   // the streams of sub-chunks s .. s + EPL - 1 of this workgroup (past its end: the last one again, discarded)
 #pragma unroll
     for (int k = 0; k < EPL; ++k) {
       const uint32_t sc = w.first_sub + min(s + (uint32_t)k, w.n_sub - 1);
       const size_t e = (size_t)sc * RB + r;
-      m[k] = __builtin_nontemporal_load(a.L.col + e);
+      const uint2 mt = col_load_meta(a.L.meta + e);
+      m[k] = mt.x; pm[k] = mt.y & 0xffffu;
       A[k] = nt_load2(a.b0 + e); B[k] = nt_load2(a.b1 + e); C[k] = nt_load2(a.b2 + e);
-      pm[k] = __builtin_nontemporal_load(a.L.perm + e);
     }
   };
   if (w.n_sub) request(0);
@@ -80,8 +84,8 @@ __global__ void __launch_bounds__(GSFM_COL_RB) k_mv_col(ColMatvecArgs a) {
 #pragma unroll
     for (int k = 0; k < EPL; ++k) {
       const bool live = s + (uint32_t)k < w.n_sub;
-      const uint16_t* sg = a.L.seg + (size_t)(w.first_sub + (live ? s + (uint32_t)k : s)) * (RB + 1);
-      s0[k] = sg[r]; s1[k] = live ? (uint32_t)sg[r + 1] : s0[k];
+      const uint32_t sg = a.L.seg[(size_t)(w.first_sub + (live ? s + (uint32_t)k : s)) * RB + r];
+      s0[k] = sg & 0xffffu; s1[k] = live ? (sg >> 16) : s0[k];
     }
     if (s + EPL < w.n_sub) request(s + EPL);   // the next iteration's streams are in flight across the barrier and the row phase
     __syncthreads();
@@ -146,11 +150,11 @@ __device__ __forceinline__ void lin_col_body(const ColLinArgs& a) {
     const uint32_t sc = w.first_sub + s;
     for (uint32_t k = 0; k < SUB / T; ++k) {
       const uint32_t d = sc * SUB + k * T + t;
-      const uint32_t cr = __builtin_nontemporal_load(a.L.col + d);
-      const uint32_t pm = __builtin_nontemporal_load(a.L.perm + d);
+      const uint2 mt = col_load_meta(a.L.meta + d);
+      const uint32_t cr = mt.x, pm = mt.y & 0xffffu;
       double g3[3] = {0, 0, 0}, G6[6] = {0, 0, 0, 0, 0, 0}, B6[6] = {0, 0, 0, 0, 0, 0};
       if (cr != GSFM_COL_PAD) {
-        const uint32_t rl = __builtin_nontemporal_load(a.L.rowl + d);
+        const uint32_t rl = mt.y >> 16;
         const LinStreams S = lin_load_streams<WM>(a.lin, d);
         const Quat qm = load_q(a.lin.q, cr & 0x7fffffffu);
         const double2 k0 = qrow[0][rl], k1 = qrow[1][rl];
@@ -176,12 +180,12 @@ __device__ __forceinline__ void lin_col_body(const ColLinArgs& a) {
 #pragma unroll
       for (int c = 0; c < 6; ++c) slots[3 + c][pm] = G6[c];
     }
-    const uint16_t* sg = a.L.seg + (size_t)sc * (RB + 1);
+    const uint32_t* sg = a.L.seg + (size_t)sc * RB;
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < RPL; ++j) {
-      const uint32_t r = t + j * T;
-      const uint32_t s0 = sg[r], s1 = sg[r + 1];
+      const uint32_t sgr = sg[t + j * T];
+      const uint32_t s0 = sgr & 0xffffu, s1 = sgr >> 16;
       for (uint32_t u = s0; u < s1; ++u) {
 #pragma unroll
         for (int c = 0; c < 9; ++c) acc[j][c] += slots[c][u];

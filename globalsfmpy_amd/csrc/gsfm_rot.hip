@@ -259,9 +259,10 @@ struct gsfm_rot_problem {
     uint32_t nch = 0, n_wg = 0;
     size_t n_pos = 0;
     DevBuf<ColWg> wg;
-    DevBuf<uint16_t> rowl, perm, seg;
+    DevBuf<uint2> meta;
+    DevBuf<uint32_t> seg;
     DevBuf<double> part;      // 9 planes of [n_wg * RB] (K2c; K3c uses the first three)
-    ColLayoutDev dev(const uint32_t* col) const { return ColLayoutDev{wg.p, col, rowl.p, perm.p, seg.p, n_wg, nch}; }
+    ColLayoutDev dev() const { return ColLayoutDev{wg.p, meta.p, seg.p, n_wg, nch}; }
   } cs;
 
   // sigma consensus (gsfm_rot_solve_sigma_consensus): the weights are computed inside the first cost sweep / linearisation of a solve
@@ -302,7 +303,7 @@ int dispatch(const gsfm_rot_problem* P, const ArgsT& args, int grid) {
 }
 template <int F, int W, int L> struct CostLauncher {
   static void go(const CostArgs& a, int grid, hipStream_t s) {
-    const bool full = a.s_only || a.rho_ext || a.s_out || a.rho01_out || a.rho2_out || a.rho1_out || a.r_out || a.sigma.on;
+    const bool full = a.s_only || a.rho_ext || a.srho_out || a.rho12_out || a.rho1_out || a.r_out || a.sigma.on;
     if (a.direct) {
       if (full) hipLaunchKernelGGL((k_cost_direct<F, W, L, true>), dim3(grid), dim3(GSFM_BLOCK), 0, s, a);
       else hipLaunchKernelGGL((k_cost_direct<F, W, L, false>), dim3(grid), dim3(GSFM_BLOCK), 0, s, a);
@@ -409,6 +410,10 @@ int prepare_loss(gsfm_rot_problem* P, const gsfm_loss_node* prog, int n) {
         d.aux[3] = C_times_two_ad_dof; d.aux[4] = one_over_sigma; d.aux[5] = one_over_sigma * gamma_difference;
         d.aux[6] = c.q * c.q * squared_sigma; d.aux[7] = c.gk;
         d.rho1_scale = C_times_two_ad_dof / (2.0 * squared_sigma * sigma);   // rho' = rho1_scale * exp(-x / 1000) for nu = 3 (loss_functions.py:311)
+        d.rho2_scale = 2.0 * C_times_two_ad_dof / (squared_sigma * 8.0 * squared_sigma * sigma);   // -rho'' / exp(..) for nu = 3 (:319-321)
+        d.e2_clamp = std::exp(-1e-7 / (2.0 * squared_sigma));
+        d.x_clamp = 0;
+        while (d.x_clamp < c.n && (double)d.x_clamp * (2.0 * squared_sigma) / 1000.0 < 1e-7) d.x_clamp++;   // cells whose s = x 2 sigma^2 / 1000 the reference lifts to 1e-7 (:317)
         const int ti = nu == 3 ? 0 : nu == 4 ? 1 : 2;
         if (!P->tables[ti].p) {
           if (P->tables[ti].upload(magsac_table(nu)) != hipSuccess) return fail(GSFM_ERR_HIP, "uploading MAGSAC table failed");
@@ -495,7 +500,7 @@ int refresh_external_rho(gsfm_rot_problem* P, const double2* q) {
 }
 
 // optional per-edge outputs of K1 (device pointers, problem edge order)
-struct CostOutputs { double* s = nullptr; double2* rho01 = nullptr; double* rho2 = nullptr; double* rho1 = nullptr; double* r = nullptr; };
+struct CostOutputs { double2* srho = nullptr; double2* rho12 = nullptr; double* rho1 = nullptr; double* r = nullptr; };
 
 int launch_lin(gsfm_rot_problem* P, const double2* q);
 
@@ -520,7 +525,7 @@ int launch_cost(gsfm_rot_problem* P, const double2* q, int slot, const CostOutpu
   }
   CostArgs a = cost_args(P, q);
   a.rho_ext = P->cb ? P->rho_ext.p : nullptr;
-  a.s_out = out.s; a.rho01_out = out.rho01; a.rho2_out = out.rho2; a.rho1_out = out.rho1; a.r_out = out.r; a.s_only = 0;
+  a.srho_out = out.srho; a.rho12_out = out.rho12; a.rho1_out = out.rho1; a.r_out = out.r; a.s_only = 0;
   if (sig && !P->cb) { a.sigma = P->sigma; a.sigma.on = 1; }
   const int tk = P->timer.begin(T_SWEEP);
   if (dispatch<CostArgs, CostLauncher>(P, a, P->nb_cost)) return fail(GSFM_ERR_UNSUPPORTED, "no kernel for this error type");
@@ -544,7 +549,7 @@ int launch_lin(gsfm_rot_problem* P, const double2* q) {
   const int tk = P->timer.begin(T_LIN);
   if (P->cs.active) {
     ColLinArgs ca{};
-    ca.lin = a; ca.L = P->cs.dev(P->col.p); ca.part = P->cs.part.p;
+    ca.lin = a; ca.L = P->cs.dev(); ca.part = P->cs.part.p;
     if (dispatch<ColLinArgs, ColLinLauncher>(P, ca, (int)P->cs.n_wg)) return fail(GSFM_ERR_UNSUPPORTED, "no kernel for this error type");
     hipLaunchKernelGGL(k_lin_col_finish, dim3(grid_for(P->n_rows)), dim3(GSFM_BLOCK), 0, P->stream, P->n_rows, P->own_begin, P->cs.nch, P->cs.n_wg, (const double*)P->cs.part.p, P->gD.p);
   } else if (dispatch<LinArgs, LinLauncher>(P, a, grid_for((size_t)P->n_rows * P->G))) return fail(GSFM_ERR_UNSUPPORTED, "no kernel for this error type");
@@ -570,7 +575,7 @@ int launch_matvec(gsfm_rot_problem* P, const double* Mblk, const double* p, doub
   if (P->cs.active) {   // graphs without locality: the column-sorted form (always Laplacian)
     auto& c = P->cs;
     ColMatvecArgs m{};
-    m.L = c.dev(P->col.p); m.b0 = P->h0.p; m.b1 = P->h1.p; m.b2 = P->h2.p; m.u = P->u_rot.p; m.part = c.part.p; m.done = done;
+    m.L = c.dev(); m.b0 = P->h0.p; m.b1 = P->h1.p; m.b2 = P->h2.p; m.u = P->u_rot.p; m.part = c.part.p; m.done = done;
     hipLaunchKernelGGL(k_mv_col, dim3(c.n_wg), dim3(GSFM_COL_RB), 0, P->stream, m);
     ColFinishArgs f{};
     f.n_rows = P->n_rows; f.row_base = P->own_begin; f.nch = c.nch; f.n_wg = c.n_wg; f.part = c.part.p; f.Mblk = Mblk; f.p = p; f.q = P->q_lin; f.y = y; f.done = done;
@@ -1173,8 +1178,8 @@ int build_colsort(gsfm_rot_problem* P, const std::vector<uint32_t>& rp, std::vec
   }
   const size_t n_sub = sub_off[nblk], n_pos = n_sub * SUB;
   if (n_pos == 0 || n_pos >= 0x7fffffffull) return 0;   // (positions are 32-bit in the kernels: stay on the row-major form)
-  std::vector<uint32_t> h_col(n_pos), h_eid(n_pos);
-  std::vector<uint16_t> h_rowl(n_pos), h_perm(n_pos), h_seg(n_sub * (RB + 1));
+  std::vector<uint32_t> h_col(n_pos), h_eid(n_pos), h_seg(n_sub * RB);
+  std::vector<uint2> h_meta(n_pos);
   std::vector<ColWg> h_wg((size_t)nblk * C.nch);
   parallel_run(std::max(1, std::min<int>(n_threads, (int)nblk)), [&](int t, int T) {
     std::vector<std::pair<uint64_t, uint32_t>> ent;   // (camera << 16 | local row, d): a repeated camera pair is ordered by d
@@ -1194,22 +1199,22 @@ int build_colsort(gsfm_rot_problem* P, const std::vector<uint32_t>& rp, std::vec
         std::fill(cnt.begin(), cnt.end(), 0u);
         for (size_t e = lo; e < hi; ++e) cnt[(ent[e].first & 0xffff) + 1]++;
         for (uint32_t r = 0; r < RB; ++r) cnt[r + 1] += cnt[r];
-        uint16_t* sg = &h_seg[(sub_off[b] + s) * (RB + 1)];
-        for (uint32_t r = 0; r <= RB; ++r) sg[r] = (uint16_t)cnt[r];
+        uint32_t* sg = &h_seg[(sub_off[b] + s) * RB];
+        for (uint32_t r = 0; r < RB; ++r) sg[r] = cnt[r] | (cnt[r + 1] << 16);
         std::copy(cnt.begin(), cnt.end() - 1, fill.begin());
         uint32_t pad_slot = (uint32_t)(hi - lo);
         for (size_t e = lo; e < lo + SUB; ++e) {
           const size_t o = base + (e - lo);
           if (e < hi) {
             const uint32_t rl = (uint32_t)(ent[e].first & 0xffff), d = ent[e].second;
-            h_col[o] = col[d]; h_eid[o] = deid[d]; h_rowl[o] = (uint16_t)rl; h_perm[o] = (uint16_t)fill[rl]++;
-          } else { h_col[o] = GSFM_COL_PAD; h_eid[o] = 0; h_rowl[o] = 0; h_perm[o] = (uint16_t)pad_slot++; }   // zero block, a slot no row reads
+            h_col[o] = col[d]; h_eid[o] = deid[d]; h_meta[o] = make_uint2(col[d], fill[rl]++ | (rl << 16));
+          } else { h_col[o] = GSFM_COL_PAD; h_eid[o] = 0; h_meta[o] = make_uint2(GSFM_COL_PAD, pad_slot++); }   // zero block, a slot no row reads
         }
       }
     }
   });
   C.n_wg = (uint32_t)h_wg.size(); C.n_pos = n_pos;
-  if (C.wg.upload(h_wg) != hipSuccess || C.rowl.upload(h_rowl) != hipSuccess || C.perm.upload(h_perm) != hipSuccess || C.seg.upload(h_seg) != hipSuccess ||
+  if (C.wg.upload(h_wg) != hipSuccess || C.meta.upload(h_meta) != hipSuccess || C.seg.upload(h_seg) != hipSuccess ||
       C.part.alloc((size_t)9 * C.n_wg * RB) != hipSuccess) {
     (void)hipGetLastError();
     C = gsfm_rot_problem::ColSort();   // out of memory: the row-major form needs none of this
@@ -1760,29 +1765,26 @@ gsfm_status gsfm_rot_residuals(gsfm_rot_problem* P, const double* rot, double* s
   if (int st = upload_state(P, rot)) return (gsfm_status)st;
   // The sweep writes in the problem's own edge order (coalesced); the caller's order is restored here, at the C-ABI edge, on the host:
   // out[edge_order[u]] = device[u].  Edges this rank does not count in the cost (sharded problems) stay zero.
-  DevBuf<double> ds, dr2, dr; DevBuf<double2> dr01;
-  if ((s_out && ds.alloc(Ec) != hipSuccess) || (rho_out && (dr01.alloc(Ec) != hipSuccess || dr2.alloc(Ec) != hipSuccess)) || (r_out && dr.alloc(R * Ec) != hipSuccess))
+  DevBuf<double> dr; DevBuf<double2> dsr, dr12;
+  if (((s_out || rho_out) && dsr.alloc(Ec) != hipSuccess) || (rho_out && dr12.alloc(Ec) != hipSuccess) || (r_out && dr.alloc(R * Ec) != hipSuccess))
     return (gsfm_status)fail(GSFM_ERR_HIP, "alloc outputs");
   CostOutputs out;
-  out.s = ds.p; out.rho01 = dr01.p; out.rho2 = dr2.p; out.r = dr.p;
+  out.srho = dsr.p; out.rho12 = dr12.p; out.r = dr.p;
   if (int st = launch_cost(P, P->q.p, SC_COST, out)) return (gsfm_status)st;
   double h[SC_N];
   if (int st = read_scalars(P, h)) return (gsfm_status)st;
   if (cost) *cost = h[SC_COST];
   const std::vector<uint32_t>& ord = P->h_cost_eid;
   std::vector<double> stage;
-  if (s_out) {
-    stage.resize(Ec);
-    if (Ec && hipMemcpy(stage.data(), ds.p, 8 * Ec, hipMemcpyDeviceToHost) != hipSuccess) return (gsfm_status)fail(GSFM_ERR_HIP, "copy s");
-    std::memset(s_out, 0, 8 * E);
-    for (size_t u = 0; u < Ec; ++u) s_out[ord[u]] = stage[u];
-  }
-  if (rho_out) {
-    stage.resize(3 * Ec);
-    if (Ec && (hipMemcpy(stage.data(), dr01.p, 16 * Ec, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(stage.data() + 2 * Ec, dr2.p, 8 * Ec, hipMemcpyDeviceToHost) != hipSuccess))
-      return (gsfm_status)fail(GSFM_ERR_HIP, "copy rho");
-    std::memset(rho_out, 0, 24 * E);
-    for (size_t u = 0; u < Ec; ++u) { double* o = rho_out + 3 * (size_t)ord[u]; o[0] = stage[2 * u]; o[1] = stage[2 * u + 1]; o[2] = stage[2 * Ec + u]; }
+  if (s_out || rho_out) {   // device planes: (s, rho) and (rho', rho'') per edge
+    stage.resize(4 * Ec);
+    if (Ec && (hipMemcpy(stage.data(), dsr.p, 16 * Ec, hipMemcpyDeviceToHost) != hipSuccess || (rho_out && hipMemcpy(stage.data() + 2 * Ec, dr12.p, 16 * Ec, hipMemcpyDeviceToHost) != hipSuccess)))
+      return (gsfm_status)fail(GSFM_ERR_HIP, "copy s / rho");
+    if (s_out) { std::memset(s_out, 0, 8 * E); for (size_t u = 0; u < Ec; ++u) s_out[ord[u]] = stage[2 * u]; }
+    if (rho_out) {
+      std::memset(rho_out, 0, 24 * E);
+      for (size_t u = 0; u < Ec; ++u) { double* o = rho_out + 3 * (size_t)ord[u]; o[0] = stage[2 * u + 1]; o[1] = stage[2 * Ec + 2 * u]; o[2] = stage[2 * Ec + 2 * u + 1]; }
+    }
   }
   if (r_out) {
     stage.resize(R * Ec);
@@ -1960,8 +1962,8 @@ gsfm_status gsfm_rot_time_sweep_variants(gsfm_rot_problem* P, const double* rot,
   DeviceGuard g(P->device);
   const size_t Ec = P->cost.n;
   if (int st = upload_state(P, rot)) return (gsfm_status)st;
-  DevBuf<double> ds, dr2; DevBuf<double2> dr01;
-  if (ds.alloc(Ec, true) != hipSuccess || dr01.alloc(Ec, true) != hipSuccess || dr2.alloc(Ec, true) != hipSuccess) return (gsfm_status)fail(GSFM_ERR_HIP, "alloc outputs");
+  DevBuf<double> ds; DevBuf<double2> dsr, dr12;
+  if (ds.alloc(Ec, true) != hipSuccess || dsr.alloc(Ec, true) != hipSuccess || dr12.alloc(Ec, true) != hipSuccess) return (gsfm_status)fail(GSFM_ERR_HIP, "alloc outputs");
   const CostArgs base = cost_args(P, P->q.p);
   hipEvent_t e0, e1;
   if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return (gsfm_status)fail(GSFM_ERR_HIP, "event create");
@@ -1974,7 +1976,7 @@ gsfm_status gsfm_rot_time_sweep_variants(gsfm_rot_problem* P, const double* rot,
   int st = 0;
   for (int k = 0; k < 8; ++k) out_ms8[k] = 0.0;
   { CostArgs a = base; st = timed([&] { dispatch<CostArgs, CostLauncher>(P, a, P->nb_cost); }, &out_ms8[0]); }                                   // trial cost: rho value only
-  if (!st) { CostArgs a = base; a.s_out = ds.p; a.rho01_out = dr01.p; a.rho2_out = dr2.p; st = timed([&] { dispatch<CostArgs, CostLauncher>(P, a, P->nb_cost); }, &out_ms8[1]); }  // s + rho triple
+  if (!st) { CostArgs a = base; a.srho_out = dsr.p; a.rho12_out = dr12.p; st = timed([&] { dispatch<CostArgs, CostLauncher>(P, a, P->nb_cost); }, &out_ms8[1]); }  // s + rho triple
   if (!st) { CostArgs a = base; a.s_out = ds.p; a.s_only = 1; st = timed([&] { dispatch<CostArgs, CostLauncher>(P, a, P->nb_cost); }, &out_ms8[2]); }   // s only (callback pass 1)
   if (!st) { CostArgs a = base; a.rho1_out = ds.p; st = timed([&] { dispatch<CostArgs, CostLauncher>(P, a, P->nb_cost); }, &out_ms8[3]); }             // the reweight sweep of SURVEY 8(d): rho' out
   if (!st && P->functor == F_AA && P->wmode == W_SCALAR && P->cost.ws.p && P->dir.ws.p) {
@@ -2047,8 +2049,8 @@ gsfm_status gsfm_rot_matvec_bytes(gsfm_rot_problem* P, double* layout_bytes, dou
     // read once; the gathered vector, the diagonal blocks, p, q in, y out once per camera.  Linearisation, per position: column 4 + local
     // row 2 + slot 2 + q_rel 32 + whitening 48 in, block 48 out; nine partial sums per row and workgroup
     const double n_sub = (double)(P->cs.n_pos / GSFM_COL_SUB);
-    if (layout_bytes) *layout_bytes = 54.0 * (double)P->cs.n_pos + 2.0 * (GSFM_COL_RB + 1) * n_sub + 2.0 * 24.0 * P->cs.n_wg * GSFM_COL_RB + (24.0 + 48.0 + 24.0 + 32.0 + 24.0) * N;
-    if (lin_bytes) *lin_bytes = (88.0 + 48.0) * (double)P->cs.n_pos + 2.0 * (GSFM_COL_RB + 1) * n_sub + 2.0 * 72.0 * P->cs.n_wg * GSFM_COL_RB + (32.0 + 72.0) * N;
+    if (layout_bytes) *layout_bytes = 56.0 * (double)P->cs.n_pos + 4.0 * GSFM_COL_RB * n_sub + 2.0 * 24.0 * P->cs.n_wg * GSFM_COL_RB + (24.0 + 48.0 + 24.0 + 32.0 + 24.0) * N;
+    if (lin_bytes) *lin_bytes = (8.0 + 32.0 + (P->wmode == W_MATRIX ? 48.0 : P->wmode == W_SCALAR ? 8.0 : 0.0) + 48.0) * (double)P->cs.n_pos + 4.0 * GSFM_COL_RB * n_sub + 2.0 * 72.0 * P->cs.n_wg * GSFM_COL_RB + (32.0 + 72.0) * N;
     if (form) *form = 2;
   } else {
     if (layout_bytes) *layout_bytes = (double)P->dir.n * (lap ? 52.0 : 76.0) + 2.0 * 24.0 * N;

@@ -474,9 +474,9 @@ struct CostArgs {
   // optional per-edge outputs (null in the solver loop), in the PROBLEM's edge order (= the order of the streamed planes; position u holds
   // original edge gsfm_rot_edge_order()[u]): every store is a coalesced non-temporal 8 / 16 B per lane.  (Round 2 stored through `eid`
   // into the caller's order: 438 MB written for 320 MB of payload, 0.43 of the HBM roofline.)
-  double* s_out;             // s
-  double2* rho01_out;        // (rho, rho')
-  double* rho2_out;          // rho''
+  double* s_out;             // s alone (s_only mode)
+  double2* srho_out;         // (s, rho)           } the full sweep: two 16-byte stores per lane
+  double2* rho12_out;        // (rho', rho'')      }
   double* rho1_out;          // rho' alone: the reweight sweep of SURVEY 8(d) (8 B out per edge)
   double* r_out;             // residuals, R planes of n
   int s_only;                // 1: write s_out only, skip the loss (callback path, phase 1)
@@ -515,9 +515,8 @@ __device__ __forceinline__ double cost_edge(const CostArgs& a, uint32_t e, const
   Rho3 rho;
   if (a.rho_ext) { const size_t o = 3 * (size_t)a.eid[e]; rho.r0 = a.rho_ext[o]; rho.r1 = a.rho_ext[o + 1]; rho.r2 = a.rho_ext[o + 2]; }
   else rho = loss_eval<LM>(a.loss, s);
-  if (a.s_out) __builtin_nontemporal_store(s, a.s_out + e);
-  if (a.rho01_out) nt_store2(a.rho01_out + e, rho.r0, rho.r1);
-  if (a.rho2_out) __builtin_nontemporal_store(rho.r2, a.rho2_out + e);
+  if (a.srho_out) nt_store2(a.srho_out + e, s, rho.r0);
+  if (a.rho12_out) nt_store2(a.rho12_out + e, rho.r1, rho.r2);
   if (a.rho1_out) __builtin_nontemporal_store(rho.r1, a.rho1_out + e);
   if (a.r_out) {
 #pragma unroll

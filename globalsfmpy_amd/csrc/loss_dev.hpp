@@ -17,6 +17,10 @@ struct DevLossNode {
   //             4 one_over_sigma, 5 weight_zero, 6 cut (= q^2 sigma^2), 7 upper_incomplete_gamma_of_k
   double aux[8];
   double rho1_scale;    // MAGSAC: C 2^((nu-1)/2) / (2 sigma^3), the constant factor of rho' = -weight'(s) (host-precomputed reciprocal)
+  double rho2_scale;    // nu = 3: 2 C 2^((nu-1)/2) / (8 sigma^5), the constant factor of -rho''
+  double e2_clamp;      // nu = 3: exp(-1e-7 / 2 sigma^2), the exponential of rho'' for cells whose s falls below the 1e-7 floor of loss_functions.py:317
+  int32_t x_clamp;      //   ... i.e. for table cells x < x_clamp
+  int32_t pad_;
   const double* table;  // device pointer, Gamma((nu-1)/2, x/1000)
   int32_t table_len;
   int32_t inverse;
@@ -175,6 +179,26 @@ __device__ __forceinline__ double loss_magsac_value(const DevLossNode& n, double
 // scripts/sfm_pipeline.py:136); the nu = 4 / 9 and inverse variants run through the general program.
 enum { LM_PROGRAM = 0, LM_SIMPLE = 1, LM_MAGSAC = 2 };
 
+// The nu = 3, non-inverted MAGSAC weight loss (LM_MAGSAC), all three values from ONE exponential and ONE exact division: with nu = 3 the
+// stored table IS the exponential, Gamma(1, x / 1000) = exp(-x / 1000) (include/gamma_values.cpp regenerates from exactly that), and the
+// derivative formulas of loss_functions.py:308-321 reduce to constants times exp(-s_q / 2 sigma^2) with s_q = x 2 sigma^2 / 1000 the
+// quantised argument, i.e. the same exponential (to ~3 ulp of its argument); the constants are host-precomputed.  The general routine
+// above spends two exp, a table gather and nine IEEE divisions on the same three numbers.  Pinned by the recorded reference rows
+// (tests/test_gpu_loss_golden.py, 1e-12 relative, tie-rounding rows included: the cell index comes from the same exact division).
+__device__ __forceinline__ Rho3 loss_magsac3(const DevLossNode& n, double sq) {
+  bool zero_derivative = false;
+  if (sq > n.aux[6]) { sq = n.aux[6]; zero_derivative = true; }
+  const long x = (long)rint(1000.0 * sq / n.aux[1]);   // Python round(): half to even
+  const double e = exp(-1e-3 * (double)x);
+  Rho3 o;
+  o.r0 = n.aux[5] - __dmul_rn(n.aux[4], e - n.aux[7]);   // (a separately rounded product, as in the reference: keeps rho(0) == 0 exactly; no FMA contraction)
+  o.r1 = n.rho1_scale * e;
+  if (o.r1 == 0.0) o.r1 = 0.00001;
+  o.r2 = -n.rho2_scale * (x < (long)n.x_clamp ? n.e2_clamp : e);
+  if (zero_derivative) { o.r1 = 0.00001; o.r2 = 0.0; }
+  return o;
+}
+
 // rho' alone, for the linearisation (K2) of losses whose rho'' is never positive -- every LM_SIMPLE leaf and the nu = 3 MAGSAC
 // weight loss (rho'' = -C / (8 sigma^5) exp(-u) < 0) -- so that Ceres' Corrector takes its alpha = 0 branch for every edge and
 // needs nothing but sqrt(rho').  nu = 3: weight'(s) = -C 2 exp(-s / 2 sigma^2) / (2 sigma^3) on the quantised s (loss_functions.py:
@@ -219,7 +243,7 @@ __device__ __forceinline__ Rho3 loss_eval_program(const DevLoss* __restrict__ lo
 template <int LM>
 __device__ __forceinline__ Rho3 loss_eval(const DevLoss* __restrict__ loss, double s) {
   if (LM == LM_SIMPLE) return loss_leaf_simple(loss->nodes[0], s);
-  if (LM == LM_MAGSAC) return loss_magsac(loss->nodes[0], s);
+  if (LM == LM_MAGSAC) return loss_magsac3(loss->nodes[0], s);
   return loss_eval_program(loss, s);
 }
 

@@ -33,6 +33,9 @@ int orc_solve(orc_problem* p, double* rot_aa_inout, const gsfm_rot_options* opt,
 int orc_solve_sigma_consensus(orc_problem* p, double* rot_aa_inout, int32_t iters_num, double sigma_max,
                               const gsfm_rot_options* opt, gsfm_rot_summary* summary);
 int32_t orc_get_trace(orc_problem* p, double* out, int32_t cap_rows);
+/* test hook: the linear systems (J^T J + diag(D)^2) y = rhs of the first LM iterations of the next solve, see ref_solver.cpp */
+int orc_capture_steps(orc_problem* p, int32_t max_steps);
+int orc_captured_step(orc_problem* p, int32_t k, double* Ji, double* Jj, double* rt, double* D, double* rhs, double* y, double* scale);
 
 void orc_loss_eval(const gsfm_loss_node* prog, int32_t n, double s, double* out3);
 int32_t orc_magsac_table(int32_t nu, double* out, int32_t cap);

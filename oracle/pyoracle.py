@@ -61,6 +61,8 @@ def lib():
             getattr(L, name).argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.orc_pairwise_rotation_error.argtypes = [C.POINTER(C.c_double)] * 3 + [C.c_double, C.POINTER(C.c_double)]
         L.orc_edge_jacobians.argtypes = [C.c_void_p, C.c_uint64] + [C.POINTER(C.c_double)] * 4
+        L.orc_capture_steps.argtypes = [C.c_void_p, C.c_int32]
+        L.orc_captured_step.argtypes = [C.c_void_p, C.c_int32] + [C.POINTER(C.c_double)] * 7
         L.orc_cov_estimate.argtypes = [C.c_uint64, C.POINTER(C.c_uint64)] + [C.POINTER(C.c_double)] * 4 + [C.c_int32] + [C.POINTER(C.c_double)] * 3 + [C.POINTER(C.c_int32)] * 2
         L.orc_sampson_residual.argtypes = [C.POINTER(C.c_double)] * 5
         L.orc_sampson_residual.restype = C.c_double
@@ -88,6 +90,20 @@ class OracleProblem(ProblemBase):
 
     def set_linear_solver(self, kind):
         self._lib.orc_set_linear_solver(self._h, {"auto": 0, "dense": 1, "pcg": 2}[kind])
+
+    def capture_steps(self, max_steps):
+        """Keep the linear systems of the first `max_steps` LM iterations of the next solve (test hook)."""
+        self._lib.orc_capture_steps(self._h, int(max_steps))
+
+    def captured_step(self, k):
+        """System k of the last solve as dict(Ji, Jj (E x R x 3), rt (E x R), D, rhs, y, scale (3N), cg): (J^T J + diag(D)^2) y = rhs."""
+        E, R, n = self.n_edges, self.residual_dim, 3 * self.n_cams
+        out = {"Ji": np.empty((E, R, 3)), "Jj": np.empty((E, R, 3)), "rt": np.empty((E, R)), "D": np.empty(n), "rhs": np.empty(n), "y": np.empty(n), "scale": np.empty(n)}
+        cg = self._lib.orc_captured_step(self._h, int(k), *[_dp(out[key]) for key in ("Ji", "Jj", "rt", "D", "rhs", "y", "scale")])
+        if cg < 0:
+            raise IndexError("LM iteration %d was not captured" % k)
+        out["cg"] = cg
+        return out
 
     def edge_jacobians(self, e, rot_aa):
         rot = np.ascontiguousarray(rot_aa, dtype=np.float64)

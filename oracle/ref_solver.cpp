@@ -66,6 +66,10 @@ struct orc_problem {
   std::vector<double> rt;      // corrected residuals, res_dim per edge
   std::vector<double> Ji, Jj;  // corrected local jacobians, res_dim x 3 per edge (row-major)
   std::vector<double> trace;   // rows of ORC_TRACE_COLS
+  // test hook (orc_capture_steps): the linear systems of the first LM iterations of the next solve, as the linear solver saw them
+  struct Captured { std::vector<double> Ji, Jj, rt, D, rhs, y, scale; int cg = 0; };
+  int capture_max = 0;
+  std::vector<Captured> captured;
   // camera -> incident edges (edge id | role << 31, role 1 = the camera is `second`), in increasing edge order: the
   // per-camera sums below visit the same terms in the same order as a serial loop over the edges, but in parallel
   std::vector<uint32_t> inc_ptr, inc;
@@ -514,6 +518,11 @@ int lm_solve(orc_problem* p, std::vector<double>& x, const gsfm_rot_options& o, 
     const bool dense = p->linear_solver == 1 || (p->linear_solver == 0 && o.dense_cholesky_max_cams > 0 && (int64_t)N <= (int64_t)o.dense_cholesky_max_cams);
     bool ok = dense ? solve_dense(p, D.data(), rhs.data(), step.data()) : solve_pcg(p, D.data(), rhs.data(), step.data(), &cg);
     sum->num_cg_iterations += cg;
+    if ((int)p->captured.size() < p->capture_max) {   // (J^T J + diag(D)^2) y = rhs with J = [Ji Jj] per edge (column-scaled), before the sign flip
+      orc_problem::Captured c;
+      c.Ji = p->Ji; c.Jj = p->Jj; c.rt = p->rt; c.D = D; c.rhs = rhs; c.y = step; c.scale = scale; c.cg = cg;
+      p->captured.push_back(std::move(c));
+    }
     bool valid = ok;
     for (size_t k = 0; k < n && valid; ++k) if (!std::isfinite(step[k])) valid = false;
     double model_cost_change = 0;
@@ -745,6 +754,24 @@ int orc_solve_sigma_consensus(orc_problem* p, double* rot, int32_t iters_num, do
   total.outer_iterations = outer; total.t_total_ms = now_ms() - t0;
   *summary = total;
   return 0;
+}
+
+// Test hook: keep the linear systems of the first `max_steps` LM iterations of the NEXT solve (0 switches it off and frees them).
+int orc_capture_steps(orc_problem* p, int32_t max_steps) { p->capture_max = max_steps; p->captured.clear(); return 0; }
+// System k of the last solve: (J^T J + diag(D)^2) y = rhs, J = per edge the (res_dim x 3) blocks Ji (column block of `first`) and Jj (of
+// `second`), Corrector and Jacobi column scaling applied; y = what the oracle's linear solver returned; the parameter step is -y * scale.
+// Any output may be NULL.  Returns the PCG iteration count of that solve (0 for the dense solver), -1 if k was not captured.
+int orc_captured_step(orc_problem* p, int32_t k, double* Ji, double* Jj, double* rt, double* D, double* rhs, double* y, double* scale) {
+  if (k < 0 || k >= (int)p->captured.size()) return -1;
+  const orc_problem::Captured& c = p->captured[k];
+  if (Ji) std::memcpy(Ji, c.Ji.data(), 8 * c.Ji.size());
+  if (Jj) std::memcpy(Jj, c.Jj.data(), 8 * c.Jj.size());
+  if (rt) std::memcpy(rt, c.rt.data(), 8 * c.rt.size());
+  if (D) std::memcpy(D, c.D.data(), 8 * c.D.size());
+  if (rhs) std::memcpy(rhs, c.rhs.data(), 8 * c.rhs.size());
+  if (y) std::memcpy(y, c.y.data(), 8 * c.y.size());
+  if (scale) std::memcpy(scale, c.scale.data(), 8 * c.scale.size());
+  return c.cg;
 }
 
 int32_t orc_get_trace(orc_problem* p, double* out, int32_t cap_rows) {
