@@ -118,6 +118,38 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_mv_col_finish(ColFinishArgs a) {
   a.y[3 * k + 2] = mp[2] - (R[6] * t0 + R[7] * t1 + R[8] * t2);
 }
 
+// s = |r_e|^2 of every entry of the layout, written per local edge (the column-sorted twin of k_row_s: host-callback losses on a sharded
+// problem need s for every edge a rank holds).  One workgroup per ColWg, one position per lane and trip.
+struct ColRowSArgs {
+  ColLayoutDev L;
+  uint32_t row_base, n_rows;
+  const uint32_t* eid;
+  const double2 *qr0, *qr1, *w0, *w1, *w2;
+  const double* ws;
+  const double2* q;
+  double* s_out;
+};
+template <int F, int WM>
+__global__ void __launch_bounds__(GSFM_BLOCK) k_col_s(ColRowSArgs a) {
+  constexpr int R = ResDim<F>::R;
+  const ColWg w = a.L.wg[blockIdx.x];
+  for (uint32_t d = w.first_sub * GSFM_COL_SUB + threadIdx.x; d < (w.first_sub + w.n_sub) * GSFM_COL_SUB; d += GSFM_BLOCK) {
+    const uint2 mt = col_load_meta(a.L.meta + d);
+    if (mt.x == GSFM_COL_PAD) continue;
+    const Quat qk = load_q(a.q, a.row_base + w.row0 + (mt.y >> 16)), qm = load_q(a.q, mt.x & 0x7fffffffu);
+    const double2 r0 = a.qr0[d], r1 = a.qr1[d];
+    const Quat qr{r0.x, r0.y, r1.x, r1.y};
+    const EdgeW W = load_w<WM>(a.w0, a.w1, a.w2, a.ws, d);
+    double r[R];
+    if (mt.x >> 31) edge_residual<F, WM>(qm, qk, qr, W, r);
+    else edge_residual<F, WM>(qk, qm, qr, W, r);
+    double s = 0.0;
+#pragma unroll
+    for (int c = 0; c < R; ++c) s += r[c] * r[c];
+    a.s_out[a.eid[d]] = s;
+  }
+}
+
 // ---- K2c ----------------------------------------------------------------------------------------------------------------
 // The linearisation in the same order: one entry per lane and trip, 256 lanes work through a sub-chunk of GSFM_COL_SUB positions in two
 // trips; the nine per-entry contributions to (g, D) of the row camera go through the LDS slots, lanes t and t + 256 own rows t and t + 256

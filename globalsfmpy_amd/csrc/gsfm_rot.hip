@@ -200,7 +200,7 @@ struct gsfm_rot_problem {
   // replayable chunk of PCG iterations (hipGraph), keyed on the by-value kernel arguments it froze
   struct PcgGraph {
     hipGraphExec_t exec = nullptr;
-    double tol = 0; int max_iters = 0, stall = 0, chunk = 0; uint32_t coarse = 0;
+    double tol = 0; int max_iters = 0, stall = 0, chunk = 0, collectives = 0; uint32_t coarse = 0;
     bool unusable = false, lap = false;
     void reset() { if (exec) (void)hipGraphExecDestroy(exec); exec = nullptr; }
   } pcg_graph, pcg2_graph;
@@ -272,6 +272,7 @@ struct gsfm_rot_problem {
 
   bool have_lin = false;
   int graph_launches = 0;
+  int n_collectives = 0, n_pcg_collectives = 0;   // issued (or replayed from a graph) since the solve started
   std::vector<double> trace;
   EventTimer timer;
 };
@@ -339,8 +340,11 @@ template <int F, int W, int L> struct ColLinLauncher {   // K2c (column-sorted l
     if constexpr (F == F_AA || F == F_QCOS) {
       const dim3 g(grid), b(GSFM_COLLIN_THREADS);
       if constexpr (L != LM_PROGRAM) {
-        if (!a.lin.rho_ext && k2_fast_enabled()) hipLaunchKernelGGL((k_lin_col<F, W, L, true>), g, b, 0, s, a);
-        else hipLaunchKernelGGL((k_lin_col<F, W, L, false>), g, b, 0, s, a);
+        const char* e = getenv("GSFM_K2C_FREE");   // A/B: registers at the compiler's choice (2 waves per SIMD, no spill) instead of >= 3 waves
+        if (!a.lin.rho_ext && k2_fast_enabled()) {
+          if (e && atoi(e) == 1) hipLaunchKernelGGL((k_lin_col_free<F, W, L, true>), g, b, 0, s, a);
+          else hipLaunchKernelGGL((k_lin_col<F, W, L, true>), g, b, 0, s, a);
+        } else hipLaunchKernelGGL((k_lin_col<F, W, L, false>), g, b, 0, s, a);
       } else hipLaunchKernelGGL((k_lin_col_free<F, W, L, false>), g, b, 0, s, a);
     }
   }
@@ -433,11 +437,13 @@ int prepare_loss(gsfm_rot_problem* P, const gsfm_loss_node* prog, int n) {
 // ---- collectives --------------------------------------------------------------------------
 int all_gather(gsfm_rot_problem* P, double* buf, size_t count_per_rank) {
   if (!P->sharded) return 0;
+  P->n_collectives++;
   if (P->shard.all_gather(P->shard.ctx, buf, count_per_rank, (void*)P->stream) != 0) return fail(GSFM_ERR_COMM, "all_gather callback failed");
   return 0;
 }
 int all_reduce(gsfm_rot_problem* P, double* buf, size_t count) {
   if (!P->sharded) return 0;
+  P->n_collectives++;
   if (P->shard.all_reduce_sum(P->shard.ctx, buf, count, (void*)P->stream) != 0) return fail(GSFM_ERR_COMM, "all_reduce callback failed");
   return 0;
 }
@@ -452,6 +458,19 @@ void launch_cache(gsfm_rot_problem* P, const double* x, double2* q) {
 
 // s of every edge this rank holds, by rows (sharded problems): see k_row_s
 int launch_row_s(gsfm_rot_problem* P, const double2* q, double* s_out, bool unit_weights) {
+  if (P->cs.active) {   // column-sorted layout (Laplacian-capable functors only); unit_weights is no longer asked for by any caller
+    ColRowSArgs ca{};
+    ca.L = P->cs.dev(); ca.row_base = P->own_begin; ca.n_rows = P->n_rows; ca.eid = P->dir.eid.p; ca.qr0 = P->dir.qr0.p; ca.qr1 = P->dir.qr1.p;
+    ca.w0 = P->dir.w0.p; ca.w1 = P->dir.w1.p; ca.w2 = P->dir.w2.p; ca.ws = P->dir.ws.p; ca.q = q; ca.s_out = s_out;
+    const dim3 grid(P->cs.n_wg), blk(GSFM_BLOCK);
+    if (unit_weights) return fail(GSFM_ERR_UNSUPPORTED, "unit-weight row sweep on the column-sorted layout");
+    if (P->functor == F_AA && P->wmode == W_NONE) hipLaunchKernelGGL((k_col_s<F_AA, W_NONE>), grid, blk, 0, P->stream, ca);
+    else if (P->functor == F_AA && P->wmode == W_SCALAR) hipLaunchKernelGGL((k_col_s<F_AA, W_SCALAR>), grid, blk, 0, P->stream, ca);
+    else if (P->functor == F_AA && P->wmode == W_MATRIX) hipLaunchKernelGGL((k_col_s<F_AA, W_MATRIX>), grid, blk, 0, P->stream, ca);
+    else if (P->functor == F_QCOS) hipLaunchKernelGGL((k_col_s<F_QCOS, W_NONE>), grid, blk, 0, P->stream, ca);
+    else return fail(GSFM_ERR_UNSUPPORTED, "no kernel for this error type");
+    return 0;
+  }
   RowSArgs ra{};
   ra.n_rows = P->n_rows; ra.row_base = P->own_begin; ra.G = P->G; ra.row_ptr = P->row_ptr.p; ra.col = P->col.p; ra.eid = P->dir.eid.p;
   ra.qr0 = P->dir.qr0.p; ra.qr1 = P->dir.qr1.p; ra.w0 = P->dir.w0.p; ra.w1 = P->dir.w1.p; ra.w2 = P->dir.w2.p; ra.ws = P->dir.ws.p; ra.q = q; ra.s_out = s_out;
@@ -664,6 +683,16 @@ int coarse_build(gsfm_rot_problem* P, bool pcg_struggles) {
   return 0;
 }
 
+// May a chunk of PCG iterations of a SHARDED problem be captured into a hipGraph together with its collectives?  Only if the
+// communicator's callbacks do nothing but enqueue work on the solver's stream (GSFM_SHARD_CAPTURABLE: the native RCCL communicator).
+// pcg_hip_graph = 1 (default) then captures; 2 is the old explicit opt-in and means the same; GSFM_PCG_GRAPH_COLLECTIVES=0 switches the
+// capture of collectives off (plain launches), e.g. to isolate a communicator problem.
+bool graph_collectives_ok(const gsfm_rot_problem* P, const gsfm_rot_options& o) {
+  if (!(P->shard.flags & GSFM_SHARD_CAPTURABLE) || o.pcg_hip_graph < 1) return false;
+  const char* e = getenv("GSFM_PCG_GRAPH_COLLECTIVES");
+  return !(e && *e && atoi(e) == 0);
+}
+
 // block-Jacobi PCG on (J^T J + Lambda) eta = -g; returns iterations
 int run_pcg(gsfm_rot_problem* P, const gsfm_rot_options& o, int* iters_out, double* rel_out) {
   CgArgs a{};
@@ -695,6 +724,7 @@ int run_pcg(gsfm_rot_problem* P, const gsfm_rot_options& o, int* iters_out, doub
   auto enqueue_chunk = [&]() -> int {  // `chunk` iterations; leaves a.par where it found it when chunk is even
     for (int c = 0; c < chunk; ++c) {
       if (int st = launch_matvec(P, P->Mblk.p, P->p.p, P->Ap.p, &P->cgsc.p->done)) return st;
+      if (P->sharded) P->n_pcg_collectives++;
       hipLaunchKernelGGL(k_cg_dot, g, blk, 0, P->stream, a);
       hipLaunchKernelGGL(k_cg_update, g, blk, 0, P->stream, a);
       if (a.coarse_n) {
@@ -708,13 +738,16 @@ int run_pcg(gsfm_rot_problem* P, const gsfm_rot_options& o, int* iters_out, doub
   };
   // The chunk between two host checks as one hipGraph launch: 4 * chunk dependent kernels whose arguments never change.
   auto& G = P->pcg_graph;
-  bool graph = o.pcg_hip_graph && (!P->sharded || (o.pcg_hip_graph >= 2 && (P->shard.flags & GSFM_SHARD_CAPTURABLE))) && chunk % 2 == 0 && !G.unusable;
+  bool graph = o.pcg_hip_graph && (!P->sharded || graph_collectives_ok(P, o)) && chunk % 2 == 0 && !G.unusable;
   if (graph && (!G.exec || G.tol != a.tol || G.max_iters != a.max_iters || G.stall != a.stall_limit || G.chunk != chunk || G.lap != P->lin_is_lap || G.coarse != a.coarse_n)) {
     G.reset();
     hipGraph_t captured = nullptr;
     if (hipStreamBeginCapture(P->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+      const int c0 = P->n_collectives, p0 = P->n_pcg_collectives;
       const int st = enqueue_chunk();
       const hipError_t e = hipStreamEndCapture(P->stream, &captured);
+      G.collectives = P->n_collectives - c0;            // captured, not issued: counted per replay below
+      P->n_collectives = c0; P->n_pcg_collectives = p0;
       if (st == 0 && e == hipSuccess && captured && hipGraphInstantiate(&G.exec, captured, nullptr, nullptr, 0) == hipSuccess) {
         G.tol = a.tol; G.max_iters = a.max_iters; G.stall = a.stall_limit; G.chunk = chunk; G.lap = P->lin_is_lap; G.coarse = a.coarse_n;
       } else { G.exec = nullptr; }
@@ -726,7 +759,7 @@ int run_pcg(gsfm_rot_problem* P, const gsfm_rot_options& o, int* iters_out, doub
   while (true) {
     const int tk = P->timer.begin(T_CG);
     for (int c = 0; c < chunks; ++c) {
-      if (graph) { HIPCHK(hipGraphLaunch(G.exec, P->stream)); P->graph_launches++; }
+      if (graph) { HIPCHK(hipGraphLaunch(G.exec, P->stream)); P->graph_launches++; P->n_collectives += G.collectives; P->n_pcg_collectives += G.collectives; }
       else if (int st = enqueue_chunk()) return st;
       launched += chunk;
     }
@@ -774,6 +807,7 @@ int run_pcg2(gsfm_rot_problem* P, const gsfm_rot_options& o, int* iters_out, dou
     else hipLaunchKernelGGL(k_matvec_cg<false>, gmv, blk, 0, P->stream, m);
     if (P->sharded) {
       if (int st = all_gather(P, P->Ap.p, (size_t)P->shard.slice_width * 3)) return st;
+      P->n_pcg_collectives++;
       hipLaunchKernelGGL(k_cg2_dots, gcam, blk, 0, P->stream, c);
     }
     hipLaunchKernelGGL(k_cg2_step, gcam, blk, 0, P->stream, c);
@@ -787,14 +821,17 @@ int run_pcg2(gsfm_rot_problem* P, const gsfm_rot_options& o, int* iters_out, dou
     P->timer.end(tk);
   }
   auto& G = P->pcg2_graph;
-  bool graph = o.pcg_hip_graph && (!P->sharded || (o.pcg_hip_graph >= 2 && (P->shard.flags & GSFM_SHARD_CAPTURABLE))) && chunk % 2 == 0 && !G.unusable && !P->pcg_graph.unusable;
+  bool graph = o.pcg_hip_graph && (!P->sharded || graph_collectives_ok(P, o)) && chunk % 2 == 0 && !G.unusable && !P->pcg_graph.unusable;
   if (graph && (!G.exec || G.tol != c.tol || G.max_iters != c.max_iters || G.chunk != chunk || G.lap != P->lin_is_lap)) {
     G.reset();
     hipGraph_t captured = nullptr;
     if (hipStreamBeginCapture(P->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
       int st = 0;
+      const int c0 = P->n_collectives, p0 = P->n_pcg_collectives;
       for (int k = 0; k < chunk && st == 0; ++k) st = enqueue_iter();
       const hipError_t e = hipStreamEndCapture(P->stream, &captured);
+      G.collectives = P->n_collectives - c0;
+      P->n_collectives = c0; P->n_pcg_collectives = p0;
       if (st == 0 && e == hipSuccess && captured && hipGraphInstantiate(&G.exec, captured, nullptr, nullptr, 0) == hipSuccess) {
         G.tol = c.tol; G.max_iters = c.max_iters; G.chunk = chunk; G.lap = P->lin_is_lap;
       } else { G.exec = nullptr; }
@@ -806,7 +843,7 @@ int run_pcg2(gsfm_rot_problem* P, const gsfm_rot_options& o, int* iters_out, dou
   while (true) {
     const int tk = P->timer.begin(T_CG);
     for (int cc = 0; cc < chunks; ++cc) {
-      if (graph) { HIPCHK(hipGraphLaunch(G.exec, P->stream)); P->graph_launches++; }
+      if (graph) { HIPCHK(hipGraphLaunch(G.exec, P->stream)); P->graph_launches++; P->n_collectives += G.collectives; P->n_pcg_collectives += G.collectives; }
       else { for (int k = 0; k < chunk; ++k) if (int st = enqueue_iter()) return st; }
       launched += chunk;
     }
@@ -1018,6 +1055,8 @@ int lm_solve(gsfm_rot_problem* P, const gsfm_rot_options& o_in, gsfm_rot_summary
   // reference's Cholesky solves every block exactly).  Disconnected problems therefore never run looser than 1e-14.
   gsfm_rot_options o = o_in;
   if (P->n_components > 1) o.cg_relative_tolerance = std::min(o.cg_relative_tolerance, 1e-14);
+  if (o.verbose && o.cg_relative_tolerance != o_in.cg_relative_tolerance)
+    fprintf(stderr, "[gsfm] the view graph has %u connected components: PCG runs to a relative residual of %.0e instead of the requested %.0e\n", P->n_components, o.cg_relative_tolerance, o_in.cg_relative_tolerance);
   const double t0 = now_ms();
   std::memset(sum, 0, sizeof(*sum));
   sum->iters_to_1e6 = -1;
@@ -1025,6 +1064,7 @@ int lm_solve(gsfm_rot_problem* P, const gsfm_rot_options& o_in, gsfm_rot_summary
   P->trace.clear();
   P->timer.acc[0] = P->timer.acc[1] = P->timer.acc[2] = 0;
   P->graph_launches = 0;
+  P->n_collectives = P->n_pcg_collectives = 0;
   P->lap = P->lap_capable;
   double h[SC_N];
   double radius = o.initial_trust_region_radius, decrease_factor = 2.0;
@@ -1041,6 +1081,7 @@ int lm_solve(gsfm_rot_problem* P, const gsfm_rot_options& o_in, gsfm_rot_summary
     sum->termination = term; sum->num_iterations = iteration; sum->final_cost = x_cost; sum->final_gradient_max_norm = gmax;
     sum->final_radius = radius; sum->t_total_ms = now_ms() - t0;
     sum->num_graph_launches = P->graph_launches;
+    sum->num_collectives = P->n_collectives; sum->num_pcg_collectives = P->n_pcg_collectives;
     sum->t_linearize_ms = P->timer.acc[T_LIN]; sum->t_sweep_ms = P->timer.acc[T_SWEEP]; sum->t_cg_ms = P->timer.acc[T_CG];
     if (!std::isfinite(x_cost)) sum->nonfinite = 1;
     return 0;
@@ -1259,34 +1300,31 @@ gsfm_status gsfm_rot_problem_create(uint32_t n_cams, uint64_t n_edges, const uin
   *out = nullptr;
   // (one rank of a sharded problem may hold no edge at all -- a slice of isolated cameras -- and still takes part in every collective)
   const bool multi_rank = shard && (shard->world_size > 1 || (shard->world_size == 1 && getenv("GSFM_FORCE_SHARD")));
-  if (n_cams == 0 || (n_edges == 0 && !multi_rank)) return (gsfm_status)fail(GSFM_ERR_EMPTY, "no cameras or no edges");
-  if (n_edges > 0 && (!edge_i_in || !edge_j_in || !rel_aa)) return (gsfm_status)fail(GSFM_ERR_INVALID_ARG, "NULL edge arrays");
-  if (error_type < 0 || error_type > 8) return (gsfm_status)fail(GSFM_ERR_INVALID_ARG, "unknown rotation error type");
-  if (n_cams >= 0x7fffffffu || n_edges >= 0x7fffffffull) return (gsfm_status)fail(GSFM_ERR_INVALID_ARG, "problem too large for 31-bit indices");
-  const bool need_cov = error_type == GSFM_ROT_ANGLE_AXIS_COVARIANCE || error_type == GSFM_ROT_ANGLE_AXIS_COV_INLIERS ||
-                        error_type == GSFM_ROT_ANGLE_AXIS_COVTRACE || error_type == GSFM_ROT_ANGLE_AXIS_COVNORM;
-  const bool need_inl = error_type == GSFM_ROT_ANGLE_AXIS_INLIERS || error_type == GSFM_ROT_ANGLE_AXIS_COV_INLIERS;
-  if (need_cov && !cov6) return (gsfm_status)fail(GSFM_ERR_INVALID_ARG, "this error type needs per-edge covariances (cov6)");
-  if (need_inl && !inlier_weight) return (gsfm_status)fail(GSFM_ERR_INVALID_ARG, "this error type needs per-edge inlier weights");
+  // Two failures cannot be agreed about with the other ranks and return at once: a descriptor without callbacks (there is nothing to call)
+  // and a process without a HIP device (the callbacks take device pointers).  Everything else below goes through bail().
+  if (multi_rank && (!shard->all_gather || !shard->all_reduce_sum)) return (gsfm_status)fail(GSFM_ERR_INVALID_ARG, "bad shard descriptor: missing collective callbacks");
   if (const char* why = no_device_reason("the rotation solver")) return (gsfm_status)fail(GSFM_ERR_NO_DEVICE, why);
 
   gsfm_rot_problem* P = new gsfm_rot_problem;
-  // Sharded: a rank-local failure (bad edge, allocation, upload) must not leave the other ranks blocked in the first collective.
-  // Every rank therefore passes through exactly one agreement all-reduce before it -- on the failure path from bail(), on the
-  // success path right before the all-gather of the active mask -- and all ranks give up together if any of them failed.
+  // Sharded: a rank-local failure (bad argument, bad edge, allocation, upload, loss set-up) must not leave the other ranks blocked in a
+  // collective.  Every rank passes through exactly ONE agreement all-reduce -- on the failure path from bail(), on the success path after
+  // ALL of its local work -- carrying (failed?, votes against the two-level preconditioner); all ranks give up together if any of them
+  // failed.  What follows the agreement are collectives only (active mask, component labels): they fail on every rank or on none.
   bool agreed = false;
   DevBuf<double> agree_buf;
-  auto agree = [&](double my_flag) -> int {   // number of ranks that failed, or -1 if the agreement itself could not be run
+  double coarse_votes_against = 0.0;
+  auto agree = [&](double my_flag, double my_vote) -> int {   // number of ranks that failed, or -1 if the agreement itself could not be run
     agreed = true;
     if (!P->sharded) return 0;
-    double h = my_flag;
-    if (agree_buf.alloc(1) != hipSuccess || hipMemcpy(agree_buf.p, &h, 8, hipMemcpyHostToDevice) != hipSuccess) return -1;
-    if (all_reduce(P, agree_buf.p, 1) != 0) return -1;
-    if (hipStreamSynchronize(P->stream) != hipSuccess || hipMemcpy(&h, agree_buf.p, 8, hipMemcpyDeviceToHost) != hipSuccess) return -1;
-    return (int)(h + 0.5);
+    double h[2] = {my_flag, my_vote};
+    if (agree_buf.alloc(2) != hipSuccess || hipMemcpy(agree_buf.p, h, 16, hipMemcpyHostToDevice) != hipSuccess) return -1;
+    if (all_reduce(P, agree_buf.p, 2) != 0) return -1;
+    if (hipStreamSynchronize(P->stream) != hipSuccess || hipMemcpy(h, agree_buf.p, 16, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    coarse_votes_against = h[1];
+    return (int)(h[0] + 0.5);
   };
   auto bail = [&](int st) {
-    if (P->sharded && !agreed) { const std::string keep = g_err; (void)agree(1.0); g_err = keep; }
+    if (P->sharded && !agreed) { const std::string keep = g_err; (void)agree(1.0, 1.0); g_err = keep; }
     gsfm_rot_problem_destroy(P);
     return (gsfm_status)st;
   };
@@ -1294,6 +1332,23 @@ gsfm_status gsfm_rot_problem_create(uint32_t n_cams, uint64_t n_edges, const uin
   double lap_t = now_ms();
   auto lap = [&](const char* what) { if (lap_on) { const double t = now_ms(); fprintf(stderr, "gsfm create: %-28s %8.1f ms\n", what, t - lap_t); lap_t = t; } };
   (void)hipGetDevice(&P->device);
+  if (hipStreamCreateWithFlags(&P->stream, hipStreamNonBlocking) != hipSuccess) { P->stream = nullptr; (void)hipGetLastError(); }   // (checked below, after the shard set-up)
+  else P->own_stream = true;
+  P->timer.stream = P->stream; P->timer.init();
+  // GSFM_FORCE_SHARD=1 keeps the collective code path alive for a single rank (tests on a 1-GPU box)
+  if (multi_rank) { P->sharded = true; P->shard = *shard; }   // from here on a failure reaches the other ranks through bail()
+  if (!P->own_stream) return bail(fail(GSFM_ERR_HIP, "hipStreamCreate failed"));
+  if (multi_rank && (shard->slice_width == 0 || shard->rank < 0 || shard->rank >= shard->world_size || (uint64_t)shard->slice_width * shard->world_size < n_cams))
+    return bail(fail(GSFM_ERR_INVALID_ARG, "bad shard descriptor"));
+  if (n_cams == 0 || (n_edges == 0 && !multi_rank)) return bail(fail(GSFM_ERR_EMPTY, "no cameras or no edges"));
+  if (n_edges > 0 && (!edge_i_in || !edge_j_in || !rel_aa)) return bail(fail(GSFM_ERR_INVALID_ARG, "NULL edge arrays"));
+  if (error_type < 0 || error_type > 8) return bail(fail(GSFM_ERR_INVALID_ARG, "unknown rotation error type"));
+  if (n_cams >= 0x7fffffffu || n_edges >= 0x7fffffffull) return bail(fail(GSFM_ERR_INVALID_ARG, "problem too large for 31-bit indices"));
+  const bool need_cov = error_type == GSFM_ROT_ANGLE_AXIS_COVARIANCE || error_type == GSFM_ROT_ANGLE_AXIS_COV_INLIERS ||
+                        error_type == GSFM_ROT_ANGLE_AXIS_COVTRACE || error_type == GSFM_ROT_ANGLE_AXIS_COVNORM;
+  const bool need_inl = error_type == GSFM_ROT_ANGLE_AXIS_INLIERS || error_type == GSFM_ROT_ANGLE_AXIS_COV_INLIERS;
+  if (need_cov && !cov6) return bail(fail(GSFM_ERR_INVALID_ARG, "this error type needs per-edge covariances (cov6)"));
+  if (need_inl && !inlier_weight) return bail(fail(GSFM_ERR_INVALID_ARG, "this error type needs per-edge inlier weights"));
   P->n_cams = n_cams; P->n_edges_in = n_edges; P->error_type = error_type;
   P->functor = error_type == GSFM_ROT_QUATERNION_COSINE ? F_QCOS : error_type == GSFM_ROT_QUATERNION_NORM ? F_QNORM
                : error_type == GSFM_ROT_ROTATION_MAT_FNORM ? F_RFNORM : F_AA;
@@ -1302,20 +1357,12 @@ gsfm_status gsfm_rot_problem_create(uint32_t n_cams, uint64_t n_edges, const uin
   P->wmode = (error_type == GSFM_ROT_ANGLE_AXIS_COVARIANCE || error_type == GSFM_ROT_ANGLE_AXIS_COV_INLIERS) ? W_MATRIX
              : (error_type == GSFM_ROT_ANGLE_AXIS_INLIERS || error_type == GSFM_ROT_ANGLE_AXIS_COVTRACE || error_type == GSFM_ROT_ANGLE_AXIS_COVNORM) ? W_SCALAR
              : W_NONE;
-  // GSFM_FORCE_SHARD=1 keeps the collective code path alive for a single rank (tests on a 1-GPU box)
   if (multi_rank) {
-    if (!shard->all_gather || !shard->all_reduce_sum || shard->slice_width == 0 || shard->rank < 0 || shard->rank >= shard->world_size ||
-        (uint64_t)shard->slice_width * shard->world_size < n_cams)
-      return bail(fail(GSFM_ERR_INVALID_ARG, "bad shard descriptor"));
-    P->sharded = true; P->shard = *shard;
     P->own_begin = std::min<uint64_t>((uint64_t)shard->rank * shard->slice_width, n_cams);
     P->own_end = std::min<uint64_t>((uint64_t)(shard->rank + 1) * shard->slice_width, n_cams);
     P->n_pad = shard->slice_width * shard->world_size;
   } else { P->own_begin = 0; P->own_end = n_cams; P->n_pad = n_cams; P->shard.slice_width = n_cams; P->shard.world_size = 1; }
   P->n_rows = P->own_end - P->own_begin;
-  if (hipStreamCreateWithFlags(&P->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(GSFM_ERR_HIP, "hipStreamCreate failed"));
-  P->own_stream = true;
-  P->timer.stream = P->stream; P->timer.init();
   if (hipHostMalloc(&P->pin, 256, hipHostMallocDefault) != hipSuccess) { P->pin = nullptr; (void)hipGetLastError(); }   // (read_back then copies to pageable memory)
 
   // ---- host-side structure: directed entries by row (counting sort), cost-owned edges ----
@@ -1529,7 +1576,10 @@ gsfm_status gsfm_rot_problem_create(uint32_t n_cams, uint64_t n_edges, const uin
     const char* env = getenv("GSFM_K3_COLSORT");
     const int mode = env && *env ? atoi(env) : -1;
     const bool lap_ok = (P->functor == F_AA || P->functor == F_QCOS) && !(getenv("GSFM_LAPLACIAN") && atoi(getenv("GSFM_LAPLACIAN")) == 0);
-    if (lap_ok && !P->sharded && nd > 0 && (mode > 0 || (mode < 0 && nd >= (size_t)4000000 && P->coarse_want == 0 && P->perm.empty()))) {
+    // What makes it pay is line sharing in the gathers: about one entry per camera and row block, i.e. rows of 512 * mean degree >= ~n_cams / 2
+    // entries (C5: 102k entries per block for 100k cameras, on one GPU and on every rank of a sharded run alike); sparser blocks gain nothing.
+    const double per_block = P->n_rows ? (double)GSFM_COL_RB * (double)nd / (double)P->n_rows : 0.0;
+    if (lap_ok && nd > 0 && (mode > 0 || (mode < 0 && nd >= (size_t)1000000 && per_block >= 0.5 * (double)n_cams && P->coarse_want == 0 && P->perm.empty()))) {
       if (int st = build_colsort(P, rp, col, deid, n_host_threads)) return bail(st);
       if (P->cs.active) { P->coarse_want = 0; P->coarse_adaptive = false; }
     }
@@ -1600,22 +1650,53 @@ gsfm_status gsfm_rot_problem_create(uint32_t n_cams, uint64_t n_edges, const uin
     std::vector<double> act(NP, 0.0);
     for (uint32_t r = 0; r < P->n_rows; ++r) act[ob + r] = (rp[r + 1] > rp[r]) ? 1.0 : 0.0;
     if (hipMemcpy(P->active.p, act.data(), 8 * NP, hipMemcpyHostToDevice) != hipSuccess) return bail(fail(GSFM_ERR_HIP, "upload active mask"));
-    if (P->sharded) {
-      const int failed = agree(0.0);
-      if (failed != 0) return bail(fail(GSFM_ERR_COMM, failed > 0 ? "problem creation failed on " + std::to_string(failed) + " other rank(s)" : std::string("the create-time agreement all-reduce failed")));
-    }
-    if (int st = all_gather(P, P->active.p, P->shard.slice_width)) return bail(st);
-    if (P->sharded && hipStreamSynchronize(P->stream) != hipSuccess) return bail(fail(GSFM_ERR_HIP, "active mask all-gather failed"));
-    if (P->sharded) {   // the two-level preconditioner is used only if every rank chose it (each judged the coherence of its own edges)
-      double vote = (P->coarse_want && !P->coarse_adaptive) ? 0.0 : 1.0;   // number of ranks against (the wait-and-see mode is single-GPU only)
-      if (agree_buf.alloc(1) != hipSuccess || hipMemcpy(agree_buf.p, &vote, 8, hipMemcpyHostToDevice) != hipSuccess) return bail(fail(GSFM_ERR_HIP, "coarse-space vote"));
-      if (int st = all_reduce(P, agree_buf.p, 1)) return bail(st);
-      if (hipStreamSynchronize(P->stream) != hipSuccess || hipMemcpy(&vote, agree_buf.p, 8, hipMemcpyDeviceToHost) != hipSuccess) return bail(fail(GSFM_ERR_HIP, "coarse-space vote"));
-      if (vote > 0.5) P->coarse_want = 0;
-    }
   }
   if (int st = prepare_loss(P, nullptr, 0)) return bail(st);
+  // connected components among this rank's own edges, as one label per camera (the smallest camera index of its component; untouched
+  // cameras label themselves): merged across the ranks below
+  std::vector<uint32_t> comp_label;
+  DevBuf<double> d_labels;
+  if (P->sharded) {
+    comp_label.resize(NP);
+    for (uint32_t c = 0; c < NP; ++c) comp_label[c] = c;
+    auto find = [&](uint32_t v) { while (comp_label[v] != v) { comp_label[v] = comp_label[comp_label[v]]; v = comp_label[v]; } return v; };
+    for (uint64_t e = 0; e < n_edges; ++e) { const uint32_t a = find(edge_i[e]), b = find(edge_j[e]); if (a != b) comp_label[a < b ? b : a] = a < b ? a : b; }
+    for (uint32_t c = 0; c < NP; ++c) comp_label[c] = find(c);
+    if (d_labels.alloc((size_t)P->shard.world_size * NP) != hipSuccess) return bail(fail(GSFM_ERR_HIP, "allocating the component labels failed"));
+    std::vector<double> lab(NP);
+    for (uint32_t c = 0; c < NP; ++c) lab[c] = (double)comp_label[c];
+    if (hipMemcpy(d_labels.p + (size_t)P->shard.rank * NP, lab.data(), 8 * NP, hipMemcpyHostToDevice) != hipSuccess) return bail(fail(GSFM_ERR_HIP, "upload component labels"));
+  }
   lap("camera buffers");
+  // ---- the agreement (sharded), then collectives only ----
+  if (P->sharded) {
+    // the two-level preconditioner is used only if every rank chose it (each judged the coherence of its own edges; the wait-and-see mode is single-GPU only)
+    const int failed = agree(0.0, (P->coarse_want && !P->coarse_adaptive) ? 0.0 : 1.0);
+    if (failed != 0) return bail(fail(GSFM_ERR_COMM, failed > 0 ? "problem creation failed on " + std::to_string(failed) + " other rank(s)" : std::string("the create-time agreement all-reduce failed")));
+    if (coarse_votes_against > 0.5) P->coarse_want = 0;
+    if (int st = all_gather(P, P->active.p, P->shard.slice_width)) return bail(st);
+    if (int st = all_gather(P, d_labels.p, NP)) return bail(st);
+    std::vector<double> all((size_t)P->shard.world_size * NP);
+    if (hipStreamSynchronize(P->stream) != hipSuccess || hipMemcpy(all.data(), d_labels.p, 8 * all.size(), hipMemcpyDeviceToHost) != hipSuccess)
+      return bail(fail(GSFM_ERR_HIP, "active mask / component labels all-gather failed"));
+    // A rank of a sharded problem sees only its own edges, so whether the GLOBAL view graph is connected -- which decides the PCG tolerance,
+    // see lm_solve -- is worked out here from every rank's local components (union of "c and its local label are connected" over all
+    // ranks), identically on every rank.  (Round 2 relied on a flag the partitioner had to set; a raw C-ABI user who forgot it got a looser
+    // solve than on one GPU.  The flag is still honoured.)
+    std::vector<uint32_t> parent(NP);
+    for (uint32_t c = 0; c < NP; ++c) parent[c] = c;
+    auto find = [&](uint32_t v) { while (parent[v] != v) { parent[v] = parent[parent[v]]; v = parent[v]; } return v; };
+    for (int r = 0; r < P->shard.world_size; ++r)
+      for (uint32_t c = 0; c < NP; ++c) {
+        const uint32_t l = (uint32_t)all[(size_t)r * NP + c];
+        if (l != c && l < NP) { const uint32_t a = find(c), b = find(l); if (a != b) parent[a < b ? b : a] = a < b ? a : b; }
+      }
+    std::vector<double> act(NP);
+    if (hipMemcpy(act.data(), P->active.p, 8 * NP, hipMemcpyDeviceToHost) != hipSuccess) return bail(fail(GSFM_ERR_HIP, "download active mask"));
+    uint32_t comps = 0;
+    for (uint32_t c = 0; c < NP; ++c) if (act[c] != 0.0 && find(c) == c) ++comps;
+    P->n_components = std::max<uint32_t>(std::max<uint32_t>(1, comps), (P->shard.flags & GSFM_SHARD_DISCONNECTED) ? 2u : 1u);
+  }
   *out = P;
   return GSFM_OK;
 }
@@ -1748,6 +1829,7 @@ gsfm_status gsfm_rot_solve_sigma_consensus(gsfm_rot_problem* P, double* rot, int
       total.final_cost = summary->final_cost; total.termination = summary->termination;
       total.final_gradient_max_norm = summary->final_gradient_max_norm; total.final_radius = summary->final_radius;
       total.num_dense_solves += summary->num_dense_solves; total.num_graph_launches += summary->num_graph_launches;
+      total.num_collectives += summary->num_collectives; total.num_pcg_collectives += summary->num_pcg_collectives;
       total.t_linearize_ms += summary->t_linearize_ms; total.t_sweep_ms += summary->t_sweep_ms; total.t_cg_ms += summary->t_cg_ms;
     }
     total.last_weight_change = avg;

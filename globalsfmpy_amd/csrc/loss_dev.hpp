@@ -186,12 +186,13 @@ enum { LM_PROGRAM = 0, LM_SIMPLE = 1, LM_MAGSAC = 2 };
 // above spends two exp, a table gather and nine IEEE divisions on the same three numbers.  Pinned by the recorded reference rows
 // (tests/test_gpu_loss_golden.py, 1e-12 relative, tie-rounding rows included: the cell index comes from the same exact division).
 __device__ __forceinline__ Rho3 loss_magsac3(const DevLossNode& n, double sq) {
+#pragma clang fp contract(off)   // rho = w(0) - w(s) must round the product before the subtraction, like the reference: rho(0) == 0 exactly
   bool zero_derivative = false;
   if (sq > n.aux[6]) { sq = n.aux[6]; zero_derivative = true; }
   const long x = (long)rint(1000.0 * sq / n.aux[1]);   // Python round(): half to even
   const double e = exp(-1e-3 * (double)x);
   Rho3 o;
-  o.r0 = n.aux[5] - __dmul_rn(n.aux[4], e - n.aux[7]);   // (a separately rounded product, as in the reference: keeps rho(0) == 0 exactly; no FMA contraction)
+  o.r0 = n.aux[5] - n.aux[4] * (e - n.aux[7]);
   o.r1 = n.rho1_scale * e;
   if (o.r1 == 0.0) o.r1 = 0.00001;
   o.r2 = -n.rho2_scale * (x < (long)n.x_clamp ? n.e2_clamp : e);

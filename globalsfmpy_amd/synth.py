@@ -173,6 +173,7 @@ def spanning_tree_init(g, seed=0, inlier_matches=(150, 1500), outlier_matches=(1
     m[out] = rng.integers(outlier_matches[0], outlier_matches[1], int(out.sum()))
     tree = minimum_spanning_tree(sp.coo_matrix((-m.astype(np.float64), (ei, ej)), shape=(n, n)).tocsr())
     order, pred = breadth_first_order(tree + tree.T, 0, directed=False)
+    order, pred = order.astype(np.int64), pred.astype(np.int64)   # (scipy returns int32: lo * n + hi below would overflow from 46k cameras on)
     keys = ei * n + ej
     srt = np.argsort(keys, kind="stable")
     q_rel = aa_to_quat(g["rel_aa"])

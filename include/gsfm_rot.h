@@ -160,10 +160,11 @@ typedef struct {
                                           (2-4 dependent kernels each) is captured once into a hipGraph and replayed -- the loop is
                                           launch-latency-bound on small graphs.  Same kernels, same order, same iterates.  Falls back to
                                           plain launches when the problem runs on a stream that cannot be captured (the legacy default stream).
-                                          On a sharded problem the chunk contains the collective callbacks: 1 leaves it to plain launches,
-                                          2 captures it too -- only honoured when the shard descriptor carries GSFM_SHARD_CAPTURABLE (the native RCCL
-                                          communicator, csrc/gsfm_rccl.cpp: RCCL collectives are stream-capturable); host-staged callbacks
-                                          (gloo) keep plain launches. */
+                                          On a sharded problem the chunk contains the collective callbacks: it is captured (collectives included)
+                                          when the shard descriptor carries GSFM_SHARD_CAPTURABLE (the native RCCL communicator,
+                                          csrc/gsfm_rccl.cpp: RCCL collectives are stream-capturable) -- the default since round 3, 2 is the old
+                                          explicit opt-in and means the same, GSFM_PCG_GRAPH_COLLECTIVES=0 in the environment switches it off;
+                                          host-staged callbacks (gloo) keep plain launches.  0: plain launches everywhere. */
 } gsfm_rot_options;
 
 typedef enum {
@@ -197,6 +198,8 @@ typedef struct {
   double t_cg_ms;                 /* GPU time in PCG kernels (and dense solves) */
   int32_t num_dense_solves;       /* LM steps solved by the dense Cholesky path */
   int32_t num_graph_launches;     /* hipGraph replays of PCG chunks / dense solves in this call (0 = every kernel was launched plainly) */
+  int32_t num_collectives;        /* sharded problems: collectives issued by this call (all-gathers + all-reduces, replayed ones included) */
+  int32_t num_pcg_collectives;    /*   ... of which inside PCG iterations: exactly one per iteration (the all-gather of the A.p slices) */
 } gsfm_rot_summary;
 
 /* ------------------------------------------------------------------------- */
@@ -210,8 +213,14 @@ typedef struct {
  * (cost, dot products) with a sum all-reduce.  Both callbacks receive DEVICE
  * pointers and must enqueue on `hip_stream` (or make it wait).
  * Failure handling: gsfm_rot_problem_create agrees on its status across ranks before
- * returning (one all-reduce: every rank fails if any did, none is left inside a
- * collective).  Inside a solve every decision (step acceptance, convergence, non-finite
+ * returning: every rank passes through ONE all-reduce after ALL of its rank-local work
+ * (argument checks, structure build, uploads, loss set-up) -- or from its failure path --
+ * and every rank fails if any did; what follows it inside create are collectives only.
+ * Two rank-local failures cannot be agreed about and return at once, leaving the peers in
+ * that all-reduce: a descriptor whose callbacks are NULL and a process without a HIP
+ * device (the callbacks take device pointers).  Whether the GLOBAL view graph is connected
+ * (it decides the PCG tolerance, see cg_relative_tolerance) is derived inside create from
+ * all ranks' edges; GSFM_SHARD_DISCONNECTED is only a hint.  Inside a solve every decision (step acceptance, convergence, non-finite
  * cost, PCG termination) is taken from replicated, bitwise identical scalars, so all
  * ranks return the same status at the same point; what is NOT agreed on is a HIP
  * runtime error or a failing callback on one rank only (a lost device, a broken link):
@@ -224,8 +233,9 @@ typedef struct {
   int32_t world_size;
   uint32_t slice_width;
   uint32_t flags;       /* GSFM_SHARD_CAPTURABLE: the callbacks only enqueue stream-ordered device work (no host synchronisation, no
-                           host staging), so a chunk of PCG iterations containing them may be captured into a hipGraph (pcg_hip_graph = 2).
-                           GSFM_SHARD_DISCONNECTED: set by the partitioner when the global graph is disconnected (a rank cannot tell) */
+                           host staging), so a chunk of PCG iterations containing them may be captured into a hipGraph (pcg_hip_graph >= 1).
+                           GSFM_SHARD_DISCONNECTED: the partitioner may say that the global graph is disconnected; create works it out
+                           from all ranks' local components anyway (one all-gather of a label per camera), the flag can only add to it */
   void* ctx;
   /* buf holds world_size * count doubles; rank r's input already sits at buf + r*count */
   int (*all_gather)(void* ctx, double* buf_dev, size_t count, void* hip_stream);

@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""profiles/r03_pmc_traffic.json from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs) over tools/r03_k3_probe.py.
+usage: make_pmc_traffic.py <fetch.db> <write.db> <out.json>
+HBM bytes per launch: fetch = 2 x FETCH_SIZE x 1024 (gfx950 correction for wide coalesced reads, MI355X_MICROARCH.md section HBM),
+write = WRITE_SIZE x 1024 (uncalibrated).  The json carries the sha of the kernel sources it was measured on: bench.py reports `traffic`
+only while that still matches (bench.kernel_source_sha16)."""
+import json
+import os
+import sqlite3
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def per_kernel(db, counter):
+    c = sqlite3.connect(db)
+    rows = c.execute("select kernel_name, count(*), avg(value), avg(duration) from counters_collection where counter_name = ? group by kernel_name", (counter,)).fetchall()
+    return {r[0]: {"calls": r[1], "avg": r[2], "dur_us": r[3] / 1e3} for r in rows}
+
+
+KEYS = [("k_matvec", ["k_mv_col(", "k_matvec<"]), ("k_matvec_finish", ["k_mv_col_finish"]), ("k_lin", ["k_lin_col<", "k_lin_fast<", "k_lin3<", "k_lin<"]),
+        ("k_cost", ["k_cost<0, 2, 2, false>", "k_cost_direct<0, 2, 2, false>"])]
+
+
+def main():
+    import bench
+    f, w = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
+    out = {"_comment": "HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in separate runs of tools/r03_k3_probe.py: the C5 problem, a few launches "
+                       "of every hot kernel); fetch = 2 x FETCH_SIZE x 1024 (gfx950 correction), write = WRITE_SIZE x 1024 (uncalibrated)",
+           "workload": {"cams": 100000, "edges": 10000000}, "kernel_source_sha16": bench.kernel_source_sha16(), "kernels": {}}
+    for key, pats in KEYS:
+        for name in f:
+            if any(p in name for p in pats) and f[name]["avg"] * 2048 > 1e5:
+                wb = w.get(name, {"avg": 0.0})["avg"] * 1024.0
+                out[key] = {"fetch_bytes": int(2.0 * f[name]["avg"] * 1024.0), "write_bytes": int(wb), "kernel": name[:120], "launches_profiled": f[name]["calls"],
+                            "mean_duration_us_profiled": round(f[name]["dur_us"], 1)}
+                break
+    json.dump(out, open(sys.argv[3], "w"), indent=1)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()

@@ -3,8 +3,10 @@
 The reference solves every graph with SPARSE_NORMAL_CHOLESKY (/root/reference/src/GSfM_nonlinear_rotation_estimator.cpp:299-305); the
 device uses block-Jacobi PCG beyond 512 cameras.  For three consecutive LM iterations (each restarted from the previous device iterate, so
 both sides linearise at bit-identical rotations) the device's accepted step must equal x (+) (-scale * y) with y from a DIRECT factorisation
-(scipy / LAPACK) of the oracle's damped normal equations at that point -- to 1e-9 of the step.  The oracle's own PCG is held to the same
-direct solves in tests/test_oracle_direct_solve.py (CPU)."""
+(scipy / LAPACK) of the oracle's damped normal equations at that point: to 1e-10 of the step with PCG run to 1e-14 (the oracle's own
+setting), and to 1e-8 of the step at the product's default relative residual of 1e-12 (the systems are weakly damped: the step error is the
+residual times a condition number of 1e3-1e4; in absolute terms 3e-12 rad here, against the parity bar of 1e-6).  The oracle's own PCG
+is held to the same direct solves in tests/test_oracle_direct_solve.py (CPU)."""
 import os
 
 import numpy as np
@@ -47,10 +49,13 @@ def test_device_lm_step_equals_a_direct_solve(oracle, case):
         sysk = o.captured_step(0)
         y, _ = direct_step(sysk, g["edge_i"], g["edge_j"], n, sparse)
         delta = (-y * sysk["scale"]).reshape(n, 3)
+        rt, st = dev.solve(x, max_num_iterations=1, cg_relative_tolerance=1e-14)
         rd, sd = dev.solve(x, max_num_iterations=1)
-        assert sd["num_successful_steps"] == 1 and sd["num_dense_solves"] == 0 and sd["num_cg_iterations"] > 0, sd
-        err = np.abs(rd - (x + delta)).max()
-        print("%s, step %d from the device's own iterate: device %d PCG iterations; |x_dev - (x + delta_direct)|_inf = %.2e for |delta|_inf = %.2e" % (
-            name, k + 1, sd["num_cg_iterations"], err, np.abs(delta).max()))
-        assert err <= 1e-9 * np.abs(delta).max(), (name, k, err)
+        for s_ in (sd, st):
+            assert s_["num_successful_steps"] == 1 and s_["num_dense_solves"] == 0 and s_["num_cg_iterations"] > 0, s_
+        err, err_t, dmax = np.abs(rd - (x + delta)).max(), np.abs(rt - (x + delta)).max(), np.abs(delta).max()
+        print("%s, step %d from the device's own iterate: |delta|_inf = %.2e; |x_dev - (x + delta_direct)|_inf = %.2e with PCG to 1e-12 (%d iterations), %.2e with PCG to 1e-14 (%d)" % (
+            name, k + 1, dmax, err, sd["num_cg_iterations"], err_t, st["num_cg_iterations"]))
+        assert err_t <= 1e-10 * dmax, (name, k, err_t)
+        assert err <= 1e-8 * dmax, (name, k, err)
         x = rd

@@ -15,11 +15,13 @@ for cs in ("0", "1"):
     p = RotationProblem(g["n_cams"], g["edge_i"], g["edge_j"], g["rel_aa"], _abi.ANGLE_AXIS_COVARIANCE, cov6=g["cov6"])
     out["create_s_colsort" + cs] = time.perf_counter() - t
     p.set_loss(MAGSACWeightBasedLoss(0.02))
-    for mode in ("0", "1"):
+    for mode, free in (("0", "0"), ("1", "0"), ("1", "1")):
         os.environ["GSFM_K2_FAST"] = mode
+        os.environ["GSFM_K2C_FREE"] = free
         kt = p.time_kernels(g["init_aa"], reps=10)
-        out["colsort%s_k2fast%s" % (cs, mode)] = {k: round(1e3 * v, 1) for k, v in kt.items()}
-        print(cs, mode, out["colsort%s_k2fast%s" % (cs, mode)], flush=True)
+        out["colsort%s_k2fast%s_free%s" % (cs, mode, free)] = {k: round(1e3 * v, 1) for k, v in kt.items()}
+        print(cs, mode, free, out["colsort%s_k2fast%s_free%s" % (cs, mode, free)], flush=True)
+    os.environ["GSFM_K2C_FREE"] = "0"
     os.environ["GSFM_K2_FAST"] = "1"
     p.solve(g["init_aa"])
     t = time.perf_counter(); rot, s = p.solve(g["init_aa"]); dt = time.perf_counter() - t
