@@ -180,18 +180,31 @@ __device__ __forceinline__ void lin_col_body(const ColLinArgs& a) {
   __syncthreads();
   for (uint32_t s = 0; s < w.n_sub; ++s) {
     const uint32_t sc = w.first_sub + s;
-    for (uint32_t k = 0; k < SUB / T; ++k) {
+    // The kernel is latency-bound (VALU ~20 % busy): both trips of the sub-chunk are requested together -- the two 8-byte records first,
+    // then, as soon as they are there, both trips' streams and neighbour quaternions -- so a sub-chunk pays two dependent memory round
+    // trips instead of four.  (Padding positions read camera 0 and their own, valid, stream slots; nothing of it is used.)
+    constexpr int K = SUB / T;
+    uint2 mt[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) mt[k] = col_load_meta(a.L.meta + (sc * SUB + k * T + t));
+    LinStreams S[K];
+    Quat qm[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
       const uint32_t d = sc * SUB + k * T + t;
-      const uint2 mt = col_load_meta(a.L.meta + d);
-      const uint32_t cr = mt.x, pm = mt.y & 0xffffu;
+      S[k] = lin_load_streams<WM>(a.lin, d);
+      qm[k] = load_q(a.lin.q, mt[k].x == GSFM_COL_PAD ? 0u : (mt[k].x & 0x7fffffffu));
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const uint32_t d = sc * SUB + k * T + t;
+      const uint32_t cr = mt[k].x, pm = mt[k].y & 0xffffu;
       double g3[3] = {0, 0, 0}, G6[6] = {0, 0, 0, 0, 0, 0}, B6[6] = {0, 0, 0, 0, 0, 0};
       if (cr != GSFM_COL_PAD) {
-        const uint32_t rl = mt.y >> 16;
-        const LinStreams S = lin_load_streams<WM>(a.lin, d);
-        const Quat qm = load_q(a.lin.q, cr & 0x7fffffffu);
+        const uint32_t rl = mt[k].y >> 16;
         const double2 k0 = qrow[0][rl], k1 = qrow[1][rl];
         const Quat qk{k0.x, k0.y, k1.x, k1.y};
-        lin_entry_eval<F, WM, LM, FAST>(a.lin, d, cr, qk, qm, S, g3, G6);
+        lin_entry_eval<F, WM, LM, FAST>(a.lin, d, cr, qk, qm[k], S[k], g3, G6);
         // body frame: B = R_k^T G R_k
         double R[9], Tm[9];
         qmat(qk, R);
@@ -233,10 +246,10 @@ __device__ __forceinline__ void lin_col_body(const ColLinArgs& a) {
     for (int c = 0; c < 9; ++c) a.part[(size_t)c * plane + o] = acc[j][c];
   }
 }
+// Registers at the compiler's choice (~200-250: two waves per SIMD, two workgroups per CU): asking for three waves spills the eighteen
+// row accumulators (76 B of scratch per lane) and costs 1010 us against 785 at C5.
 template <int F, int WM, int LM, bool FAST>
-__global__ void __launch_bounds__(GSFM_COLLIN_THREADS) GSFM_K2_ATTR k_lin_col(ColLinArgs a) { lin_col_body<F, WM, LM, FAST>(a); }
-template <int F, int WM, int LM, bool FAST>
-__global__ void __launch_bounds__(GSFM_COLLIN_THREADS) k_lin_col_free(ColLinArgs a) { lin_col_body<F, WM, LM, FAST>(a); }
+__global__ void __launch_bounds__(GSFM_COLLIN_THREADS) k_lin_col(ColLinArgs a) { lin_col_body<F, WM, LM, FAST>(a); }
 
 // gD[k] = sum_{c < NCH} part[block(k) * NCH + c][k mod RB]  (nine values per camera)
 __global__ void __launch_bounds__(GSFM_BLOCK) k_lin_col_finish(uint32_t n_rows, uint32_t row_base, uint32_t nch, uint32_t n_wg, const double* __restrict__ part, double* __restrict__ gD) {

@@ -340,12 +340,9 @@ template <int F, int W, int L> struct ColLinLauncher {   // K2c (column-sorted l
     if constexpr (F == F_AA || F == F_QCOS) {
       const dim3 g(grid), b(GSFM_COLLIN_THREADS);
       if constexpr (L != LM_PROGRAM) {
-        const char* e = getenv("GSFM_K2C_FREE");   // A/B: registers at the compiler's choice (2 waves per SIMD, no spill) instead of >= 3 waves
-        if (!a.lin.rho_ext && k2_fast_enabled()) {
-          if (e && atoi(e) == 1) hipLaunchKernelGGL((k_lin_col_free<F, W, L, true>), g, b, 0, s, a);
-          else hipLaunchKernelGGL((k_lin_col<F, W, L, true>), g, b, 0, s, a);
-        } else hipLaunchKernelGGL((k_lin_col<F, W, L, false>), g, b, 0, s, a);
-      } else hipLaunchKernelGGL((k_lin_col_free<F, W, L, false>), g, b, 0, s, a);
+        if (!a.lin.rho_ext && k2_fast_enabled()) hipLaunchKernelGGL((k_lin_col<F, W, L, true>), g, b, 0, s, a);
+        else hipLaunchKernelGGL((k_lin_col<F, W, L, false>), g, b, 0, s, a);
+      } else hipLaunchKernelGGL((k_lin_col<F, W, L, false>), g, b, 0, s, a);
     }
   }
 };
