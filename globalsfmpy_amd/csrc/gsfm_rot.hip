@@ -84,6 +84,9 @@ template <typename F> void parallel_run(int T, F body) {
 
 // counts[k + 1] += number of items with key(u) == k, u in [0, n): per-thread histograms over contiguous item ranges, summed in thread order
 template <typename K> void parallel_count(int T, size_t n, size_t n_keys, K key, uint32_t* counts_plus_one) {
+  // one histogram per thread: cap the threads so that T * n_keys stays below 64 M counters (256 MB) -- the tile buckets have up to
+  // 16.7 M keys; the serial loop needs one table
+  T = (int)std::min<size_t>((size_t)T, std::max<size_t>(1, ((size_t)64 << 20) / std::max<size_t>(1, n_keys)));
   if (T <= 1 || n < 200000) { for (size_t u = 0; u < n; ++u) counts_plus_one[key(u)]++; return; }
   std::vector<std::vector<uint32_t>> h((size_t)T);
   parallel_run(T, [&](int t, int TT) {
@@ -1290,9 +1293,9 @@ void gsfm_rot_options_default(gsfm_rot_options* o) {
 
 int32_t gsfm_rot_residual_dim(int32_t t) { return t == GSFM_ROT_QUATERNION_NORM ? 4 : t == GSFM_ROT_ROTATION_MAT_FNORM ? 9 : 3; }
 
-gsfm_status gsfm_rot_problem_create(uint32_t n_cams, uint64_t n_edges, const uint32_t* edge_i_in, const uint32_t* edge_j_in,
-                                    const double* rel_aa, int32_t error_type, const double* cov6, const double* inlier_weight,
-                                    const gsfm_rot_shard* shard, gsfm_rot_problem** out) {
+static gsfm_status problem_create_impl(uint32_t n_cams, uint64_t n_edges, const uint32_t* edge_i_in, const uint32_t* edge_j_in,
+                                       const double* rel_aa, int32_t error_type, const double* cov6, const double* inlier_weight,
+                                       const gsfm_rot_shard* shard, gsfm_rot_problem** out, gsfm_rot_problem** live) {
   if (!out) return (gsfm_status)fail(GSFM_ERR_INVALID_ARG, "out is NULL");
   *out = nullptr;
   // (one rank of a sharded problem may hold no edge at all -- a slice of isolated cameras -- and still takes part in every collective)
@@ -1303,6 +1306,7 @@ gsfm_status gsfm_rot_problem_create(uint32_t n_cams, uint64_t n_edges, const uin
   if (const char* why = no_device_reason("the rotation solver")) return (gsfm_status)fail(GSFM_ERR_NO_DEVICE, why);
 
   gsfm_rot_problem* P = new gsfm_rot_problem;
+  *live = P;   // (for the exception path of the public wrapper)
   // Sharded: a rank-local failure (bad argument, bad edge, allocation, upload, loss set-up) must not leave the other ranks blocked in a
   // collective.  Every rank passes through exactly ONE agreement all-reduce -- on the failure path from bail(), on the success path after
   // ALL of its local work -- carrying (failed?, votes against the two-level preconditioner); all ranks give up together if any of them
@@ -1322,6 +1326,7 @@ gsfm_status gsfm_rot_problem_create(uint32_t n_cams, uint64_t n_edges, const uin
   };
   auto bail = [&](int st) {
     if (P->sharded && !agreed) { const std::string keep = g_err; (void)agree(1.0, 1.0); g_err = keep; }
+    *live = nullptr;
     gsfm_rot_problem_destroy(P);
     return (gsfm_status)st;
   };
@@ -1694,8 +1699,23 @@ gsfm_status gsfm_rot_problem_create(uint32_t n_cams, uint64_t n_edges, const uin
     for (uint32_t c = 0; c < NP; ++c) if (act[c] != 0.0 && find(c) == c) ++comps;
     P->n_components = std::max<uint32_t>(std::max<uint32_t>(1, comps), (P->shard.flags & GSFM_SHARD_DISCONNECTED) ? 2u : 1u);
   }
+  *live = nullptr;
   *out = P;
   return GSFM_OK;
+}
+
+gsfm_status gsfm_rot_problem_create(uint32_t n_cams, uint64_t n_edges, const uint32_t* edge_i, const uint32_t* edge_j, const double* rel_aa, int32_t error_type,
+                                    const double* cov6, const double* inlier_weight, const gsfm_rot_shard* shard, gsfm_rot_problem** out) {
+  // The host-side structure build allocates O(E) vectors and starts threads: an exception (std::bad_alloc, std::system_error) must not
+  // cross the C boundary.  (On a sharded problem the peers of a rank that fails THIS way are not told: they wait in the agreement.)
+  gsfm_rot_problem* live = nullptr;
+  try {
+    return problem_create_impl(n_cams, n_edges, edge_i, edge_j, rel_aa, error_type, cov6, inlier_weight, shard, out, &live);
+  } catch (const std::exception& e) {
+    if (live) gsfm_rot_problem_destroy(live);
+    if (out) *out = nullptr;
+    return (gsfm_status)fail(GSFM_ERR_INVALID_ARG, std::string("problem creation ran out of host resources: ") + e.what());
+  }
 }
 
 void gsfm_rot_problem_destroy(gsfm_rot_problem* P) {
@@ -1954,31 +1974,40 @@ gsfm_status gsfm_rot_edge_sq_norms(uint32_t n_cams, uint64_t n_edges, const uint
   if (n_cams == 0 || n_edges == 0) { if (n_kept) *n_kept = 0; return GSFM_OK; }
   if (!edge_i || !edge_j || !rel_aa || !rot_aa || !s_out) return (gsfm_status)fail(GSFM_ERR_INVALID_ARG, "NULL argument");
   for (uint64_t e = 0; e < n_edges; ++e) if (edge_i[e] >= n_cams || edge_j[e] >= n_cams) return (gsfm_status)fail(GSFM_ERR_INVALID_ARG, "edge with an out-of-range camera index");
+  // (no host fallback: like every entry point of this library the sweep runs on the device or fails loudly)
   if (const char* why = no_device_reason("the edge sweep")) return (gsfm_status)fail(GSFM_ERR_NO_DEVICE, why);
-  DevBuf<uint32_t> di, dj; DevBuf<double> drel, dcov, drot, ds; DevBuf<double2> dq; DevBuf<uint8_t> dkeep; DevBuf<unsigned long long> dcount;
-  bool ok = di.alloc(n_edges) == hipSuccess && dj.alloc(n_edges) == hipSuccess && drel.alloc(3 * n_edges) == hipSuccess && drot.alloc(3 * (size_t)n_cams) == hipSuccess &&
-            ds.alloc(n_edges) == hipSuccess && dq.alloc(2 * (size_t)n_cams) == hipSuccess && dcount.alloc(1, true) == hipSuccess &&
-            (!cov6 || dcov.alloc(6 * n_edges) == hipSuccess) && (!keep_out || dkeep.alloc(n_edges) == hipSuccess);
-  if (!ok) return (gsfm_status)fail(GSFM_ERR_HIP, "allocating the edge sweep buffers failed");
-  HIPCHK_S(hipMemcpy(di.p, edge_i, 4 * n_edges, hipMemcpyHostToDevice)); HIPCHK_S(hipMemcpy(dj.p, edge_j, 4 * n_edges, hipMemcpyHostToDevice));
-  HIPCHK_S(hipMemcpy(drel.p, rel_aa, 24 * n_edges, hipMemcpyHostToDevice)); HIPCHK_S(hipMemcpy(drot.p, rot_aa, 24 * (size_t)n_cams, hipMemcpyHostToDevice));
-  if (cov6) HIPCHK_S(hipMemcpy(dcov.p, cov6, 48 * n_edges, hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(k_cam_cache, dim3(grid_for(n_cams)), dim3(GSFM_BLOCK), 0, 0, (const double*)drot.p, n_cams, 3, dq.p);
+  // One device slab, one private stream, stream-ordered copies: no hipDeviceSynchronize (it would stall every problem's stream of the
+  // process) and nothing to leak on an error path (the guard below owns stream, events and slab).
+  struct Guard {
+    hipStream_t s = nullptr; hipEvent_t e0 = nullptr, e1 = nullptr; void* slab = nullptr;
+    ~Guard() { if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); if (slab) (void)hipFree(slab); if (s) (void)hipStreamDestroy(s); }
+  } G;
+  auto up = [](size_t b) { return (b + 255) / 256 * 256; };
+  const size_t o_i = 0, o_j = o_i + up(4 * n_edges), o_rel = o_j + up(4 * n_edges), o_cov = o_rel + up(24 * n_edges), o_rot = o_cov + (cov6 ? up(48 * n_edges) : 0),
+               o_s = o_rot + up(24 * (size_t)n_cams), o_q = o_s + up(8 * n_edges), o_keep = o_q + up(32 * (size_t)n_cams), o_cnt = o_keep + (keep_out ? up(n_edges) : 0), total = o_cnt + 256;
+  HIPCHK_S(hipStreamCreateWithFlags(&G.s, hipStreamNonBlocking));
+  HIPCHK_S(hipEventCreate(&G.e0)); HIPCHK_S(hipEventCreate(&G.e1));
+  if (hipMalloc(&G.slab, total) != hipSuccess) { G.slab = nullptr; return (gsfm_status)fail(GSFM_ERR_HIP, "allocating the edge sweep buffers failed"); }
+  char* base = (char*)G.slab;
+  HIPCHK_S(hipMemcpyAsync(base + o_i, edge_i, 4 * n_edges, hipMemcpyHostToDevice, G.s)); HIPCHK_S(hipMemcpyAsync(base + o_j, edge_j, 4 * n_edges, hipMemcpyHostToDevice, G.s));
+  HIPCHK_S(hipMemcpyAsync(base + o_rel, rel_aa, 24 * n_edges, hipMemcpyHostToDevice, G.s)); HIPCHK_S(hipMemcpyAsync(base + o_rot, rot_aa, 24 * (size_t)n_cams, hipMemcpyHostToDevice, G.s));
+  if (cov6) HIPCHK_S(hipMemcpyAsync(base + o_cov, cov6, 48 * n_edges, hipMemcpyHostToDevice, G.s));
+  HIPCHK_S(hipMemsetAsync(base + o_cnt, 0, 8, G.s));
+  hipLaunchKernelGGL(k_cam_cache, dim3(grid_for(n_cams)), dim3(GSFM_BLOCK), 0, G.s, (const double*)(base + o_rot), n_cams, 3, (double2*)(base + o_q));
   EdgeSweepArgs a{};
-  a.n = n_edges; a.ei = di.p; a.ej = dj.p; a.rel_aa = drel.p; a.cov6 = dcov.p; a.q = dq.p; a.max_sq = max_sq_norm; a.s_out = ds.p; a.keep = dkeep.p; a.n_kept = dcount.p;
-  hipEvent_t e0, e1;
-  HIPCHK_S(hipEventCreate(&e0)); HIPCHK_S(hipEventCreate(&e1));
-  HIPCHK_S(hipEventRecord(e0, 0));
-  hipLaunchKernelGGL(k_edge_sweep, dim3(grid_for(n_edges)), dim3(GSFM_BLOCK), 0, 0, a);
-  HIPCHK_S(hipEventRecord(e1, 0));
-  HIPCHK_S(hipDeviceSynchronize());
-  HIPCHK_S(hipGetLastError());
-  float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-  if (kernel_ms) *kernel_ms = ms;
-  HIPCHK_S(hipMemcpy(s_out, ds.p, 8 * n_edges, hipMemcpyDeviceToHost));
-  if (keep_out) HIPCHK_S(hipMemcpy(keep_out, dkeep.p, n_edges, hipMemcpyDeviceToHost));
+  a.n = n_edges; a.ei = (const uint32_t*)(base + o_i); a.ej = (const uint32_t*)(base + o_j); a.rel_aa = (const double*)(base + o_rel); a.cov6 = cov6 ? (const double*)(base + o_cov) : nullptr;
+  a.q = (const double2*)(base + o_q); a.max_sq = max_sq_norm; a.s_out = (double*)(base + o_s); a.keep = keep_out ? (uint8_t*)(base + o_keep) : nullptr; a.n_kept = (unsigned long long*)(base + o_cnt);
+  HIPCHK_S(hipEventRecord(G.e0, G.s));
+  hipLaunchKernelGGL(k_edge_sweep, dim3(grid_for(n_edges)), dim3(GSFM_BLOCK), 0, G.s, a);
+  HIPCHK_S(hipEventRecord(G.e1, G.s));
+  HIPCHK_S(hipMemcpyAsync(s_out, base + o_s, 8 * n_edges, hipMemcpyDeviceToHost, G.s));
+  if (keep_out) HIPCHK_S(hipMemcpyAsync(keep_out, base + o_keep, n_edges, hipMemcpyDeviceToHost, G.s));
   unsigned long long cnt = 0;
-  HIPCHK_S(hipMemcpy(&cnt, dcount.p, 8, hipMemcpyDeviceToHost));
+  HIPCHK_S(hipMemcpyAsync(&cnt, base + o_cnt, 8, hipMemcpyDeviceToHost, G.s));
+  HIPCHK_S(hipStreamSynchronize(G.s));
+  HIPCHK_S(hipGetLastError());
+  float ms = 0; (void)hipEventElapsedTime(&ms, G.e0, G.e1);
+  if (kernel_ms) *kernel_ms = ms;
   if (n_kept) *n_kept = keep_out ? (uint64_t)cnt : n_edges;
   return GSFM_OK;
 }

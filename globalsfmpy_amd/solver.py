@@ -40,6 +40,9 @@ class ProblemBase(object):
         return getattr(self._lib, self._prefix + name)
 
     def _check(self, st, what):
+        # every C call may have run the host-callback loss: an exception parked by the trampoline surfaces HERE, from the call that caused
+        # it, not from some later, unrelated one
+        self._reraise_callback_error()
         if st != 0:
             raise SolverError("%s failed with status %d: %s" % (what, st, self._last_error()))
 

@@ -514,8 +514,11 @@ int lm_solve(orc_problem* p, std::vector<double>& x, const gsfm_rot_options& o, 
     for (size_t k = 0; k < n; ++k) D[k] = std::sqrt(std::fmin(std::fmax(diag[k], o.min_lm_diagonal), o.max_lm_diagonal) / radius);
     Jt_times(p, p->rt.data(), rhs.data());
     int cg = 0;
-    // 'auto' follows the product's rule: exact Cholesky steps up to dense_cholesky_max_cams cameras (default 512), PCG(1e-14 floor) beyond
-    const bool dense = p->linear_solver == 1 || (p->linear_solver == 0 && o.dense_cholesky_max_cams > 0 && (int64_t)N <= (int64_t)o.dense_cholesky_max_cams);
+    // 'auto': exact Cholesky steps -- what the reference's SPARSE_NORMAL_CHOLESKY computes -- wherever a dense factorisation is affordable
+    // for a test (up to 512 cameras), PCG(1e-14) beyond.  A fixed rule of the ORACLE: it does not read the product's
+    // dense_cholesky_max_cams option (round-2 advisor: mirroring it made the checker follow the thing it checks); tests that want a
+    // particular solver on the oracle side say so with orc_set_linear_solver.
+    const bool dense = p->linear_solver == 1 || (p->linear_solver == 0 && N <= 512);
     bool ok = dense ? solve_dense(p, D.data(), rhs.data(), step.data()) : solve_pcg(p, D.data(), rhs.data(), step.data(), &cg);
     sum->num_cg_iterations += cg;
     if ((int)p->captured.size() < p->capture_max) {   // (J^T J + diag(D)^2) y = rhs with J = [Ji Jj] per edge (column-scaled), before the sign flip
