@@ -100,11 +100,14 @@ __global__ void __launch_bounds__(GSFM_COL_RB) k_mv_col(ColMatvecArgs a) {
 struct ColFinishArgs {
   uint32_t n_rows, row_base, nch, n_wg;
   const double* part; const double* Mblk; const double* p; const double2* q; double* y; const int* done;
+  double* dot_part;   // PCG on one GPU: this block's share of p . (A p), so that k_cg_dot need not be launched (null: not wanted)
 };
 __global__ void __launch_bounds__(GSFM_BLOCK) k_mv_col_finish(ColFinishArgs a) {
   if (a.done && *a.done) return;
+  __shared__ double lds[8];
   const uint32_t row = blockIdx.x * GSFM_BLOCK + threadIdx.x;
-  if (row >= a.n_rows) return;
+  double pAp = 0.0;
+  if (row < a.n_rows) {
   const uint32_t blk = row / GSFM_COL_RB, r = row % GSFM_COL_RB;
   const size_t plane = (size_t)a.n_wg * GSFM_COL_RB;
   double t0 = 0.0, t1 = 0.0, t2 = 0.0;
@@ -113,9 +116,14 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_mv_col_finish(ColFinishArgs a) {
   double R[9], mp[3];
   qmat(load_q(a.q, (uint32_t)k), R);
   sym3_mulvec(a.Mblk + 6 * k, a.p + 3 * k, mp);
-  a.y[3 * k] = mp[0] - (R[0] * t0 + R[1] * t1 + R[2] * t2);
-  a.y[3 * k + 1] = mp[1] - (R[3] * t0 + R[4] * t1 + R[5] * t2);
-  a.y[3 * k + 2] = mp[2] - (R[6] * t0 + R[7] * t1 + R[8] * t2);
+  const double y0 = mp[0] - (R[0] * t0 + R[1] * t1 + R[2] * t2), y1 = mp[1] - (R[3] * t0 + R[4] * t1 + R[5] * t2), y2 = mp[2] - (R[6] * t0 + R[7] * t1 + R[8] * t2);
+  a.y[3 * k] = y0; a.y[3 * k + 1] = y1; a.y[3 * k + 2] = y2;
+  pAp = a.p[3 * k] * y0 + a.p[3 * k + 1] * y1 + a.p[3 * k + 2] * y2;   // (the same product, block size and reduction tree as k_cg_dot: same bits)
+  }
+  if (a.dot_part) {
+    const double t = block_sum_bcast(pAp, lds);
+    if (threadIdx.x == 0) a.dot_part[blockIdx.x] = t;
+  }
 }
 
 // s = |r_e|^2 of every entry of the layout, written per local edge (the column-sorted twin of k_row_s: host-callback losses on a sharded

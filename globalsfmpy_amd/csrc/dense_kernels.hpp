@@ -12,7 +12,11 @@
 //     schedule and irrelevant here; the chain per step is one kernel instead of three (round 1: 111 launches, 2.2 ms at 3N = 1182);
 //   * L goes to a second buffer (a workgroup's inputs A_kk, A_ik, A_jk are never written during step k, so there is no race);
 //   * the backward substitution L^T x = y is one workgroup sweeping the block rows of L bottom-up.
-// fp64 VALU throughout; MFMA tiles would buy nothing at these sizes.
+// fp64 VALU throughout at these sizes.  Beyond ~50 block columns (more than 512 cameras) the redundancy of that schedule (every trailing
+// workgroup repeating the diagonal factorisation) and its per-lane 1 x 4 update dominate, and the work is done by two kernels per step
+// instead: k_chol_panel (one wavefront per panel tile: the same fused factorisation + substitution, once per tile ROW instead of once per
+// trailing tile) and k_chol_update_mfma (one wavefront per trailing tile: A_ij -= L_ik L_jk^T as 2 x 2 x 8 v_mfma_f64_16x16x4_f64 -- the
+// one dense contraction on this path, on the matrix cores).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -24,7 +28,9 @@ namespace gsfm {
 #ifndef GSFM_CHOL_BATCH
 #define GSFM_CHOL_BATCH 8
 #endif
-#define GSFM_DENSE_MAX_T 160   // block rows the backward kernel keeps in LDS: 3N <= 5120
+#define GSFM_DENSE_MAX_T 500   // block rows whose right-hand side the backward kernel keeps in LDS (125 KB of the 160): 3N <= 16000, 5333 cameras
+#define GSFM_CHOL_SPLIT_T 48   // LDS capacity (block rows) of the single-workgroup backward kernel: the fused schedule is never used beyond
+#define GSFM_CHOL_SPLIT_DEFAULT 48   // more block columns than this: the two-kernel MFMA schedule (see run_dense)
 
 __host__ __device__ inline size_t chol_tile_off(uint32_t i, uint32_t j) { return ((size_t)i * (i + 1) / 2 + j) * GSFM_TILE_ELEMS; }
 __host__ __device__ inline size_t chol_num_tiles(uint32_t T) { return (size_t)(T + 1) * (T + 2) / 2; }   // block rows 0..T (row T = rhs)
@@ -133,6 +139,99 @@ __global__ void __launch_bounds__(256) k_chol_step(CholArgs a) {
   for (int q = 0; q < 4; ++q) d[q] = own[q] - acc[q];
 }
 
+// The same 64-row elimination as in k_chol_step (lanes 0..31: rows of A_kk, lanes 32..63: rows of a panel tile), as a device routine.
+__device__ __forceinline__ int chol_eliminate64(double* r, uint32_t lane) {
+  int bad = 0;
+#pragma unroll
+  for (int c0 = 0; c0 < GSFM_CB; ++c0) {
+    double piv = readlane_f64(r[c0], c0);
+    if (!(piv > 0.0)) { if (!bad) bad = c0 + 1; piv = 1.0; }
+    const double inv = rsqrt(piv);
+    r[c0] = (lane == (uint32_t)c0) ? piv * inv : r[c0] * inv;
+#pragma unroll
+    for (int cb = c0 + 1; cb < GSFM_CB; cb += GSFM_CHOL_BATCH) {
+      double m[GSFM_CHOL_BATCH];
+#pragma unroll
+      for (int q = 0; q < GSFM_CHOL_BATCH; ++q) if (cb + q < GSFM_CB) m[q] = readlane_f64(r[c0], cb + q);
+#pragma unroll
+      for (int q = 0; q < GSFM_CHOL_BATCH; ++q) if (cb + q < GSFM_CB) r[cb + q] -= r[c0] * m[q];
+    }
+  }
+  return bad;
+}
+
+// Step k of the two-kernel schedule, first half: workgroup 0 (one wavefront) factors A_kk and writes L_kk; workgroup b >= 1 factors A_kk
+// again in its lower lanes and, with the same instructions, turns the panel tile A_ik, i = k + b (block row T = the right-hand side), into
+// L_ik = A_ik L_kk^-T in its upper lanes.  Reads A, writes L: no race with anything in this step.
+__global__ void __launch_bounds__(64) k_chol_panel(CholArgs a) {
+  const uint32_t k = a.k, lane = threadIdx.x, rr = lane & 31, b = blockIdx.x;
+  const uint32_t i = k + b;   // b == 0: the diagonal tile itself in both halves
+  const double2* src = (const double2*)(a.A + (lane < 32 ? chol_tile_off(k, k) : chol_tile_off(i, k)) + rr * GSFM_CB);
+  double r[GSFM_CB];
+#pragma unroll
+  for (int q = 0; q < GSFM_CB / 2; ++q) { const double2 v = src[q]; r[2 * q] = v.x; r[2 * q + 1] = v.y; }
+  const int bad = chol_eliminate64(r, lane);
+  if (b == 0) {
+    if (lane < 32) {
+      double2* dl = (double2*)(a.L + chol_tile_off(k, k) + rr * GSFM_CB);
+#pragma unroll
+      for (int q = 0; q < GSFM_CB / 2; ++q) dl[q] = make_double2((uint32_t)(2 * q) <= lane ? r[2 * q] : 0.0, (uint32_t)(2 * q + 1) <= lane ? r[2 * q + 1] : 0.0);
+      if (lane == 0 && bad && *a.info == 0) *a.info = (int)(k * GSFM_CB + bad);
+    }
+  } else if (lane >= 32) {
+    double2* dl = (double2*)(a.L + chol_tile_off(i, k) + rr * GSFM_CB);
+#pragma unroll
+    for (int q = 0; q < GSFM_CB / 2; ++q) dl[q] = make_double2(r[2 * q], r[2 * q + 1]);
+  }
+}
+
+// Second half: A_ij -= L_ik L_jk^T for every trailing tile k < j <= i <= T ((T, T) does not exist), one wavefront per tile, on the matrix
+// cores: v_mfma_f64_16x16x4_f64 computes D(16x16) = A(16x4) B(4x16) + C; lane l supplies A[l & 15][l >> 4] and B[l >> 4][l & 15] and holds
+// C/D[(l >> 4) + 4 reg][l & 15], reg = 0..3 (MI355X guide, fragment layout of the f64 form).  A 32 x 32 tile is 2 x 2 such blocks times
+// 8 steps of K = 4; the A operand is -L_ik, the B operand L_jk read row-wise (= L_jk^T column-wise).
+typedef double chol_d4 __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(256) k_chol_update_mfma(CholArgs a) {
+  const uint32_t k = a.k, T = a.T, lane = threadIdx.x & 63;
+  const uint64_t b = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const uint32_t m = T - k;                               // trailing block rows k+1 .. T
+  if (b >= (uint64_t)m * (m + 1) / 2) return;
+  uint32_t t = (uint32_t)((sqrt(8.0 * (double)b + 1.0) - 1.0) * 0.5);
+  while ((uint64_t)(t + 1) * (t + 2) / 2 <= b) ++t;
+  while ((uint64_t)t * (t + 1) / 2 > b) --t;
+  const uint32_t i = k + 1 + t, j = k + 1 + (uint32_t)(b - (uint64_t)t * (t + 1) / 2);
+  if (i == T && j == T) return;
+  const uint32_t c = lane & 15, g = lane >> 4;
+  const double* Li = a.L + chol_tile_off(i, k);
+  const double* Lj = a.L + chol_tile_off(j, k);
+  // The contraction index may be dealt to (MFMA step kk, lane group g) in any way, as long as A and B agree: lane group g takes
+  // k = 8 g .. 8 g + 7, eight CONSECUTIVE doubles of a tile row, so the operand loads are 64 contiguous bytes per lane (whole rows per
+  // 4 lanes) instead of eight 8-byte pieces 32 bytes apart.
+  double aop[2][8], bop[2][8];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const double2* ra = (const double2*)(Li + (16 * s + c) * GSFM_CB + 8 * g);
+    const double2* rb = (const double2*)(Lj + (16 * s + c) * GSFM_CB + 8 * g);
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      const double2 va = ra[h], vb = rb[h];
+      aop[s][2 * h] = -va.x; aop[s][2 * h + 1] = -va.y; bop[s][2 * h] = vb.x; bop[s][2 * h + 1] = vb.y;
+    }
+  }
+  double* Aij = a.A + chol_tile_off(i, j);
+#pragma unroll
+  for (int si = 0; si < 2; ++si)
+#pragma unroll
+    for (int sj = 0; sj < 2; ++sj) {
+      chol_d4 acc;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[r] = Aij[(16 * si + g + 4 * r) * GSFM_CB + 16 * sj + c];
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[si][kk], bop[sj][kk], acc, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Aij[(16 * si + g + 4 * r) * GSFM_CB + 16 * sj + c] = acc[r];
+    }
+}
+
 // x = L^-T y, one workgroup: block rows bottom-up; y stays in LDS.  Software-pipelined: while the other 15 wavefronts fold x_k into the
 // right-hand sides of the block rows j <= k - 2 (L_kj tiles are contiguous: block row k of L) and prefetch the next diagonal tile,
 // wavefront 0 folds x_k into block row k - 1 and runs that block's 32-step substitution (running right-hand side in lane registers,
@@ -147,8 +246,9 @@ __device__ __forceinline__ void chol_back_block(const double (*Lk)[GSFM_CB + 1],
   }
   if (lane < GSFM_CB) { const double mine = v * rinv; xk_out[lane] = mine; if (g0 + lane < n) x[g0 + lane] = mine; }   // lane t was never modified after step t
 }
+template <int MAXT>
 __global__ void __launch_bounds__(1024) k_chol_back(const double* __restrict__ L, uint32_t n, uint32_t T, double* __restrict__ x) {
-  __shared__ double y[GSFM_DENSE_MAX_T * GSFM_CB];
+  __shared__ double y[MAXT * GSFM_CB];
   __shared__ double Lk[2][GSFM_CB][GSFM_CB + 1];
   __shared__ double xk[2][GSFM_CB];
   const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -181,6 +281,49 @@ __global__ void __launch_bounds__(1024) k_chol_back(const double* __restrict__ L
     }
     __syncthreads();
   }
+}
+
+// Backward substitution for the larger matrices (two-kernel schedule), one launch per block row k = T-1 .. 0 instead of one workgroup
+// streaming all of L: workgroup j < k folds x_k into the running right-hand side, y_j -= L_kj^T x_k (one 8 KiB tile each, all tiles of
+// block row k in parallel), and the workgroup of j = k - 1 -- whose right-hand side is complete with that -- solves L_{k-1,k-1}^T x_{k-1} =
+// y_{k-1} and publishes x_{k-1} for the next launch.  y lives in global memory (block row T of L: the forward-substituted right-hand side).
+// Launch k = T (no x yet): only the solve of the last block.  ~5 us per block row instead of 26 (3.4 ms at 3N = 4500 for the single
+// workgroup, bound by one CU streaming 81 MB).
+struct CholBackArgs { double* L; double* x; uint32_t n, T, k; };   // the running right-hand side y_j = first row of tile (T, j) of L
+__global__ void __launch_bounds__(64) k_chol_back_step(CholBackArgs a) {
+  __shared__ double Lk[GSFM_CB][GSFM_CB + 1];
+  __shared__ double xs[GSFM_CB];
+  const uint32_t lane = threadIdx.x, l = lane & 31, k = a.k, j = blockIdx.x;   // grid: max(k, 1) workgroups; k == T: one
+  double v = 0.0;
+  if (k < a.T) {
+    if (lane < GSFM_CB) xs[lane] = a.x[k * GSFM_CB + lane];
+    __syncthreads();
+    const double* t = a.L + chol_tile_off(k, j) + l;      // column l of tile (k, j), rows r = 0..31 (lanes 32..63 take the odd rows' half)
+    double s2 = 0.0;
+    const uint32_t r0 = lane < 32 ? 0 : 16;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s2 += t[(r0 + r) * GSFM_CB] * xs[r0 + r];
+    s2 += __shfl_xor(s2, 32, 64);
+    double* yj = a.L + chol_tile_off(a.T, j);
+    v = yj[l] - s2;
+    if (lane < GSFM_CB) yj[l] = v;
+    if (j + 1 != k) return;
+  } else {
+    if (j != 0) return;
+    v = a.L[chol_tile_off(a.T, a.T - 1) + l];
+  }
+  // this workgroup's block (index k - 1) is ready: triangular solve, as in chol_back_block
+  const uint32_t kb = k - 1;
+  const double* d = a.L + chol_tile_off(kb, kb);
+  for (uint32_t e = lane; e < GSFM_TILE_ELEMS; e += 64) Lk[e / GSFM_CB][e % GSFM_CB] = d[e];
+  __syncthreads();
+  const double rinv = 1.0 / Lk[l][l];
+#pragma unroll
+  for (int t = GSFM_CB - 1; t >= 0; --t) {
+    const double xt = readlane_f64(v * rinv, t);
+    if (l < (uint32_t)t) v -= Lk[t][l] * xt;
+  }
+  if (lane < GSFM_CB) a.x[kb * GSFM_CB + lane] = v * rinv;   // (entries beyond n belong to the identity padding: harmless)
 }
 
 }  // namespace gsfm

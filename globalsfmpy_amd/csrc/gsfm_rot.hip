@@ -237,7 +237,7 @@ struct gsfm_rot_problem {
   DevBuf<double> coarseA, coarseAinv, coarse_rc, coarse_xc, coarse_scale, coarse_part;
   std::vector<double> h_coarse, h_coarse_inv;
   void* pin = nullptr;              // 256 B of pinned host memory: staging for the small read-backs of the solve loop (read_back)
-  DevBuf<double> denseA, denseL;
+  DevBuf<double> denseA, denseL, dense_x;
   hipGraphExec_t dense_graph = nullptr;   // zero + assemble + blocked Cholesky + solve, captured once
   bool dense_graph_lap = false;           // form of the blocks the captured assemble kernel expects
   int nb_mv = 1, mv_reps = 1;
@@ -586,7 +586,8 @@ void launch_prep(gsfm_rot_problem* P, const gsfm_rot_options& o, double radius, 
   hipLaunchKernelGGL(k_max_partials, dim3(1), dim3(GSFM_BLOCK), 0, P->stream, P->part_cam.p, P->nb_cam, P->scal.p + SC_GMAX);
 }
 
-int launch_matvec(gsfm_rot_problem* P, const double* Mblk, const double* p, double* y, const int* done) {
+int launch_matvec(gsfm_rot_problem* P, const double* Mblk, const double* p, double* y, const int* done, double* dot_part = nullptr, bool* dot_done = nullptr) {
+  if (dot_done) *dot_done = false;
   MatvecArgs a{};
   a.n_rows = P->n_rows; a.row_base = P->own_begin; a.G = P->G; a.row_ptr = P->row_ptr.p; a.col = P->col.p;
   a.h0 = P->h0.p; a.h1 = P->h1.p; a.h2 = P->h2.p; a.h3 = P->h3.p; a.h4 = P->h4.p; a.Mblk = Mblk; a.p = p; a.y = y; a.done = done;
@@ -598,6 +599,7 @@ int launch_matvec(gsfm_rot_problem* P, const double* Mblk, const double* p, doub
     hipLaunchKernelGGL(k_mv_col, dim3(c.n_wg), dim3(GSFM_COL_RB), 0, P->stream, m);
     ColFinishArgs f{};
     f.n_rows = P->n_rows; f.row_base = P->own_begin; f.nch = c.nch; f.n_wg = c.n_wg; f.part = c.part.p; f.Mblk = Mblk; f.p = p; f.q = P->q_lin; f.y = y; f.done = done;
+    if (dot_part && !P->sharded) { f.dot_part = dot_part; *dot_done = true; }   // (one GPU: rows = cameras, the finish grid is the camera kernels' grid)
     hipLaunchKernelGGL(k_mv_col_finish, dim3(grid_for(P->n_rows)), dim3(GSFM_BLOCK), 0, P->stream, f);
     return all_gather(P, y, (size_t)P->shard.slice_width * 3);
   }
@@ -723,9 +725,10 @@ int run_pcg(gsfm_rot_problem* P, const gsfm_rot_options& o, int* iters_out, doub
   const int chunk = std::max(1, o.cg_check_interval);
   auto enqueue_chunk = [&]() -> int {  // `chunk` iterations; leaves a.par where it found it when chunk is even
     for (int c = 0; c < chunk; ++c) {
-      if (int st = launch_matvec(P, P->Mblk.p, P->p.p, P->Ap.p, &P->cgsc.p->done)) return st;
+      bool dotted = false;
+      if (int st = launch_matvec(P, P->Mblk.p, P->p.p, P->Ap.p, &P->cgsc.p->done, a.part_a, &dotted)) return st;
       if (P->sharded) P->n_pcg_collectives++;
-      hipLaunchKernelGGL(k_cg_dot, g, blk, 0, P->stream, a);
+      if (!dotted) hipLaunchKernelGGL(k_cg_dot, g, blk, 0, P->stream, a);
       hipLaunchKernelGGL(k_cg_update, g, blk, 0, P->stream, a);
       if (a.coarse_n) {
         if (!fused_restrict) hipLaunchKernelGGL(k_coarse_restrict, dim3(a.coarse_n), blk, 0, P->stream, ca);
@@ -881,8 +884,12 @@ int run_dense(gsfm_rot_problem* P, bool* used) {
   if (T > GSFM_DENSE_MAX_T || P->cs.active) return 0;   // (the assembly walks the row-major entry order)
   const size_t elems = chol_num_tiles(T) * GSFM_TILE_ELEMS;
   if (!P->denseA.p) {
-    if (P->denseA.alloc(elems) != hipSuccess || P->denseL.alloc(elems, true) != hipSuccess) { P->denseA.release(); return 0; }
+    if (P->denseA.alloc(elems) != hipSuccess || P->denseL.alloc(elems, true) != hipSuccess || P->dense_x.alloc((size_t)T * GSFM_CB, true) != hipSuccess) { P->denseA.release(); return 0; }
   }
+  // schedule: one fused kernel per block column (shortest chain for tiny matrices), or panel + MFMA update + one backward launch per block
+  // row.  Measured (tools/bench_chol.hip): the second wins from 3N = 1182 on (0.75 vs 0.84 ms), 1.75 vs 2.7 ms at 2400, 4.3 vs 10.2 ms at
+  // 4500.  GSFM_CHOL_SPLIT_T overrides the switch point (block columns; A/B measurements).
+  static const uint32_t split_T = [] { const char* e = getenv("GSFM_CHOL_SPLIT_T"); const int v = e && *e ? atoi(e) : GSFM_CHOL_SPLIT_DEFAULT; return (uint32_t)std::max(0, std::min(v, GSFM_CHOL_SPLIT_T)); }();
   auto enqueue = [&]() {
     (void)hipMemsetAsync(P->denseA.p, 0, 8 * elems, P->stream);
     int* const info = (int*)(P->scal.p + SC_DENSE_INFO);
@@ -892,10 +899,21 @@ int run_dense(gsfm_rot_problem* P, bool* used) {
     hipLaunchKernelGGL(k_dense_assemble, dim3(P->n_rows), dim3(GSFM_BLOCK), 0, P->stream, a);
     for (uint32_t k = 0; k < T; ++k) {
       CholArgs c{P->denseA.p, P->denseL.p, T, k, info};
-      const uint32_t m = T - k;
-      hipLaunchKernelGGL(k_chol_step, dim3(1 + m * (m + 1) / 2), dim3(256), 0, P->stream, c);
+      const uint64_t m = T - k;
+      if (T <= split_T) hipLaunchKernelGGL(k_chol_step, dim3((uint32_t)(1 + m * (m + 1) / 2)), dim3(256), 0, P->stream, c);
+      else {   // larger matrices: panel (one wavefront per tile row), then the trailing update on the matrix cores
+        hipLaunchKernelGGL(k_chol_panel, dim3((uint32_t)(m + 1)), dim3(64), 0, P->stream, c);
+        hipLaunchKernelGGL(k_chol_update_mfma, dim3((uint32_t)((m * (m + 1) / 2 + 3) / 4)), dim3(256), 0, P->stream, c);
+      }
     }
-    hipLaunchKernelGGL(k_chol_back, dim3(1), dim3(1024), 0, P->stream, (const double*)P->denseL.p, n, T, P->xcg.p);
+    if (T <= split_T) hipLaunchKernelGGL(k_chol_back<GSFM_CHOL_SPLIT_T>, dim3(1), dim3(1024), 0, P->stream, (const double*)P->denseL.p, n, T, P->xcg.p);
+    else {   // one launch per block row, all tiles of the row in parallel; the running right-hand side is block row T of L, x goes to dense_x (padded to T * 32)
+      for (uint32_t k = T; k >= 1; --k) {
+        CholBackArgs b{P->denseL.p, P->dense_x.p, n, T, k};
+        hipLaunchKernelGGL(k_chol_back_step, dim3(k == T ? 1 : k), dim3(64), 0, P->stream, b);
+      }
+      (void)hipMemcpyAsync(P->xcg.p, P->dense_x.p, 8 * (size_t)n, hipMemcpyDeviceToDevice, P->stream);
+    }
     // (exact solve: the PCG residual term of the model decrease is zero -- k_dense_assemble cleared it)
   };
   const int tk = P->timer.begin(T_CG);

@@ -327,10 +327,11 @@ def test_locality_relabelling_is_adopted_only_when_it_helps(monkeypatch):
     assert out["random"] and not out["local"]
 
 
-@pytest.mark.parametrize("n_cams,n_edges", [(300, 3000), (77, 900), (530, 9000), (64, 700)])
+@pytest.mark.parametrize("n_cams,n_edges", [(300, 3000), (77, 900), (530, 9000), (64, 700), (900, 12000)])
 def test_dense_cholesky_step_matches_the_oracles_cholesky(oracle, n_cams, n_edges):
     """`dense_cholesky_max_cams`: the LM step from an exact blocked Cholesky of the damped normal matrix on the device (sizes that
-    are and are not multiples of the 32-column block) against the oracle's dense Cholesky -- the reference's own linear solver."""
+    are and are not multiples of the 32-column block; 530 and 900 cameras run the two-kernel schedule with the trailing update on
+    fp64 MFMA) against the oracle's dense Cholesky -- the reference's own linear solver."""
     from globalsfmpy_amd.solver import RotationProblem
     g = synth.make_graph(n_cams, n_edges, 17, outlier_frac=0.2)
     loss = LF.MAGSACWeightBasedLoss(0.02)
@@ -469,10 +470,11 @@ def test_threaded_structure_build_is_invisible(monkeypatch):
 
 
 def test_default_linear_solver_by_problem_size():
-    """dense_cholesky_max_cams = 512 by default: exact Cholesky steps up to 512 cameras (3N = 1536 = 48 full tiles), PCG from 513 on; a
-    request beyond the 1706 cameras the backward kernel holds in LDS falls back to PCG instead of failing."""
+    """dense_cholesky_max_cams = 512 by default: exact Cholesky steps up to 512 cameras (3N = 1536 = 48 full tiles), PCG from 513 on; on
+    request up to 5333 cameras (the two-kernel MFMA schedule, right-hand side of the backward kernel in LDS); a request beyond that falls
+    back to PCG instead of failing."""
     from globalsfmpy_amd.solver import RotationProblem
-    for n, want_dense, kw in ((512, True, {}), (513, False, {}), (2000, False, dict(dense_cholesky_max_cams=5000))):
+    for n, want_dense, kw in ((512, True, {}), (513, False, {}), (2000, True, dict(dense_cholesky_max_cams=5000)), (5400, False, dict(dense_cholesky_max_cams=6000))):
         g = synth.make_graph(n, 12 * n, seed=n, outlier_frac=0.1)
         p = RotationProblem(g["n_cams"], g["edge_i"], g["edge_j"], g["rel_aa"], _abi.ANGLE_AXIS)
         p.set_loss(LF.SoftLOneLoss(0.1))

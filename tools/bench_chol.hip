@@ -6,6 +6,7 @@
 #include <cmath>
 #include <vector>
 #include <random>
+#include <algorithm>
 #include "../globalsfmpy_amd/csrc/dense_kernels.hpp"
 using namespace gsfm;
 #define CHK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
@@ -13,8 +14,9 @@ using namespace gsfm;
 int main(int argc, char** argv) {
   std::vector<uint32_t> sizes;
   for (int k = 1; k < argc; ++k) sizes.push_back(atoi(argv[k]));
-  if (sizes.empty()) sizes = {96, 1182, 2400, 4500};
-  for (uint32_t n : sizes) {
+  if (sizes.empty()) sizes = {96, 1182, 2400, 4500, 9000};
+  for (uint32_t n : sizes) for (int split = 0; split < 2; ++split) {
+    if (!split && n > 5000) continue;   // (the one-kernel-per-step schedule needs minutes there)
     const uint32_t T = (n + GSFM_CB - 1) / GSFM_CB;
     const size_t elems = chol_num_tiles(T) * GSFM_TILE_ELEMS;
     std::mt19937_64 rng(n);
@@ -39,10 +41,15 @@ int main(int argc, char** argv) {
       CHK(hipMemcpyAsync(dA, dA0, 8 * elems, hipMemcpyDeviceToDevice, st));
       for (uint32_t k = 0; k < T; ++k) {
         CholArgs c{dA, dL, T, k, dinfo};
-        const uint32_t m = T - k;
-        hipLaunchKernelGGL(k_chol_step, dim3(1 + m * (m + 1) / 2), dim3(256), 0, st, c);
+        const uint64_t m = T - k;
+        if (!split) hipLaunchKernelGGL(k_chol_step, dim3((uint32_t)(1 + m * (m + 1) / 2)), dim3(256), 0, st, c);
+        else {
+          hipLaunchKernelGGL(k_chol_panel, dim3((uint32_t)(m + 1)), dim3(64), 0, st, c);
+          hipLaunchKernelGGL(k_chol_update_mfma, dim3((uint32_t)((m * (m + 1) / 2 + 3) / 4)), dim3(256), 0, st, c);
+        }
       }
-      hipLaunchKernelGGL(k_chol_back, dim3(1), dim3(1024), 0, st, (const double*)dL, n, T, dx);
+      if (!split) hipLaunchKernelGGL(k_chol_back<GSFM_DENSE_MAX_T>, dim3(1), dim3(1024), 0, st, (const double*)dL, n, T, dx);
+      else for (uint32_t k = T; k >= 1; --k) { CholBackArgs b{dL, dx, n, T, k}; hipLaunchKernelGGL(k_chol_back_step, dim3(k == T ? 1 : k), dim3(64), 0, st, b); }
     };
     hipGraph_t g; hipGraphExec_t ge;
     CHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal)); enqueue(); CHK(hipStreamEndCapture(st, &g)); CHK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
@@ -56,9 +63,10 @@ int main(int argc, char** argv) {
     CHK(hipEventRecord(e0, st)); for (int k = 0; k < reps; ++k) CHK(hipGraphLaunch(ge, st)); CHK(hipEventRecord(e1, st)); CHK(hipEventSynchronize(e1));
     float ms; CHK(hipEventElapsedTime(&ms, e0, e1));
     // the backward kernel alone
-    CHK(hipEventRecord(e0, st)); for (int k = 0; k < reps; ++k) hipLaunchKernelGGL(k_chol_back, dim3(1), dim3(1024), 0, st, (const double*)dL, n, T, dx); CHK(hipEventRecord(e1, st)); CHK(hipEventSynchronize(e1));
+    CHK(hipEventRecord(e0, st)); for (int k = 0; k < reps; ++k) hipLaunchKernelGGL(k_chol_back<GSFM_CHOL_SPLIT_T>, dim3(1), dim3(1024), 0, st, (const double*)dL, n, std::min<uint32_t>(T, GSFM_CHOL_SPLIT_T), dx); CHK(hipEventRecord(e1, st)); CHK(hipEventSynchronize(e1));
     float msb; CHK(hipEventElapsedTime(&msb, e0, e1));
-    printf("n = %5u (T = %3u): info %d  max |Ax - b| / max|b| = %.2e   factor+solve %.3f ms (graph replay), backward alone %.3f ms\n", n, T, info, rmax / bmax, ms / reps, msb / reps);
+    printf("n = %5u (T = %3u) %-28s: info %d  max |Ax - b| / max|b| = %.2e   factor+solve %.3f ms (graph replay), single-workgroup backward of min(T, 48) block rows alone %.3f ms\n", n, T,
+           split ? "panel + MFMA update per step" : "one kernel per step", info, rmax / bmax, ms / reps, msb / reps);
     CHK(hipFree(dA0)); CHK(hipFree(dA)); CHK(hipFree(dL)); CHK(hipFree(dx)); CHK(hipFree(dinfo));
   }
   return 0;
