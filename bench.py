@@ -405,6 +405,10 @@ def main():
             "iters_to_1e-6": summ["iters_to_1e6"], "lm_iterations": summ["num_iterations"],
             "residual_sweeps_per_solve": summ["num_residual_sweeps"], "cg_iterations_per_solve": summ["num_cg_iterations"],
             "termination": summ["termination_name"], "final_cost": summ["final_cost"],
+            "collectives_per_solve": summ["num_collectives"],
+            # one all-gather (the A.p slices) per LAUNCHED PCG iteration and nothing else inside the PCG loop (launched = chunks of cg_check_interval)
+            "collectives_per_pcg_iteration": (summ["num_pcg_collectives"] / summ["num_pcg_launched"]) if (summ["num_pcg_launched"] and (world > 1 or force_shard)) else 0.0,
+            "pcg_chunks_replayed_as_hipgraphs": summ["num_graph_launches"],
             "mean_angular_error_vs_ground_truth_deg": float(np.rad2deg(err.mean())),
             "gpu_ms_per_solve": {"linearize": summ["t_linearize_ms"], "sweep": summ["t_sweep_ms"], "pcg": summ["t_cg_ms"]},
             "setup_s": {"generate": t_gen, "create_problem": t_create},

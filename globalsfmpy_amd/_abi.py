@@ -66,6 +66,7 @@ class Summary(C.Structure):
         ("t_sweep_ms", C.c_double), ("t_cg_ms", C.c_double),
         ("num_dense_solves", C.c_int32), ("num_graph_launches", C.c_int32),
         ("num_collectives", C.c_int32), ("num_pcg_collectives", C.c_int32),
+        ("num_pcg_launched", C.c_int32), ("reserved_", C.c_int32),
     ]
 
     def as_dict(self):

@@ -275,7 +275,7 @@ struct gsfm_rot_problem {
 
   bool have_lin = false;
   int graph_launches = 0;
-  int n_collectives = 0, n_pcg_collectives = 0;   // issued (or replayed from a graph) since the solve started
+  int n_collectives = 0, n_pcg_collectives = 0, n_pcg_launched = 0;   // issued (or replayed from a graph) since the solve started
   std::vector<double> trace;
   EventTimer timer;
 };
@@ -764,7 +764,7 @@ int run_pcg(gsfm_rot_problem* P, const gsfm_rot_options& o, int* iters_out, doub
     for (int c = 0; c < chunks; ++c) {
       if (graph) { HIPCHK(hipGraphLaunch(G.exec, P->stream)); P->graph_launches++; P->n_collectives += G.collectives; P->n_pcg_collectives += G.collectives; }
       else if (int st = enqueue_chunk()) return st;
-      launched += chunk;
+      launched += chunk; P->n_pcg_launched += chunk;
     }
     P->timer.end(tk);
     if (int st = read_back(P, &h, P->cgsc.p, sizeof(h), "pcg")) return st;
@@ -820,7 +820,7 @@ int run_pcg2(gsfm_rot_problem* P, const gsfm_rot_options& o, int* iters_out, dou
   int launched = 0;
   {  // iterations 0 and 1 (first = 1, then par = 1): plain launches; afterwards par == 0 at every chunk start
     const int tk = P->timer.begin(T_CG);
-    for (int k = 0; k < 2; ++k) { if (int st = enqueue_iter()) return st; ++launched; }
+    for (int k = 0; k < 2; ++k) { if (int st = enqueue_iter()) return st; ++launched; P->n_pcg_launched++; }
     P->timer.end(tk);
   }
   auto& G = P->pcg2_graph;
@@ -848,7 +848,7 @@ int run_pcg2(gsfm_rot_problem* P, const gsfm_rot_options& o, int* iters_out, dou
     for (int cc = 0; cc < chunks; ++cc) {
       if (graph) { HIPCHK(hipGraphLaunch(G.exec, P->stream)); P->graph_launches++; P->n_collectives += G.collectives; P->n_pcg_collectives += G.collectives; }
       else { for (int k = 0; k < chunk; ++k) if (int st = enqueue_iter()) return st; }
-      launched += chunk;
+      launched += chunk; P->n_pcg_launched += chunk;
     }
     P->timer.end(tk);
     if (int st = read_back(P, &h, P->cg2sc.p, sizeof(h), "pcg")) return st;
@@ -1082,7 +1082,7 @@ int lm_solve(gsfm_rot_problem* P, const gsfm_rot_options& o_in, gsfm_rot_summary
   P->trace.clear();
   P->timer.acc[0] = P->timer.acc[1] = P->timer.acc[2] = 0;
   P->graph_launches = 0;
-  P->n_collectives = P->n_pcg_collectives = 0;
+  P->n_collectives = P->n_pcg_collectives = P->n_pcg_launched = 0;
   P->lap = P->lap_capable;
   double h[SC_N];
   double radius = o.initial_trust_region_radius, decrease_factor = 2.0;
@@ -1099,7 +1099,7 @@ int lm_solve(gsfm_rot_problem* P, const gsfm_rot_options& o_in, gsfm_rot_summary
     sum->termination = term; sum->num_iterations = iteration; sum->final_cost = x_cost; sum->final_gradient_max_norm = gmax;
     sum->final_radius = radius; sum->t_total_ms = now_ms() - t0;
     sum->num_graph_launches = P->graph_launches;
-    sum->num_collectives = P->n_collectives; sum->num_pcg_collectives = P->n_pcg_collectives;
+    sum->num_collectives = P->n_collectives; sum->num_pcg_collectives = P->n_pcg_collectives; sum->num_pcg_launched = P->n_pcg_launched;
     sum->t_linearize_ms = P->timer.acc[T_LIN]; sum->t_sweep_ms = P->timer.acc[T_SWEEP]; sum->t_cg_ms = P->timer.acc[T_CG];
     if (!std::isfinite(x_cost)) sum->nonfinite = 1;
     return 0;
@@ -1864,7 +1864,7 @@ gsfm_status gsfm_rot_solve_sigma_consensus(gsfm_rot_problem* P, double* rot, int
       total.final_cost = summary->final_cost; total.termination = summary->termination;
       total.final_gradient_max_norm = summary->final_gradient_max_norm; total.final_radius = summary->final_radius;
       total.num_dense_solves += summary->num_dense_solves; total.num_graph_launches += summary->num_graph_launches;
-      total.num_collectives += summary->num_collectives; total.num_pcg_collectives += summary->num_pcg_collectives;
+      total.num_collectives += summary->num_collectives; total.num_pcg_collectives += summary->num_pcg_collectives; total.num_pcg_launched += summary->num_pcg_launched;
       total.t_linearize_ms += summary->t_linearize_ms; total.t_sweep_ms += summary->t_sweep_ms; total.t_cg_ms += summary->t_cg_ms;
     }
     total.last_weight_change = avg;

@@ -302,11 +302,8 @@ def make_sharded_problem(graph, error_type, loss=None, prefer_native=True, group
     if part is None:
         part = partition_cameras(n, graph["edge_i"], graph["edge_j"], world)
     comm = make_comm(part.width, prefer_native, group)
-    # a rank sees only its own edges: whether the GLOBAL graph is disconnected (tighter PCG tolerance, gsfm_rot.h) is decided here
-    gi = np.ascontiguousarray(graph["edge_i"], dtype=np.uint32)
-    gj = np.ascontiguousarray(graph["edge_j"], dtype=np.uint32)
-    if _abi.load_library().gsfm_rot_count_components(int(n), int(gi.size), gi.ctypes.data_as(C.POINTER(C.c_uint32)), gj.ctypes.data_as(C.POINTER(C.c_uint32))) > 1:
-        comm.shard.flags |= _abi.SHARD_DISCONNECTED
+    # (whether the GLOBAL graph is disconnected -- it decides the PCG tolerance -- is worked out inside gsfm_rot_problem_create from all
+    # ranks' edges since round 3; the SHARD_DISCONNECTED flag is no longer needed here)
     ei, ej = part.relabel(graph["edge_i"]), part.relabel(graph["edge_j"])
     m = local_edge_mask(part, ei, ej, rank)
     cov6 = graph["cov6"][m] if graph.get("cov6") is not None else None

@@ -199,7 +199,10 @@ typedef struct {
   int32_t num_dense_solves;       /* LM steps solved by the dense Cholesky path */
   int32_t num_graph_launches;     /* hipGraph replays of PCG chunks / dense solves in this call (0 = every kernel was launched plainly) */
   int32_t num_collectives;        /* sharded problems: collectives issued by this call (all-gathers + all-reduces, replayed ones included) */
-  int32_t num_pcg_collectives;    /*   ... of which inside PCG iterations: exactly one per iteration (the all-gather of the A.p slices) */
+  int32_t num_pcg_collectives;    /*   ... of which inside PCG iterations: exactly one per LAUNCHED iteration (the all-gather of the A.p slices) */
+  int32_t num_pcg_launched;       /* PCG iterations enqueued (chunks of cg_check_interval: the ones past convergence return at once, but a sharded
+                                     problem's collective in them still runs); num_cg_iterations counts the effective ones */
+  int32_t reserved_;
 } gsfm_rot_summary;
 
 /* ------------------------------------------------------------------------- */

@@ -44,6 +44,7 @@ def test_bench_two_ranks_on_one_gpu_over_gloo():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     out = _json_line(r.stdout)
     assert out["n_gpus"] == 2 and out["value"] > 0 and out["config"]["parallelism"] == "camera-slice x2" and out["config"]["collectives"] == "gloo"
+    assert out["collectives_per_pcg_iteration"] == 1.0 and out["collectives_per_solve"] > out["cg_iterations_per_solve"]   # exactly one collective per PCG iteration
     one = _json_line(subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + SMALL + ["--sigma-pass", "0"], cwd=ROOT, capture_output=True, text=True, timeout=900).stdout)
     assert out["lm_iterations"] == one["lm_iterations"] and out["residual_sweeps_per_solve"] == one["residual_sweeps_per_solve"]
     assert abs(out["final_cost"] - one["final_cost"]) <= 1e-6 * one["final_cost"]
@@ -63,3 +64,6 @@ def test_bench_single_rank_over_native_rccl_prints_exactly_one_stdout_line():
     assert len(lines) == 1, lines[:5]
     out = json.loads(lines[0])
     assert out["config"]["collectives"] == "rccl-native" and out["value"] > 0 and out["n_gpus"] == 1
+    # the native communicator's callbacks only enqueue on the solver's stream: the PCG chunks are captured WITH their all-gathers and
+    # replayed as hipGraphs by default, one collective per PCG iteration
+    assert out["collectives_per_pcg_iteration"] == 1.0 and out["pcg_chunks_replayed_as_hipgraphs"] > 0

@@ -103,8 +103,9 @@ def test_host_callback_loss_on_a_sharded_problem(tmp_path):
 
 
 def test_disconnected_graph_keeps_its_tighter_pcg_tolerance_when_sharded(tmp_path):
-    """A rank sees only its own edges, so the partitioner tells the library that the global graph is disconnected
-    (GSFM_SHARD_DISCONNECTED): same PCG iteration count as the single-GPU solve, which counts the components itself."""
+    """A rank sees only its own edges; gsfm_rot_problem_create merges every rank's local components (one all-gather of a label per camera)
+    and finds the global graph disconnected without being told: same PCG iteration count as the single-GPU solve, which counts the
+    components itself.  (Round 2 needed the partitioner to set GSFM_SHARD_DISCONNECTED; sharding.py no longer does.)"""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from sharded_worker import two_component_graph
     from globalsfmpy_amd.solver import RotationProblem
@@ -116,6 +117,34 @@ def test_disconnected_graph_keeps_its_tighter_pcg_tolerance_when_sharded(tmp_pat
     assert s12["num_cg_iterations"] == s["num_cg_iterations"]
     res = _launch(2, "gloo", str(tmp_path / "disc.npz"), case="disconnected")
     assert int(res["iters"]) == s["num_iterations"] and int(res["cg"]) == s["num_cg_iterations"]
+    assert synth.angular_distance(synth.align_rotations(res["rot"], rot), rot).mean() <= 1e-6
+
+
+@pytest.mark.parametrize("world,case", [(2, "default"), (3, "default"), (2, "callback"), (2, "sigma")])
+def test_column_sorted_layout_on_a_sharded_problem(tmp_path, world, case):
+    """K2c / K3c on every rank (GSFM_K3_COLSORT=1 forces the layout on this small graph; at C5 size each rank of an 8-GPU run chooses it by
+    itself: 512 rows x degree 200 entries per block for 100k cameras, whatever the number of rows a rank owns): same solve as one GPU on
+    the row-major kernels, for a native loss, for a host-callback loss (k_col_s: s of every held edge) and for sigma consensus."""
+    from globalsfmpy_amd.solver import RotationProblem
+    res = _launch(world, "gloo", str(tmp_path / ("cs_%s%d.npz" % (case, world))), {"GSFM_K3_COLSORT": "1"}, case=case)
+    if case == "default":
+        _compare(res, _reference())
+        return
+    g = synth.make_graph(1203, 40000, seed=23, outlier_frac=0.3)
+    if case == "callback":
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from sharded_worker import python_only_loss
+        p = RotationProblem(g["n_cams"], g["edge_i"], g["edge_j"], g["rel_aa"], _abi.ANGLE_AXIS_COVARIANCE, cov6=g["cov6"])
+        p.set_loss_callback(python_only_loss)
+        rot, s = p.solve(g["init_aa"], max_num_iterations=6, dense_cholesky_max_cams=0)
+    else:
+        from globalsfmpy_amd.loss_functions import TrivialLoss
+        p = RotationProblem(g["n_cams"], g["edge_i"], g["edge_j"], g["rel_aa"], _abi.ANGLE_AXIS)
+        p.set_loss(TrivialLoss())
+        rot, s = p.solve_sigma_consensus(g["init_aa"], 4, 0.05, dense_cholesky_max_cams=0)
+        assert int(res["outer"]) == s["outer_iterations"] and abs(float(res["wchange"]) - s["last_weight_change"]) <= 1e-9 * max(1.0, s["last_weight_change"])
+    assert int(res["iters"]) == s["num_iterations"]
+    assert abs(float(res["cost"]) - s["final_cost"]) <= 1e-8 * s["final_cost"]
     assert synth.angular_distance(synth.align_rotations(res["rot"], rot), rot).mean() <= 1e-6
 
 
