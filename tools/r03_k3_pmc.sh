@@ -7,7 +7,7 @@ set -u
 cd "$(dirname "$0")/.."
 ROOT=$PWD
 PROBE=${1:-tools/r03_k3_probe.py}
-OUT=$ROOT/gpurun_out/r03_k3_pmc
+OUT=${K3_PMC_OUT:-$ROOT/gpurun_out/r03_k3_pmc}
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 declare -A PMCG
@@ -21,7 +21,7 @@ PMCG[ta]="TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_
 PMCG[td]="TD_TD_BUSY_sum TD_TC_STALL_sum TD_LOAD_WAVEFRONT_sum"
 PMCG[sq_a]="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_VMEM SQ_INSTS_VMEM_RD GRBM_GUI_ACTIVE"
 PMCG[sq_b]="SQ_INST_LEVEL_VMEM SQ_INST_CYCLES_VMEM_RD SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_LEVEL_WAVES"
-for g in tcp_req tcp_stall tcp_fifo tcp_tlb tcc_hit tcc_ea ta td sq_a sq_b; do
+for g in ${K3_PMC_GROUPS:-tcp_req tcp_stall tcp_fifo tcp_tlb tcc_hit tcc_ea ta td sq_a sq_b}; do
   d=$OUT/$g
   rm -rf "$d"; mkdir -p "$d"
   ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc ${PMCG[$g]} -d "$d" -o pmc -- python "$ROOT/$PROBE" > "$d/run.log" 2>&1 )
