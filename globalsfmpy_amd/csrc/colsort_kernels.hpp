@@ -190,7 +190,8 @@ __device__ __forceinline__ void lin_col_body(const ColLinArgs& a) {
     const uint32_t sc = w.first_sub + s;
     // The kernel is latency-bound (VALU ~20 % busy): both trips of the sub-chunk are requested together -- the two 8-byte records first,
     // then, as soon as they are there, both trips' streams and neighbour quaternions -- so a sub-chunk pays two dependent memory round
-    // trips instead of four.  (Padding positions read camera 0 and their own, valid, stream slots; nothing of it is used.)
+    // trips instead of four.  (Padding positions read camera 0 and their own, valid, stream slots; nothing of it is used.)  Requesting the
+    // NEXT sub-chunk's records ahead as well was measured and dropped: 793 us against 745 for the row-major K2 on the same box.
     constexpr int K = SUB / T;
     uint2 mt[K];
 #pragma unroll

@@ -17,6 +17,25 @@ def test_randomised_device_vs_oracle(oracle, seed, monkeypatch):
     assert fuzz_differential.run(trials=120, seed=seed, quick=True) == 0
 
 
+@pytest.mark.parametrize("seed", [21])
+def test_randomised_device_vs_oracle_on_the_column_sorted_layout(oracle, seed, monkeypatch):
+    """The same adversarial graphs with the column-sorted layout forced on (GSFM_K3_COLSORT=1: K2c / K3c for the Laplacian-capable error
+    types; the others ignore it): repeated pairs, isolated cameras, ragged last row blocks, every loss incl. the general Corrector path and
+    host-evaluated ones.  At production sizes the layout switches itself on (C5); here nothing else would exercise it on awkward inputs."""
+    monkeypatch.delenv("FUZZ_ONLY", raising=False)
+    monkeypatch.setenv("GSFM_K3_COLSORT", "1")
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "manual"))
+    import fuzz_differential
+    assert fuzz_differential.run(trials=120, seed=seed, quick=True) == 0
+
+
+def test_randomised_sigma_consensus_on_the_column_sorted_layout(oracle, monkeypatch):
+    monkeypatch.setenv("GSFM_K3_COLSORT", "1")
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "manual"))
+    import fuzz_sigma
+    assert fuzz_sigma.run(trials=20, seed=16) == 0
+
+
 def test_randomised_covariance_estimation_vs_oracle(oracle):
     """gsfm_cov_estimate on awkward view pairs (5-60 matches, gross outliers, zero / tiny translation, identical or collinear matches,
     far-off initial rotations): same status, same iteration count and the same covariance as the oracle wherever the refinement is short;
