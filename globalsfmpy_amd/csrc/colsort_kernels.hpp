@@ -12,8 +12,9 @@
 // mat-vec becomes a stream of its own 54 B per entry.  Per-row sums stay deterministic and atomic-free: a sub-chunk of SUB entries is
 // evaluated entry-parallel, each entry's contribution is written to its slot of a ROW-sorted LDS staging area (2-byte permutation index
 // per entry), and after a barrier the lane that owns row r adds the slots of row r, in slot order, to the sums it keeps in registers
-// (seg[] = slot range per row and sub-chunk).  The sub-chunks of a block are dealt to NCH workgroups; a finishing kernel adds
-// the NCH partials of a row in fixed order.  K2c stores the edge blocks in the BODY frame, B = R_k^T G R_k (it has R_k at hand), so K3c
+// (the number of slots of row r in a sub-chunk rides in spare bits of the record at POSITION r of that sub-chunk -- as many rows as
+// positions -- and a workgroup-wide prefix sum turns the counts into slot ranges: no separate index stream).  The sub-chunks of a block
+// are dealt to NCH workgroups; a finishing kernel adds the NCH partials of a row in fixed order.  K2c stores the edge blocks in the BODY frame, B = R_k^T G R_k (it has R_k at hand), so K3c
 // applies R_k once per row, in its finish, instead of once per entry.
 //   measured at C5 (tools/bench_matvec6.hip, random data): row-major mat-vec 322 us -> 193 + 3 us.
 #pragma once
@@ -23,17 +24,42 @@ namespace gsfm {
 
 #define GSFM_COL_RB 512    // rows per block = positions per sub-chunk = lanes of a K3c workgroup
 #define GSFM_COL_SUB GSFM_COL_RB
-#define GSFM_COL_EPL 2     // K3c: sub-chunks in flight per iteration (entries per lane)
+#ifndef GSFM_COL_EPL
+#define GSFM_COL_EPL 1     // K3c: sub-chunks in flight per iteration (entries per lane); -DGSFM_COL_EPL=n: 1 measured best in the product (2: +4..9 %, 3: +8 %)
+#endif
 #define GSFM_COL_PAD 0xffffffffu   // column value of a padding position (zero block, reads camera 0)
 
 struct ColWg { uint32_t first_sub, n_sub, row0, pad; };   // sub-chunk range; first row of the block (local to the owned rows)
 struct ColLayoutDev {
   const ColWg* wg;
-  const uint2* meta;        // per position: .x = neighbour camera | role << 31 (GSFM_COL_PAD = padding), .y = slot in the row-sorted staging area
-                            //   of its sub-chunk | row inside its block << 16  -- one 8-byte load per entry
-  const uint32_t* seg;      // per sub-chunk and row: first slot | one-past-last slot << 16  -- one 4-byte load per row
+  const uint2* meta;        // per position p of a sub-chunk: .x = neighbour camera | role << 31 (GSFM_COL_PAD = padding);
+                            //   .y = slot of the entry in the row-sorted staging area (bits 0-9) | number of entries ROW p of the block has in this
+                            //   sub-chunk (bits 10-19) | row of the entry inside its block (bits 20-28)  -- one 8-byte load per entry
+  // The mat-vec's own, narrower copy of what it needs of the record: kcol = camera (all ones in `cbits` bits = padding) | slot << cbits |
+  // row count << (cbits + 9), the count saturating at `cmax` = 2^(23 - cbits) - 1, in which case (and always when cmax == 0, i.e. with 2^22
+  // cameras or more... the layout is not built beyond that) the true count is read from kcnt: 4 bytes per position for graphs below
+  // 2^19 cameras, 6 above, instead of 8.
+  const uint32_t* kcol;
+  const uint16_t* kcnt;
+  uint32_t cbits, cmax;
   uint32_t n_wg, nch;
 };
+__device__ __forceinline__ uint32_t col_slot(uint32_t y) { return y & 0x3ffu; }
+__device__ __forceinline__ uint32_t col_rowcount(uint32_t y) { return (y >> 10) & 0x3ffu; }
+__device__ __forceinline__ uint32_t col_rowl(uint32_t y) { return y >> 20; }
+// inclusive prefix sum over the 64 lanes of a wavefront: DPP row shifts inside the rows of 16 lanes, then the two row broadcasts (six VALU
+// instructions, no LDS traffic)
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x) {
+  int v = (int)x;
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);   // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);   // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);   // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);   // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
+  return (uint32_t)v;
+}
+
 __device__ __forceinline__ uint2 col_load_meta(const uint2* p) {
   uint2 v;
   v.x = __builtin_nontemporal_load(&p->x); v.y = __builtin_nontemporal_load(&p->y);
@@ -54,44 +80,48 @@ __global__ void __launch_bounds__(GSFM_COL_RB) k_mv_col(ColMatvecArgs a) {
   // plane-major: the slot-contiguous reads of one row are conflict-free; two buffers, so one barrier per iteration suffices (a buffer is
   // written again two iterations later, after the barrier every lane passes once it has finished reading it)
   __shared__ double slots[2][EPL][3][RB];
+  __shared__ uint32_t wtot[2][EPL][RB / 64];   // per wavefront: number of slots of its 64 rows
   const ColWg w = a.L.wg[blockIdx.x];
-  const uint32_t r = threadIdx.x;
+  const uint32_t r = threadIdx.x, wave = r >> 6;
   double y0 = 0.0, y1 = 0.0, y2 = 0.0;
-  uint32_t m[EPL], pm[EPL]; double2 A[EPL], B[EPL], C[EPL];
+  uint32_t m[EPL], pos[EPL]; double2 A[EPL], B[EPL], C[EPL];
+  const uint32_t cmask = (1u << a.L.cbits) - 1u, cshift = a.L.cbits + 9u, cmax = a.L.cmax;
   auto request = [&](uint32_t s) {   // the streams of sub-chunks s .. s + EPL - 1 of this workgroup (past its end: the last one again, discarded)
 #pragma unroll
     for (int k = 0; k < EPL; ++k) {
       const uint32_t sc = w.first_sub + min(s + (uint32_t)k, w.n_sub - 1);
       const size_t e = (size_t)sc * RB + r;
-      const uint2 mt = col_load_meta(a.L.meta + e);
-      m[k] = mt.x; pm[k] = mt.y & 0xffffu;
+      m[k] = __builtin_nontemporal_load(a.L.kcol + e); pos[k] = (uint32_t)e;
       A[k] = nt_load2(a.b0 + e); B[k] = nt_load2(a.b1 + e); C[k] = nt_load2(a.b2 + e);
     }
   };
   if (w.n_sub) request(0);
   int buf = 0;
   for (uint32_t s = 0; s < w.n_sub; s += EPL, buf ^= 1) {
+    uint32_t cnt[EPL], inc[EPL];
 #pragma unroll
     for (int k = 0; k < EPL; ++k) {
-      const uint32_t cam = m[k] == GSFM_COL_PAD ? 0u : (m[k] & 0x7fffffffu);
+      const uint32_t cam = (m[k] & cmask) == cmask ? 0u : (m[k] & cmask), pm = (m[k] >> a.L.cbits) & 0x1ffu;
       const double* um = a.u + 3 * (size_t)cam;
       const double u0 = um[0], u1 = um[1], u2 = um[2];
-      slots[buf][k][0][pm[k]] = A[k].x * u0 + A[k].y * u1 + B[k].x * u2;
-      slots[buf][k][1][pm[k]] = A[k].y * u0 + B[k].y * u1 + C[k].x * u2;
-      slots[buf][k][2][pm[k]] = B[k].x * u0 + C[k].x * u1 + C[k].y * u2;
-    }
-    uint32_t s0[EPL], s1[EPL];
-#pragma unroll
-    for (int k = 0; k < EPL; ++k) {
-      const bool live = s + (uint32_t)k < w.n_sub;
-      const uint32_t sg = a.L.seg[(size_t)(w.first_sub + (live ? s + (uint32_t)k : s)) * RB + r];
-      s0[k] = sg & 0xffffu; s1[k] = live ? (sg >> 16) : s0[k];
+      slots[buf][k][0][pm] = A[k].x * u0 + A[k].y * u1 + B[k].x * u2;
+      slots[buf][k][1][pm] = A[k].y * u0 + B[k].y * u1 + C[k].x * u2;
+      slots[buf][k][2][pm] = B[k].x * u0 + C[k].x * u1 + C[k].y * u2;
+      // slot range of row r: prefix sum of the rows' counts, inside the wavefront here, across wavefronts after the barrier
+      uint32_t c = m[k] >> cshift;
+      if (c == cmax) c = a.L.kcnt[pos[k]];   // (saturated: a row with very many entries in this sub-chunk, or no room for counts in the word)
+      cnt[k] = s + (uint32_t)k < w.n_sub ? c : 0u;
+      inc[k] = wave_incl_scan(cnt[k]);
+      if ((r & 63u) == 63u) wtot[buf][k][wave] = inc[k];
     }
     if (s + EPL < w.n_sub) request(s + EPL);   // the next iteration's streams are in flight across the barrier and the row phase
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < EPL; ++k)
-      for (uint32_t t = s0[k]; t < s1[k]; ++t) { y0 += slots[buf][k][0][t]; y1 += slots[buf][k][1][t]; y2 += slots[buf][k][2][t]; }
+    for (int k = 0; k < EPL; ++k) {
+      uint32_t s1 = inc[k];
+      for (uint32_t v = 0; v < wave; ++v) s1 += wtot[buf][k][v];
+      for (uint32_t t = s1 - cnt[k]; t < s1; ++t) { y0 += slots[buf][k][0][t]; y1 += slots[buf][k][1][t]; y2 += slots[buf][k][2][t]; }
+    }
   }
   const size_t o = (size_t)blockIdx.x * RB + r, plane = (size_t)a.L.n_wg * RB;
   a.part[o] = y0; a.part[plane + o] = y1; a.part[2 * plane + o] = y2;
@@ -144,7 +174,7 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_col_s(ColRowSArgs a) {
   for (uint32_t d = w.first_sub * GSFM_COL_SUB + threadIdx.x; d < (w.first_sub + w.n_sub) * GSFM_COL_SUB; d += GSFM_BLOCK) {
     const uint2 mt = col_load_meta(a.L.meta + d);
     if (mt.x == GSFM_COL_PAD) continue;
-    const Quat qk = load_q(a.q, a.row_base + w.row0 + (mt.y >> 16)), qm = load_q(a.q, mt.x & 0x7fffffffu);
+    const Quat qk = load_q(a.q, a.row_base + w.row0 + col_rowl(mt.y)), qm = load_q(a.q, mt.x & 0x7fffffffu);
     const double2 r0 = a.qr0[d], r1 = a.qr1[d];
     const Quat qr{r0.x, r0.y, r1.x, r1.y};
     const EdgeW W = load_w<WM>(a.w0, a.w1, a.w2, a.ws, d);
@@ -163,7 +193,9 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_col_s(ColRowSArgs a) {
 // trips; the nine per-entry contributions to (g, D) of the row camera go through the LDS slots, lanes t and t + 256 own rows t and t + 256
 // of the block (37 KB of slots + 16 KB of row quaternions per workgroup: three workgroups, i.e. three waves per SIMD, per CU).  The row cameras' quaternions are staged in LDS once per workgroup (a lane's row is arbitrary inside the block); the
 // neighbour's quaternion is gathered -- line-sharing, like u in K3c.  a.h0..h2 receive the BODY-frame block at the entry's position.
+#ifndef GSFM_COLLIN_THREADS
 #define GSFM_COLLIN_THREADS 256
+#endif
 struct ColLinArgs {
   LinArgs lin;              // streams (qr, w, col, eid: all in position order), q, loss, rho_ext, sigma, h0..h2 (out); row_base
   ColLayoutDev L;
@@ -174,6 +206,7 @@ __device__ __forceinline__ void lin_col_body(const ColLinArgs& a) {
   constexpr int RB = GSFM_COL_RB, SUB = GSFM_COL_SUB, T = GSFM_COLLIN_THREADS, RPL = RB / T;
   __shared__ double slots[9][SUB];
   __shared__ double2 qrow[2][RB];
+  __shared__ uint32_t wtot[RPL][T / 64];
   const ColWg w = a.L.wg[blockIdx.x];
   const uint32_t t = threadIdx.x;
   for (uint32_t r = t; r < RB; r += T) {
@@ -207,10 +240,10 @@ __device__ __forceinline__ void lin_col_body(const ColLinArgs& a) {
 #pragma unroll
     for (int k = 0; k < K; ++k) {
       const uint32_t d = sc * SUB + k * T + t;
-      const uint32_t cr = mt[k].x, pm = mt[k].y & 0xffffu;
+      const uint32_t cr = mt[k].x, pm = col_slot(mt[k].y);
       double g3[3] = {0, 0, 0}, G6[6] = {0, 0, 0, 0, 0, 0}, B6[6] = {0, 0, 0, 0, 0, 0};
       if (cr != GSFM_COL_PAD) {
-        const uint32_t rl = mt[k].y >> 16;
+        const uint32_t rl = col_rowl(mt[k].y);
         const double2 k0 = qrow[0][rl], k1 = qrow[1][rl];
         const Quat qk{k0.x, k0.y, k1.x, k1.y};
         lin_entry_eval<F, WM, LM, FAST>(a.lin, d, cr, qk, qm[k], S[k], g3, G6);
@@ -234,12 +267,22 @@ __device__ __forceinline__ void lin_col_body(const ColLinArgs& a) {
 #pragma unroll
       for (int c = 0; c < 6; ++c) slots[3 + c][pm] = G6[c];
     }
-    const uint32_t* sg = a.L.seg + (size_t)sc * RB;
-    __syncthreads();
+    // slot ranges of rows t + j * T: the rows' counts ride in the records of positions t + j * T, i.e. in mt[j] (K == RPL)
+    static_assert(K == RPL, "one record per owned row");
+    uint32_t cnt[RPL], inc[RPL];
 #pragma unroll
     for (int j = 0; j < RPL; ++j) {
-      const uint32_t sgr = sg[t + j * T];
-      const uint32_t s0 = sgr & 0xffffu, s1 = sgr >> 16;
+      cnt[j] = col_rowcount(mt[j].y);
+      inc[j] = wave_incl_scan(cnt[j]);
+      if ((t & 63u) == 63u) wtot[j][t >> 6] = inc[j];
+    }
+    __syncthreads();
+    uint32_t carry = 0;
+#pragma unroll
+    for (int j = 0; j < RPL; ++j) {
+      uint32_t s1 = carry + inc[j];
+      for (uint32_t v = 0; v < T / 64; ++v) { const uint32_t wt = wtot[j][v]; if (v < (t >> 6)) s1 += wt; carry += wt; }
+      const uint32_t s0 = s1 - cnt[j];
       for (uint32_t u = s0; u < s1; ++u) {
 #pragma unroll
         for (int c = 0; c < 9; ++c) acc[j][c] += slots[c][u];

@@ -15,6 +15,7 @@
 #include <sched.h>
 #include <string>
 #include <thread>
+#include <atomic>
 #include <vector>
 
 #include "../../include/gsfm_rot.h"
@@ -263,9 +264,11 @@ struct gsfm_rot_problem {
     size_t n_pos = 0;
     DevBuf<ColWg> wg;
     DevBuf<uint2> meta;
-    DevBuf<uint32_t> seg;
+    DevBuf<uint32_t> kcol;
+    DevBuf<uint16_t> kcnt;
+    uint32_t cbits = 0, cmax = 0;
     DevBuf<double> part;      // 9 planes of [n_wg * RB] (K2c; K3c uses the first three)
-    ColLayoutDev dev() const { return ColLayoutDev{wg.p, meta.p, seg.p, n_wg, nch}; }
+    ColLayoutDev dev() const { return ColLayoutDev{wg.p, meta.p, kcol.p, kcnt.p, cbits, cmax, n_wg, nch}; }
   } cs;
 
   // sigma consensus (gsfm_rot_solve_sigma_consensus): the weights are computed inside the first cost sweep / linearisation of a solve
@@ -596,6 +599,7 @@ int launch_matvec(gsfm_rot_problem* P, const double* Mblk, const double* p, doub
     auto& c = P->cs;
     ColMatvecArgs m{};
     m.L = c.dev(); m.b0 = P->h0.p; m.b1 = P->h1.p; m.b2 = P->h2.p; m.u = P->u_rot.p; m.part = c.part.p; m.done = done;
+    // (occupancy: four workgroups per CU; holding it at 3 / 2 / 1 with unused dynamic LDS measured 215 / 226 / 306 us against 196)
     hipLaunchKernelGGL(k_mv_col, dim3(c.n_wg), dim3(GSFM_COL_RB), 0, P->stream, m);
     ColFinishArgs f{};
     f.n_rows = P->n_rows; f.row_base = P->own_begin; f.nch = c.nch; f.n_wg = c.n_wg; f.part = c.part.p; f.Mblk = Mblk; f.p = p; f.q = P->q_lin; f.y = y; f.done = done;
@@ -1228,8 +1232,14 @@ int build_colsort(gsfm_rot_problem* P, const std::vector<uint32_t>& rp, std::vec
   constexpr uint32_t RB = GSFM_COL_RB, SUB = GSFM_COL_SUB;
   auto& C = P->cs;
   const uint32_t n_rows = P->n_rows, nblk = (n_rows + RB - 1) / RB;
-  if (nblk == 0) return 0;
-  C.nch = std::min<uint32_t>(16, std::max<uint32_t>(1, (1536 + nblk - 1) / nblk));
+  if (nblk == 0 || P->n_cams >= (1u << 22) - 1u) return 0;
+  uint32_t cbits = 1;
+  while (((1u << cbits) - 1u) <= P->n_cams) ++cbits;   // cameras 0 .. n_cams - 1 and the all-ones padding value
+  const uint32_t cmax = cbits <= 19 ? (1u << (23 - cbits)) - 1u : 0u, kpad = (1u << cbits) - 1u;
+  uint32_t want_wgs = 1760;   // ~7 workgroups per CU: best of 784 .. 3100 at C5 for both K2c and K3c, by 4-8 % over the neighbouring values on the same box (boxes differ by
+                               // +-4 %; shifting the planes' base addresses against each other changes nothing; profiles/r03_k3c_tuning.txt; GSFM_COL_WGS overrides)
+  if (const char* e = getenv("GSFM_COL_WGS")) { const int v = atoi(e); if (v > 0) want_wgs = (uint32_t)v; }
+  C.nch = std::min<uint32_t>(32, std::max<uint32_t>(1, (want_wgs + nblk - 1) / nblk));
   std::vector<size_t> sub_off((size_t)nblk + 1, 0);
   for (uint32_t b = 0; b < nblk; ++b) {
     const size_t ne = rp[std::min(n_rows, (b + 1) * RB)] - rp[b * RB];
@@ -1237,8 +1247,10 @@ int build_colsort(gsfm_rot_problem* P, const std::vector<uint32_t>& rp, std::vec
   }
   const size_t n_sub = sub_off[nblk], n_pos = n_sub * SUB;
   if (n_pos == 0 || n_pos >= 0x7fffffffull) return 0;   // (positions are 32-bit in the kernels: stay on the row-major form)
-  std::vector<uint32_t> h_col(n_pos), h_eid(n_pos), h_seg(n_sub * RB);
+  std::vector<uint32_t> h_col(n_pos), h_eid(n_pos);
   std::vector<uint2> h_meta(n_pos);
+  std::vector<uint32_t> h_kcol(n_pos);
+  std::vector<uint16_t> h_kcnt(n_pos);
   std::vector<ColWg> h_wg((size_t)nblk * C.nch);
   parallel_run(std::max(1, std::min<int>(n_threads, (int)nblk)), [&](int t, int T) {
     std::vector<std::pair<uint64_t, uint32_t>> ent;   // (camera << 16 | local row, d): a repeated camera pair is ordered by d
@@ -1258,22 +1270,24 @@ int build_colsort(gsfm_rot_problem* P, const std::vector<uint32_t>& rp, std::vec
         std::fill(cnt.begin(), cnt.end(), 0u);
         for (size_t e = lo; e < hi; ++e) cnt[(ent[e].first & 0xffff) + 1]++;
         for (uint32_t r = 0; r < RB; ++r) cnt[r + 1] += cnt[r];
-        uint32_t* sg = &h_seg[(sub_off[b] + s) * RB];
-        for (uint32_t r = 0; r < RB; ++r) sg[r] = cnt[r] | (cnt[r + 1] << 16);
         std::copy(cnt.begin(), cnt.end() - 1, fill.begin());
         uint32_t pad_slot = (uint32_t)(hi - lo);
         for (size_t e = lo; e < lo + SUB; ++e) {
           const size_t o = base + (e - lo);
+          const uint32_t p = (uint32_t)(e - lo), rows_here = (cnt[p + 1] - cnt[p]) << 10;   // position p also carries the slot count of ROW p
           if (e < hi) {
             const uint32_t rl = (uint32_t)(ent[e].first & 0xffff), d = ent[e].second;
-            h_col[o] = col[d]; h_eid[o] = deid[d]; h_meta[o] = make_uint2(col[d], fill[rl]++ | (rl << 16));
-          } else { h_col[o] = GSFM_COL_PAD; h_eid[o] = 0; h_meta[o] = make_uint2(GSFM_COL_PAD, pad_slot++); }   // zero block, a slot no row reads
+            h_col[o] = col[d]; h_eid[o] = deid[d]; h_meta[o] = make_uint2(col[d], fill[rl]++ | rows_here | (rl << 20));
+          } else { h_col[o] = GSFM_COL_PAD; h_eid[o] = 0; h_meta[o] = make_uint2(GSFM_COL_PAD, pad_slot++ | rows_here); }   // zero block, a slot no row reads
+          const uint32_t rc = rows_here >> 10;
+          h_kcol[o] = (h_meta[o].x == GSFM_COL_PAD ? kpad : (h_meta[o].x & 0x7fffffffu)) | ((h_meta[o].y & 0x1ffu) << cbits) | (std::min(rc, cmax) << (cbits + 9));
+          h_kcnt[o] = (uint16_t)rc;
         }
       }
     }
   });
-  C.n_wg = (uint32_t)h_wg.size(); C.n_pos = n_pos;
-  if (C.wg.upload(h_wg) != hipSuccess || C.meta.upload(h_meta) != hipSuccess || C.seg.upload(h_seg) != hipSuccess ||
+  C.n_wg = (uint32_t)h_wg.size(); C.n_pos = n_pos; C.cbits = cbits; C.cmax = cmax;
+  if (C.wg.upload(h_wg) != hipSuccess || C.meta.upload(h_meta) != hipSuccess || C.kcol.upload(h_kcol) != hipSuccess || C.kcnt.upload(h_kcnt) != hipSuccess ||
       C.part.alloc((size_t)9 * C.n_wg * RB) != hipSuccess) {
     (void)hipGetLastError();
     C = gsfm_rot_problem::ColSort();   // out of memory: the row-major form needs none of this
@@ -2171,12 +2185,11 @@ gsfm_status gsfm_rot_matvec_bytes(gsfm_rot_problem* P, double* layout_bytes, dou
   const double N = (double)P->n_rows;
   const bool lap = P->lap_capable;
   if (lap && P->cs.active) {
-    // mat-vec, per position: column 4 + body-frame block 48 + slot permutation 2; per sub-chunk the row offsets; partial sums written and
-    // read once; the gathered vector, the diagonal blocks, p, q in, y out once per camera.  Linearisation, per position: column 4 + local
-    // row 2 + slot 2 + q_rel 32 + whitening 48 in, block 48 out; nine partial sums per row and workgroup
-    const double n_sub = (double)(P->cs.n_pos / GSFM_COL_SUB);
-    if (layout_bytes) *layout_bytes = 56.0 * (double)P->cs.n_pos + 4.0 * GSFM_COL_RB * n_sub + 2.0 * 24.0 * P->cs.n_wg * GSFM_COL_RB + (24.0 + 48.0 + 24.0 + 32.0 + 24.0) * N;
-    if (lin_bytes) *lin_bytes = (8.0 + 32.0 + (P->wmode == W_MATRIX ? 48.0 : P->wmode == W_SCALAR ? 8.0 : 0.0) + 48.0) * (double)P->cs.n_pos + 4.0 * GSFM_COL_RB * n_sub + 2.0 * 72.0 * P->cs.n_wg * GSFM_COL_RB + (32.0 + 72.0) * N;
+    // mat-vec, per position: its 4- or 6-byte record (column | slot | row count) + body-frame block 48; partial sums written and
+    // read once; the gathered vector, the diagonal blocks, p, q in, y out once per camera.  Linearisation, per position: record 8 +
+    // q_rel 32 + whitening 48 in, block 48 out; nine partial sums per row and workgroup
+    if (layout_bytes) *layout_bytes = (P->cs.cmax ? 52.0 : 54.0) * (double)P->cs.n_pos + 2.0 * 24.0 * P->cs.n_wg * GSFM_COL_RB + (24.0 + 48.0 + 24.0 + 32.0 + 24.0) * N;
+    if (lin_bytes) *lin_bytes = (8.0 + 32.0 + (P->wmode == W_MATRIX ? 48.0 : P->wmode == W_SCALAR ? 8.0 : 0.0) + 48.0) * (double)P->cs.n_pos + 2.0 * 72.0 * P->cs.n_wg * GSFM_COL_RB + (32.0 + 72.0) * N;
     if (form) *form = 2;
   } else {
     if (layout_bytes) *layout_bytes = (double)P->dir.n * (lap ? 52.0 : 76.0) + 2.0 * 24.0 * N;

@@ -169,3 +169,29 @@ def test_sigma_consensus_with_fused_weights_matches_the_oracle(oracle, loss):
     # a second call starts from zero weights again (the reference's zero-initialised last_weights), whatever the first one left in the planes
     rd2, sd2 = dev.solve_sigma_consensus(g["init_aa"], 6, 0.05)
     assert np.array_equal(rd, rd2) and sd2["last_weight_change"] == sd["last_weight_change"]
+
+
+@pytest.mark.parametrize("n,e,hub", [(70000, 300000, 40000),      # 17 camera bits: the hub row saturates the 6-bit count field of K3c's record
+                                     (600000, 1200000, 3000)])    # 20 camera bits: no room for counts in the word, all from the 2-byte plane
+def test_column_sorted_record_widths_and_saturated_row_counts(oracle, n, e, hub):
+    g = synth.make_graph(n_cams=n, n_edges=e, seed=13, outlier_frac=0.1)
+    rng = np.random.default_rng(3)
+    others = rng.choice(np.arange(6, n, dtype=np.uint32), size=hub, replace=False)
+    ei = np.concatenate([g["edge_i"], np.full(hub, 5, dtype=np.uint32)]); ej = np.concatenate([g["edge_j"], others])
+    rel = np.concatenate([g["rel_aa"], 0.3 * rng.standard_normal((hub, 3))]); c6 = np.concatenate([g["cov6"], g["cov6"][:hub]])
+    v = rng.standard_normal((n, 3))
+    y = {}
+    for mode in (0, 1):
+        with _Env(GSFM_K3_COLSORT=mode, GSFM_PCG_COARSE=0, GSFM_REORDER=0):
+            dev = RotationProblem(n, ei, ej, rel, _abi.ANGLE_AXIS_COVARIANCE, cov6=c6)
+            dev.set_loss(LF.HuberLoss(0.05))
+            assert dev.matvec_bytes()[1] == (2 if mode else 1)
+            lin = dev.linearize(g["init_aa"])
+            y[mode] = (dev.normal_matvec(v), lin["gradient"], lin["diag_blocks"])
+            dev.close()
+    for k in range(3):
+        assert _rel(y[1][k], y[0][k]) < 1e-12, k
+    ora = oracle.OracleProblem(n, ei, ej, rel, _abi.ANGLE_AXIS_COVARIANCE, cov6=c6)
+    ora.set_loss(LF.HuberLoss(0.05))
+    ora.linearize(g["init_aa"])
+    assert _rel(y[1][0], ora.normal_matvec(v)) < 1e-9
