@@ -74,8 +74,7 @@ struct ColMatvecArgs {
   double* part;             // 3 planes of [n_wg * RB]
   const int* done;          // PCG convergence flag (may be null)
 };
-__global__ void __launch_bounds__(GSFM_COL_RB) k_mv_col(ColMatvecArgs a) {
-  if (a.done && *a.done) return;
+__device__ __forceinline__ void mv_col_body(const ColMatvecArgs& a) {
   constexpr int RB = GSFM_COL_RB, EPL = GSFM_COL_EPL;
   // plane-major: the slot-contiguous reads of one row are conflict-free; two buffers, so one barrier per iteration suffices (a buffer is
   // written again two iterations later, after the barrier every lane passes once it has finished reading it)
@@ -125,6 +124,40 @@ __global__ void __launch_bounds__(GSFM_COL_RB) k_mv_col(ColMatvecArgs a) {
   }
   const size_t o = (size_t)blockIdx.x * RB + r, plane = (size_t)a.L.n_wg * RB;
   a.part[o] = y0; a.part[plane + o] = y1; a.part[2 * plane + o] = y2;
+}
+__global__ void __launch_bounds__(GSFM_COL_RB) k_mv_col(ColMatvecArgs a) {
+  if (a.done && *a.done) return;
+  mv_col_body(a);
+}
+// The same product as the mat-vec of the single-reduction PCG (run_pcg2): the convergence decision of k_matvec_cg at its entry -- every
+// workgroup re-sums the gamma partials in the order and with the reduction tree of the 256-lane kernels, so all of them, and the vector
+// kernel that follows, see bit-identical scalars -- then the rows.  The delta partials come from k_mv_col_finish (dot_part).
+struct ColMatvecCgArgs { ColMatvecArgs mv; Cg2Args cg; };
+__global__ void __launch_bounds__(GSFM_COL_RB) k_mv_col_cg(ColMatvecCgArgs aa) {
+  __shared__ double lds[4];
+  const Cg2Args& c = aa.cg;
+  const int done = c.sc->done, iters = c.sc->iters;
+  const double gamma0 = c.sc->gamma0;
+  double gpart = 0.0;
+  if (threadIdx.x < GSFM_BLOCK) for (int k = threadIdx.x; k < c.nb_cam; k += GSFM_BLOCK) gpart += c.part_g[(size_t)c.par * c.nb_cam + k];
+  gpart = wave_sum(gpart);
+  if ((threadIdx.x & 63u) == 0 && threadIdx.x < GSFM_BLOCK) lds[threadIdx.x >> 6] = gpart;
+  __syncthreads();
+  double gamma = 0.0;
+#pragma unroll
+  for (int k = 0; k < GSFM_BLOCK / 64; ++k) gamma += lds[k];
+  if (done) return;
+  bool conv;
+  if (c.first) {
+    conv = !(gamma > 0.0);
+    if (blockIdx.x == 0 && threadIdx.x == 0) { c.sc->gamma0 = gamma; if (conv) c.sc->done = 1; }
+  } else {
+    const double rel = sqrt(gamma / gamma0);
+    conv = !(rel > c.tol) || iters >= c.max_iters;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { c.sc->last_rel = rel; if (conv) c.sc->done = 1; }
+  }
+  if (conv) return;
+  mv_col_body(aa.mv);
 }
 // y_k = M_k p_k - R_k sum_{c < NCH} part[block(k) * NCH + c][k mod RB]
 struct ColFinishArgs {

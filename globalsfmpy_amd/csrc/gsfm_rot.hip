@@ -792,7 +792,7 @@ int run_pcg(gsfm_rot_problem* P, const gsfm_rot_options& o, int* iters_out, doub
 int run_pcg2(gsfm_rot_problem* P, const gsfm_rot_options& o, int* iters_out, double* rel_out) {
   Cg2Args c{};
   const int nb_mv = P->nb_mv, reps = P->mv_reps;
-  c.n = P->n_cams; c.nb_cam = P->nb_cam; c.n_part_d = P->sharded ? P->nb_cam : nb_mv; c.par = 0; c.first = 1; c.tol = o.cg_relative_tolerance; c.max_iters = o.max_cg_iterations;
+  c.n = P->n_cams; c.nb_cam = P->nb_cam; c.n_part_d = (P->sharded || P->cs.active) ? P->nb_cam : nb_mv; c.par = 0; c.first = 1; c.tol = o.cg_relative_tolerance; c.max_iters = o.max_cg_iterations;
   c.Minv = P->Minv.p; c.b = P->b.p; c.x = P->xcg.p; c.r = P->r.p; c.u = P->z.p; c.w = P->Ap.p; c.p = P->p.p; c.s = P->s_dir.p;
   c.part_g = P->part_g2.p; c.part_d = P->part_d2.p; c.sc = P->cg2sc.p;
   c.q = P->q_lin; c.urot = P->lin_is_lap ? P->u_rot.p : nullptr;
@@ -810,7 +810,17 @@ int run_pcg2(gsfm_rot_problem* P, const gsfm_rot_options& o, int* iters_out, dou
   // start at par == 0, first == 0, so the very first iteration is launched plainly and chunks have even length.
   auto enqueue_iter = [&]() -> int {
     m.cg = c;
-    if (P->lin_is_lap) hipLaunchKernelGGL(k_matvec_cg<true>, gmv, blk, 0, P->stream, m);
+    if (P->cs.active) {   // column-sorted layout: K3c with the same entry decision, delta partials from its finishing kernel (one per camera block)
+      auto& L = P->cs;
+      ColMatvecCgArgs cm{};
+      cm.mv.L = L.dev(); cm.mv.b0 = P->h0.p; cm.mv.b1 = P->h1.p; cm.mv.b2 = P->h2.p; cm.mv.u = P->u_rot.p; cm.mv.part = L.part.p; cm.mv.done = nullptr; cm.cg = c;
+      hipLaunchKernelGGL(k_mv_col_cg, dim3(L.n_wg), dim3(GSFM_COL_RB), 0, P->stream, cm);
+      ColFinishArgs f{};
+      f.n_rows = P->n_rows; f.row_base = P->own_begin; f.nch = L.nch; f.n_wg = L.n_wg; f.part = L.part.p; f.Mblk = P->Mblk.p; f.p = P->z.p; f.q = P->q_lin; f.y = P->Ap.p;
+      f.done = &P->cg2sc.p->done; f.dot_part = P->sharded ? nullptr : P->part_d2.p;
+      hipLaunchKernelGGL(k_mv_col_finish, dim3(grid_for(P->n_rows)), dim3(GSFM_BLOCK), 0, P->stream, f);
+    }
+    else if (P->lin_is_lap) hipLaunchKernelGGL(k_matvec_cg<true>, gmv, blk, 0, P->stream, m);
     else hipLaunchKernelGGL(k_matvec_cg<false>, gmv, blk, 0, P->stream, m);
     if (P->sharded) {
       if (int st = all_gather(P, P->Ap.p, (size_t)P->shard.slice_width * 3)) return st;
@@ -874,10 +884,12 @@ int run_pcg2(gsfm_rot_problem* P, const gsfm_rot_options& o, int* iters_out, dou
 bool use_single_reduction(const gsfm_rot_problem* P, const gsfm_rot_options& o) {
   if (o.pcg_single_reduction >= 0) return o.pcg_single_reduction != 0;
   if (o.cg_stall_iterations > 0) return false;   // stagnation detection lives in the textbook variant's scalar kernel
+  // (On the column-sorted layout the variant exists too -- k_mv_col_cg, one vector kernel instead of two -- and measures the same as the
+  // textbook recurrence at C5: 30.69 against 30.63 ms per solve, 129 iterations both; the entry decision of its mat-vec costs what the
+  // saved launch gains.  tools/r03_pcg_variants.py)
   return !P->sharded && P->dir.n <= (size_t)2000000;
 }
-bool single_reduction_possible(const gsfm_rot_problem* P) { return !P->cs.active;   // (its fused mat-vec is the row-major one)
-}
+bool single_reduction_possible(const gsfm_rot_problem*) { return true; }
 
 // Exact step for small graphs: dense Cholesky of (J^T J + Lambda) in the left-tangent space (dense_kernels.hpp).  Enqueues only: the
 // factorisation's status lands in the scalar block (SC_DENSE_INFO) and is read together with the trial cost, one host synchronisation

@@ -6,7 +6,8 @@ both sides linearise at bit-identical rotations) the device's accepted step must
 (scipy / LAPACK) of the oracle's damped normal equations at that point: to 1e-10 of the step with PCG run to 1e-14 (the oracle's own
 setting), and to 1e-8 of the step at the product's default relative residual of 1e-12 (the systems are weakly damped: the step error is the
 residual times a condition number of 1e3-1e4; in absolute terms 3e-12 rad here, against the parity bar of 1e-6).  The oracle's own PCG
-is held to the same direct solves in tests/test_oracle_direct_solve.py (CPU)."""
+is held to the same direct solves in tests/test_oracle_direct_solve.py (CPU).  Up to 5 333 cameras the device can also take the step exactly
+(dense_cholesky_max_cams): that step is held to the same direct solve, the Trafalgar-sized case (5 288 cameras, 3N = 15 864) included."""
 import os
 
 import numpy as np
@@ -58,4 +59,11 @@ def test_device_lm_step_equals_a_direct_solve(oracle, case):
             name, k + 1, dmax, err, sd["num_cg_iterations"], err_t, st["num_cg_iterations"]))
         assert err_t <= 1e-10 * dmax, (name, k, err_t)
         assert err <= 1e-8 * dmax, (name, k, err)
+        if n <= 5333 and not env:
+            # the device's own exact step at this size (tiled Cholesky, trailing update on the fp64 matrix cores) against the same direct solve
+            rx, sx = dev.solve(x, max_num_iterations=1, dense_cholesky_max_cams=n)
+            assert sx["num_dense_solves"] == 1 and sx["num_cg_iterations"] == 0 and sx["num_successful_steps"] == 1, sx
+            err_x = np.abs(rx - (x + delta)).max()
+            print("    device dense Cholesky step: |x_dev - (x + delta_direct)|_inf = %.2e" % err_x)
+            assert err_x <= 1e-10 * dmax, (name, k, err_x)
         x = rd

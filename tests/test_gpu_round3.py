@@ -195,3 +195,34 @@ def test_column_sorted_record_widths_and_saturated_row_counts(oracle, n, e, hub)
     ora.set_loss(LF.HuberLoss(0.05))
     ora.linearize(g["init_aa"])
     assert _rel(y[1][0], ora.normal_matvec(v)) < 1e-9
+
+
+@pytest.mark.parametrize("et,loss,n,e", [
+    (_abi.ANGLE_AXIS_COVARIANCE, lambda: LF.MAGSACWeightBasedLoss(0.02), 3000, 90000),
+    (_abi.QUATERNION_COSINE, lambda: LF.HuberLoss(0.1), 1100, 15000),
+])
+def test_single_reduction_pcg_on_the_column_sorted_layout(oracle, et, loss, n, e):
+    """K3c inside the single-reduction recurrence (k_mv_col_cg + k_mv_col_finish + k_cg2_step: three launches per iteration) against the
+    textbook recurrence on the same layout and against the oracle."""
+    g = synth.make_graph(n_cams=n, n_edges=e, seed=17, outlier_frac=0.2)
+    res = {}
+    with _Env(GSFM_K3_COLSORT=1, GSFM_PCG_COARSE=0):
+        dev = RotationProblem(n, g["edge_i"], g["edge_j"], g["rel_aa"], et, cov6=g["cov6"])
+    dev.set_loss(loss())
+    assert dev.matvec_bytes()[1] == 2
+    for sr in (0, 1):
+        for graph in (1, 0):
+            res[(sr, graph)] = dev.solve(g["init_aa"], dense_cholesky_max_cams=0, pcg_single_reduction=sr, pcg_hip_graph=graph)
+    for graph in (1, 0):
+        assert np.array_equal(res[(1, graph)][0], res[(1, 1)][0]) and np.array_equal(res[(0, graph)][0], res[(0, 1)][0])   # replayed or launched: same bits
+    (r0, s0), (r1, s1) = res[(0, 1)], res[(1, 1)]
+    assert s0["num_iterations"] == s1["num_iterations"] and s0["termination"] == s1["termination"]
+    assert abs(s1["num_cg_iterations"] - s0["num_cg_iterations"]) <= 2 * s0["num_iterations"]
+    assert abs(s0["final_cost"] - s1["final_cost"]) <= 1e-11 * s0["final_cost"]
+    assert synth.angular_distance(synth.align_rotations(r1, r0), r0).mean() < 1e-9
+    ora = oracle.OracleProblem(n, g["edge_i"], g["edge_j"], g["rel_aa"], et, cov6=g["cov6"])
+    ora.set_loss(loss())
+    ora.set_linear_solver("pcg")
+    ro, so = ora.solve(g["init_aa"])
+    assert s1["num_iterations"] == so["num_iterations"] and s1["termination"] == so["termination"]
+    assert synth.angular_distance(synth.align_rotations(r1, ro), ro).mean() <= 1e-6
