@@ -221,6 +221,36 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_col_s(ColRowSArgs a) {
   }
 }
 
+// Dense assembly for the exact Cholesky step (k_dense_assemble's twin on this layout): the blocks are stored in the body frame,
+// H_km = -R_k B R_m^T; the lower triangle takes the entry whose row camera has the larger index.  One workgroup per ColWg for the
+// entries, a grid-stride loop over the cameras for the diagonal blocks, the right-hand side and the padding.  A is zero-filled before.
+__global__ void __launch_bounds__(GSFM_BLOCK) k_dense_assemble_col(DenseArgs a, ColLayoutDev L) {
+  for (uint32_t row = blockIdx.x * GSFM_BLOCK + threadIdx.x; row < a.n_rows; row += gridDim.x * GSFM_BLOCK) {
+    for (int c = 0; c < 3; ++c) a.rcg[3 * (size_t)row + c] = 0.0;
+    if (row == 0) *a.info_slot = 0.0;
+    const double* M = a.Mblk + 6 * (size_t)row;
+    const double m[9] = {M[0], M[1], M[2], M[1], M[3], M[4], M[2], M[4], M[5]};
+    for (int r = 0; r < 3; ++r) for (int c = 0; c <= r; ++c) *dense_elem(a.A, 3 * row + r, 3 * row + c) = m[3 * r + c];
+    for (int c = 0; c < 3; ++c) a.A[(((size_t)a.T * (a.T + 1) / 2) + (3 * row + c) / 32) * 1024 + (3 * row + c) % 32] = a.b[3 * (size_t)row + c];
+    if (row == 0) for (uint32_t g = a.n; g < a.T * 32; ++g) *dense_elem(a.A, g, g) = 1.0;
+  }
+  const ColWg w = L.wg[blockIdx.x];
+  for (uint32_t d = w.first_sub * GSFM_COL_SUB + threadIdx.x; d < (w.first_sub + w.n_sub) * GSFM_COL_SUB; d += GSFM_BLOCK) {
+    const uint2 mt = col_load_meta(L.meta + d);
+    if (mt.x == GSFM_COL_PAD) continue;
+    const uint32_t row = w.row0 + col_rowl(mt.y), m = mt.x & 0x7fffffffu;
+    if (m >= row) continue;
+    const double2 A0 = a.h0[d], B0 = a.h1[d], C0 = a.h2[d];
+    const double Bm[9] = {A0.x, A0.y, B0.x, A0.y, B0.y, C0.x, B0.x, C0.x, C0.y};
+    double Rk[9], Rm[9], T[9], H[9];
+    qmat(load_q(a.q, row), Rk);
+    qmat(load_q(a.q, m), Rm);
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) T[3 * r + c] = Bm[3 * r] * Rm[3 * c] + Bm[3 * r + 1] * Rm[3 * c + 1] + Bm[3 * r + 2] * Rm[3 * c + 2];   // B R_m^T
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) H[3 * r + c] = -(Rk[3 * r] * T[c] + Rk[3 * r + 1] * T[3 + c] + Rk[3 * r + 2] * T[6 + c]);
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) atomicAdd(dense_elem(a.A, 3 * row + r, 3 * m + c), H[3 * r + c]);
+  }
+}
+
 // ---- K2c ----------------------------------------------------------------------------------------------------------------
 // The linearisation in the same order: one entry per lane and trip, 256 lanes work through a sub-chunk of GSFM_COL_SUB positions in two
 // trips; the nine per-entry contributions to (g, D) of the row camera go through the LDS slots, lanes t and t + 256 own rows t and t + 256

@@ -897,7 +897,7 @@ bool single_reduction_possible(const gsfm_rot_problem*) { return true; }
 int run_dense(gsfm_rot_problem* P, bool* used) {
   *used = false;
   const uint32_t n = 3 * P->n_cams, T = (n + GSFM_CB - 1) / GSFM_CB;
-  if (T > GSFM_DENSE_MAX_T || P->cs.active) return 0;   // (the assembly walks the row-major entry order)
+  if (T > GSFM_DENSE_MAX_T) return 0;
   const size_t elems = chol_num_tiles(T) * GSFM_TILE_ELEMS;
   if (!P->denseA.p) {
     if (P->denseA.alloc(elems) != hipSuccess || P->denseL.alloc(elems, true) != hipSuccess || P->dense_x.alloc((size_t)T * GSFM_CB, true) != hipSuccess) { P->denseA.release(); return 0; }
@@ -912,7 +912,8 @@ int run_dense(gsfm_rot_problem* P, bool* used) {
     DenseArgs a{};
     a.n_rows = P->n_rows; a.row_ptr = P->row_ptr.p; a.col = P->col.p; a.h0 = P->h0.p; a.h1 = P->h1.p; a.h2 = P->h2.p; a.h3 = P->h3.p; a.h4 = P->h4.p;
     a.Mblk = P->Mblk.p; a.b = P->b.p; a.A = P->denseA.p; a.n = n; a.T = T; a.q = P->q_lin; a.lap = P->lin_is_lap; a.info_slot = P->scal.p + SC_DENSE_INFO; a.rcg = P->r.p;
-    hipLaunchKernelGGL(k_dense_assemble, dim3(P->n_rows), dim3(GSFM_BLOCK), 0, P->stream, a);
+    if (P->cs.active) hipLaunchKernelGGL(k_dense_assemble_col, dim3(P->cs.n_wg), dim3(GSFM_BLOCK), 0, P->stream, a, P->cs.dev());
+    else hipLaunchKernelGGL(k_dense_assemble, dim3(P->n_rows), dim3(GSFM_BLOCK), 0, P->stream, a);
     for (uint32_t k = 0; k < T; ++k) {
       CholArgs c{P->denseA.p, P->denseL.p, T, k, info};
       const uint64_t m = T - k;

@@ -24,6 +24,7 @@ CASES = [   # name, cameras, edges, error type, loss, outliers, local window, sp
     ("random 2000/40k covariance + MAGSAC", 2000, 40000, _abi.ANGLE_AXIS_COVARIANCE, lambda: LF.MAGSACWeightBasedLoss(0.02), 0.3, 0, False, {}),
     ("random 2000/40k SoftL1, column-sorted kernels", 2000, 40000, _abi.ANGLE_AXIS, lambda: LF.SoftLOneLoss(0.1), 0.3, 0, False, {"GSFM_K3_COLSORT": "1"}),
     ("Trafalgar-sized random 5288/80k covariance + MAGSAC", 5288, 80000, _abi.ANGLE_AXIS_COVARIANCE, lambda: LF.MAGSACWeightBasedLoss(0.02), 0.3, 0, False, {}),
+    ("Trafalgar-sized and Trafalgar-dense random 5288/680k covariance + MAGSAC (column-sorted layout chosen by the density rule)", 5288, 680000, _abi.ANGLE_AXIS_COVARIANCE, lambda: LF.MAGSACWeightBasedLoss(0.02), 0.3, 0, False, {}),
     ("C2-sized coherent 10k/200k Geman-McClure", 10000, 200000, _abi.ANGLE_AXIS, lambda: LF.GemanMcClureLoss(0.1, 1.0), 0.1, 120, True, {}),
 ]
 
@@ -40,6 +41,8 @@ def test_device_lm_step_equals_a_direct_solve(oracle, case):
         for k, v in old.items():
             os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
     dev.set_loss(mk())
+    if e == 680000:
+        assert dev.matvec_bytes()[1] == 2   # 1.36 M directed entries without locality: K2c / K3c, and the dense assembly from that layout
     o = oracle.OracleProblem(n, g["edge_i"], g["edge_j"], g["rel_aa"], et, cov6=g["cov6"])
     o.set_loss(mk())
     o.set_linear_solver("pcg")

@@ -226,3 +226,22 @@ def test_single_reduction_pcg_on_the_column_sorted_layout(oracle, et, loss, n, e
     ro, so = ora.solve(g["init_aa"])
     assert s1["num_iterations"] == so["num_iterations"] and s1["termination"] == so["termination"]
     assert synth.angular_distance(synth.align_rotations(r1, ro), ro).mean() <= 1e-6
+
+
+def test_exact_cholesky_step_from_the_column_sorted_layout():
+    """dense_cholesky_max_cams must be honoured whatever layout the entries are in: the dense matrix assembled from the body-frame blocks of
+    the column-sorted layout (k_dense_assemble_col) against the one assembled from the row-major planes."""
+    g = synth.make_graph(n_cams=450, n_edges=9000, seed=23, outlier_frac=0.25)
+    out = {}
+    for mode in (0, 1):
+        with _Env(GSFM_K3_COLSORT=mode):
+            dev = RotationProblem(g["n_cams"], g["edge_i"], g["edge_j"], g["rel_aa"], _abi.ANGLE_AXIS_COVARIANCE, cov6=g["cov6"])
+        dev.set_loss(LF.MAGSACWeightBasedLoss(0.02))
+        assert dev.matvec_bytes()[1] == (2 if mode else 1)
+        out[mode] = dev.solve(g["init_aa"])
+        dev.close()
+    (r0, s0), (r1, s1) = out[0], out[1]
+    assert s0["num_dense_solves"] == s0["num_iterations"] > 0 and s1["num_dense_solves"] == s1["num_iterations"] and s1["num_cg_iterations"] == 0
+    assert s0["num_iterations"] == s1["num_iterations"] and s0["termination"] == s1["termination"]
+    assert abs(s0["final_cost"] - s1["final_cost"]) <= 1e-11 * s0["final_cost"]
+    assert synth.angular_distance(synth.align_rotations(r1, r0), r0).mean() < 1e-9
