@@ -231,6 +231,8 @@ struct gsfm_rot_problem {
   DevBuf<double> x, x_trial, aa_io, active, scale, gD, Mblk, Minv, Lam, Tinv, b, D6;
   DevBuf<double2> q, q_trial;
   DevBuf<double> xcg, r, z, p, Ap, s_dir, part_g2, part_d2;
+  DevBuf<double> w_gather;   // sharded single-reduction PCG: per rank [slice of A u | delta partials of its rows] (run_pcg2)
+  uint32_t w_tail = 0;
   DevBuf<Cg2Scalars> cg2sc;
   // two-level preconditioner (kernels.hpp, k_coarse_*): aggregates wanted (0 = off, decided at create) / in use for the current LM step
   uint32_t coarse_want = 0, coarse_n = 0, coarse_chunk = 0;
@@ -796,10 +798,21 @@ int run_pcg2(gsfm_rot_problem* P, const gsfm_rot_options& o, int* iters_out, dou
   c.Minv = P->Minv.p; c.b = P->b.p; c.x = P->xcg.p; c.r = P->r.p; c.u = P->z.p; c.w = P->Ap.p; c.p = P->p.p; c.s = P->s_dir.p;
   c.part_g = P->part_g2.p; c.part_d = P->part_d2.p; c.sc = P->cg2sc.p;
   c.q = P->q_lin; c.urot = P->lin_is_lap ? P->u_rot.p : nullptr;
+  // Sharded: A u and the delta partials of a rank's rows leave in ONE all-gather (slot = slice of w, then the partials); the mat-vec kernels
+  // address y by global camera index, so they get the slot's base shifted back by the rank's first camera.
+  double* w_own = P->Ap.p;          // what the mat-vec writes through (indexed 3 * global camera)
+  double* dots_own = P->part_d2.p;  // where its delta partials go
+  if (P->sharded) {
+    const uint32_t slice = P->shard.slice_width, tail = P->w_tail, stride = 3 * slice + tail;
+    if (!P->w_gather.p && P->w_gather.alloc((size_t)stride * P->shard.world_size, true) != hipSuccess) return fail(GSFM_ERR_HIP, "alloc all-gather buffer");
+    c.w = P->w_gather.p; c.w_stride = stride; c.w_slice = slice; c.w_tail = tail; c.n_part_d = (int)(tail * P->shard.world_size);
+    double* slot = P->w_gather.p + (size_t)P->shard.rank * stride;
+    w_own = slot - 3 * (size_t)P->own_begin; dots_own = slot + 3 * (size_t)slice;
+  }
   MatvecCgArgs m{};
   m.mv.n_rows = P->n_rows; m.mv.row_base = P->own_begin; m.mv.G = P->G; m.mv.row_ptr = P->row_ptr.p; m.mv.col = P->col.p;
   m.mv.h0 = P->h0.p; m.mv.h1 = P->h1.p; m.mv.h2 = P->h2.p; m.mv.h3 = P->h3.p; m.mv.h4 = P->h4.p; m.mv.Mblk = P->Mblk.p;
-  m.mv.p = P->z.p; m.mv.y = P->Ap.p; m.mv.done = nullptr; m.mv.q = P->q_lin; m.mv.u = P->u_rot.p; m.with_dots = P->sharded ? 0 : 1; m.reps = (uint32_t)reps;
+  m.mv.p = P->z.p; m.mv.y = w_own; m.mv.done = nullptr; m.mv.q = P->q_lin; m.mv.u = P->u_rot.p; m.with_dots = 1; m.reps = (uint32_t)reps;
   const dim3 gcam(P->nb_cam), gmv(nb_mv), blk(GSFM_BLOCK);
   const int tk0 = P->timer.begin(T_CG);
   hipLaunchKernelGGL(k_cg2_init, gcam, blk, 0, P->stream, c);
@@ -809,23 +822,22 @@ int run_pcg2(gsfm_rot_problem* P, const gsfm_rot_options& o, int* iters_out, dou
   // One iteration = mat-vec (+ delta partials), vector step.  `first` / `par` are by-value kernel arguments: a captured chunk must
   // start at par == 0, first == 0, so the very first iteration is launched plainly and chunks have even length.
   auto enqueue_iter = [&]() -> int {
-    m.cg = c;
+    m.cg = c; m.cg.part_d = dots_own;
     if (P->cs.active) {   // column-sorted layout: K3c with the same entry decision, delta partials from its finishing kernel (one per camera block)
       auto& L = P->cs;
       ColMatvecCgArgs cm{};
       cm.mv.L = L.dev(); cm.mv.b0 = P->h0.p; cm.mv.b1 = P->h1.p; cm.mv.b2 = P->h2.p; cm.mv.u = P->u_rot.p; cm.mv.part = L.part.p; cm.mv.done = nullptr; cm.cg = c;
       hipLaunchKernelGGL(k_mv_col_cg, dim3(L.n_wg), dim3(GSFM_COL_RB), 0, P->stream, cm);
       ColFinishArgs f{};
-      f.n_rows = P->n_rows; f.row_base = P->own_begin; f.nch = L.nch; f.n_wg = L.n_wg; f.part = L.part.p; f.Mblk = P->Mblk.p; f.p = P->z.p; f.q = P->q_lin; f.y = P->Ap.p;
-      f.done = &P->cg2sc.p->done; f.dot_part = P->sharded ? nullptr : P->part_d2.p;
+      f.n_rows = P->n_rows; f.row_base = P->own_begin; f.nch = L.nch; f.n_wg = L.n_wg; f.part = L.part.p; f.Mblk = P->Mblk.p; f.p = P->z.p; f.q = P->q_lin; f.y = w_own;
+      f.done = &P->cg2sc.p->done; f.dot_part = dots_own;
       hipLaunchKernelGGL(k_mv_col_finish, dim3(grid_for(P->n_rows)), dim3(GSFM_BLOCK), 0, P->stream, f);
     }
     else if (P->lin_is_lap) hipLaunchKernelGGL(k_matvec_cg<true>, gmv, blk, 0, P->stream, m);
     else hipLaunchKernelGGL(k_matvec_cg<false>, gmv, blk, 0, P->stream, m);
     if (P->sharded) {
-      if (int st = all_gather(P, P->Ap.p, (size_t)P->shard.slice_width * 3)) return st;
+      if (int st = all_gather(P, P->w_gather.p, (size_t)c.w_stride)) return st;
       P->n_pcg_collectives++;
-      hipLaunchKernelGGL(k_cg2_dots, gcam, blk, 0, P->stream, c);
     }
     hipLaunchKernelGGL(k_cg2_step, gcam, blk, 0, P->stream, c);
     c.par ^= 1; c.first = 0;
@@ -887,7 +899,12 @@ bool use_single_reduction(const gsfm_rot_problem* P, const gsfm_rot_options& o) 
   // (On the column-sorted layout the variant exists too -- k_mv_col_cg, one vector kernel instead of two -- and measures the same as the
   // textbook recurrence at C5: 30.69 against 30.63 ms per solve, 129 iterations both; the entry decision of its mat-vec costs what the
   // saved launch gains.  tools/r03_pcg_variants.py)
-  return !P->sharded && P->dir.n <= (size_t)2000000;
+  // Sharded: always -- there every launch counts (the per-rank kernels shrink with the rank count, the launches do not), and the variant is
+  // 3 kernels + 1 collective per iteration (mat-vec, finish, [all-gather of A u with the delta partials in its tail], vector step) against
+  // 5 + 1 for the textbook recurrence; except at tolerances below 1e-13 (disconnected graphs, lm_solve), where the recursively updated
+  // residual of the textbook form is the safer one.
+  if (P->sharded) return o.cg_relative_tolerance >= 1e-13 && P->n_components <= 1;
+  return P->dir.n <= (size_t)2000000;
 }
 bool single_reduction_possible(const gsfm_rot_problem*) { return true; }
 
@@ -1700,7 +1717,12 @@ static gsfm_status problem_create_impl(uint32_t n_cams, uint64_t n_edges, const 
   ok &= P->scal.alloc(SC_N, true) == hipSuccess; ok &= P->cgsc.alloc(1, true) == hipSuccess;
   {  // fused mat-vec of the single-reduction PCG: one row group (256 / G rows) per workgroup unless that leaves too many partials
     const size_t rows_per_group = GSFM_BLOCK / P->G, groups = (P->n_rows + rows_per_group - 1) / rows_per_group;
-    P->mv_reps = (int)std::max<size_t>(1, (groups + GSFM_MV_MAX_PARTIALS - 1) / GSFM_MV_MAX_PARTIALS);
+    size_t max_partials = GSFM_MV_MAX_PARTIALS;
+    if (P->sharded) {   // the delta partials travel in the tail of the all-gather slot: the same, rank-independent bound on every rank
+      P->w_tail = 8u * (uint32_t)grid_for(P->shard.slice_width);
+      max_partials = std::min<size_t>(max_partials, P->w_tail);
+    }
+    P->mv_reps = (int)std::max<size_t>(1, (groups + max_partials - 1) / max_partials);
     P->nb_mv = (int)std::max<size_t>(1, (groups + P->mv_reps - 1) / P->mv_reps);
   }
   ok &= P->s_dir.alloc(3 * N, true) == hipSuccess; ok &= P->part_g2.alloc((size_t)2 * P->nb_cam, true) == hipSuccess;

@@ -1700,7 +1700,14 @@ struct Cg2Args {
   Cg2Scalars* sc;
   const double2* q;      // Laplacian form: camera quaternions and
   double* urot;          //   urot_k = R_k^T u_k, written wherever u is (null otherwise): the vector the mat-vec gathers
+  // Sharded problems: w lives in the all-gather buffer, one slot of `w_stride` doubles per rank = its slice of w (3 * w_slice doubles)
+  // followed by `w_tail` delta partials of its own rows -- the partial dot products travel with A u in the ONE collective of the
+  // iteration, every rank sums all tails in the same order.  w_stride == 0: w is a plain vector and part_d a plain array.
+  uint32_t w_stride, w_slice, w_tail;
 };
+__device__ __forceinline__ size_t cg2_w_index(const Cg2Args& a, uint32_t k) {
+  return a.w_stride ? (size_t)(k / a.w_slice) * a.w_stride + 3 * (size_t)(k % a.w_slice) : 3 * (size_t)k;
+}
 
 // x = 0, r = b, u = M^-1 r, p = s = 0, gamma_0 partials
 __global__ void __launch_bounds__(GSFM_BLOCK) k_cg2_init(Cg2Args a) {
@@ -1870,14 +1877,16 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_cg2_step(Cg2Args a) {
   const double gamma_prev = a.sc->gamma[a.par ^ 1], alpha_prev = a.sc->alpha[a.par ^ 1];
   double gpart = 0.0, dsum = 0.0;
   for (int k = threadIdx.x; k < a.nb_cam; k += GSFM_BLOCK) gpart += a.part_g[(size_t)a.par * a.nb_cam + k];
-  for (int k = threadIdx.x; k < a.n_part_d; k += GSFM_BLOCK) dsum += a.part_d[k];
+  if (a.w_stride) {
+    for (int k = threadIdx.x; k < a.n_part_d; k += GSFM_BLOCK) dsum += a.w[(size_t)(k / a.w_tail) * a.w_stride + 3 * (size_t)a.w_slice + k % a.w_tail];
+  } else for (int k = threadIdx.x; k < a.n_part_d; k += GSFM_BLOCK) dsum += a.part_d[k];
   const uint32_t k = blockIdx.x * GSFM_BLOCK + threadIdx.x;
   const bool live = k < a.n;
-  const size_t k3 = 3 * (size_t)(live ? k : 0);
+  const size_t k3 = 3 * (size_t)(live ? k : 0), kw = cg2_w_index(a, live ? k : 0);
   double uo[3], po[3], wo[3], so[3], xo[3], ro[3], Mi[6];
   Quat qq{0, 0, 0, 1};
 #pragma unroll
-  for (int c = 0; c < 3; ++c) { uo[c] = a.u[k3 + c]; po[c] = a.p[k3 + c]; wo[c] = a.w[k3 + c]; so[c] = a.s[k3 + c]; xo[c] = a.x[k3 + c]; ro[c] = a.r[k3 + c]; }
+  for (int c = 0; c < 3; ++c) { uo[c] = a.u[k3 + c]; po[c] = a.p[k3 + c]; wo[c] = a.w[kw + c]; so[c] = a.s[k3 + c]; xo[c] = a.x[k3 + c]; ro[c] = a.r[k3 + c]; }
 #pragma unroll
   for (int c = 0; c < 6; ++c) Mi[c] = a.Minv[2 * k3 + c];
   if (a.urot) qq = load_q(a.q, live ? k : 0);

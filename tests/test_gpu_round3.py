@@ -245,3 +245,29 @@ def test_exact_cholesky_step_from_the_column_sorted_layout():
     assert s0["num_iterations"] == s1["num_iterations"] and s0["termination"] == s1["termination"]
     assert abs(s0["final_cost"] - s1["final_cost"]) <= 1e-11 * s0["final_cost"]
     assert synth.angular_distance(synth.align_rotations(r1, r0), r0).mean() < 1e-9
+
+
+@pytest.mark.parametrize("et", [_abi.ANGLE_AXIS, _abi.ANGLE_AXIS_INLIERS])
+def test_set_edge_weights_in_both_layouts(oracle, et):
+    """gsfm_rot_set_edge_weights (scalar weights replaced after creation; ANGLE_AXIS is promoted to a scalar-weight problem) gathers the
+    caller's per-edge weights into the entry planes in THEIR order -- row-major or column-sorted -- and into the cost planes."""
+    g = synth.make_graph(n_cams=900, n_edges=14000, seed=29, outlier_frac=0.2)
+    w = np.random.default_rng(5).uniform(0.2, 3.0, size=14000)
+    ora = oracle.OracleProblem(g["n_cams"], g["edge_i"], g["edge_j"], g["rel_aa"], et, inlier_weight=g["inlier_weight"])
+    ora.set_loss(LF.HuberLoss(0.1))
+    ora.set_edge_weights(w)
+    ora.set_linear_solver("pcg")
+    ro, so = ora.solve(g["init_aa"])
+    lo = ora.linearize(g["init_aa"])
+    for mode in (0, 1):
+        with _Env(GSFM_K3_COLSORT=mode, GSFM_PCG_COARSE=0):
+            dev = RotationProblem(g["n_cams"], g["edge_i"], g["edge_j"], g["rel_aa"], et, inlier_weight=g["inlier_weight"])
+        dev.set_loss(LF.HuberLoss(0.1))
+        dev.set_edge_weights(w)
+        assert dev.matvec_bytes()[1] == (2 if mode else 1)
+        ld = dev.linearize(g["init_aa"])
+        assert _rel(ld["gradient"], lo["gradient"]) < 1e-9 and _rel(ld["diag_blocks"], lo["diag_blocks"]) < 1e-9 and abs(ld["cost"] - lo["cost"]) <= 1e-12 * lo["cost"]
+        rd, sd = dev.solve(g["init_aa"])
+        assert sd["num_iterations"] == so["num_iterations"] and sd["termination"] == so["termination"]
+        assert synth.angular_distance(synth.align_rotations(rd, ro), ro).mean() <= 1e-6
+        dev.close()
