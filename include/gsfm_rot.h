@@ -138,9 +138,12 @@ typedef struct {
   int32_t verbose;                     /* 1: print one line per LM iteration to stderr */
   int32_t pcg_single_reduction;        /* 0: textbook PCG, 4 dependent kernels per iteration; 1: Chronopoulos-Gear single-reduction PCG, 2 kernels
                                           per iteration (mat-vec with the fused w.u partials, then one vector kernel; same iterates to
-                                          rounding); -1 (default): the latter when the problem has at most 2M directed entries and is not
-                                          sharded -- there the iteration is bounded by dependent-launch latency, not by bandwidth
-                                          (C2: 10k cameras / 200k edges).  Large problems keep the textbook recurrence. */
+                                          rounding; 3 on the column-sorted layout); -1 (default): the latter when the problem has at most
+                                          2M directed entries -- there the iteration is bounded by dependent-launch latency, not by
+                                          bandwidth (C2: 10k cameras / 200k edges) -- and on every sharded problem that is connected and
+                                          solved to a tolerance >= 1e-13: its delta partials travel in the tail of the iteration's one
+                                          all-gather (3 kernels + 1 collective per iteration instead of 5 + 1).  Large single-GPU problems
+                                          keep the textbook recurrence (measured equal there). */
   int32_t cg_stall_iterations;         /* opt-in: stop PCG when the relative residual has not halved for this many
                                           iterations (default 0 = never).  On the real Madrid graph (MAGSAC weights spanning
                                           1e-5..5e4, vanishing damping) PCG needs up to 574 iterations per step; 64 here saves
