@@ -131,6 +131,23 @@ const std::vector<double>& magsac_table(int nu) {
   return (nu == 3) ? t3 : (nu == 4) ? t4 : t9;
 }
 
+// Host staging arrays of tens of millions of elements that are filled completely, in parallel, right after they are sized: an allocator whose
+// default construction does nothing, so that sizing them does not zero (and fault in) hundreds of megabytes on one thread first.
+template <typename T>
+struct NoInitAlloc {
+  using value_type = T;
+  NoInitAlloc() = default;
+  template <typename U> NoInitAlloc(const NoInitAlloc<U>&) {}
+  T* allocate(size_t n) { return std::allocator<T>().allocate(n); }
+  void deallocate(T* p, size_t n) { std::allocator<T>().deallocate(p, n); }
+  template <typename U, typename... A> void construct(U* p, A&&... a) {
+    if constexpr (sizeof...(A) == 0) ::new ((void*)p) U; else ::new ((void*)p) U(std::forward<A>(a)...);
+  }
+  template <typename U> bool operator==(const NoInitAlloc<U>&) const { return true; }
+  template <typename U> bool operator!=(const NoInitAlloc<U>&) const { return false; }
+};
+template <typename T> using hvec = std::vector<T, NoInitAlloc<T>>;
+
 template <typename T>
 struct DevBuf {
   T* p = nullptr;
@@ -144,7 +161,7 @@ struct DevBuf {
     if (zero) { e = hipMemset(p, 0, count * sizeof(T)); if (e == hipSuccess) e = hipDeviceSynchronize(); }
     return e;
   }
-  hipError_t upload(const std::vector<T>& h) {
+  template <typename A> hipError_t upload(const std::vector<T, A>& h) {
     hipError_t e = alloc(h.size());
     if (e != hipSuccess || h.empty()) return e;
     return hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice);
@@ -991,8 +1008,9 @@ int read_scalars(gsfm_rot_problem* P, double* h) {
 // relabelling is therefore adopted only if it shrinks the mean |i - j| over the edges by more than half AND brings it
 // under 1024 (neighbours within about +-2000); small problems (< 2048 cameras: everything is cache-resident) are left alone.
 // GSFM_REORDER=0 disables it, =1 forces adoption.  Returns true when `perm` (external -> internal) must be applied.
+template <typename AdjVec>
 bool reorder_for_locality(uint32_t n_cams, uint64_t n_edges, const uint32_t* ei, const uint32_t* ej, const std::vector<uint32_t>& ptr,
-                          const std::vector<uint32_t>& adj /* neighbour | role << 31 */, std::vector<uint32_t>* perm) {
+                          const AdjVec& adj /* neighbour | role << 31 */, std::vector<uint32_t>* perm) {
   perm->clear();
   const char* env = getenv("GSFM_REORDER");
   const int mode = env ? atoi(env) : -1;  // -1 auto, 0 off, 1 force
@@ -1242,7 +1260,8 @@ struct DeviceGuard {
   ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
 };
 
-int upload_planes(gsfm_rot_problem* P, EdgePlanes& pl, const std::vector<uint32_t>& eid, const double* d_rel_aa) {
+template <typename EidVec>
+int upload_planes(gsfm_rot_problem* P, EdgePlanes& pl, const EidVec& eid, const double* d_rel_aa) {
   pl.n = eid.size();
   if (pl.eid.upload(eid) != hipSuccess || pl.qr0.alloc(pl.n) != hipSuccess || pl.qr1.alloc(pl.n) != hipSuccess)
     return fail(GSFM_ERR_HIP, "uploading edge planes failed (out of memory?)");
@@ -1258,7 +1277,7 @@ int upload_planes(gsfm_rot_problem* P, EdgePlanes& pl, const std::vector<uint32_
 // cut into sub-chunks of GSFM_COL_SUB (each with its row-sorted slot permutation and per-row slot offsets), the sub-chunks of a block
 // dealt to `nch` workgroups.  Host, once per problem, blocks in parallel.  In: the row-major CSR (rp, col with the role bit, deid = edge of
 // every entry).  Out: col / deid REPLACED by their position-ordered forms (padding: GSFM_COL_PAD / edge 0), the layout arrays on the device.
-int build_colsort(gsfm_rot_problem* P, const std::vector<uint32_t>& rp, std::vector<uint32_t>& col, std::vector<uint32_t>& deid, int n_threads) {
+int build_colsort(gsfm_rot_problem* P, const std::vector<uint32_t>& rp, hvec<uint32_t>& col, hvec<uint32_t>& deid, int n_threads) {
   constexpr uint32_t RB = GSFM_COL_RB, SUB = GSFM_COL_SUB;
   auto& C = P->cs;
   const uint32_t n_rows = P->n_rows, nblk = (n_rows + RB - 1) / RB;
@@ -1277,10 +1296,9 @@ int build_colsort(gsfm_rot_problem* P, const std::vector<uint32_t>& rp, std::vec
   }
   const size_t n_sub = sub_off[nblk], n_pos = n_sub * SUB;
   if (n_pos == 0 || n_pos >= 0x7fffffffull) return 0;   // (positions are 32-bit in the kernels: stay on the row-major form)
-  std::vector<uint32_t> h_col(n_pos), h_eid(n_pos);
-  std::vector<uint2> h_meta(n_pos);
-  std::vector<uint32_t> h_kcol(n_pos);
-  std::vector<uint16_t> h_kcnt(n_pos);
+  hvec<uint32_t> h_col(n_pos), h_eid(n_pos), h_kcol(n_pos);   // (every position is written below)
+  hvec<uint2> h_meta(n_pos);
+  hvec<uint16_t> h_kcnt(n_pos);
   std::vector<ColWg> h_wg((size_t)nblk * C.nch);
   parallel_run(std::max(1, std::min<int>(n_threads, (int)nblk)), [&](int t, int T) {
     std::vector<std::pair<uint64_t, uint32_t>> ent;   // (camera << 16 | local row, d): a repeated camera pair is ordered by d
@@ -1447,7 +1465,8 @@ static gsfm_status problem_create_impl(uint32_t n_cams, uint64_t n_edges, const 
   std::vector<uint32_t> ei_perm, ej_perm;
   const uint32_t ob = P->own_begin, oe = P->own_end;
   auto owned = [&](uint32_t c) { return c >= ob && c < oe; };
-  std::vector<uint32_t> rp, cost_eid, col, deid;
+  std::vector<uint32_t> rp, cost_eid;
+  hvec<uint32_t> col, deid;   // (sized once, filled completely by the threads below)
   const int n_host_threads = host_threads();
   auto build_rows = [&]() -> int {
     rp.assign((size_t)P->n_rows + 1, 0);
