@@ -74,7 +74,10 @@ struct ColMatvecArgs {
   double* part;             // 3 planes of [n_wg * RB]
   const int* done;          // PCG convergence flag (may be null)
 };
-__device__ __forceinline__ void mv_col_body(const ColMatvecArgs& a) {
+// `stop_after_request`: evaluated once the first sub-chunk's streams are in flight (the single-reduction PCG decides about convergence
+// there, behind the loads instead of in front of them); true = leave without touching anything.
+template <typename Stop>
+__device__ __forceinline__ void mv_col_body(const ColMatvecArgs& a, Stop stop_after_request) {
   constexpr int RB = GSFM_COL_RB, EPL = GSFM_COL_EPL;
   // plane-major: the slot-contiguous reads of one row are conflict-free; two buffers, so one barrier per iteration suffices (a buffer is
   // written again two iterations later, after the barrier every lane passes once it has finished reading it)
@@ -95,6 +98,7 @@ __device__ __forceinline__ void mv_col_body(const ColMatvecArgs& a) {
     }
   };
   if (w.n_sub) request(0);
+  if (stop_after_request()) return;
   int buf = 0;
   for (uint32_t s = 0; s < w.n_sub; s += EPL, buf ^= 1) {
     uint32_t cnt[EPL], inc[EPL];
@@ -127,7 +131,7 @@ __device__ __forceinline__ void mv_col_body(const ColMatvecArgs& a) {
 }
 __global__ void __launch_bounds__(GSFM_COL_RB) k_mv_col(ColMatvecArgs a) {
   if (a.done && *a.done) return;
-  mv_col_body(a);
+  mv_col_body(a, [] { return false; });
 }
 // The same product as the mat-vec of the single-reduction PCG (run_pcg2): the convergence decision of k_matvec_cg at its entry -- every
 // workgroup re-sums the gamma partials in the order and with the reduction tree of the 256-lane kernels, so all of them, and the vector
@@ -136,28 +140,29 @@ struct ColMatvecCgArgs { ColMatvecArgs mv; Cg2Args cg; };
 __global__ void __launch_bounds__(GSFM_COL_RB) k_mv_col_cg(ColMatvecCgArgs aa) {
   __shared__ double lds[4];
   const Cg2Args& c = aa.cg;
-  const int done = c.sc->done, iters = c.sc->iters;
-  const double gamma0 = c.sc->gamma0;
-  double gpart = 0.0;
-  if (threadIdx.x < GSFM_BLOCK) for (int k = threadIdx.x; k < c.nb_cam; k += GSFM_BLOCK) gpart += c.part_g[(size_t)c.par * c.nb_cam + k];
-  gpart = wave_sum(gpart);
-  if ((threadIdx.x & 63u) == 0 && threadIdx.x < GSFM_BLOCK) lds[threadIdx.x >> 6] = gpart;
-  __syncthreads();
-  double gamma = 0.0;
+  mv_col_body(aa.mv, [&]() -> bool {
+    const int done = c.sc->done, iters = c.sc->iters;
+    const double gamma0 = c.sc->gamma0;
+    double gpart = 0.0;
+    if (threadIdx.x < GSFM_BLOCK) for (int k = threadIdx.x; k < c.nb_cam; k += GSFM_BLOCK) gpart += c.part_g[(size_t)c.par * c.nb_cam + k];
+    gpart = wave_sum(gpart);
+    if ((threadIdx.x & 63u) == 0 && threadIdx.x < GSFM_BLOCK) lds[threadIdx.x >> 6] = gpart;
+    __syncthreads();
+    double gamma = 0.0;
 #pragma unroll
-  for (int k = 0; k < GSFM_BLOCK / 64; ++k) gamma += lds[k];
-  if (done) return;
-  bool conv;
-  if (c.first) {
-    conv = !(gamma > 0.0);
-    if (blockIdx.x == 0 && threadIdx.x == 0) { c.sc->gamma0 = gamma; if (conv) c.sc->done = 1; }
-  } else {
-    const double rel = sqrt(gamma / gamma0);
-    conv = !(rel > c.tol) || iters >= c.max_iters;
-    if (blockIdx.x == 0 && threadIdx.x == 0) { c.sc->last_rel = rel; if (conv) c.sc->done = 1; }
-  }
-  if (conv) return;
-  mv_col_body(aa.mv);
+    for (int k = 0; k < GSFM_BLOCK / 64; ++k) gamma += lds[k];
+    if (done) return true;
+    bool conv;
+    if (c.first) {
+      conv = !(gamma > 0.0);
+      if (blockIdx.x == 0 && threadIdx.x == 0) { c.sc->gamma0 = gamma; if (conv) c.sc->done = 1; }
+    } else {
+      const double rel = sqrt(gamma / gamma0);
+      conv = !(rel > c.tol) || iters >= c.max_iters;
+      if (blockIdx.x == 0 && threadIdx.x == 0) { c.sc->last_rel = rel; if (conv) c.sc->done = 1; }
+    }
+    return conv;
+  });
 }
 // y_k = M_k p_k - R_k sum_{c < NCH} part[block(k) * NCH + c][k mod RB]
 struct ColFinishArgs {
