@@ -9,14 +9,15 @@
 // How: rows are grouped into blocks of RB = 512 and the entries of a block are sorted by COLUMN; this order replaces the row-major one
 // for all per-entry planes of the problem (measurements, whitening, blocks).  A wavefront then touches 64 neighbouring cameras -- at the C5
 // shape 100k cameras / 102k entries per block, ~5 lanes per 128-byte line -- and the gather's L2 requests drop about fivefold; the
-// mat-vec becomes a stream of its own 54 B per entry.  Per-row sums stay deterministic and atomic-free: a sub-chunk of SUB entries is
+// mat-vec becomes a stream of its own 52 B per entry (48 B block + a 4-byte record; 60 when the layout was first built).  Per-row sums stay deterministic and atomic-free: a sub-chunk of SUB entries is
 // evaluated entry-parallel, each entry's contribution is written to its slot of a ROW-sorted LDS staging area (2-byte permutation index
 // per entry), and after a barrier the lane that owns row r adds the slots of row r, in slot order, to the sums it keeps in registers
 // (the number of slots of row r in a sub-chunk rides in spare bits of the record at POSITION r of that sub-chunk -- as many rows as
 // positions -- and a workgroup-wide prefix sum turns the counts into slot ranges: no separate index stream).  The sub-chunks of a block
-// are dealt to NCH workgroups; a finishing kernel adds the NCH partials of a row in fixed order.  K2c stores the edge blocks in the BODY frame, B = R_k^T G R_k (it has R_k at hand), so K3c
-// applies R_k once per row, in its finish, instead of once per entry.
-//   measured at C5 (tools/bench_matvec6.hip, random data): row-major mat-vec 322 us -> 193 + 3 us.
+// are dealt to NCH workgroups; a finishing kernel adds the NCH partials of a row in fixed order.  K2c stores the edge blocks in the BODY
+// frame, B = R_k^T G R_k (it has R_k at hand), so K3c applies R_k once per row, in its finish, instead of once per entry.
+//   measured at C5: prototype on random data (tools/bench_matvec6.hip) row-major 322 us -> 193 + 3 us; in the product 296 -> 182-201 us
+//   (profiles/r03_k3c_tuning.txt has every step in between).
 #pragma once
 #include "kernels.hpp"
 
@@ -36,9 +37,9 @@ struct ColLayoutDev {
                             //   .y = slot of the entry in the row-sorted staging area (bits 0-9) | number of entries ROW p of the block has in this
                             //   sub-chunk (bits 10-19) | row of the entry inside its block (bits 20-28)  -- one 8-byte load per entry
   // The mat-vec's own, narrower copy of what it needs of the record: kcol = camera (all ones in `cbits` bits = padding) | slot << cbits |
-  // row count << (cbits + 9), the count saturating at `cmax` = 2^(23 - cbits) - 1, in which case (and always when cmax == 0, i.e. with 2^22
-  // cameras or more... the layout is not built beyond that) the true count is read from kcnt: 4 bytes per position for graphs below
-  // 2^19 cameras, 6 above, instead of 8.
+  // row count << (cbits + 9), the count saturating at `cmax` = 2^(23 - cbits) - 1, in which case -- and always when cmax == 0: from 2^19
+  // cameras on the word has no room for counts (the layout is not built for 2^22 cameras or more) -- the true count is read from kcnt:
+  // 4 bytes per position for graphs below 2^19 cameras, 6 above, instead of 8.
   const uint32_t* kcol;
   const uint16_t* kcnt;
   uint32_t cbits, cmax;
