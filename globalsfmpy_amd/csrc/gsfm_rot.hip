@@ -2174,11 +2174,16 @@ gsfm_status gsfm_rot_time_sweep_variants(gsfm_rot_problem* P, const double* rot,
   const CostArgs base = cost_args(P, P->q.p);
   hipEvent_t e0, e1;
   if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return (gsfm_status)fail(GSFM_ERR_HIP, "event create");
-  auto timed = [&](auto&& launch, double* out) -> int {
-    for (int k = -2; k < reps; ++k) { if (k == 0) (void)hipEventRecord(e0, P->stream); launch(); }
-    (void)hipEventRecord(e1, P->stream);
-    if (int st = sync_check(P, "time_sweep_variants")) return st;
-    float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1); *out = ms / reps; return 0;
+  auto timed = [&](auto&& launch, double* out) -> int {   // two rounds, the faster one counts (a round now and then is hit by something else on the box)
+    double best = 0.0;
+    for (int round = 0; round < 2; ++round) {
+      for (int k = -2; k < reps; ++k) { if (k == 0) (void)hipEventRecord(e0, P->stream); launch(); }
+      (void)hipEventRecord(e1, P->stream);
+      if (int st = sync_check(P, "time_sweep_variants")) return st;
+      float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
+      if (round == 0 || ms / reps < best) best = ms / reps;
+    }
+    *out = best; return 0;
   };
   int st = 0;
   for (int k = 0; k < 8; ++k) out_ms8[k] = 0.0;
@@ -2231,17 +2236,19 @@ gsfm_status gsfm_rot_time_kernels(gsfm_rot_problem* P, const double* rot, int32_
   for (int which = 0; which < 4; ++which) {
     out_ms4[which] = 0.0;
     if (which == 3) continue;   // (reserved)
-    for (int k = -2; k < reps; ++k) {  // two warm-up launches
-      if (k == 0) (void)hipEventRecord(e0, P->stream);
-      if (which == 0) { if (int st = launch_cost(P, P->q.p, SC_COST)) return (gsfm_status)st; }
-      else if (which == 1) { if (int st = launch_lin(P, P->q.p)) return (gsfm_status)st; }
-      else if (which == 2) { if (int st = launch_matvec(P, P->Mblk.p, P->b.p, P->Ap.p, nullptr)) return (gsfm_status)st; }
+    for (int round = 0; round < 2; ++round) {   // two rounds of `reps` launches each, the faster round's mean counts
+      for (int k = -2; k < reps; ++k) {  // two warm-up launches
+        if (k == 0) (void)hipEventRecord(e0, P->stream);
+        if (which == 0) { if (int st = launch_cost(P, P->q.p, SC_COST)) return (gsfm_status)st; }
+        else if (which == 1) { if (int st = launch_lin(P, P->q.p)) return (gsfm_status)st; }
+        else if (which == 2) { if (int st = launch_matvec(P, P->Mblk.p, P->b.p, P->Ap.p, nullptr)) return (gsfm_status)st; }
+      }
+      (void)hipEventRecord(e1, P->stream);
+      if (int st = sync_check(P, "time_kernels")) return (gsfm_status)st;
+      float ms = 0;
+      (void)hipEventElapsedTime(&ms, e0, e1);
+      if (round == 0 || ms / reps < out_ms4[which]) out_ms4[which] = ms / reps;
     }
-    (void)hipEventRecord(e1, P->stream);
-    if (int st = sync_check(P, "time_kernels")) return (gsfm_status)st;
-    float ms = 0;
-    (void)hipEventElapsedTime(&ms, e0, e1);
-    out_ms4[which] = ms / reps;
   }
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   return GSFM_OK;
