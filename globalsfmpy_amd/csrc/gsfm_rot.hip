@@ -821,7 +821,7 @@ int run_pcg2(gsfm_rot_problem* P, const gsfm_rot_options& o, int* iters_out, dou
   double* dots_own = P->part_d2.p;  // where its delta partials go
   if (P->sharded) {
     const uint32_t slice = P->shard.slice_width, tail = P->w_tail, stride = 3 * slice + tail;
-    if (!P->w_gather.p && P->w_gather.alloc((size_t)stride * P->shard.world_size, true) != hipSuccess) return fail(GSFM_ERR_HIP, "alloc all-gather buffer");
+    if (!P->w_gather.p) return fail(GSFM_ERR_HIP, "the all-gather buffer of the sharded PCG was not allocated");   // (create allocates it, before the ranks agree)
     c.w = P->w_gather.p; c.w_stride = stride; c.w_slice = slice; c.w_tail = tail; c.n_part_d = (int)(tail * P->shard.world_size);
     double* slot = P->w_gather.p + (size_t)P->shard.rank * stride;
     w_own = slot - 3 * (size_t)P->own_begin; dots_own = slot + 3 * (size_t)slice;
@@ -1746,6 +1746,8 @@ static gsfm_status problem_create_impl(uint32_t n_cams, uint64_t n_edges, const 
   }
   ok &= P->s_dir.alloc(3 * N, true) == hipSuccess; ok &= P->part_g2.alloc((size_t)2 * P->nb_cam, true) == hipSuccess;
   ok &= P->part_d2.alloc(std::max(P->nb_mv, P->nb_cam), true) == hipSuccess; ok &= P->cg2sc.alloc(1, true) == hipSuccess;
+  // (here, not at the first solve: an allocation that fails on one rank only must be part of the create-time agreement)
+  if (P->sharded) ok &= P->w_gather.alloc(((size_t)3 * P->shard.slice_width + P->w_tail) * P->shard.world_size, true) == hipSuccess;
   if (!ok) return bail(fail(GSFM_ERR_HIP, "allocating camera buffers failed"));
   {  // cameras touched by at least one edge (Ceres only knows parameter blocks that appear in a residual block)
     std::vector<double> act(NP, 0.0);
