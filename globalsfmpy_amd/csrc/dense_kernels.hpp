@@ -190,46 +190,68 @@ __global__ void __launch_bounds__(64) k_chol_panel(CholArgs a) {
 // C/D[(l >> 4) + 4 reg][l & 15], reg = 0..3 (MI355X guide, fragment layout of the f64 form).  A 32 x 32 tile is 2 x 2 such blocks times
 // 8 steps of K = 4; the A operand is -L_ik, the B operand L_jk read row-wise (= L_jk^T column-wise).
 typedef double chol_d4 __attribute__((ext_vector_type(4)));
-__global__ void __launch_bounds__(256) k_chol_update_mfma(CholArgs a) {
-  const uint32_t k = a.k, T = a.T, lane = threadIdx.x & 63;
+// Block columns k .. k + ncol - 1 of L (ncol = 1 or 2) are folded into the tiles (i, j), j0 <= j <= i <= T -- or, col_only, into the tiles
+// (i, j0) of one block column alone.  Two columns per pass read and write every trailing tile once instead of twice (the update is bound by
+// those 16 KB per tile from ~100 block rows on); the accumulation order per tile -- column k, then column k + 1 -- is the one two separate
+// passes have, so the factor is bit-identical whichever way the host pairs the columns.
+struct CholUpdArgs { double* A; const double* L; uint32_t T, k, j0, col_only; };
+template <int NCOL>
+__global__ void __launch_bounds__(256) k_chol_update_mfma(CholUpdArgs a) {
+  const uint32_t T = a.T, lane = threadIdx.x & 63, j0 = a.j0;
   const uint64_t b = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  const uint32_t m = T - k;                               // trailing block rows k+1 .. T
-  if (b >= (uint64_t)m * (m + 1) / 2) return;
-  uint32_t t = (uint32_t)((sqrt(8.0 * (double)b + 1.0) - 1.0) * 0.5);
-  while ((uint64_t)(t + 1) * (t + 2) / 2 <= b) ++t;
-  while ((uint64_t)t * (t + 1) / 2 > b) --t;
-  const uint32_t i = k + 1 + t, j = k + 1 + (uint32_t)(b - (uint64_t)t * (t + 1) / 2);
+  const uint32_t m = T - j0 + 1;                          // block rows j0 .. T
+  uint32_t i, j;
+  if (a.col_only) {
+    if (b >= m) return;
+    i = j0 + (uint32_t)b; j = j0;
+  } else {
+    if (b >= (uint64_t)m * (m + 1) / 2) return;
+    uint32_t t = (uint32_t)((sqrt(8.0 * (double)b + 1.0) - 1.0) * 0.5);
+    while ((uint64_t)(t + 1) * (t + 2) / 2 <= b) ++t;
+    while ((uint64_t)t * (t + 1) / 2 > b) --t;
+    i = j0 + t; j = j0 + (uint32_t)(b - (uint64_t)t * (t + 1) / 2);
+  }
   if (i == T && j == T) return;
   const uint32_t c = lane & 15, g = lane >> 4;
-  const double* Li = a.L + chol_tile_off(i, k);
-  const double* Lj = a.L + chol_tile_off(j, k);
-  // The contraction index may be dealt to (MFMA step kk, lane group g) in any way, as long as A and B agree: lane group g takes
-  // k = 8 g .. 8 g + 7, eight CONSECUTIVE doubles of a tile row, so the operand loads are 64 contiguous bytes per lane (whole rows per
-  // 4 lanes) instead of eight 8-byte pieces 32 bytes apart.
-  double aop[2][8], bop[2][8];
-#pragma unroll
-  for (int s = 0; s < 2; ++s) {
-    const double2* ra = (const double2*)(Li + (16 * s + c) * GSFM_CB + 8 * g);
-    const double2* rb = (const double2*)(Lj + (16 * s + c) * GSFM_CB + 8 * g);
-#pragma unroll
-    for (int h = 0; h < 4; ++h) {
-      const double2 va = ra[h], vb = rb[h];
-      aop[s][2 * h] = -va.x; aop[s][2 * h + 1] = -va.y; bop[s][2 * h] = vb.x; bop[s][2 * h + 1] = vb.y;
-    }
-  }
   double* Aij = a.A + chol_tile_off(i, j);
+  chol_d4 acc[2][2];
 #pragma unroll
   for (int si = 0; si < 2; ++si)
 #pragma unroll
-    for (int sj = 0; sj < 2; ++sj) {
-      chol_d4 acc;
+    for (int sj = 0; sj < 2; ++sj)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) acc[r] = Aij[(16 * si + g + 4 * r) * GSFM_CB + 16 * sj + c];
+      for (int r = 0; r < 4; ++r) acc[si][sj][r] = Aij[(16 * si + g + 4 * r) * GSFM_CB + 16 * sj + c];
 #pragma unroll
-      for (int kk = 0; kk < 8; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[si][kk], bop[sj][kk], acc, 0, 0, 0);
+  for (uint32_t cc = 0; cc < (uint32_t)NCOL; ++cc) {
+    const double* Li = a.L + chol_tile_off(i, a.k + cc);
+    const double* Lj = a.L + chol_tile_off(j, a.k + cc);
+    // The contraction index may be dealt to (MFMA step kk, lane group g) in any way, as long as A and B agree: lane group g takes
+    // k = 8 g .. 8 g + 7, eight CONSECUTIVE doubles of a tile row, so the operand loads are 64 contiguous bytes per lane (whole rows per
+    // 4 lanes) instead of eight 8-byte pieces 32 bytes apart.
+    double aop[2][8], bop[2][8];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) Aij[(16 * si + g + 4 * r) * GSFM_CB + 16 * sj + c] = acc[r];
+    for (int s = 0; s < 2; ++s) {
+      const double2* ra = (const double2*)(Li + (16 * s + c) * GSFM_CB + 8 * g);
+      const double2* rb = (const double2*)(Lj + (16 * s + c) * GSFM_CB + 8 * g);
+#pragma unroll
+      for (int h = 0; h < 4; ++h) {
+        const double2 va = ra[h], vb = rb[h];
+        aop[s][2 * h] = -va.x; aop[s][2 * h + 1] = -va.y; bop[s][2 * h] = vb.x; bop[s][2 * h + 1] = vb.y;
+      }
     }
+#pragma unroll
+    for (int si = 0; si < 2; ++si)
+#pragma unroll
+      for (int sj = 0; sj < 2; ++sj)
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) acc[si][sj] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[si][kk], bop[sj][kk], acc[si][sj], 0, 0, 0);
+  }
+#pragma unroll
+  for (int si = 0; si < 2; ++si)
+#pragma unroll
+    for (int sj = 0; sj < 2; ++sj)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Aij[(16 * si + g + 4 * r) * GSFM_CB + 16 * sj + c] = acc[si][sj][r];
 }
 
 // x = L^-T y, one workgroup: block rows bottom-up; y stays in LDS.  Software-pipelined: while the other 15 wavefronts fold x_k into the

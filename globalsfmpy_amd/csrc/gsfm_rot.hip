@@ -948,13 +948,32 @@ int run_dense(gsfm_rot_problem* P, bool* used) {
     a.Mblk = P->Mblk.p; a.b = P->b.p; a.A = P->denseA.p; a.n = n; a.T = T; a.q = P->q_lin; a.lap = P->lin_is_lap; a.info_slot = P->scal.p + SC_DENSE_INFO; a.rcg = P->r.p;
     if (P->cs.active) hipLaunchKernelGGL(k_dense_assemble_col, dim3(P->cs.n_wg), dim3(GSFM_BLOCK), 0, P->stream, a, P->cs.dev());
     else hipLaunchKernelGGL(k_dense_assemble, dim3(P->n_rows), dim3(GSFM_BLOCK), 0, P->stream, a);
-    for (uint32_t k = 0; k < T; ++k) {
-      CholArgs c{P->denseA.p, P->denseL.p, T, k, info};
-      const uint64_t m = T - k;
-      if (T <= split_T) hipLaunchKernelGGL(k_chol_step, dim3((uint32_t)(1 + m * (m + 1) / 2)), dim3(256), 0, P->stream, c);
-      else {   // larger matrices: panel (one wavefront per tile row), then the trailing update on the matrix cores
-        hipLaunchKernelGGL(k_chol_panel, dim3((uint32_t)(m + 1)), dim3(64), 0, P->stream, c);
-        hipLaunchKernelGGL(k_chol_update_mfma, dim3((uint32_t)((m * (m + 1) / 2 + 3) / 4)), dim3(256), 0, P->stream, c);
+    if (T <= split_T) {
+      for (uint32_t k = 0; k < T; ++k) {
+        CholArgs c{P->denseA.p, P->denseL.p, T, k, info};
+        const uint64_t m = T - k;
+        hipLaunchKernelGGL(k_chol_step, dim3((uint32_t)(1 + m * (m + 1) / 2)), dim3(256), 0, P->stream, c);
+      }
+    } else {
+      // larger matrices: panel (one wavefront per tile row), then the trailing update on the matrix cores -- block columns in PAIRS: column k
+      // is folded into block column k + 1 alone first, so that panel k + 1 can run, and then both are folded into the rest in one pass
+      // (every trailing tile read and written once per pair; same launch count, bit-identical factor)
+      auto update = [&](uint32_t k, uint32_t ncol, uint32_t j0, bool col_only) {
+        CholUpdArgs u{P->denseA.p, P->denseL.p, T, k, j0, col_only ? 1u : 0u};
+        const uint64_t m = T - j0 + 1, tiles = col_only ? m : m * (m + 1) / 2;
+        if (j0 > T || !tiles) return;
+        if (ncol == 2) hipLaunchKernelGGL(k_chol_update_mfma<2>, dim3((uint32_t)((tiles + 3) / 4)), dim3(256), 0, P->stream, u);
+        else hipLaunchKernelGGL(k_chol_update_mfma<1>, dim3((uint32_t)((tiles + 3) / 4)), dim3(256), 0, P->stream, u);
+      };
+      for (uint32_t k = 0; k < T; k += 2) {
+        CholArgs c{P->denseA.p, P->denseL.p, T, k, info};
+        hipLaunchKernelGGL(k_chol_panel, dim3(T - k + 1), dim3(64), 0, P->stream, c);
+        if (k + 1 < T) {
+          update(k, 1, k + 1, true);
+          CholArgs c1{P->denseA.p, P->denseL.p, T, k + 1, info};
+          hipLaunchKernelGGL(k_chol_panel, dim3(T - k), dim3(64), 0, P->stream, c1);
+          update(k, 2, k + 2, false);
+        } else update(k, 1, k + 1, false);   // (odd count: the last column alone; only the right-hand side row is left to update)
       }
     }
     if (T <= split_T) hipLaunchKernelGGL(k_chol_back<GSFM_CHOL_SPLIT_T>, dim3(1), dim3(1024), 0, P->stream, (const double*)P->denseL.p, n, T, P->xcg.p);

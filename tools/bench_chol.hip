@@ -39,14 +39,30 @@ int main(int argc, char** argv) {
     hipStream_t st; CHK(hipStreamCreate(&st));
     auto enqueue = [&]() {
       CHK(hipMemcpyAsync(dA, dA0, 8 * elems, hipMemcpyDeviceToDevice, st));
-      for (uint32_t k = 0; k < T; ++k) {
+      auto update = [&](uint32_t k, uint32_t ncol, uint32_t j0, bool col_only) {
+        CholUpdArgs u{dA, dL, T, k, j0, col_only ? 1u : 0u};
+        const uint64_t m = T - j0 + 1, tiles = col_only ? m : m * (m + 1) / 2;
+        if (j0 > T || !tiles) return;
+        if (ncol == 2) hipLaunchKernelGGL(k_chol_update_mfma<2>, dim3((uint32_t)((tiles + 3) / 4)), dim3(256), 0, st, u);
+        else hipLaunchKernelGGL(k_chol_update_mfma<1>, dim3((uint32_t)((tiles + 3) / 4)), dim3(256), 0, st, u);
+      };
+      if (!split) for (uint32_t k = 0; k < T; ++k) {
         CholArgs c{dA, dL, T, k, dinfo};
         const uint64_t m = T - k;
-        if (!split) hipLaunchKernelGGL(k_chol_step, dim3((uint32_t)(1 + m * (m + 1) / 2)), dim3(256), 0, st, c);
-        else {
-          hipLaunchKernelGGL(k_chol_panel, dim3((uint32_t)(m + 1)), dim3(64), 0, st, c);
-          hipLaunchKernelGGL(k_chol_update_mfma, dim3((uint32_t)((m * (m + 1) / 2 + 3) / 4)), dim3(256), 0, st, c);
-        }
+        hipLaunchKernelGGL(k_chol_step, dim3((uint32_t)(1 + m * (m + 1) / 2)), dim3(256), 0, st, c);
+      } else if (getenv("CHOL_SINGLE_COLUMN_UPDATES")) for (uint32_t k = 0; k < T; ++k) {   // (the schedule before the columns were paired)
+        CholArgs c{dA, dL, T, k, dinfo};
+        hipLaunchKernelGGL(k_chol_panel, dim3(T - k + 1), dim3(64), 0, st, c);
+        update(k, 1, k + 1, false);
+      } else for (uint32_t k = 0; k < T; k += 2) {   // the product's schedule (run_dense)
+        CholArgs c{dA, dL, T, k, dinfo};
+        hipLaunchKernelGGL(k_chol_panel, dim3(T - k + 1), dim3(64), 0, st, c);
+        if (k + 1 < T) {
+          update(k, 1, k + 1, true);
+          CholArgs c1{dA, dL, T, k + 1, dinfo};
+          hipLaunchKernelGGL(k_chol_panel, dim3(T - k), dim3(64), 0, st, c1);
+          update(k, 2, k + 2, false);
+        } else update(k, 1, k + 1, false);
       }
       if (!split) hipLaunchKernelGGL(k_chol_back<GSFM_DENSE_MAX_T>, dim3(1), dim3(1024), 0, st, (const double*)dL, n, T, dx);
       else for (uint32_t k = T; k >= 1; --k) { CholBackArgs b{dL, dx, n, T, k}; hipLaunchKernelGGL(k_chol_back_step, dim3(k == T ? 1 : k), dim3(64), 0, st, b); }
