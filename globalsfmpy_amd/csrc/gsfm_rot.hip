@@ -955,25 +955,29 @@ int run_dense(gsfm_rot_problem* P, bool* used) {
         hipLaunchKernelGGL(k_chol_step, dim3((uint32_t)(1 + m * (m + 1) / 2)), dim3(256), 0, P->stream, c);
       }
     } else {
-      // larger matrices: panel (one wavefront per tile row), then the trailing update on the matrix cores -- block columns in PAIRS: column k
-      // is folded into block column k + 1 alone first, so that panel k + 1 can run, and then both are folded into the rest in one pass
-      // (every trailing tile read and written once per pair; same launch count, bit-identical factor)
+      // larger matrices: panel (one wavefront per tile row), then the trailing update on the matrix cores -- block columns in GROUPS of two (four beyond 192 block columns):
+      // inside a group the finished columns are folded into the NEXT block column alone, so that its panel can run, and after the group all
+      // of them are folded into the rest in one pass (every trailing tile read and written once per group instead of once per column; same
+      // launch count; per tile the columns are still applied in ascending order, so the factor is bit-identical to the column-by-column schedule)
       auto update = [&](uint32_t k, uint32_t ncol, uint32_t j0, bool col_only) {
         CholUpdArgs u{P->denseA.p, P->denseL.p, T, k, j0, col_only ? 1u : 0u};
         const uint64_t m = T - j0 + 1, tiles = col_only ? m : m * (m + 1) / 2;
         if (j0 > T || !tiles) return;
-        if (ncol == 2) hipLaunchKernelGGL(k_chol_update_mfma<2>, dim3((uint32_t)((tiles + 3) / 4)), dim3(256), 0, P->stream, u);
-        else hipLaunchKernelGGL(k_chol_update_mfma<1>, dim3((uint32_t)((tiles + 3) / 4)), dim3(256), 0, P->stream, u);
+        const dim3 grid((uint32_t)((tiles + 3) / 4)), blk(256);
+        if (ncol == 4) hipLaunchKernelGGL(k_chol_update_mfma<4>, grid, blk, 0, P->stream, u);
+        else if (ncol == 3) hipLaunchKernelGGL(k_chol_update_mfma<3>, grid, blk, 0, P->stream, u);
+        else if (ncol == 2) hipLaunchKernelGGL(k_chol_update_mfma<2>, grid, blk, 0, P->stream, u);
+        else hipLaunchKernelGGL(k_chol_update_mfma<1>, grid, blk, 0, P->stream, u);
       };
-      for (uint32_t k = 0; k < T; k += 2) {
-        CholArgs c{P->denseA.p, P->denseL.p, T, k, info};
-        hipLaunchKernelGGL(k_chol_panel, dim3(T - k + 1), dim3(64), 0, P->stream, c);
-        if (k + 1 < T) {
-          update(k, 1, k + 1, true);
-          CholArgs c1{P->denseA.p, P->denseL.p, T, k + 1, info};
-          hipLaunchKernelGGL(k_chol_panel, dim3(T - k), dim3(64), 0, P->stream, c1);
-          update(k, 2, k + 2, false);
-        } else update(k, 1, k + 1, false);   // (odd count: the last column alone; only the right-hand side row is left to update)
+      const uint32_t GROUP = T > 192 ? 4 : 2;   // (3N = 2400 / 4500 / 9000: pairs 1.42 / 3.44 / 14.7 ms, fours 1.48 / 3.50 / 13.8; column by column 1.48 / 3.75 / 17.4)
+      for (uint32_t k = 0; k < T; k += GROUP) {
+        const uint32_t g = std::min(GROUP, T - k);
+        for (uint32_t c = 0; c < g; ++c) {
+          CholArgs pc{P->denseA.p, P->denseL.p, T, k + c, info};
+          hipLaunchKernelGGL(k_chol_panel, dim3(T - (k + c) + 1), dim3(64), 0, P->stream, pc);
+          if (c + 1 < g) update(k, c + 1, k + c + 1, true);    // columns k .. k + c into block column k + c + 1 alone: the next panel's input
+        }
+        update(k, g, k + g, false);                            // all g columns into the rest (for the last group: the right-hand side row only)
       }
     }
     if (T <= split_T) hipLaunchKernelGGL(k_chol_back<GSFM_CHOL_SPLIT_T>, dim3(1), dim3(1024), 0, P->stream, (const double*)P->denseL.p, n, T, P->xcg.p);

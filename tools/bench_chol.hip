@@ -43,8 +43,11 @@ int main(int argc, char** argv) {
         CholUpdArgs u{dA, dL, T, k, j0, col_only ? 1u : 0u};
         const uint64_t m = T - j0 + 1, tiles = col_only ? m : m * (m + 1) / 2;
         if (j0 > T || !tiles) return;
-        if (ncol == 2) hipLaunchKernelGGL(k_chol_update_mfma<2>, dim3((uint32_t)((tiles + 3) / 4)), dim3(256), 0, st, u);
-        else hipLaunchKernelGGL(k_chol_update_mfma<1>, dim3((uint32_t)((tiles + 3) / 4)), dim3(256), 0, st, u);
+        const dim3 grid((uint32_t)((tiles + 3) / 4)), blk(256);
+        if (ncol == 4) hipLaunchKernelGGL(k_chol_update_mfma<4>, grid, blk, 0, st, u);
+        else if (ncol == 3) hipLaunchKernelGGL(k_chol_update_mfma<3>, grid, blk, 0, st, u);
+        else if (ncol == 2) hipLaunchKernelGGL(k_chol_update_mfma<2>, grid, blk, 0, st, u);
+        else hipLaunchKernelGGL(k_chol_update_mfma<1>, grid, blk, 0, st, u);
       };
       if (!split) for (uint32_t k = 0; k < T; ++k) {
         CholArgs c{dA, dL, T, k, dinfo};
@@ -54,15 +57,17 @@ int main(int argc, char** argv) {
         CholArgs c{dA, dL, T, k, dinfo};
         hipLaunchKernelGGL(k_chol_panel, dim3(T - k + 1), dim3(64), 0, st, c);
         update(k, 1, k + 1, false);
-      } else for (uint32_t k = 0; k < T; k += 2) {   // the product's schedule (run_dense)
-        CholArgs c{dA, dL, T, k, dinfo};
-        hipLaunchKernelGGL(k_chol_panel, dim3(T - k + 1), dim3(64), 0, st, c);
-        if (k + 1 < T) {
-          update(k, 1, k + 1, true);
-          CholArgs c1{dA, dL, T, k + 1, dinfo};
-          hipLaunchKernelGGL(k_chol_panel, dim3(T - k), dim3(64), 0, st, c1);
-          update(k, 2, k + 2, false);
-        } else update(k, 1, k + 1, false);
+      } else {   // the product's schedule (run_dense): groups of 2 block columns, 4 beyond 192 (CHOL_GROUP=1..4 overrides)
+        const uint32_t GROUP = getenv("CHOL_GROUP") ? (uint32_t)std::max(1, std::min(4, atoi(getenv("CHOL_GROUP")))) : (T > 192 ? 4u : 2u);
+        for (uint32_t k = 0; k < T; k += GROUP) {
+          const uint32_t g = std::min(GROUP, T - k);
+          for (uint32_t c = 0; c < g; ++c) {
+            CholArgs pc{dA, dL, T, k + c, dinfo};
+            hipLaunchKernelGGL(k_chol_panel, dim3(T - (k + c) + 1), dim3(64), 0, st, pc);
+            if (c + 1 < g) update(k, c + 1, k + c + 1, true);
+          }
+          update(k, g, k + g, false);
+        }
       }
       if (!split) hipLaunchKernelGGL(k_chol_back<GSFM_DENSE_MAX_T>, dim3(1), dim3(1024), 0, st, (const double*)dL, n, T, dx);
       else for (uint32_t k = T; k >= 1; --k) { CholBackArgs b{dL, dx, n, T, k}; hipLaunchKernelGGL(k_chol_back_step, dim3(k == T ? 1 : k), dim3(64), 0, st, b); }
