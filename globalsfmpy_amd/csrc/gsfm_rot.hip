@@ -1309,16 +1309,22 @@ int build_colsort(gsfm_rot_problem* P, const std::vector<uint32_t>& rp, hvec<uin
   uint32_t cbits = 1;
   while (((1u << cbits) - 1u) <= P->n_cams) ++cbits;   // cameras 0 .. n_cams - 1 and the all-ones padding value
   const uint32_t cmax = cbits <= 19 ? (1u << (23 - cbits)) - 1u : 0u, kpad = (1u << cbits) - 1u;
-  uint32_t want_wgs = 1760;   // ~7 workgroups per CU: best of 784 .. 3100 at C5 for both K2c and K3c, by 4-8 % over the neighbouring values on the same box (boxes differ by
-                               // +-4 %; shifting the planes' base addresses against each other changes nothing; profiles/r03_k3c_tuning.txt; GSFM_COL_WGS overrides)
-  if (const char* e = getenv("GSFM_COL_WGS")) { const int v = atoi(e); if (v > 0) want_wgs = (uint32_t)v; }
-  C.nch = std::min<uint32_t>(32, std::max<uint32_t>(1, (want_wgs + nblk - 1) / nblk));
   std::vector<size_t> sub_off((size_t)nblk + 1, 0);
   for (uint32_t b = 0; b < nblk; ++b) {
     const size_t ne = rp[std::min(n_rows, (b + 1) * RB)] - rp[b * RB];
     sub_off[b + 1] = sub_off[b] + (ne + SUB - 1) / SUB;
   }
   const size_t n_sub = sub_off[nblk], n_pos = n_sub * SUB;
+  // Workgroups per block (each writes one partial sum per row, which the finish kernels add): about 22 sub-chunks (11 k entries) per
+  // workgroup, but at least ~400 workgroups in all.  Measured on K3c + finish, same box each (profiles/r03_k3c_tuning.txt, r03_rank_share.txt):
+  // C5 on one GPU (196 blocks of ~200 sub-chunks) 8 / 9 / 10 per block = 208 / 202 / 203 us; one rank of 4 (49 blocks) 8 / 13 / 17 / 32 =
+  // 51 / 57 / 61 / 64 us; one rank of 8 (25 blocks) 8 / 16 / 24 / 32 = 39.5 / 33.3 / 38 / 39 us.  GSFM_COL_WGS=n asks for n workgroups in all.
+  {
+    const double per_block = (double)n_sub / nblk;
+    uint32_t nch = std::max<uint32_t>((uint32_t)std::lround(per_block / 22.0), (400 + nblk - 1) / nblk);
+    if (const char* e = getenv("GSFM_COL_WGS")) { const int v = atoi(e); if (v > 0) nch = ((uint32_t)v + nblk - 1) / nblk; }
+    C.nch = std::min<uint32_t>(32, std::max<uint32_t>(1, nch));
+  }
   if (n_pos == 0 || n_pos >= 0x7fffffffull) return 0;   // (positions are 32-bit in the kernels: stay on the row-major form)
   hvec<uint32_t> h_col(n_pos), h_eid(n_pos), h_kcol(n_pos);   // (every position is written below)
   hvec<uint2> h_meta(n_pos);
