@@ -27,4 +27,10 @@ for world in worlds:
     kt = p.time_kernels(init, reps=20)
     print("GSFM_COL_WGS=%s " % os.environ.get("GSFM_COL_WGS", "default") + "ranks %d: rank 0 holds %d edges (%.1f %%), layout form %d; k_cost %.1f us, k_lin %.1f us, k_matvec (+ finish) %.1f us"
           % (world, n_local, 100.0 * n_local / len(g["edge_i"]), p.matvec_bytes()[1], 1e3 * kt["k_cost"], 1e3 * kt["k_lin"], 1e3 * kt["k_matvec"]), flush=True)
+    if world > 1:   # a PCG run without communication: wrong numbers, real launches -- kernels + gaps of one rank's iteration
+        for graph in (1, 0):
+            p.solve(init, max_num_iterations=1, max_cg_iterations=400, pcg_hip_graph=graph)
+            r, s = p.solve(init, max_num_iterations=1, max_cg_iterations=400, pcg_hip_graph=graph)
+            print("    one LM step, PCG capped at 400: %d iterations launched, %.2f ms of PCG -> %.1f us per iteration without the collective (%s)"
+                  % (s["num_pcg_launched"], s["t_cg_ms"], 1e3 * s["t_cg_ms"] / max(1, s["num_pcg_launched"]), "hipGraph replay" if graph else "plain launches"), flush=True)
     p.close()
