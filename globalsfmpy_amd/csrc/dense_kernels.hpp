@@ -361,4 +361,82 @@ __global__ void __launch_bounds__(64) k_chol_back_step(CholBackArgs a) {
   if (lane < GSFM_CB) a.x[kb * GSFM_CB + lane] = v * rinv;   // (entries beyond n belong to the identity padding: harmless)
 }
 
+// Backward substitution in GROUPS of block rows (both schedules): `k_chol_back_group` -- one workgroup -- solves the block rows k1 - 1 .. k0
+// bottom-up (wavefront 0: the 32-step substitution of block k, as chol_back_block; wavefronts 1..7: one tile (k, j) of the group each, loaded
+// while wavefront 0 solves, folded into the group's right-hand sides once x_k is there), then `k_chol_back_update` -- one workgroup per block
+// row ABOVE the group, all of them in parallel on their own CUs -- folds the group's x into the rest: y_j -= L_kj^T x_k, k descending.  Per
+// tile the dot products run over r = 0 .. 31 in order and the subtractions over k descending, exactly as the single-workgroup kernel above
+// did them: the same bits.  That kernel streamed all of L through one CU (135 us at 3N = 1182, 21 % of a Madrid LM iteration); here a group
+// costs its 8 or 16 dependent block rows inside one launch and the bulk of L is read by many CUs at once (2 launches per group).
+struct CholBackGroupArgs { double* L; double* x; uint32_t n, T, k0, k1; };   // x: T * 32 doubles (padded); y_j = first row of tile (T, j) of L
+template <int GR>   // block rows per group = wavefronts of the workgroup (8 or 16)
+__global__ void __launch_bounds__(64 * GR) k_chol_back_group(CholBackGroupArgs a) {
+  constexpr uint32_t NT = 64 * GR, LOADERS = 32 * (GR - 1), PER = (GSFM_TILE_ELEMS + LOADERS - 1) / LOADERS;
+  __shared__ double yg[GR][GSFM_CB];
+  __shared__ double Lk[2][GSFM_CB][GSFM_CB + 1];
+  __shared__ double xk[2][GSFM_CB];
+  const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 31, k0 = a.k0, k1 = a.k1, G = k1 - k0;
+  for (uint32_t idx = tid; idx < G * GSFM_CB; idx += NT) yg[idx / GSFM_CB][idx % GSFM_CB] = a.L[chol_tile_off(a.T, k0 + idx / GSFM_CB) + idx % GSFM_CB];
+  for (uint32_t e = tid; e < GSFM_TILE_ELEMS; e += NT) Lk[(k1 - 1) & 1][e / GSFM_CB][e % GSFM_CB] = a.L[chol_tile_off(k1 - 1, k1 - 1) + e];
+  __syncthreads();
+  for (uint32_t k = k1; k-- > k0;) {
+    // wavefronts 1 .. GR - 1, lower half: column c of tile (k, j), j = k0 + wave - 1 (requested before x_k exists); upper half: the next diagonal tile
+    const uint32_t j = k0 + wave - 1;
+    const bool tile = wave >= 1 && lane < GSFM_CB && j < k;
+    double tv[GSFM_CB], dv[PER];
+    if (tile) {
+      const double* t = a.L + chol_tile_off(k, j) + c;
+#pragma unroll
+      for (int r = 0; r < GSFM_CB; ++r) tv[r] = t[r * GSFM_CB];
+    }
+    const bool diag = wave >= 1 && lane >= GSFM_CB && k > k0;
+    const uint32_t e0 = (wave - 1) * GSFM_CB + c;     // LOADERS lanes, PER elements each
+    if (diag) {
+      const double* d = a.L + chol_tile_off(k - 1, k - 1);
+#pragma unroll
+      for (int i = 0; i < (int)PER; ++i) { const uint32_t e = e0 + LOADERS * i; dv[i] = e < GSFM_TILE_ELEMS ? d[e] : 0.0; }
+    }
+    if (wave == 0) chol_back_block(Lk[k & 1], yg[k - k0][c], lane, xk[k & 1], a.x, k * GSFM_CB, a.T * GSFM_CB);
+    __syncthreads();
+    if (tile) {
+      double s2 = 0.0;
+#pragma unroll
+      for (int r = 0; r < GSFM_CB; ++r) s2 += tv[r] * xk[k & 1][r];
+      yg[j - k0][c] -= s2;
+    }
+    if (diag) {
+#pragma unroll
+      for (int i = 0; i < (int)PER; ++i) { const uint32_t e = e0 + LOADERS * i; if (e < GSFM_TILE_ELEMS) Lk[(k - 1) & 1][e / GSFM_CB][e % GSFM_CB] = dv[i]; }
+    }
+    __syncthreads();
+  }
+}
+template <int GR>
+__global__ void __launch_bounds__(32 * GR) k_chol_back_update(CholBackGroupArgs a) {
+  __shared__ double xs[GR][GSFM_CB], s2s[GR][GSFM_CB];
+  const uint32_t tid = threadIdx.x, c = tid & 31, kk = tid >> 5, j = blockIdx.x, G = a.k1 - a.k0;   // kk: block row k0 + kk of the group
+  double tv[GSFM_CB];
+  if (kk < G) {
+    const double* t = a.L + chol_tile_off(a.k0 + kk, j) + c;
+#pragma unroll
+    for (int r = 0; r < GSFM_CB; ++r) tv[r] = t[r * GSFM_CB];
+    xs[kk][c] = a.x[(a.k0 + kk) * GSFM_CB + c];
+  }
+  __syncthreads();
+  if (kk < G) {
+    double s2 = 0.0;
+#pragma unroll
+    for (int r = 0; r < GSFM_CB; ++r) s2 += tv[r] * xs[kk][r];
+    s2s[kk][c] = s2;
+  }
+  __syncthreads();
+  if (tid < GSFM_CB) {
+    double* yj = a.L + chol_tile_off(a.T, j);
+    double v = yj[c];
+    for (uint32_t q = G; q-- > 0;) v -= s2s[q][c];
+    yj[c] = v;
+  }
+}
+
+
 }  // namespace gsfm

@@ -981,7 +981,26 @@ int run_dense(gsfm_rot_problem* P, bool* used) {
         update(k, g, k + g, false);                            // all g columns into the rest (for the last group: the right-hand side row only)
       }
     }
-    if (T <= split_T) hipLaunchKernelGGL(k_chol_back<GSFM_CHOL_SPLIT_T>, dim3(1), dim3(1024), 0, P->stream, (const double*)P->denseL.p, n, T, P->xcg.p);
+    // backward substitution, L^T x = y (y = block row T of L), in groups of 8 block rows: one workgroup solves a group, one launch
+    // folds its x into all block rows above it (dense_kernels.hpp).  GSFM_CHOL_BACK_GROUPS=0: the forms it replaced (one workgroup for
+    // everything up to 48 block rows, one launch per block row beyond), kept for A/B measurements.
+    static const bool grouped = [] { const char* e = getenv("GSFM_CHOL_BACK_GROUPS"); return !(e && atoi(e) == 0); }();
+    if (grouped) {
+      static const uint32_t GR = [] { const char* e = getenv("GSFM_CHOL_BACK_GROUP"); return e && atoi(e) == 16 ? 16u : 8u; }();   // (Madrid, linear solves per solve: 8 rows per group 35.1 ms, 16: 36.0, the single workgroup it replaces 37.6)
+      for (uint32_t k1 = T; k1 > 0;) {
+        const uint32_t k0 = k1 > GR ? k1 - GR : 0;
+        CholBackGroupArgs b{P->denseL.p, P->dense_x.p, n, T, k0, k1};
+        if (GR == 16) {
+          hipLaunchKernelGGL(k_chol_back_group<16>, dim3(1), dim3(1024), 0, P->stream, b);
+          if (k0) hipLaunchKernelGGL(k_chol_back_update<16>, dim3(k0), dim3(512), 0, P->stream, b);
+        } else {
+          hipLaunchKernelGGL(k_chol_back_group<8>, dim3(1), dim3(512), 0, P->stream, b);
+          if (k0) hipLaunchKernelGGL(k_chol_back_update<8>, dim3(k0), dim3(256), 0, P->stream, b);
+        }
+        k1 = k0;
+      }
+      (void)hipMemcpyAsync(P->xcg.p, P->dense_x.p, 8 * (size_t)n, hipMemcpyDeviceToDevice, P->stream);
+    } else if (T <= split_T) hipLaunchKernelGGL(k_chol_back<GSFM_CHOL_SPLIT_T>, dim3(1), dim3(1024), 0, P->stream, (const double*)P->denseL.p, n, T, P->xcg.p);
     else {   // one launch per block row, all tiles of the row in parallel; the running right-hand side is block row T of L, x goes to dense_x (padded to T * 32)
       for (uint32_t k = T; k >= 1; --k) {
         CholBackArgs b{P->denseL.p, P->dense_x.p, n, T, k};

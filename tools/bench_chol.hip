@@ -69,8 +69,16 @@ int main(int argc, char** argv) {
           update(k, g, k + g, false);
         }
       }
-      if (!split) hipLaunchKernelGGL(k_chol_back<GSFM_DENSE_MAX_T>, dim3(1), dim3(1024), 0, st, (const double*)dL, n, T, dx);
-      else for (uint32_t k = T; k >= 1; --k) { CholBackArgs b{dL, dx, n, T, k}; hipLaunchKernelGGL(k_chol_back_step, dim3(k == T ? 1 : k), dim3(64), 0, st, b); }
+      if (getenv("CHOL_BACK_OLD")) {   // (the backward forms before the grouped one)
+        if (!split) hipLaunchKernelGGL(k_chol_back<GSFM_DENSE_MAX_T>, dim3(1), dim3(1024), 0, st, (const double*)dL, n, T, dx);
+        else for (uint32_t k = T; k >= 1; --k) { CholBackArgs b{dL, dx, n, T, k}; hipLaunchKernelGGL(k_chol_back_step, dim3(k == T ? 1 : k), dim3(64), 0, st, b); }
+      } else for (uint32_t k1 = T; k1 > 0;) {   // the product's backward substitution (run_dense): groups of 8 block rows
+        const uint32_t k0 = k1 > 8 ? k1 - 8 : 0;
+        CholBackGroupArgs b{dL, dx, n, T, k0, k1};
+        hipLaunchKernelGGL(k_chol_back_group<8>, dim3(1), dim3(512), 0, st, b);
+        if (k0) hipLaunchKernelGGL(k_chol_back_update<8>, dim3(k0), dim3(256), 0, st, b);
+        k1 = k0;
+      }
     };
     hipGraph_t g; hipGraphExec_t ge;
     CHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal)); enqueue(); CHK(hipStreamEndCapture(st, &g)); CHK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
