@@ -50,96 +50,9 @@ struct CholArgs {
   int* info;      // 0, or 1 + index of the first non-positive pivot
 };
 
-// Step k.  Workgroup 0: L_kk and the right-hand side's panel tile; workgroup 1 + t(t+1)/2 + u: trailing tile (k+1+t, k+1+u), u <= t.
-// Wavefront 0 holds the rows of A_kk in lanes 0..31 and the rows of the panel tile A_ik in lanes 32..63, one row per lane in
-// registers, and runs the right-looking elimination on all 64 rows at once: for the lower lanes that is the Cholesky factorisation,
-// for the upper lanes the same instructions are the substitution P_i = A_ik L_kk^-T (the multipliers L[c][c0] are wave-uniform
-// v_readlane broadcasts from the diagonal rows), so the panel costs nothing extra.  Wavefront 1 does the same with A_jk.
-__global__ void __launch_bounds__(256) k_chol_step(CholArgs a) {
-  __shared__ double Pi[GSFM_CB][GSFM_CB + 1], Pj[GSFM_CB][GSFM_CB + 1];
-  const uint32_t k = a.k, T = a.T, tid = threadIdx.x;
-  uint32_t i, j;
-  const bool diag_wg = blockIdx.x == 0;
-  if (diag_wg) { i = T; j = k; }
-  else {
-    const uint32_t b = blockIdx.x - 1;
-    uint32_t t = (uint32_t)((sqrt(8.0 * (double)b + 1.0) - 1.0) * 0.5);
-    while ((uint64_t)(t + 1) * (t + 2) / 2 <= b) ++t;
-    while ((uint64_t)t * (t + 1) / 2 > b) --t;
-    i = k + 1 + t; j = k + 1 + (b - t * (t + 1) / 2);
-    if (i == T && j == T) return;   // the right-hand side has no diagonal tile
-  }
-  const bool same = !diag_wg && i == j;
-  const uint32_t ur = tid / 8, uc4 = (tid % 8) * 4;   // this lane's 1 x 4 piece of the trailing tile
-  double own[4] = {0, 0, 0, 0};
-  if (!diag_wg) {
-    const double* so = a.A + chol_tile_off(i, j) + ur * GSFM_CB + uc4;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) own[q] = so[q];
-  }
-  const uint32_t wave = tid >> 6, lane = tid & 63;
-  if (wave == 0 || (wave == 1 && !diag_wg && !same)) {
-    const uint32_t rr = lane & 31;
-    const double2* src = (const double2*)(a.A + (lane < 32 ? chol_tile_off(k, k) : chol_tile_off(wave == 0 ? i : j, k)) + rr * GSFM_CB);
-    double r[GSFM_CB];
-#pragma unroll
-    for (int q = 0; q < GSFM_CB / 2; ++q) { const double2 v = src[q]; r[2 * q] = v.x; r[2 * q + 1] = v.y; }
-    int bad = 0;
-#pragma unroll
-    for (int c0 = 0; c0 < GSFM_CB; ++c0) {
-      double piv = readlane_f64(r[c0], c0);
-      if (!(piv > 0.0)) { if (!bad) bad = c0 + 1; piv = 1.0; }
-      const double inv = rsqrt(piv);
-      r[c0] = (lane == (uint32_t)c0) ? piv * inv : r[c0] * inv;
-      // entries above the diagonal of the diagonal rows (lane < c) are never read by anyone, so they may hold anything
-      // multipliers L[c][c0] (held by lane c) in batches: all v_readlane of a batch first, then the FMAs -- one SGPR-hazard wait per
-      // batch instead of one per multiplier
-#pragma unroll
-      for (int cb = c0 + 1; cb < GSFM_CB; cb += GSFM_CHOL_BATCH) {
-        double m[GSFM_CHOL_BATCH];
-#pragma unroll
-        for (int q = 0; q < GSFM_CHOL_BATCH; ++q) if (cb + q < GSFM_CB) m[q] = readlane_f64(r[c0], cb + q);
-#pragma unroll
-        for (int q = 0; q < GSFM_CHOL_BATCH; ++q) if (cb + q < GSFM_CB) r[cb + q] -= r[c0] * m[q];
-      }
-    }
-    if (lane >= 32) {
-      double (*P)[GSFM_CB + 1] = wave == 0 ? Pi : Pj;
-#pragma unroll
-      for (int c = 0; c < GSFM_CB; ++c) P[rr][c] = r[c];
-    } else if (diag_wg) {
-      double2* dl = (double2*)(a.L + chol_tile_off(k, k) + rr * GSFM_CB);
-#pragma unroll
-      for (int q = 0; q < GSFM_CB / 2; ++q) dl[q] = make_double2((uint32_t)(2 * q) <= lane ? r[2 * q] : 0.0, (uint32_t)(2 * q + 1) <= lane ? r[2 * q + 1] : 0.0);
-      if (lane == 0 && bad && *a.info == 0) *a.info = (int)(k * GSFM_CB + bad);
-    }
-  }
-  __syncthreads();
-  if (diag_wg) {   // y_k = row T of L
-    double* dy = a.L + chol_tile_off(T, k) + ur * GSFM_CB + uc4;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) dy[q] = Pi[ur][uc4 + q];
-    return;
-  }
-  if (j == k + 1 && i < T) {   // first trailing column: this workgroup publishes L_ik
-    double* dl = a.L + chol_tile_off(i, k) + ur * GSFM_CB + uc4;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) dl[q] = Pi[ur][uc4 + q];
-  }
-  double (*Q)[GSFM_CB + 1] = same ? Pi : Pj;
-  double acc[4] = {0, 0, 0, 0};
-#pragma unroll
-  for (int t = 0; t < GSFM_CB; ++t) {
-    const double pv = Pi[ur][t];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) acc[q] += pv * Q[uc4 + q][t];
-  }
-  double* d = a.A + chol_tile_off(i, j) + ur * GSFM_CB + uc4;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) d[q] = own[q] - acc[q];
-}
-
-// The same 64-row elimination as in k_chol_step (lanes 0..31: rows of A_kk, lanes 32..63: rows of a panel tile), as a device routine.
+// The 64-row elimination (lanes 0..31: rows of A_kk, lanes 32..63: rows of a panel tile): entries above the diagonal of the diagonal rows
+// (lane < c) are never read by anyone, so they may hold anything; the multipliers L[c][c0] (held by lane c) are fetched in batches -- all
+// v_readlane of a batch first, then the FMAs: one SGPR-hazard wait per batch instead of one per multiplier.
 __device__ __forceinline__ int chol_eliminate64(double* r, uint32_t lane) {
   int bad = 0;
 #pragma unroll
@@ -158,6 +71,98 @@ __device__ __forceinline__ int chol_eliminate64(double* r, uint32_t lane) {
     }
   }
   return bad;
+}
+
+// Step k.  Workgroup 0: L_kk and the right-hand side's panel tile; every other workgroup: up to NT = 1, 2 or 3 neighbouring trailing tiles
+// (i, j0 .. j0 + NT - 1) of ONE tile row i = k + 1 + t (row t has t + 1 tiles, i.e. ceil((t + 1) / NT) workgroups).
+// Wavefront 0 holds the rows of A_kk in lanes 0..31 and the rows of the panel tile A_ik in lanes 32..63, one row per lane in
+// registers, and runs the right-looking elimination on all 64 rows at once: for the lower lanes that is the Cholesky factorisation,
+// for the upper lanes the same instructions are the substitution P_i = A_ik L_kk^-T (the multipliers L[c][c0] are wave-uniform
+// v_readlane broadcasts from the diagonal rows), so the panel costs nothing extra.  Wavefronts 1 .. NT do the same with A_jk of the workgroup's
+// tiles.  NT per step: chol_step_tiles_per_wg -- with one tile per workgroup the wide early steps run two or three workgroups, i.e. four or
+// six eliminations, per CU (16-17 us per step against 9-10 once a step fits one workgroup per CU); two or three tiles per workgroup need 3 / 2 or
+// 4 / 3 eliminations per tile instead of 2.
+__host__ __device__ inline uint32_t chol_step_grid(uint32_t m /* trailing block rows k+1 .. T */, uint32_t nt_per_wg) {
+  uint32_t n = 1;
+  for (uint32_t t = 0; t < m; ++t) n += (t + nt_per_wg) / nt_per_wg;
+  return n;
+}
+// tiles per workgroup for a step with m trailing block rows: as few as keep the step at about one workgroup per CU (measured per step at 3N = 1182,
+// profiles/r03_chol_steps.txt: the eliminations of a CU share more than its SIMDs -- two side by side run at full speed, four at ~0.7, six at ~0.6)
+inline uint32_t chol_step_tiles_per_wg(uint32_t m) { const uint32_t tiles = m * (m + 1) / 2; return tiles <= 256 ? 1u : tiles <= 512 ? 2u : 3u; }
+template <int GSFM_CHOL_NT>
+__global__ void __launch_bounds__(256) k_chol_step(CholArgs a) {
+  __shared__ double Pi[GSFM_CB][GSFM_CB + 1], Pj[GSFM_CHOL_NT][GSFM_CB][GSFM_CB + 1];
+  const uint32_t k = a.k, T = a.T, tid = threadIdx.x;
+  uint32_t i, j0 = k, nt = 1;   // nt tiles (i, j0 .. j0 + nt - 1)
+  const bool diag_wg = blockIdx.x == 0;
+  if (diag_wg) i = T;
+  else {
+    uint32_t b = blockIdx.x - 1, t = 0;
+    while (b >= (t + GSFM_CHOL_NT) / GSFM_CHOL_NT) { b -= (t + GSFM_CHOL_NT) / GSFM_CHOL_NT; ++t; }
+    i = k + 1 + t; j0 = k + 1 + GSFM_CHOL_NT * b;
+    nt = min((uint32_t)GSFM_CHOL_NT, i - j0 + 1);
+    if (i == T && j0 + nt - 1 == T) --nt;    // the right-hand side has no diagonal tile
+    if (nt == 0) return;
+  }
+  const uint32_t ur = tid / 8, uc4 = (tid % 8) * 4;   // this lane's 1 x 4 piece of each trailing tile
+  double own[GSFM_CHOL_NT][4];
+  if (!diag_wg) {
+#pragma unroll
+    for (int u = 0; u < GSFM_CHOL_NT; ++u) if ((uint32_t)u < nt) {
+      const double* so = a.A + chol_tile_off(i, j0 + u) + ur * GSFM_CB + uc4;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) own[u][q] = so[q];
+    }
+  }
+  const uint32_t wave = tid >> 6, lane = tid & 63;
+  // wavefront 0: the panel tile of row i (or of the right-hand side); wavefront w >= 1: the panel tile of column tile j0 + w - 1, unless that
+  // is row i itself (the diagonal tile of the trailing matrix uses P_i twice)
+  const uint32_t jw = j0 + wave - 1;
+  if (wave == 0 || (!diag_wg && wave - 1 < nt && jw != i)) {
+    const uint32_t rr = lane & 31;
+    const double2* src = (const double2*)(a.A + (lane < 32 ? chol_tile_off(k, k) : chol_tile_off(wave == 0 ? i : jw, k)) + rr * GSFM_CB);
+    double r[GSFM_CB];
+#pragma unroll
+    for (int q = 0; q < GSFM_CB / 2; ++q) { const double2 v = src[q]; r[2 * q] = v.x; r[2 * q + 1] = v.y; }
+    const int bad = chol_eliminate64(r, lane);
+    if (lane >= 32) {
+      double (*P)[GSFM_CB + 1] = wave == 0 ? Pi : Pj[wave - 1];
+#pragma unroll
+      for (int c = 0; c < GSFM_CB; ++c) P[rr][c] = r[c];
+    } else if (diag_wg) {
+      double2* dl = (double2*)(a.L + chol_tile_off(k, k) + rr * GSFM_CB);
+#pragma unroll
+      for (int q = 0; q < GSFM_CB / 2; ++q) dl[q] = make_double2((uint32_t)(2 * q) <= lane ? r[2 * q] : 0.0, (uint32_t)(2 * q + 1) <= lane ? r[2 * q + 1] : 0.0);
+      if (lane == 0 && bad && *a.info == 0) *a.info = (int)(k * GSFM_CB + bad);
+    }
+  }
+  __syncthreads();
+  if (diag_wg) {   // y_k = row T of L
+    double* dy = a.L + chol_tile_off(T, k) + ur * GSFM_CB + uc4;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) dy[q] = Pi[ur][uc4 + q];
+    return;
+  }
+  if (j0 == k + 1 && i < T) {   // first trailing column: this workgroup publishes L_ik
+    double* dl = a.L + chol_tile_off(i, k) + ur * GSFM_CB + uc4;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) dl[q] = Pi[ur][uc4 + q];
+  }
+#pragma unroll
+  for (int u = 0; u < GSFM_CHOL_NT; ++u) if ((uint32_t)u < nt) {
+    double (*Q)[GSFM_CB + 1] = (j0 + u == i) ? Pi : Pj[u];
+    double acc[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int t = 0; t < GSFM_CB; ++t) {
+      const double pv = Pi[ur][t];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[q] += pv * Q[uc4 + q][t];
+    }
+    double* d = a.A + chol_tile_off(i, j0 + u) + ur * GSFM_CB + uc4;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) d[q] = own[u][q] - acc[q];
+  }
 }
 
 // Step k of the two-kernel schedule, first half: workgroup 0 (one wavefront) factors A_kk and writes L_kk; workgroup b >= 1 factors A_kk

@@ -953,7 +953,8 @@ int run_dense(gsfm_rot_problem* P, bool* used) {
       for (uint32_t k = 0; k < T; ++k) {
         CholArgs c{P->denseA.p, P->denseL.p, T, k, info};
         const uint64_t m = T - k;
-        hipLaunchKernelGGL(k_chol_step, dim3((uint32_t)(1 + m * (m + 1) / 2)), dim3(256), 0, P->stream, c);
+        { const uint32_t nt = getenv("GSFM_CHOL_NT") ? (uint32_t)std::max(1, std::min(3, atoi(getenv("GSFM_CHOL_NT")))) : chol_step_tiles_per_wg((uint32_t)m); const dim3 grid(chol_step_grid((uint32_t)m, nt));
+          if (nt == 3) hipLaunchKernelGGL(k_chol_step<3>, grid, dim3(256), 0, P->stream, c); else if (nt == 2) hipLaunchKernelGGL(k_chol_step<2>, grid, dim3(256), 0, P->stream, c); else hipLaunchKernelGGL(k_chol_step<1>, grid, dim3(256), 0, P->stream, c); }
       }
     } else {
       // larger matrices: panel (one wavefront per tile row), then the trailing update on the matrix cores -- block columns in GROUPS of two (four beyond 192 block columns):

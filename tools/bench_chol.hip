@@ -52,7 +52,8 @@ int main(int argc, char** argv) {
       if (!split) for (uint32_t k = 0; k < T; ++k) {
         CholArgs c{dA, dL, T, k, dinfo};
         const uint64_t m = T - k;
-        hipLaunchKernelGGL(k_chol_step, dim3((uint32_t)(1 + m * (m + 1) / 2)), dim3(256), 0, st, c);
+        { const uint32_t nt = getenv("GSFM_CHOL_NT") ? (uint32_t)std::max(1, std::min(3, atoi(getenv("GSFM_CHOL_NT")))) : chol_step_tiles_per_wg((uint32_t)m); const dim3 grid(chol_step_grid((uint32_t)m, nt));
+          if (nt == 3) hipLaunchKernelGGL(k_chol_step<3>, grid, dim3(256), 0, st, c); else if (nt == 2) hipLaunchKernelGGL(k_chol_step<2>, grid, dim3(256), 0, st, c); else hipLaunchKernelGGL(k_chol_step<1>, grid, dim3(256), 0, st, c); }
       } else if (getenv("CHOL_SINGLE_COLUMN_UPDATES")) for (uint32_t k = 0; k < T; ++k) {   // (the schedule before the columns were paired)
         CholArgs c{dA, dL, T, k, dinfo};
         hipLaunchKernelGGL(k_chol_panel, dim3(T - k + 1), dim3(64), 0, st, c);
