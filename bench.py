@@ -248,6 +248,21 @@ def main():
         else:
             dist.init_process_group(backend=backend)
 
+    watchdog = None
+    if world > 1:
+        # a collective that never returns (a communicator that did not come up on some rank) must not hold the launcher until ITS limit:
+        # every rank gives set-up, warm-up and the timed solves this long, then says so and leaves
+        import threading
+        limit = float(os.environ.get("GSFM_BENCH_WATCHDOG_S", "900"))
+
+        def _give_up():
+            sys.stderr.write("bench.py rank %d: no progress for %.0f s (set-up / collectives hung?): giving up\n" % (rank, limit))
+            sys.stderr.flush()
+            os._exit(124)
+        watchdog = threading.Timer(limit, _give_up)
+        watchdog.daemon = True
+        watchdog.start()
+
     from globalsfmpy_amd import _abi, synth, sharding
     from globalsfmpy_amd.loss_functions import MAGSACWeightBasedLoss
     from globalsfmpy_amd.solver import RotationProblem
@@ -320,6 +335,8 @@ def main():
         sweeps += summ["num_residual_sweeps"]
     barrier()
     elapsed = time.perf_counter() - t0
+    if watchdog is not None:
+        watchdog.cancel()
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
