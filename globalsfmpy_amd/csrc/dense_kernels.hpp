@@ -42,6 +42,8 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
   return __hiloint2double(hi, lo);
 }
 
+typedef double chol_d4 __attribute__((ext_vector_type(4)));
+
 struct CholArgs {
   double* A;      // tiles (i >= j), block rows 0..T; row T = right-hand side (first row of each tile)
   double* L;      // same layout: L_ik (i > k), L_kk, and in row T the forward-substituted y = L^-1 b
@@ -105,17 +107,20 @@ __global__ void __launch_bounds__(256) k_chol_step(CholArgs a) {
     if (i == T && j0 + nt - 1 == T) --nt;    // the right-hand side has no diagonal tile
     if (nt == 0) return;
   }
-  const uint32_t ur = tid / 8, uc4 = (tid % 8) * 4;   // this lane's 1 x 4 piece of each trailing tile
-  double own[GSFM_CHOL_NT][4];
+  const uint32_t ur = tid / 8, uc4 = (tid % 8) * 4;   // this lane's 1 x 4 piece of a tile (publishing L)
+  const uint32_t wave = tid >> 6, lane = tid & 63;
+  // trailing update on the matrix cores: wavefront w owns the 16 x 16 quadrant (w >> 1, w & 1) of each of the workgroup's tiles, in the C / D
+  // layout of v_mfma_f64_16x16x4_f64 (lane l: column l & 15, rows (l >> 4) + 4 reg) -- the per-lane 1 x 4 VALU form cost 1.8 us of a 12 us step
+  const uint32_t mq = (16 * (wave >> 1) + (lane >> 4)) * GSFM_CB + 16 * (wave & 1) + (lane & 15);   // element of reg 0; reg r: + 4 r rows
+  chol_d4 own[GSFM_CHOL_NT];
   if (!diag_wg) {
 #pragma unroll
     for (int u = 0; u < GSFM_CHOL_NT; ++u) if ((uint32_t)u < nt) {
-      const double* so = a.A + chol_tile_off(i, j0 + u) + ur * GSFM_CB + uc4;
+      const double* so = a.A + chol_tile_off(i, j0 + u) + mq;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) own[u][q] = so[q];
+      for (int q = 0; q < 4; ++q) own[u][q] = so[4 * q * GSFM_CB];
     }
   }
-  const uint32_t wave = tid >> 6, lane = tid & 63;
   // wavefront 0: the panel tile of row i (or of the right-hand side); wavefront w >= 1: the panel tile of column tile j0 + w - 1, unless that
   // is row i itself (the diagonal tile of the trailing matrix uses P_i twice)
   const uint32_t jw = j0 + wave - 1;
@@ -149,19 +154,21 @@ __global__ void __launch_bounds__(256) k_chol_step(CholArgs a) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) dl[q] = Pi[ur][uc4 + q];
   }
+  {
+    const uint32_t c = lane & 15, g = lane >> 4, ri = 16 * (wave >> 1) + c, rj = 16 * (wave & 1) + c;
+    double aop[8];
 #pragma unroll
-  for (int u = 0; u < GSFM_CHOL_NT; ++u) if ((uint32_t)u < nt) {
-    double (*Q)[GSFM_CB + 1] = (j0 + u == i) ? Pi : Pj[u];
-    double acc[4] = {0, 0, 0, 0};
+    for (int kk = 0; kk < 8; ++kk) aop[kk] = -Pi[ri][4 * kk + g];
 #pragma unroll
-    for (int t = 0; t < GSFM_CB; ++t) {
-      const double pv = Pi[ur][t];
+    for (int u = 0; u < GSFM_CHOL_NT; ++u) if ((uint32_t)u < nt) {
+      double (*Q)[GSFM_CB + 1] = (j0 + u == i) ? Pi : Pj[u];
+      chol_d4 acc = own[u];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) acc[q] += pv * Q[uc4 + q][t];
+      for (int kk = 0; kk < 8; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[kk], Q[rj][4 * kk + g], acc, 0, 0, 0);
+      double* d = a.A + chol_tile_off(i, j0 + u) + mq;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) d[4 * q * GSFM_CB] = acc[q];
     }
-    double* d = a.A + chol_tile_off(i, j0 + u) + ur * GSFM_CB + uc4;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) d[q] = own[u][q] - acc[q];
   }
 }
 
@@ -194,7 +201,6 @@ __global__ void __launch_bounds__(64) k_chol_panel(CholArgs a) {
 // cores: v_mfma_f64_16x16x4_f64 computes D(16x16) = A(16x4) B(4x16) + C; lane l supplies A[l & 15][l >> 4] and B[l >> 4][l & 15] and holds
 // C/D[(l >> 4) + 4 reg][l & 15], reg = 0..3 (MI355X guide, fragment layout of the f64 form).  A 32 x 32 tile is 2 x 2 such blocks times
 // 8 steps of K = 4; the A operand is -L_ik, the B operand L_jk read row-wise (= L_jk^T column-wise).
-typedef double chol_d4 __attribute__((ext_vector_type(4)));
 // Block columns k .. k + ncol - 1 of L (ncol = 1 or 2) are folded into the tiles (i, j), j0 <= j <= i <= T -- or, col_only, into the tiles
 // (i, j0) of one block column alone.  Two columns per pass read and write every trailing tile once instead of twice (the update is bound by
 // those 16 KB per tile from ~100 block rows on); the accumulation order per tile -- column k, then column k + 1 -- is the one two separate
