@@ -29,8 +29,8 @@ namespace gsfm {
 #define GSFM_CHOL_BATCH 8
 #endif
 #define GSFM_DENSE_MAX_T 500   // block rows whose right-hand side the backward kernel keeps in LDS (125 KB of the 160): 3N <= 16000, 5333 cameras
-#define GSFM_CHOL_SPLIT_T 48   // LDS capacity (block rows) of the single-workgroup backward kernel: the fused schedule is never used beyond
-#define GSFM_CHOL_SPLIT_DEFAULT 48   // more block columns than this: the two-kernel MFMA schedule (see run_dense)
+#define GSFM_CHOL_SPLIT_T 64   // LDS capacity (block rows) of the single-workgroup backward kernel kept for A/B runs: the fused schedule is never used beyond
+#define GSFM_CHOL_SPLIT_DEFAULT 64   // more block columns than this: the two-kernel MFMA schedule (see run_dense; crossover measured at ~68: 3N = 2048 1.06 vs 1.10 ms, 2304 1.30 vs 1.27)
 
 __host__ __device__ inline size_t chol_tile_off(uint32_t i, uint32_t j) { return ((size_t)i * (i + 1) / 2 + j) * GSFM_TILE_ELEMS; }
 __host__ __device__ inline size_t chol_num_tiles(uint32_t T) { return (size_t)(T + 1) * (T + 2) / 2; }   // block rows 0..T (row T = rhs)
