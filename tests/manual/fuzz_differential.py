@@ -166,7 +166,9 @@ def run(trials=200, seed=1, quick=False):
                     print("   relative cost difference per iteration:", " ".join("%.0e" % x for x in d), flush=True)
                 run_max = max(d[0], 1e-15)
                 for k in range(1, m):   # from rounding level up to 1e-9 (beyond that borderline accept / reject decisions flip and the costs jump by a step)
-                    if d[k] > 1000.0 * run_max or (run_max <= 1e-9 < d[k] and d[k] > 1e-6):
+                    # (ratios are taken from 1e-11 up: below that the difference is a handful of ulps and its size is luck -- trial 1101 of seed 112 under
+                    # the forced layout goes 2e-12 -> 8e-9 with one device build and 2e-11 -> 1e-8 with another in the same 14-rad step across the cut locus)
+                    if d[k] > 1000.0 * max(run_max, 1e-11) or (run_max <= 1e-9 < d[k] and d[k] > 1e-6):
                         smooth = False
                     run_max = max(run_max, d[k])
                     if run_max > 1e-9:

@@ -9,6 +9,8 @@ from globalsfmpy_amd import _abi, synth
 from globalsfmpy_amd import loss_functions as LF
 from globalsfmpy_amd.solver import RotationProblem
 from oracle import pyoracle
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import sensitivity
 
 
 def run(trials=40, seed=1):
@@ -36,6 +38,20 @@ def run(trials=40, seed=1):
         if so["final_cost"] == 0.0 and sd["final_cost"] == 0.0:
             d = 0.0     # sigma_max so small that every edge got weight zero: nothing determines the rotations any more
         ok = sd["outer_iterations"] == so["outer_iterations"] and abs(sd["last_weight_change"] - so["last_weight_change"]) < 1e-7 and d <= (1e-6 if its <= 25 else 1e-4 if its <= 40 else 1e-2)   # graded by the length of the solve
+        if not ok and sd["outer_iterations"] == so["outer_iterations"]:
+            # the oracle against itself on measurements moved by one ulp (tests/sensitivity.py): a sparse graph whose edges mostly end at weight
+            # zero leaves cameras undetermined, and long inner solves are as chaotic here as anywhere
+            prng = np.random.default_rng(t)
+            spread = []
+            for _ in range(3):
+                o2 = pyoracle.OracleProblem(n, ei, ej, sensitivity.ulp_perturbed(rel, prng), _abi.ANGLE_AXIS); o2.set_loss(LF.TrivialLoss())
+                r2, s2 = o2.solve_sigma_consensus(init, iters, smax)
+                spread.append((float(synth.angular_distance(synth.align_rotations(r2[act], ro[act]), ro[act]).mean()), s2["num_iterations"]))
+                o2.close()
+            if max(x[0] for x in spread) >= d / 3.0:
+                print("trial %d: device %.2e rad / %d LM iterations from the oracle (%d); the oracle on 1-ulp-perturbed measurements: %s -> within the oracle's own sensitivity" % (
+                    t, d, sd["num_iterations"], so["num_iterations"], ["%.2e / %d" % x for x in spread]), flush=True)
+                ok = True
         if not ok:
             bad += 1
             print("MISMATCH trial %d n=%d e=%d mode=%d outer cap %d sigma_max %.3g: outer %d vs %d, LM iterations %d vs %d, weight change %.3e vs %.3e, mean dR %.2e" % (
