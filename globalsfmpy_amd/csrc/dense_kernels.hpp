@@ -158,16 +158,16 @@ __global__ void __launch_bounds__(256) k_chol_step(CholArgs a) {
     const uint32_t c = lane & 15, g = lane >> 4, ri = 16 * (wave >> 1) + c, rj = 16 * (wave & 1) + c;
     double aop[8];
 #pragma unroll
-    for (int kk = 0; kk < 8; ++kk) aop[kk] = -Pi[ri][4 * kk + g];
+    for (int kk = 0; kk < 8; ++kk) aop[kk] = Pi[ri][4 * kk + g];
 #pragma unroll
     for (int u = 0; u < GSFM_CHOL_NT; ++u) if ((uint32_t)u < nt) {
       double (*Q)[GSFM_CB + 1] = (j0 + u == i) ? Pi : Pj[u];
-      chol_d4 acc = own[u];
+      chol_d4 acc = {0.0, 0.0, 0.0, 0.0};   // the product first, from zero, then own - product: the order of the per-lane form this replaced
 #pragma unroll
       for (int kk = 0; kk < 8; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[kk], Q[rj][4 * kk + g], acc, 0, 0, 0);
       double* d = a.A + chol_tile_off(i, j0 + u) + mq;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) d[4 * q * GSFM_CB] = acc[q];
+      for (int q = 0; q < 4; ++q) d[4 * q * GSFM_CB] = own[u][q] - acc[q];
     }
   }
 }
