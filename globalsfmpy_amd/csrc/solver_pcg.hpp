@@ -1,0 +1,302 @@
+// Host side, part 3: the linear solve of an LM step by block-Jacobi PCG -- textbook recurrence (run_pcg), single-reduction recurrence
+// (run_pcg2), the two-level preconditioner's coarse matrix (coarse_build) -- with the chunks between two host looks replayed as hipGraphs.
+#pragma once
+#include "host_common.hpp"
+
+namespace {
+
+// Inverse of a symmetric positive definite n x n matrix (row-major) through its Cholesky factor; false if a pivot is not positive.
+bool spd_inverse(std::vector<double>& A, size_t n, std::vector<double>& inv) {
+  for (size_t j = 0; j < n; ++j) {          // A <- L (lower), column by column
+    double d = A[j * n + j];
+    for (size_t k = 0; k < j; ++k) d -= A[j * n + k] * A[j * n + k];
+    if (!(d > 0.0) || !std::isfinite(d)) return false;
+    const double l = std::sqrt(d);
+    A[j * n + j] = l;
+    for (size_t i = j + 1; i < n; ++i) {
+      double v = A[i * n + j];
+      for (size_t k = 0; k < j; ++k) v -= A[i * n + k] * A[j * n + k];
+      A[i * n + j] = v / l;
+    }
+  }
+  std::vector<double> Li(n * n, 0.0);       // L^-1 (lower), row by row: row_i = (e_i - sum_{k<i} L[i][k] row_k) / L[i][i]  (contiguous rows only)
+  for (size_t i = 0; i < n; ++i) {
+    double* ri = &Li[i * n];
+    ri[i] = 1.0;
+    for (size_t k = 0; k < i; ++k) {
+      const double l = A[i * n + k];
+      const double* rk = &Li[k * n];
+      for (size_t c = 0; c <= k; ++c) ri[c] -= l * rk[c];
+    }
+    const double d = 1.0 / A[i * n + i];
+    for (size_t c = 0; c <= i; ++c) ri[c] *= d;
+  }
+  inv.assign(n * n, 0.0);                   // A^-1 = L^-T L^-1 as a sum of rank-one updates of the lower triangle, then mirrored
+  for (size_t k = 0; k < n; ++k) {
+    const double* rk = &Li[k * n];
+    for (size_t i = 0; i <= k; ++i) {
+      const double a = rk[i];
+      double* oi = &inv[i * n];
+      for (size_t j = 0; j <= i; ++j) oi[j] += a * rk[j];
+    }
+  }
+  for (size_t i = 0; i < n; ++i) for (size_t j = 0; j < i; ++j) inv[j * n + i] = inv[i * n + j];
+  return true;
+}
+
+// Coarse matrix of the two-level preconditioner for the current linearisation and damping: assembled on the device, inverted on the host
+// (3 n_agg <= 384 unknowns).  Leaves P->coarse_n = 0 (plain block-Jacobi for this step) if the matrix is not positive definite.
+int coarse_build(gsfm_rot_problem* P, bool pcg_struggles) {
+  P->coarse_n = 0;
+  if (!P->coarse_want || !P->lin_is_lap || (P->coarse_adaptive && !pcg_struggles)) return 0;
+  const uint32_t na = P->coarse_want, nc = 3 * na;   // (buffers: allocated at creation, before the ranks of a sharded problem vote)
+  const int tk = P->timer.begin(T_CG);
+  HIPCHK(hipMemsetAsync(P->coarseA.p, 0, 8 * (size_t)nc * nc, P->stream));
+  CoarseAsmArgs a{};
+  a.n_rows = P->n_rows; a.G = P->G; a.n_agg = na; a.chunk = P->coarse_chunk; a.row_ptr = P->row_ptr.p; a.col = P->col.p;
+  a.h0 = P->h0.p; a.h1 = P->h1.p; a.h2 = P->h2.p; a.Mblk = P->Mblk.p; a.q = P->q_lin; a.Ac = P->coarseA.p;
+  a.row_base = P->own_begin; a.scale = P->coarse_scale.p;
+  {  // the fixed-point scale must be the same on every rank: the largest diagonal entry over ALL cameras (Mblk is complete everywhere)
+    const uint32_t nb = (uint32_t)grid_for(P->n_cams);
+    hipLaunchKernelGGL(k_coarse_scale, dim3(nb), dim3(GSFM_BLOCK), 0, P->stream, (const double*)P->Mblk.p, P->n_cams, 0u, P->part_a.p, P->coarse_scale.p, 0);
+    hipLaunchKernelGGL(k_coarse_scale, dim3(1), dim3(GSFM_BLOCK), 0, P->stream, (const double*)P->Mblk.p, nb, 0u, P->part_a.p, P->coarse_scale.p, 1);
+  }
+  if (P->n_rows) hipLaunchKernelGGL(k_coarse_assemble, dim3(grid_for((size_t)P->n_rows * P->G)), dim3(GSFM_BLOCK), 0, P->stream, a);
+  hipLaunchKernelGGL(k_coarse_unscale, dim3(grid_for((size_t)nc * nc)), dim3(GSFM_BLOCK), 0, P->stream, P->coarseA.p, (size_t)nc * nc, (const double*)P->coarse_scale.p);
+  P->timer.end(tk);
+  // sharded: every rank summed the rows it owns; the vector side (restriction, coarse solve, prolongation) then runs replicated on the
+  // replicated PCG vectors like every other O(N) step, so this all-reduce per LM step is the only collective the preconditioner adds
+  if (int st = all_reduce(P, P->coarseA.p, (size_t)nc * nc)) return st;
+  P->h_coarse.resize((size_t)nc * nc);
+  HIPCHK(hipMemcpyAsync(P->h_coarse.data(), P->coarseA.p, 8 * (size_t)nc * nc, hipMemcpyDeviceToHost, P->stream));
+  const double t_a = now_ms();
+  if (int st = sync_check(P, "coarse matrix")) return st;
+  const double t_b = now_ms();
+  auto& A = P->h_coarse;
+  for (size_t i = 0; i < nc; ++i) for (size_t j = 0; j < i; ++j) { const double v = 0.5 * (A[i * nc + j] + A[j * nc + i]); A[i * nc + j] = A[j * nc + i] = v; }
+  for (size_t i = 0; i < nc; ++i) if (A[i * nc + i] == 0.0) A[i * nc + i] = 1.0;   // an aggregate of cameras without edges: decoupled, its correction stays zero
+  if (!spd_inverse(A, nc, P->h_coarse_inv)) return 0;
+  if (getenv("GSFM_COARSE_TIMING")) fprintf(stderr, "gsfm coarse: assemble + download (wait) %.2f ms, host inverse of %u unknowns %.2f ms\n", t_b - t_a, nc, now_ms() - t_b);
+  HIPCHK(hipMemcpyAsync(P->coarseAinv.p, P->h_coarse_inv.data(), 8 * (size_t)nc * nc, hipMemcpyHostToDevice, P->stream));
+  P->coarse_n = na;
+  return 0;
+}
+
+// May a chunk of PCG iterations of a SHARDED problem be captured into a hipGraph together with its collectives?  Only if the
+// communicator's callbacks do nothing but enqueue work on the solver's stream (GSFM_SHARD_CAPTURABLE: the native RCCL communicator).
+// pcg_hip_graph = 1 (default) then captures; 2 is the old explicit opt-in and means the same; GSFM_PCG_GRAPH_COLLECTIVES=0 switches the
+// capture of collectives off (plain launches), e.g. to isolate a communicator problem.
+bool graph_collectives_ok(const gsfm_rot_problem* P, const gsfm_rot_options& o) {
+  if (!(P->shard.flags & GSFM_SHARD_CAPTURABLE) || o.pcg_hip_graph < 1) return false;
+  const char* e = getenv("GSFM_PCG_GRAPH_COLLECTIVES");
+  return !(e && *e && atoi(e) == 0);
+}
+
+// block-Jacobi PCG on (J^T J + Lambda) eta = -g; returns iterations
+int run_pcg(gsfm_rot_problem* P, const gsfm_rot_options& o, int* iters_out, double* rel_out) {
+  CgArgs a{};
+  a.n = P->n_cams; a.nb = P->nb_cam; a.par = 0; a.tol = o.cg_relative_tolerance; a.max_iters = o.max_cg_iterations; a.stall_limit = o.cg_stall_iterations;
+  a.Minv = P->Minv.p; a.b = P->b.p; a.xcg = P->xcg.p; a.r = P->r.p; a.z = P->z.p; a.p = P->p.p; a.Ap = P->Ap.p;
+  a.part_a = P->part_a.p; a.part_b = P->part_b.p; a.sc = P->cgsc.p;
+  a.q = P->q_lin; a.u = P->lin_is_lap ? P->u_rot.p : nullptr;
+  a.coarse_n = P->coarse_n; a.coarse_chunk = P->coarse_chunk; a.xc = P->coarse_xc.p; a.active = P->active.p;
+  // aggregates at least as wide as a block of the camera kernels (always, unless forced narrower): the restriction rides along in k_cg_update
+  const bool fused_restrict = P->coarse_n && P->coarse_chunk >= GSFM_BLOCK;
+  a.rc_part = fused_restrict ? P->coarse_part.p : nullptr;
+  CoarseArgs ca{};
+  ca.n = P->n_cams; ca.n_agg = P->coarse_n; ca.chunk = P->coarse_chunk; ca.q = P->q_lin; ca.r = P->r.p; ca.rc = P->coarse_rc.p; ca.Ainv = P->coarseAinv.p;
+  ca.xc = P->coarse_xc.p; ca.done = nullptr; ca.active = P->active.p; ca.rc_part = nullptr; ca.nb = (uint32_t)P->nb_cam;
+  const dim3 g(P->nb_cam), blk(GSFM_BLOCK);
+  const int tk0 = P->timer.begin(T_CG);
+  hipLaunchKernelGGL(k_cg_init, g, blk, 0, P->stream, a);
+  hipLaunchKernelGGL(k_cg_init_fin, dim3(1), blk, 0, P->stream, a);
+  if (a.coarse_n) {   // z_0 = Minv r_0 + P Ac^-1 P^T r_0
+    hipLaunchKernelGGL(k_coarse_restrict, dim3(a.coarse_n), blk, 0, P->stream, ca);
+    hipLaunchKernelGGL(k_coarse_apply, dim3(1), dim3(1024), 0, P->stream, ca);
+    hipLaunchKernelGGL(k_cg_init_coarse, g, blk, 0, P->stream, a);
+    hipLaunchKernelGGL(k_cg_init_coarse_fin, dim3(1), dim3(1), 0, P->stream, a);
+  }
+  ca.done = &P->cgsc.p->done; ca.rc_part = a.rc_part;
+  P->timer.end(tk0);
+  CgScalars h{};
+  const int chunk = std::max(1, o.cg_check_interval);
+  auto enqueue_chunk = [&]() -> int {  // `chunk` iterations; leaves a.par where it found it when chunk is even
+    for (int c = 0; c < chunk; ++c) {
+      bool dotted = false;
+      if (int st = launch_matvec(P, P->Mblk.p, P->p.p, P->Ap.p, &P->cgsc.p->done, a.part_a, &dotted)) return st;
+      if (P->sharded) P->n_pcg_collectives++;
+      if (!dotted) hipLaunchKernelGGL(k_cg_dot, g, blk, 0, P->stream, a);
+      hipLaunchKernelGGL(k_cg_update, g, blk, 0, P->stream, a);
+      if (a.coarse_n) {
+        if (!fused_restrict) hipLaunchKernelGGL(k_coarse_restrict, dim3(a.coarse_n), blk, 0, P->stream, ca);
+        hipLaunchKernelGGL(k_coarse_apply, dim3(1), dim3(1024), 0, P->stream, ca);
+      }
+      hipLaunchKernelGGL(k_cg_pupdate, g, blk, 0, P->stream, a);
+      a.par ^= 1;
+    }
+    return 0;
+  };
+  // The chunk between two host checks as one hipGraph launch: 4 * chunk dependent kernels whose arguments never change.
+  auto& G = P->pcg_graph;
+  bool graph = o.pcg_hip_graph && (!P->sharded || graph_collectives_ok(P, o)) && chunk % 2 == 0 && !G.unusable;
+  if (graph && (!G.exec || G.tol != a.tol || G.max_iters != a.max_iters || G.stall != a.stall_limit || G.chunk != chunk || G.lap != P->lin_is_lap || G.coarse != a.coarse_n)) {
+    G.reset();
+    hipGraph_t captured = nullptr;
+    if (hipStreamBeginCapture(P->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+      const int c0 = P->n_collectives, p0 = P->n_pcg_collectives;
+      const int st = enqueue_chunk();
+      const hipError_t e = hipStreamEndCapture(P->stream, &captured);
+      G.collectives = P->n_collectives - c0;            // captured, not issued: counted per replay below
+      P->n_collectives = c0; P->n_pcg_collectives = p0;
+      if (st == 0 && e == hipSuccess && captured && hipGraphInstantiate(&G.exec, captured, nullptr, nullptr, 0) == hipSuccess) {
+        G.tol = a.tol; G.max_iters = a.max_iters; G.stall = a.stall_limit; G.chunk = chunk; G.lap = P->lin_is_lap; G.coarse = a.coarse_n;
+      } else { G.exec = nullptr; }
+      if (captured) (void)hipGraphDestroy(captured);
+    }
+    if (!G.exec) { (void)hipGetLastError(); G.unusable = true; graph = false; }  // e.g. a stream that cannot be captured: plain launches
+  }
+  int launched = 0, chunks = 1;
+  while (true) {
+    const int tk = P->timer.begin(T_CG);
+    for (int c = 0; c < chunks; ++c) {
+      if (graph) { HIPCHK(hipGraphLaunch(G.exec, P->stream)); P->graph_launches++; P->n_collectives += G.collectives; P->n_pcg_collectives += G.collectives; }
+      else if (int st = enqueue_chunk()) return st;
+      launched += chunk; P->n_pcg_launched += chunk;
+    }
+    P->timer.end(tk);
+    if (int st = read_back(P, &h, P->cgsc.p, sizeof(h), "pcg")) return st;
+    if (h.done || launched >= o.max_cg_iterations + chunk) break;
+    // Fewer host round trips: extrapolate the average convergence factor so far to the tolerance and enqueue that many
+    // chunks before looking again (kernels past convergence return at their first instruction, so overshoot is cheap).
+    chunks = 1;
+    if (h.iters > 0 && h.last_rel > 0.0 && h.last_rel < 1.0 && a.tol > 0.0 && a.tol < h.last_rel) {
+      const double per_iter = std::log(h.last_rel) / h.iters;
+      const double remaining = std::log(a.tol / h.last_rel) / per_iter;
+      chunks = (int)std::min(8.0, std::max(1.0, std::ceil(remaining / chunk)));
+    }
+    chunks = std::min(chunks, std::max(1, (o.max_cg_iterations + chunk - launched + chunk - 1) / chunk));
+  }
+  *iters_out = h.iters; *rel_out = h.last_rel;
+  return 0;
+}
+
+// single-reduction PCG (Chronopoulos-Gear): 2 kernels per iteration (3 + one all-gather when sharded); the launch-latency regime's
+// default (see use_single_reduction).  The chunk between two host checks replays as one hipGraph, like run_pcg's.
+int run_pcg2(gsfm_rot_problem* P, const gsfm_rot_options& o, int* iters_out, double* rel_out) {
+  Cg2Args c{};
+  const int nb_mv = P->nb_mv, reps = P->mv_reps;
+  c.n = P->n_cams; c.nb_cam = P->nb_cam; c.n_part_d = (P->sharded || P->cs.active) ? P->nb_cam : nb_mv; c.par = 0; c.first = 1; c.tol = o.cg_relative_tolerance; c.max_iters = o.max_cg_iterations;
+  c.Minv = P->Minv.p; c.b = P->b.p; c.x = P->xcg.p; c.r = P->r.p; c.u = P->z.p; c.w = P->Ap.p; c.p = P->p.p; c.s = P->s_dir.p;
+  c.part_g = P->part_g2.p; c.part_d = P->part_d2.p; c.sc = P->cg2sc.p;
+  c.q = P->q_lin; c.urot = P->lin_is_lap ? P->u_rot.p : nullptr;
+  // Sharded: A u and the delta partials of a rank's rows leave in ONE all-gather (slot = slice of w, then the partials); the mat-vec kernels
+  // address y by global camera index, so they get the slot's base shifted back by the rank's first camera.
+  double* w_own = P->Ap.p;          // what the mat-vec writes through (indexed 3 * global camera)
+  double* dots_own = P->part_d2.p;  // where its delta partials go
+  if (P->sharded) {
+    const uint32_t slice = P->shard.slice_width, tail = P->w_tail, stride = 3 * slice + tail;
+    if (!P->w_gather.p) return fail(GSFM_ERR_HIP, "the all-gather buffer of the sharded PCG was not allocated");   // (create allocates it, before the ranks agree)
+    c.w = P->w_gather.p; c.w_stride = stride; c.w_slice = slice; c.w_tail = tail; c.n_part_d = (int)(tail * P->shard.world_size);
+    double* slot = P->w_gather.p + (size_t)P->shard.rank * stride;
+    w_own = slot - 3 * (size_t)P->own_begin; dots_own = slot + 3 * (size_t)slice;
+  }
+  MatvecCgArgs m{};
+  m.mv.n_rows = P->n_rows; m.mv.row_base = P->own_begin; m.mv.G = P->G; m.mv.row_ptr = P->row_ptr.p; m.mv.col = P->col.p;
+  m.mv.h0 = P->h0.p; m.mv.h1 = P->h1.p; m.mv.h2 = P->h2.p; m.mv.h3 = P->h3.p; m.mv.h4 = P->h4.p; m.mv.Mblk = P->Mblk.p;
+  m.mv.p = P->z.p; m.mv.y = w_own; m.mv.done = nullptr; m.mv.q = P->q_lin; m.mv.u = P->u_rot.p; m.with_dots = 1; m.reps = (uint32_t)reps;
+  const dim3 gcam(P->nb_cam), gmv(nb_mv), blk(GSFM_BLOCK);
+  const int tk0 = P->timer.begin(T_CG);
+  hipLaunchKernelGGL(k_cg2_init, gcam, blk, 0, P->stream, c);
+  P->timer.end(tk0);
+  Cg2Scalars h{};
+  const int chunk = std::max(1, o.cg_check_interval);
+  // One iteration = mat-vec (+ delta partials), vector step.  `first` / `par` are by-value kernel arguments: a captured chunk must
+  // start at par == 0, first == 0, so the very first iteration is launched plainly and chunks have even length.
+  auto enqueue_iter = [&]() -> int {
+    m.cg = c; m.cg.part_d = dots_own;
+    if (P->cs.active) {   // column-sorted layout: K3c with the same entry decision, delta partials from its finishing kernel (one per camera block)
+      auto& L = P->cs;
+      ColMatvecCgArgs cm{};
+      cm.mv.L = L.dev(); cm.mv.b0 = P->h0.p; cm.mv.b1 = P->h1.p; cm.mv.b2 = P->h2.p; cm.mv.u = P->u_rot.p; cm.mv.part = L.part.p; cm.mv.done = nullptr; cm.cg = c;
+      hipLaunchKernelGGL(k_mv_col_cg, dim3(L.n_wg), dim3(GSFM_COL_RB), 0, P->stream, cm);
+      ColFinishArgs f{};
+      f.n_rows = P->n_rows; f.row_base = P->own_begin; f.nch = L.nch; f.n_wg = L.n_wg; f.part = L.part.p; f.Mblk = P->Mblk.p; f.p = P->z.p; f.q = P->q_lin; f.y = w_own;
+      f.done = &P->cg2sc.p->done; f.dot_part = dots_own;
+      hipLaunchKernelGGL(k_mv_col_finish, dim3(grid_for(P->n_rows)), dim3(GSFM_BLOCK), 0, P->stream, f);
+    }
+    else if (P->lin_is_lap) hipLaunchKernelGGL(k_matvec_cg<true>, gmv, blk, 0, P->stream, m);
+    else hipLaunchKernelGGL(k_matvec_cg<false>, gmv, blk, 0, P->stream, m);
+    if (P->sharded) {
+      if (int st = all_gather(P, P->w_gather.p, (size_t)c.w_stride)) return st;
+      P->n_pcg_collectives++;
+    }
+    hipLaunchKernelGGL(k_cg2_step, gcam, blk, 0, P->stream, c);
+    c.par ^= 1; c.first = 0;
+    return 0;
+  };
+  int launched = 0;
+  {  // iterations 0 and 1 (first = 1, then par = 1): plain launches; afterwards par == 0 at every chunk start
+    const int tk = P->timer.begin(T_CG);
+    for (int k = 0; k < 2; ++k) { if (int st = enqueue_iter()) return st; ++launched; P->n_pcg_launched++; }
+    P->timer.end(tk);
+  }
+  auto& G = P->pcg2_graph;
+  bool graph = o.pcg_hip_graph && (!P->sharded || graph_collectives_ok(P, o)) && chunk % 2 == 0 && !G.unusable && !P->pcg_graph.unusable;
+  if (graph && (!G.exec || G.tol != c.tol || G.max_iters != c.max_iters || G.chunk != chunk || G.lap != P->lin_is_lap)) {
+    G.reset();
+    hipGraph_t captured = nullptr;
+    if (hipStreamBeginCapture(P->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+      int st = 0;
+      const int c0 = P->n_collectives, p0 = P->n_pcg_collectives;
+      for (int k = 0; k < chunk && st == 0; ++k) st = enqueue_iter();
+      const hipError_t e = hipStreamEndCapture(P->stream, &captured);
+      G.collectives = P->n_collectives - c0;
+      P->n_collectives = c0; P->n_pcg_collectives = p0;
+      if (st == 0 && e == hipSuccess && captured && hipGraphInstantiate(&G.exec, captured, nullptr, nullptr, 0) == hipSuccess) {
+        G.tol = c.tol; G.max_iters = c.max_iters; G.chunk = chunk; G.lap = P->lin_is_lap;
+      } else { G.exec = nullptr; }
+      if (captured) (void)hipGraphDestroy(captured);
+    }
+    if (!G.exec) { (void)hipGetLastError(); G.unusable = true; graph = false; }
+  }
+  int chunks = 1;
+  while (true) {
+    const int tk = P->timer.begin(T_CG);
+    for (int cc = 0; cc < chunks; ++cc) {
+      if (graph) { HIPCHK(hipGraphLaunch(G.exec, P->stream)); P->graph_launches++; P->n_collectives += G.collectives; P->n_pcg_collectives += G.collectives; }
+      else { for (int k = 0; k < chunk; ++k) if (int st = enqueue_iter()) return st; }
+      launched += chunk; P->n_pcg_launched += chunk;
+    }
+    P->timer.end(tk);
+    if (int st = read_back(P, &h, P->cg2sc.p, sizeof(h), "pcg")) return st;
+    if (h.done || launched >= o.max_cg_iterations + chunk + 2) break;
+    chunks = 1;   // same look-ahead as run_pcg: extrapolate the convergence factor, enqueue that many chunks before looking again
+    if (h.iters > 0 && h.last_rel > 0.0 && h.last_rel < 1.0 && c.tol > 0.0 && c.tol < h.last_rel) {
+      const double per_iter = std::log(h.last_rel) / h.iters;
+      const double remaining = std::log(c.tol / h.last_rel) / per_iter;
+      chunks = (int)std::min(8.0, std::max(1.0, std::ceil(remaining / chunk)));
+    }
+  }
+  *iters_out = h.iters; *rel_out = h.last_rel;
+  return 0;
+}
+
+// Which PCG: the single-reduction variant halves the dependent launches per iteration (2 instead of 4), which is what bounds small
+// graphs (tools/small_graph_pcg.py: 22 -> 14 -> 8 us per iteration at C2 size); from ~1M directed entries on the kernels dominate
+// and the textbook recurrence is kept (its residual is the recursively updated one of the reference description).
+bool use_single_reduction(const gsfm_rot_problem* P, const gsfm_rot_options& o) {
+  if (o.pcg_single_reduction >= 0) return o.pcg_single_reduction != 0;
+  if (o.cg_stall_iterations > 0) return false;   // stagnation detection lives in the textbook variant's scalar kernel
+  // (On the column-sorted layout the variant exists too -- k_mv_col_cg, one vector kernel instead of two -- and measures the same as the
+  // textbook recurrence at C5: 30.69 against 30.63 ms per solve, 129 iterations both; the entry decision of its mat-vec costs what the
+  // saved launch gains.  tools/r03_pcg_variants.py)
+  // Sharded: always -- there every launch counts (the per-rank kernels shrink with the rank count, the launches do not), and the variant is
+  // 3 kernels + 1 collective per iteration (mat-vec, finish, [all-gather of A u with the delta partials in its tail], vector step) against
+  // 5 + 1 for the textbook recurrence; except at tolerances below 1e-13 (disconnected graphs, lm_solve), where the recursively updated
+  // residual of the textbook form is the safer one.
+  if (P->sharded) return o.cg_relative_tolerance >= 1e-13 && P->n_components <= 1;
+  return P->dir.n <= (size_t)2000000;
+}
+bool single_reduction_possible(const gsfm_rot_problem*) { return true; }
+
+}  // namespace
