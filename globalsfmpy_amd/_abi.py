@@ -48,6 +48,7 @@ class Options(C.Structure):
         ("cg_check_interval", C.c_int32), ("verbose", C.c_int32),
         ("pcg_single_reduction", C.c_int32), ("cg_stall_iterations", C.c_int32),
         ("dense_cholesky_max_cams", C.c_int32), ("pcg_hip_graph", C.c_int32),
+        ("pcg_forcing", C.c_int32), ("reserved0_", C.c_int32), ("pcg_forcing_tolerance", C.c_double),
     ]
 
 
@@ -66,7 +67,8 @@ class Summary(C.Structure):
         ("t_sweep_ms", C.c_double), ("t_cg_ms", C.c_double),
         ("num_dense_solves", C.c_int32), ("num_graph_launches", C.c_int32),
         ("num_collectives", C.c_int32), ("num_pcg_collectives", C.c_int32),
-        ("num_pcg_launched", C.c_int32), ("reserved_", C.c_int32),
+        ("num_pcg_launched", C.c_int32), ("num_forcing_refinements", C.c_int32),
+        ("num_inexact_steps", C.c_int32), ("reserved_", C.c_int32),
     ]
 
     def as_dict(self):
@@ -178,7 +180,7 @@ def load_library():
             "globalsfmpy_amd: %s not found. The HIP extension is the product and has no CPU fallback; "
             "build it with `python -c 'import __graft_entry__ as g; g.build()'`." % LIB_PATH)
     lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
-    if lib.gsfm_rot_abi_version() != 2:
+    if lib.gsfm_rot_abi_version() != 3:
         raise ImportError("globalsfmpy_amd: ABI version mismatch in %s" % LIB_PATH)
     lib.gsfm_last_error.restype = C.c_char_p
     lib.gsfm_rot_options_default.argtypes = [C.POINTER(Options)]

@@ -143,7 +143,8 @@ __global__ void __launch_bounds__(GSFM_COL_RB) k_mv_col_cg(ColMatvecCgArgs aa) {
   const Cg2Args& c = aa.cg;
   mv_col_body(aa.mv, [&]() -> bool {
     const int done = c.sc->done, iters = c.sc->iters;
-    const double gamma0 = c.sc->gamma0;
+    const double gamma0 = c.sc->gamma0, tol = c.sc->tol;
+    const bool estop = cg_energy_stop(c.sc->einc, c.sc->esum, c.sc->etol2, iters);
     double gpart = 0.0;
     if (threadIdx.x < GSFM_BLOCK) for (int k = threadIdx.x; k < c.nb_cam; k += GSFM_BLOCK) gpart += c.part_g[(size_t)c.par * c.nb_cam + k];
     gpart = wave_sum(gpart);
@@ -159,7 +160,7 @@ __global__ void __launch_bounds__(GSFM_COL_RB) k_mv_col_cg(ColMatvecCgArgs aa) {
       if (blockIdx.x == 0 && threadIdx.x == 0) { c.sc->gamma0 = gamma; if (conv) c.sc->done = 1; }
     } else {
       const double rel = sqrt(gamma / gamma0);
-      conv = !(rel > c.tol) || iters >= c.max_iters;
+      conv = !(rel > tol) || iters >= c.max_iters || estop;
       if (blockIdx.x == 0 && threadIdx.x == 0) { c.sc->last_rel = rel; if (conv) c.sc->done = 1; }
     }
     return conv;

@@ -248,6 +248,7 @@ struct gsfm_rot_problem {
   DevBuf<double> x, x_trial, aa_io, active, scale, gD, Mblk, Minv, Lam, Tinv, b, D6;
   DevBuf<double2> q, q_trial;
   DevBuf<double> xcg, r, z, p, Ap, s_dir, part_g2, part_d2;
+  DevBuf<double> eta_fix, rcg_fix;   // forcing schedule: a loose step with its gauge component removed, and the residual that goes with it (launch_step)
   DevBuf<double> w_gather;   // sharded single-reduction PCG: per rank [slice of A u | delta partials of its rows] (run_pcg2)
   uint32_t w_tail = 0;
   DevBuf<Cg2Scalars> cg2sc;
@@ -262,7 +263,7 @@ struct gsfm_rot_problem {
   bool dense_graph_lap = false;           // form of the blocks the captured assemble kernel expects
   int nb_mv = 1, mv_reps = 1;
   uint32_t n_components = 1;  // connected components of the view graph (1 when sharded: a rank sees only its own edges)
-  DevBuf<double> part_a, part_b, part_cost, part_cam, scal;
+  DevBuf<double> part_a, part_b, part_cost, part_cam, part_gauge, scal;
   DevBuf<CgScalars> cgsc;
   int nb_cam = 1, nb_cost = 1;
 

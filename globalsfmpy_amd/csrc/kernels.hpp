@@ -1153,6 +1153,67 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_max_partials(const double* __res
   if (threadIdx.x == 0) out[0] = t;
 }
 
+// Forcing schedule: a LOOSE PCG iterate carries a component along the gauge direction eta_k = R_k v (all cameras rotated by the same v in their body
+// frames: the exact null space of J^T J, held only by the LM damping, hence the last thing PCG resolves and invisible to its energy norm).  The
+// exact step has none: v^T sum_k R_k^T Lam_k eta_k = 0 for every v, because the gradient is orthogonal to the gauge.  These two kernels remove it
+// from an inexact step the same way -- w = (sum R^T Lam R)^-1 sum R^T Lam eta, eta_k -= R_k w -- and keep the PCG residual consistent
+// (r += Lam R_k w; J^T J R w = 0), so that the model decrease computed from (eta, r) stays exact for the corrected step.
+// Out of place (eta_out, rcg_out): the PCG state itself must stay what the stopping iteration left, so that the solve can be continued.
+struct GaugeArgs { uint32_t n; int nb; const double* active; const double2* q; const double* Lam; const double* eta; const double* rcg; double* part; /* [9][nb] */ double* eta_out; double* rcg_out; };
+__global__ void __launch_bounds__(GSFM_BLOCK) k_gauge_part(GaugeArgs a) {
+  __shared__ double lds[8];
+  double v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  const uint32_t k = blockIdx.x * GSFM_BLOCK + threadIdx.x;
+  if (k < a.n && a.active[k] != 0.0) {
+    double R[9], le[3];
+    qmat(load_q(a.q, k), R);
+    const double* L = a.Lam + 6 * (size_t)k;
+    sym3_mulvec(L, a.eta + 3 * (size_t)k, le);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) v[c] = R[c] * le[0] + R[3 + c] * le[1] + R[6 + c] * le[2];   // R^T Lam eta
+    // R^T Lam R (symmetric: 00 01 02 11 12 22)
+    double LR[9];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      LR[c] = L[0] * R[c] + L[1] * R[3 + c] + L[2] * R[6 + c];
+      LR[3 + c] = L[1] * R[c] + L[3] * R[3 + c] + L[4] * R[6 + c];
+      LR[6 + c] = L[2] * R[c] + L[4] * R[3 + c] + L[5] * R[6 + c];
+    }
+    v[3] = R[0] * LR[0] + R[3] * LR[3] + R[6] * LR[6]; v[4] = R[0] * LR[1] + R[3] * LR[4] + R[6] * LR[7]; v[5] = R[0] * LR[2] + R[3] * LR[5] + R[6] * LR[8];
+    v[6] = R[1] * LR[1] + R[4] * LR[4] + R[7] * LR[7]; v[7] = R[1] * LR[2] + R[4] * LR[5] + R[7] * LR[8]; v[8] = R[2] * LR[2] + R[5] * LR[5] + R[8] * LR[8];
+  }
+#pragma unroll
+  for (int c = 0; c < 9; ++c) {
+    const double t = block_sum_bcast(v[c], lds);
+    if (threadIdx.x == 0) a.part[(size_t)c * a.nb + blockIdx.x] = t;
+  }
+}
+__global__ void __launch_bounds__(GSFM_BLOCK) k_gauge_apply(GaugeArgs a) {
+  __shared__ double lds[8];
+  double S[9];
+#pragma unroll
+  for (int c = 0; c < 9; ++c) S[c] = sum_partials_bcast(a.part + (size_t)c * a.nb, a.nb, lds);   // (every block: same partials, same order, same bits)
+  // w = A^-1 s, A symmetric (S[3..8]) by cofactors; a singular A (no damping at all) leaves the step alone
+  const double a00 = S[3], a01 = S[4], a02 = S[5], a11 = S[6], a12 = S[7], a22 = S[8];
+  const double c00 = a11 * a22 - a12 * a12, c01 = a02 * a12 - a01 * a22, c02 = a01 * a12 - a02 * a11;
+  const double det = a00 * c00 + a01 * c01 + a02 * c02;
+  const bool ok = fabs(det) > 0.0;
+  const double c11 = a00 * a22 - a02 * a02, c12 = a01 * a02 - a00 * a12, c22 = a00 * a11 - a01 * a01, id = ok ? 1.0 / det : 0.0;
+  const double w0 = id * (c00 * S[0] + c01 * S[1] + c02 * S[2]), w1 = id * (c01 * S[0] + c11 * S[1] + c12 * S[2]), w2 = id * (c02 * S[0] + c12 * S[1] + c22 * S[2]);
+  const uint32_t k = blockIdx.x * GSFM_BLOCK + threadIdx.x;
+  if (k < a.n) {
+    double d[3] = {0.0, 0.0, 0.0}, ld[3] = {0.0, 0.0, 0.0};
+    if (a.active[k] != 0.0) {
+      double R[9];
+      qmat(load_q(a.q, k), R);
+      d[0] = R[0] * w0 + R[1] * w1 + R[2] * w2; d[1] = R[3] * w0 + R[4] * w1 + R[5] * w2; d[2] = R[6] * w0 + R[7] * w1 + R[8] * w2;
+      sym3_mulvec(a.Lam + 6 * (size_t)k, d, ld);
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { a.eta_out[3 * (size_t)k + c] = a.eta[3 * (size_t)k + c] - d[c]; a.rcg_out[3 * (size_t)k + c] = a.rcg[3 * (size_t)k + c] + ld[c]; }
+  }
+}
+
 struct StepArgs {
   uint32_t n;
   int param_dim;
@@ -1278,12 +1339,32 @@ struct CgScalars {
   int iters;
   int stall;        // iterations since best_rel last halved
   int stalled;      // 1 if the solve ended by stagnation
+  int done_seen;    // `done` as k_cg_update found it: what k_cg_pupdate -- the kernel that SETS done -- tests at its entry, so that the launch that
+                    // detects convergence still updates p on every block and leaves a state the solve can be resumed from (k_cg_resume)
+  int pad_;
+  double tol;       // relative tolerance of the current run: device-resident, so that a captured chunk does not freeze it (forcing schedule,
+                    // solver_lm.hpp: a loose solve may be continued to the tight tolerance, bit for bit as if it had never stopped)
+  double etol2;     // loose solves: stop once the ESTIMATED relative energy-norm error of the iterate, squared, is below this (0 = off); see cg_energy_stop
+  double esum;      // sum of the iterations' decreases of the quadratic model, alpha_j (r_j . z_j) = |x_{j+1}|_A^2 - |x_j|_A^2 growth (Hestenes-Stiefel)
+  double einc[4];   // the last four of them (ring, indexed by iteration & 3)
 };
+// Energy-norm stopping rule of the forcing schedule.  PCG from x_0 = 0 gains inc_j = alpha_j (r_j . z_j) of |x|_A^2 per iteration, and the squared
+// energy error after k iterations is the sum of all LATER gains (Hestenes & Stiefel 1952; Strakos & Tichy 2002).  The later gains are extrapolated
+// geometrically from the last four: q = (inc_{k-1} + inc_{k-2}) / (inc_{k-3} + inc_{k-4}) is the decay per two iterations, the remainder
+// (inc_{k-1} + inc_{k-2}) q / (1 - q).  Unlike a residual norm this bounds what an LM step is about -- the share of the model decrease still
+// missing -- whatever the conditioning and the preconditioner.  `k` = iterations done (>= 4), ring = einc.
+__device__ __forceinline__ bool cg_energy_stop(const double* ring, double esum, double etol2, int k) {
+  if (!(etol2 > 0.0) || k < 4) return false;
+  const double a = ring[(k - 1) & 3] + ring[(k - 2) & 3], b = ring[(k - 3) & 3] + ring[(k - 4) & 3];
+  if (!(a < b) || !(a >= 0.0)) return false;   // no decay (or a breakdown): carry on
+  const double q = a / b;
+  return a * q <= etol2 * esum * (1.0 - q);
+}
 struct CgArgs {
   uint32_t n;        // cameras
   int nb;            // blocks of the camera kernels (= number of partials)
   int par;           // iteration parity
-  double tol;
+  double tol, etol2; // (read by the init kernels only: the run's tolerances live in CgScalars)
   int max_iters;
   int stall_limit;   // 0 = off
   const double* Minv;
@@ -1339,8 +1420,16 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_cg_init_fin(CgArgs a) {
   const double rz = sum_partials_bcast(a.part_b, a.nb, lds);
   if (threadIdx.x == 0) {
     a.sc->rz[0] = rz; a.sc->rz[1] = rz; a.sc->rz0 = rz; a.sc->last_rel = 1.0; a.sc->best_rel = 1.0;
-    a.sc->done = !(rz > 0.0); a.sc->iters = 0; a.sc->stall = 0; a.sc->stalled = 0;
+    a.sc->done = !(rz > 0.0); a.sc->iters = 0; a.sc->stall = 0; a.sc->stalled = 0; a.sc->done_seen = a.sc->done; a.sc->tol = a.tol;
+    a.sc->etol2 = a.etol2; a.sc->esum = 0.0; a.sc->einc[0] = a.sc->einc[1] = a.sc->einc[2] = a.sc->einc[3] = 0.0;
   }
+}
+// Continue a stopped solve to a tighter tolerance: the vectors, rz and the iteration count are exactly what the stopping iteration left
+// (see done_seen), so the iterates that follow are those of a solve that ran at `tol` from the start.
+__global__ void k_cg_resume(CgScalars* sc, double tol, double etol2, int max_iters) {
+  sc->tol = tol; sc->etol2 = etol2;
+  sc->done = !(sc->rz0 > 0.0) || !(sc->last_rel > tol) || sc->iters >= max_iters || sc->stalled;
+  sc->done_seen = sc->done;
 }
 // partial p.Ap
 __global__ void __launch_bounds__(GSFM_BLOCK) k_cg_dot(CgArgs a) {
@@ -1357,10 +1446,13 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_cg_dot(CgArgs a) {
 }
 // alpha = rz / pAp; x += alpha p; r -= alpha Ap; z = Minv r; partial r.z
 __global__ void __launch_bounds__(GSFM_BLOCK) k_cg_update(CgArgs a) {
-  if (a.sc->done) return;
+  const int done = a.sc->done;
+  if (blockIdx.x == 0 && threadIdx.x == 0) a.sc->done_seen = done;   // (nobody writes `done` during this launch)
+  if (done) return;
   __shared__ double lds[8];
   const double pAp = sum_partials_bcast(a.part_a, a.nb, lds);
   const double alpha = a.sc->rz[a.par] / pAp;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { const double inc = alpha * a.sc->rz[a.par]; a.sc->einc[a.sc->iters & 3] = inc; a.sc->esum += inc; }
   double v = 0.0, rc6[6] = {0, 0, 0, 0, 0, 0};
   const uint32_t k = blockIdx.x * GSFM_BLOCK + threadIdx.x;
   if (k < a.n) {
@@ -1397,7 +1489,7 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_cg_update(CgArgs a) {
 }
 // beta = rz_new / rz; p = z + beta p; convergence test
 __global__ void __launch_bounds__(GSFM_BLOCK) k_cg_pupdate(CgArgs a) {
-  if (a.sc->done) return;
+  if (a.sc->done_seen) return;   // not `done`: block 0 of THIS launch sets it, and every block must still finish the p update (resumable state)
   __shared__ double lds[8];
   double rz_new = sum_partials_bcast(a.part_b, a.nb, lds);
   if (a.coarse_n) rz_new += a.xc[3 * a.coarse_n];   // r . (Minv r + P xc) = r . Minv r + (P^T r) . xc
@@ -1423,9 +1515,8 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_cg_pupdate(CgArgs a) {
     a.sc->iters = it;
     const double rel = sqrt(rz_new / a.sc->rz0);
     a.sc->last_rel = rel;
-    // A block of this launch that already sees done == 1 merely skips its p update, which nobody reads
-    // any more; every later kernel observes the flag at its entry (kernel boundary).
-    if (!(rel > a.tol) || it >= a.max_iters) a.sc->done = 1;
+    // Every block of this launch finishes its p update (the entry test reads done_seen); every later kernel observes the flag at its entry.
+    if (!(rel > a.sc->tol) || it >= a.max_iters || cg_energy_stop(a.sc->einc, a.sc->esum, a.sc->etol2, it)) a.sc->done = 1;
     if (a.stall_limit > 0) {  // numerically singular system: the residual plateaus at rounding level
       if (rel < 0.5 * a.sc->best_rel) { a.sc->best_rel = rel; a.sc->stall = 0; }
       else if (++a.sc->stall >= a.stall_limit) { a.sc->done = 1; a.sc->stalled = 1; }
@@ -1683,6 +1774,8 @@ struct Cg2Scalars {
   double last_rel;
   int done;
   int iters;
+  double tol;        // relative tolerance of the current run (device-resident: see CgScalars::tol)
+  double etol2, esum, einc[4];   // energy-norm stopping rule of the loose solves (cg_energy_stop): inc_j = alpha_j gamma_j
 };
 struct Cg2Args {
   uint32_t n;            // cameras
@@ -1691,7 +1784,7 @@ struct Cg2Args {
   int par;               // iteration parity
   int first;             // 1 on iteration 0
   int max_iters;
-  double tol;
+  double tol, etol2;     // (read by k_cg2_init only: the run's tolerances live in Cg2Scalars)
   const double* Minv;
   const double* b;
   double *x, *r, *u, *w, *p, *s;
@@ -1730,7 +1823,15 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_cg2_init(Cg2Args a) {
   }
   const double t = block_sum_bcast(v, lds);
   if (threadIdx.x == 0) a.part_g[blockIdx.x] = t;
-  if (blockIdx.x == 0 && threadIdx.x == 0) { a.sc->done = 0; a.sc->iters = 0; a.sc->last_rel = 1.0; a.sc->gamma0 = 0.0; }
+  if (blockIdx.x == 0 && threadIdx.x == 0) { a.sc->done = 0; a.sc->iters = 0; a.sc->last_rel = 1.0; a.sc->gamma0 = 0.0; a.sc->tol = a.tol;
+    a.sc->etol2 = a.etol2; a.sc->esum = 0.0; a.sc->einc[0] = a.sc->einc[1] = a.sc->einc[2] = a.sc->einc[3] = 0.0; }
+}
+// Continue a stopped solve to a tighter tolerance.  The recurrence stops at a mat-vec ENTRY (every workgroup takes the same decision from
+// the same gamma partials, nothing of the iteration has been written), so clearing the flag lets the next mat-vec -- launched with the
+// parity and `first` flag of the iteration that stopped -- take the decision again, against the new tolerance.
+__global__ void k_cg2_resume(Cg2Scalars* sc, double tol, double etol2) {
+  sc->tol = tol; sc->etol2 = etol2;
+  sc->done = 0;
 }
 
 // w = A u on the owned rows (G lanes per row, `reps` row groups per workgroup) + delta partials (unsharded only).
@@ -1760,7 +1861,8 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_matvec_cg(MatvecCgArgs aa) {
   const double* __restrict__ vec = LAP ? a.u : a.p;   // the gathered vector: R^T u (Laplacian form) or u itself
   // ---- request phase ----
   const int done = c.sc->done, iters = c.sc->iters;
-  const double gamma0 = c.sc->gamma0;
+  const double gamma0 = c.sc->gamma0, tol = c.sc->tol;
+  const bool estop = cg_energy_stop(c.sc->einc, c.sc->esum, c.sc->etol2, iters);
   double gpart = 0.0;
   for (int k = threadIdx.x; k < c.nb_cam; k += GSFM_BLOCK) gpart += c.part_g[(size_t)c.par * c.nb_cam + k];
   const uint32_t G = a.G, rows_per_group = GSFM_BLOCK / G;
@@ -1801,7 +1903,7 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_matvec_cg(MatvecCgArgs aa) {
     const double rel = sqrt(gamma / gamma0);
     // the iteration cap is applied here, at a kernel entry, from a counter written by the PREVIOUS launch: every workgroup takes
     // the same decision, and no workgroup of a vector-update launch can see the flag flip half way through an update of x
-    conv = !(rel > c.tol) || iters >= c.max_iters;
+    conv = !(rel > tol) || iters >= c.max_iters || estop;
     if (blockIdx.x == 0 && threadIdx.x == 0) { c.sc->last_rel = rel; if (conv) c.sc->done = 1; }
   }
   if (conv) return;
@@ -1922,7 +2024,11 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_cg2_step(Cg2Args a) {
   }
   const double t = block_sum_bcast(v, lds);
   if (threadIdx.x == 0) a.part_g[(size_t)(a.par ^ 1) * a.nb_cam + blockIdx.x] = t;
-  if (blockIdx.x == 0 && threadIdx.x == 0) { a.sc->gamma[a.par] = gamma; a.sc->alpha[a.par] = alpha; a.sc->iters = a.sc->iters + 1; }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    const int it = a.sc->iters;
+    const double inc = alpha * gamma;
+    a.sc->gamma[a.par] = gamma; a.sc->alpha[a.par] = alpha; a.sc->einc[it & 3] = inc; a.sc->esum += inc; a.sc->iters = it + 1;
+  }
 }
 
 // ------------------------------------------------------------------------------------------

@@ -547,6 +547,7 @@ static gsfm_status problem_create_impl(uint32_t n_cams, uint64_t n_edges, const 
   ok &= P->Mblk.alloc(6 * N) == hipSuccess; ok &= P->Minv.alloc(6 * N) == hipSuccess; ok &= P->Lam.alloc(6 * N) == hipSuccess;
   ok &= P->Tinv.alloc(9 * N) == hipSuccess; ok &= P->b.alloc(3 * N) == hipSuccess; ok &= P->D6.alloc(6 * N) == hipSuccess;
   ok &= P->q.alloc(2 * N) == hipSuccess; ok &= P->q_trial.alloc(2 * N) == hipSuccess;
+  ok &= P->eta_fix.alloc(3 * N) == hipSuccess; ok &= P->rcg_fix.alloc(3 * N) == hipSuccess;
   ok &= P->xcg.alloc(3 * N) == hipSuccess; ok &= P->r.alloc(3 * N) == hipSuccess; ok &= P->z.alloc(3 * N) == hipSuccess;
   ok &= P->p.alloc(3 * NP, true) == hipSuccess; ok &= P->Ap.alloc(3 * NP, true) == hipSuccess; ok &= P->u_rot.alloc(3 * NP, true) == hipSuccess;
   {
@@ -555,7 +556,7 @@ static gsfm_status problem_create_impl(uint32_t n_cams, uint64_t n_edges, const 
     P->lap = P->lap_capable;
   }
   ok &= P->part_a.alloc(P->nb_cam) == hipSuccess; ok &= P->part_b.alloc(P->nb_cam) == hipSuccess;
-  ok &= P->part_cam.alloc((size_t)5 * P->nb_cam) == hipSuccess; ok &= P->part_cost.alloc((size_t)2 * P->nb_cost) == hipSuccess;
+  ok &= P->part_cam.alloc((size_t)5 * P->nb_cam) == hipSuccess; ok &= P->part_gauge.alloc((size_t)9 * P->nb_cam) == hipSuccess; ok &= P->part_cost.alloc((size_t)2 * P->nb_cost) == hipSuccess;
   ok &= P->scal.alloc(SC_N, true) == hipSuccess; ok &= P->cgsc.alloc(1, true) == hipSuccess;
   {  // fused mat-vec of the single-reduction PCG: one row group (256 / G rows) per workgroup unless that leaves too many partials
     const size_t rows_per_group = GSFM_BLOCK / P->G, groups = (P->n_rows + rows_per_group - 1) / rows_per_group;

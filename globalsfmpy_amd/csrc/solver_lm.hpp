@@ -5,9 +5,16 @@
 
 namespace {
 
-int launch_step(gsfm_rot_problem* P) {
+int launch_step(gsfm_rot_problem* P, bool inexact = false) {
+  const double *eta = P->xcg.p, *rcg = P->r.p;
+  if (inexact && P->lap_capable) {   // (functors whose cost depends on R_j R_i^T alone: for those the gauge is an exact symmetry) a loose PCG iterate: its gauge component is taken out first (kernels.hpp, k_gauge_part) -- into copies, the PCG state stays resumable
+    GaugeArgs ga{P->n_cams, P->nb_cam, P->active.p, P->q_lin ? P->q_lin : P->q.p, P->Lam.p, P->xcg.p, P->r.p, P->part_gauge.p, P->eta_fix.p, P->rcg_fix.p};
+    hipLaunchKernelGGL(k_gauge_part, dim3(P->nb_cam), dim3(GSFM_BLOCK), 0, P->stream, ga);
+    hipLaunchKernelGGL(k_gauge_apply, dim3(P->nb_cam), dim3(GSFM_BLOCK), 0, P->stream, ga);
+    eta = P->eta_fix.p; rcg = P->rcg_fix.p;
+  }
   StepArgs a{};
-  a.n = P->n_cams; a.param_dim = P->param_dim; a.x = P->x.p; a.active = P->active.p; a.eta = P->xcg.p; a.b = P->b.p; a.rcg = P->r.p;
+  a.n = P->n_cams; a.param_dim = P->param_dim; a.x = P->x.p; a.active = P->active.p; a.eta = eta; a.b = P->b.p; a.rcg = rcg;
   a.Lam = P->Lam.p; a.Tinv = P->Tinv.p; a.x_trial = P->x_trial.p; a.q_trial = P->q_trial.p; a.partials = P->part_cam.p;
   hipLaunchKernelGGL(k_cam_step, dim3(P->nb_cam), dim3(GSFM_BLOCK), 0, P->stream, a);
   hipLaunchKernelGGL(k_sum_partials_multi, dim3(1), dim3(GSFM_BLOCK), 0, P->stream, P->part_cam.p, P->nb_cam, 5, P->scal.p + SC_STEP);
@@ -110,6 +117,12 @@ int lm_solve(gsfm_rot_problem* P, const gsfm_rot_options& o_in, gsfm_rot_summary
   if (!std::isfinite(x_cost)) return finish(GSFM_TERM_FAILURE);
   if (gmax <= o.gradient_tolerance) return finish(GSFM_TERM_GRADIENT_TOLERANCE);
   bool last_successful = false, pcg_struggles = false;
+  // Forcing schedule (gsfm_rot_options::pcg_forcing): steps far from convergence may deviate from the exact step by at most `eps_rad` (rms over the
+  // cameras); off for disconnected graphs (their 1e-14 rule stands).
+  const double eps_rad = o.pcg_forcing_tolerance, refine_margin = 1e2, tau_max = 1e-2, sqrt_n = std::sqrt((double)std::max<uint32_t>(1, P->n_cams));
+  const bool forcing = o.pcg_forcing > 0 && P->n_components <= 1 && eps_rad > 0.0;
+  bool near_convergence = false;   // the last accepted step changed the cost by less than 1e-3 relative: every step from here on is exact from the start
+  double pred_rms = -1.0;          // rms size of the last accepted step: the (conservative: steps shrink) prediction of the next one's
   while (true) {
     if (iteration >= o.max_num_iterations) return finish(GSFM_TERM_NO_CONVERGENCE);
     if (last_successful && gmax <= o.gradient_tolerance) return finish(GSFM_TERM_GRADIENT_TOLERANCE);
@@ -120,6 +133,13 @@ int lm_solve(gsfm_rot_problem* P, const gsfm_rot_options& o_in, gsfm_rot_summary
     prep_valid = false;
     int cg = 0; double cg_rel = 0;
     bool dense_used = false;
+    // Forcing schedule: an LM step that cannot be one of the last is solved loosely -- to a relative (energy-norm) error tau chosen so that
+    // tau * |step|_rms <= eps_rad, with the step size predicted from the previous accepted step (first step: tau_max, corrected below).
+    const bool can_be_last = iteration >= o.max_num_iterations || near_convergence;
+    bool loose = forcing && !can_be_last;
+    double tau = pred_rms > 0.0 ? std::fmin(tau_max, eps_rad / pred_rms) : tau_max;
+    if (tau <= 4.0 * o.cg_relative_tolerance) loose = false;
+    bool use_pcg2 = false;
     // dense_cholesky_max_cams > 0: exact Cholesky steps for graphs up to that size; < 0: up to |value| cameras, but only
     // once a PCG solve of this run has needed more than 150 iterations (2.5 ms of factorisation beats that many mat-vecs)
     const int64_t dense_cap = o.dense_cholesky_max_cams > 0 ? o.dense_cholesky_max_cams : -(int64_t)o.dense_cholesky_max_cams;
@@ -129,19 +149,43 @@ int lm_solve(gsfm_rot_problem* P, const gsfm_rot_options& o_in, gsfm_rot_summary
     for (int attempt = 0; attempt < 2; ++attempt) {
       if (!dense_used) {
         if (int st = coarse_build(P, pcg_struggles)) return st;
-        if (int st = ((P->coarse_n == 0 && single_reduction_possible(P) && use_single_reduction(P, o)) ? run_pcg2(P, o, &cg, &cg_rel) : run_pcg(P, o, &cg, &cg_rel))) return st;
+        use_pcg2 = P->coarse_n == 0 && use_single_reduction(P, o);
+        if (int st = (use_pcg2 ? run_pcg2(P, o, o.cg_relative_tolerance, loose ? tau * tau : 0.0, -1, &cg, &cg_rel) : run_pcg(P, o, o.cg_relative_tolerance, loose ? tau * tau : 0.0, -1, &cg, &cg_rel))) return st;
       }
-      launch_step(P);
+      launch_step(P, !dense_used && loose);
       if (int st = launch_cost(P, P->q_trial.p, SC_TRIAL)) return st;
       if (int st = read_scalars(P, h)) return st;
+      for (int pass = 0; pass < 3 && !dense_used && loose && cg_rel > o.cg_relative_tolerance; ++pass) {
+        // The loose step has been evaluated.  It stands only if (a) the iteration is clearly an ordinary successful one -- anything that could
+        // end the solve or that the trust-region logic reacts to (a cost change within `refine_margin` of the function tolerance, a step near
+        // the parameter tolerance, a step that is not accepted, an invalid model) is decided on the exact step instead -- and (b) its estimated
+        // deviation from the exact step, tau * |step|_rms, is within eps_rad now that the step's size is known.  Otherwise PCG CONTINUES from
+        // where it stopped -- to the tight tolerance for (a), to the tau the measured step size asks for for (b): the same iterates as an
+        // uninterrupted solve at that tolerance -- and the step and its cost are evaluated again.
+        const double mcc = -0.5 * h[SC_STEP] + 0.5 * h[SC_STEP + 1] + 0.5 * h[SC_STEP + 2];
+        const double cc = x_cost - h[SC_TRIAL], sn = std::sqrt(h[SC_STEP + 3]);
+        const bool ordinary = std::isfinite(mcc) && mcc > 0.0 && std::isfinite(h[SC_TRIAL]) && cc / mcc > std::fmax(o.min_relative_decrease, 0.25)
+                              && cc > refine_margin * o.function_tolerance * x_cost
+                              && sn > refine_margin * o.parameter_tolerance * (x_norm + o.parameter_tolerance);
+        const double tau_need = ordinary ? eps_rad / std::fmax(sn / sqrt_n, 1e-300) : 0.0;
+        if (ordinary && tau <= 1.5 * tau_need && o.pcg_forcing != 2) { sum->num_inexact_steps++; break; }
+        if (!ordinary || o.pcg_forcing == 2 || tau_need <= 4.0 * o.cg_relative_tolerance || pass == 2) { loose = false; tau = 0.0; } else tau = std::fmin(tau, tau_need);
+        if (int st = (use_pcg2 ? run_pcg2(P, o, o.cg_relative_tolerance, tau * tau, cg, &cg, &cg_rel) : run_pcg(P, o, o.cg_relative_tolerance, tau * tau, cg, &cg, &cg_rel))) return st;
+        launch_step(P, loose);
+        if (int st = launch_cost(P, P->q_trial.p, SC_TRIAL)) return st;
+        if (int st = read_scalars(P, h)) return st;
+        sum->num_forcing_refinements++;
+        if (!loose) break;
+      }
       if (!dense_used) break;
       int info = 0;
       std::memcpy(&info, &h[SC_DENSE_INFO], sizeof(int));
       if (info == 0) { sum->num_dense_solves++; break; }
       dense_used = false;   // not positive definite to working precision: the step just evaluated is meaningless, PCG solves it again
     }
-    if (cg > 150) pcg_struggles = true;
-    if (o.verbose && !dense_used && cg >= o.max_cg_iterations && cg_rel > o.cg_relative_tolerance)
+    // (a loose solve's count is projected to the tight tolerance -- PCG converges about linearly in the logarithm -- before it is held against the 150)
+    if ((loose && tau > 0.0 ? cg * std::log(o.cg_relative_tolerance) / std::log(std::fmin(0.5, tau)) : (double)cg) > 150.0) pcg_struggles = true;
+    if (o.verbose && !dense_used && !loose && cg >= o.max_cg_iterations && cg_rel > o.cg_relative_tolerance)
       fprintf(stderr, "[gsfm] it %3d: PCG stopped at its cap of %d iterations with a relative residual of %.1e (tolerance %.1e): this step is inexact\n", iteration, o.max_cg_iterations, cg_rel, o.cg_relative_tolerance);
     sum->num_cg_iterations += cg;
     sum->num_residual_sweeps++;
@@ -182,6 +226,8 @@ int lm_solve(gsfm_rot_problem* P, const gsfm_rot_options& o_in, gsfm_rot_summary
       gmax = h[SC_GMAX];
       sum->num_successful_steps++;
       last_successful = true;
+      if (std::fabs(cost_change) <= 1e-3 * cand_cost) near_convergence = true;
+      pred_rms = step_norm / sqrt_n;
     } else {  // HandleUnsuccessfulStep
       radius /= decrease_factor; decrease_factor *= 2.0;
       sum->num_unsuccessful_steps++;

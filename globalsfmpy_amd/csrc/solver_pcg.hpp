@@ -92,10 +92,14 @@ bool graph_collectives_ok(const gsfm_rot_problem* P, const gsfm_rot_options& o) 
   return !(e && *e && atoi(e) == 0);
 }
 
-// block-Jacobi PCG on (J^T J + Lambda) eta = -g; returns iterations
-int run_pcg(gsfm_rot_problem* P, const gsfm_rot_options& o, int* iters_out, double* rel_out) {
+// block-Jacobi PCG on (J^T J + Lambda) eta = -g to the relative residual `tol` -- or, etol2 > 0 (a loose solve of the forcing schedule), until the
+// estimated relative energy-norm error squared falls below etol2 (kernels.hpp, cg_energy_stop); returns iterations.  resume_iters >= 0: continue the solve
+// that stopped after that many iterations (at a looser tolerance) instead of starting one -- the device state is exactly what the stopping
+// iteration left (kernels.hpp, CgScalars::done_seen), so the iterates are those of an uninterrupted solve at `tol`.
+int run_pcg(gsfm_rot_problem* P, const gsfm_rot_options& o, double tol, double etol2, int resume_iters, int* iters_out, double* rel_out) {
+  const bool resume = resume_iters >= 0;
   CgArgs a{};
-  a.n = P->n_cams; a.nb = P->nb_cam; a.par = 0; a.tol = o.cg_relative_tolerance; a.max_iters = o.max_cg_iterations; a.stall_limit = o.cg_stall_iterations;
+  a.n = P->n_cams; a.nb = P->nb_cam; a.par = 0; a.tol = tol; a.etol2 = etol2; a.max_iters = o.max_cg_iterations; a.stall_limit = o.cg_stall_iterations;
   a.Minv = P->Minv.p; a.b = P->b.p; a.xcg = P->xcg.p; a.r = P->r.p; a.z = P->z.p; a.p = P->p.p; a.Ap = P->Ap.p;
   a.part_a = P->part_a.p; a.part_b = P->part_b.p; a.sc = P->cgsc.p;
   a.q = P->q_lin; a.u = P->lin_is_lap ? P->u_rot.p : nullptr;
@@ -108,6 +112,8 @@ int run_pcg(gsfm_rot_problem* P, const gsfm_rot_options& o, int* iters_out, doub
   ca.xc = P->coarse_xc.p; ca.done = nullptr; ca.active = P->active.p; ca.rc_part = nullptr; ca.nb = (uint32_t)P->nb_cam;
   const dim3 g(P->nb_cam), blk(GSFM_BLOCK);
   const int tk0 = P->timer.begin(T_CG);
+  if (resume) hipLaunchKernelGGL(k_cg_resume, dim3(1), dim3(1), 0, P->stream, P->cgsc.p, tol, etol2, a.max_iters);
+  else {
   hipLaunchKernelGGL(k_cg_init, g, blk, 0, P->stream, a);
   hipLaunchKernelGGL(k_cg_init_fin, dim3(1), blk, 0, P->stream, a);
   if (a.coarse_n) {   // z_0 = Minv r_0 + P Ac^-1 P^T r_0
@@ -116,30 +122,34 @@ int run_pcg(gsfm_rot_problem* P, const gsfm_rot_options& o, int* iters_out, doub
     hipLaunchKernelGGL(k_cg_init_coarse, g, blk, 0, P->stream, a);
     hipLaunchKernelGGL(k_cg_init_coarse_fin, dim3(1), dim3(1), 0, P->stream, a);
   }
+  }
   ca.done = &P->cgsc.p->done; ca.rc_part = a.rc_part;
   P->timer.end(tk0);
   CgScalars h{};
   const int chunk = std::max(1, o.cg_check_interval);
-  auto enqueue_chunk = [&]() -> int {  // `chunk` iterations; leaves a.par where it found it when chunk is even
-    for (int c = 0; c < chunk; ++c) {
-      bool dotted = false;
-      if (int st = launch_matvec(P, P->Mblk.p, P->p.p, P->Ap.p, &P->cgsc.p->done, a.part_a, &dotted)) return st;
-      if (P->sharded) P->n_pcg_collectives++;
-      if (!dotted) hipLaunchKernelGGL(k_cg_dot, g, blk, 0, P->stream, a);
-      hipLaunchKernelGGL(k_cg_update, g, blk, 0, P->stream, a);
-      if (a.coarse_n) {
-        if (!fused_restrict) hipLaunchKernelGGL(k_coarse_restrict, dim3(a.coarse_n), blk, 0, P->stream, ca);
-        hipLaunchKernelGGL(k_coarse_apply, dim3(1), dim3(1024), 0, P->stream, ca);
-      }
-      hipLaunchKernelGGL(k_cg_pupdate, g, blk, 0, P->stream, a);
-      a.par ^= 1;
+  auto enqueue_iter = [&]() -> int {
+    bool dotted = false;
+    if (int st = launch_matvec(P, P->Mblk.p, P->p.p, P->Ap.p, &P->cgsc.p->done, a.part_a, &dotted)) return st;
+    if (P->sharded) P->n_pcg_collectives++;
+    if (!dotted) hipLaunchKernelGGL(k_cg_dot, g, blk, 0, P->stream, a);
+    hipLaunchKernelGGL(k_cg_update, g, blk, 0, P->stream, a);
+    if (a.coarse_n) {
+      if (!fused_restrict) hipLaunchKernelGGL(k_coarse_restrict, dim3(a.coarse_n), blk, 0, P->stream, ca);
+      hipLaunchKernelGGL(k_coarse_apply, dim3(1), dim3(1024), 0, P->stream, ca);
     }
+    hipLaunchKernelGGL(k_cg_pupdate, g, blk, 0, P->stream, a);
+    a.par ^= 1;
+    return 0;
+  };
+  auto enqueue_chunk = [&]() -> int {  // `chunk` iterations; leaves a.par where it found it when chunk is even
+    for (int c = 0; c < chunk; ++c) if (int st = enqueue_iter()) return st;
     return 0;
   };
   // The chunk between two host checks as one hipGraph launch: 4 * chunk dependent kernels whose arguments never change.
   auto& G = P->pcg_graph;
   bool graph = o.pcg_hip_graph && (!P->sharded || graph_collectives_ok(P, o)) && chunk % 2 == 0 && !G.unusable;
-  if (graph && (!G.exec || G.tol != a.tol || G.max_iters != a.max_iters || G.stall != a.stall_limit || G.chunk != chunk || G.lap != P->lin_is_lap || G.coarse != a.coarse_n)) {
+  // (the tolerance is device-resident, CgScalars::tol: a captured chunk serves every tolerance)
+  if (graph && (!G.exec || G.max_iters != a.max_iters || G.stall != a.stall_limit || G.chunk != chunk || G.lap != P->lin_is_lap || G.coarse != a.coarse_n)) {
     G.reset();
     hipGraph_t captured = nullptr;
     if (hipStreamBeginCapture(P->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
@@ -156,6 +166,16 @@ int run_pcg(gsfm_rot_problem* P, const gsfm_rot_options& o, int* iters_out, doub
     if (!G.exec) { (void)hipGetLastError(); G.unusable = true; graph = false; }  // e.g. a stream that cannot be captured: plain launches
   }
   int launched = 0, chunks = 1;
+  if (resume) {   // the parity of the iteration that follows the stop; a captured chunk starts at parity 0
+    launched = resume_iters;
+    if (resume_iters & 1) {
+      a.par = 1;
+      const int tk = P->timer.begin(T_CG);
+      if (int st = enqueue_iter()) return st;
+      P->timer.end(tk);
+      ++launched; P->n_pcg_launched++;
+    }
+  }
   while (true) {
     const int tk = P->timer.begin(T_CG);
     for (int c = 0; c < chunks; ++c) {
@@ -169,9 +189,9 @@ int run_pcg(gsfm_rot_problem* P, const gsfm_rot_options& o, int* iters_out, doub
     // Fewer host round trips: extrapolate the average convergence factor so far to the tolerance and enqueue that many
     // chunks before looking again (kernels past convergence return at their first instruction, so overshoot is cheap).
     chunks = 1;
-    if (h.iters > 0 && h.last_rel > 0.0 && h.last_rel < 1.0 && a.tol > 0.0 && a.tol < h.last_rel) {
+    if (!(etol2 > 0.0) && h.iters > 0 && h.last_rel > 0.0 && h.last_rel < 1.0 && tol > 0.0 && tol < h.last_rel) {
       const double per_iter = std::log(h.last_rel) / h.iters;
-      const double remaining = std::log(a.tol / h.last_rel) / per_iter;
+      const double remaining = std::log(tol / h.last_rel) / per_iter;
       chunks = (int)std::min(8.0, std::max(1.0, std::ceil(remaining / chunk)));
     }
     chunks = std::min(chunks, std::max(1, (o.max_cg_iterations + chunk - launched + chunk - 1) / chunk));
@@ -182,10 +202,11 @@ int run_pcg(gsfm_rot_problem* P, const gsfm_rot_options& o, int* iters_out, doub
 
 // single-reduction PCG (Chronopoulos-Gear): 2 kernels per iteration (3 + one all-gather when sharded); the launch-latency regime's
 // default (see use_single_reduction).  The chunk between two host checks replays as one hipGraph, like run_pcg's.
-int run_pcg2(gsfm_rot_problem* P, const gsfm_rot_options& o, int* iters_out, double* rel_out) {
+int run_pcg2(gsfm_rot_problem* P, const gsfm_rot_options& o, double tol, double etol2, int resume_iters, int* iters_out, double* rel_out) {
+  const bool resume = resume_iters >= 0;
   Cg2Args c{};
   const int nb_mv = P->nb_mv, reps = P->mv_reps;
-  c.n = P->n_cams; c.nb_cam = P->nb_cam; c.n_part_d = (P->sharded || P->cs.active) ? P->nb_cam : nb_mv; c.par = 0; c.first = 1; c.tol = o.cg_relative_tolerance; c.max_iters = o.max_cg_iterations;
+  c.n = P->n_cams; c.nb_cam = P->nb_cam; c.n_part_d = (P->sharded || P->cs.active) ? P->nb_cam : nb_mv; c.par = 0; c.first = 1; c.tol = tol; c.etol2 = etol2; c.max_iters = o.max_cg_iterations;
   c.Minv = P->Minv.p; c.b = P->b.p; c.x = P->xcg.p; c.r = P->r.p; c.u = P->z.p; c.w = P->Ap.p; c.p = P->p.p; c.s = P->s_dir.p;
   c.part_g = P->part_g2.p; c.part_d = P->part_d2.p; c.sc = P->cg2sc.p;
   c.q = P->q_lin; c.urot = P->lin_is_lap ? P->u_rot.p : nullptr;
@@ -206,7 +227,8 @@ int run_pcg2(gsfm_rot_problem* P, const gsfm_rot_options& o, int* iters_out, dou
   m.mv.p = P->z.p; m.mv.y = w_own; m.mv.done = nullptr; m.mv.q = P->q_lin; m.mv.u = P->u_rot.p; m.with_dots = 1; m.reps = (uint32_t)reps;
   const dim3 gcam(P->nb_cam), gmv(nb_mv), blk(GSFM_BLOCK);
   const int tk0 = P->timer.begin(T_CG);
-  hipLaunchKernelGGL(k_cg2_init, gcam, blk, 0, P->stream, c);
+  if (resume) hipLaunchKernelGGL(k_cg2_resume, dim3(1), dim3(1), 0, P->stream, P->cg2sc.p, tol, etol2);
+  else hipLaunchKernelGGL(k_cg2_init, gcam, blk, 0, P->stream, c);
   P->timer.end(tk0);
   Cg2Scalars h{};
   const int chunk = std::max(1, o.cg_check_interval);
@@ -235,14 +257,19 @@ int run_pcg2(gsfm_rot_problem* P, const gsfm_rot_options& o, int* iters_out, dou
     return 0;
   };
   int launched = 0;
-  {  // iterations 0 and 1 (first = 1, then par = 1): plain launches; afterwards par == 0 at every chunk start
+  if (resume) {   // the launch that stopped had parity resume_iters & 1 (and `first` set only if nothing had run): take it again, plainly, up to parity 0
+    launched = resume_iters; c.par = resume_iters & 1; c.first = resume_iters == 0;
+    const int tk = P->timer.begin(T_CG);
+    while (c.par || c.first) { if (int st = enqueue_iter()) return st; ++launched; P->n_pcg_launched++; }
+    P->timer.end(tk);
+  } else {  // iterations 0 and 1 (first = 1, then par = 1): plain launches; afterwards par == 0 at every chunk start
     const int tk = P->timer.begin(T_CG);
     for (int k = 0; k < 2; ++k) { if (int st = enqueue_iter()) return st; ++launched; P->n_pcg_launched++; }
     P->timer.end(tk);
   }
   auto& G = P->pcg2_graph;
   bool graph = o.pcg_hip_graph && (!P->sharded || graph_collectives_ok(P, o)) && chunk % 2 == 0 && !G.unusable && !P->pcg_graph.unusable;
-  if (graph && (!G.exec || G.tol != c.tol || G.max_iters != c.max_iters || G.chunk != chunk || G.lap != P->lin_is_lap)) {
+  if (graph && (!G.exec || G.max_iters != c.max_iters || G.chunk != chunk || G.lap != P->lin_is_lap)) {
     G.reset();
     hipGraph_t captured = nullptr;
     if (hipStreamBeginCapture(P->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
@@ -271,9 +298,9 @@ int run_pcg2(gsfm_rot_problem* P, const gsfm_rot_options& o, int* iters_out, dou
     if (int st = read_back(P, &h, P->cg2sc.p, sizeof(h), "pcg")) return st;
     if (h.done || launched >= o.max_cg_iterations + chunk + 2) break;
     chunks = 1;   // same look-ahead as run_pcg: extrapolate the convergence factor, enqueue that many chunks before looking again
-    if (h.iters > 0 && h.last_rel > 0.0 && h.last_rel < 1.0 && c.tol > 0.0 && c.tol < h.last_rel) {
+    if (!(etol2 > 0.0) && h.iters > 0 && h.last_rel > 0.0 && h.last_rel < 1.0 && tol > 0.0 && tol < h.last_rel) {
       const double per_iter = std::log(h.last_rel) / h.iters;
-      const double remaining = std::log(c.tol / h.last_rel) / per_iter;
+      const double remaining = std::log(tol / h.last_rel) / per_iter;
       chunks = (int)std::min(8.0, std::max(1.0, std::ceil(remaining / chunk)));
     }
   }
@@ -297,6 +324,5 @@ bool use_single_reduction(const gsfm_rot_problem* P, const gsfm_rot_options& o) 
   if (P->sharded) return o.cg_relative_tolerance >= 1e-13 && P->n_components <= 1;
   return P->dir.n <= (size_t)2000000;
 }
-bool single_reduction_possible(const gsfm_rot_problem*) { return true; }
 
 }  // namespace

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define GSFM_ROT_ABI_VERSION 2
+#define GSFM_ROT_ABI_VERSION 3
 
 typedef enum {
   GSFM_OK = 0,
@@ -168,6 +168,34 @@ typedef struct {
                                           csrc/gsfm_rccl.cpp: RCCL collectives are stream-capturable) -- the default since round 3, 2 is the old
                                           explicit opt-in and means the same, GSFM_PCG_GRAPH_COLLECTIVES=0 in the environment switches it off;
                                           host-staged callbacks (gloo) keep plain launches.  0: plain launches everywhere. */
+  int32_t pcg_forcing;                 /* default 1: forcing schedule for the PCG solves -- steps far from convergence are solved only as accurately
+                                          as the answer needs.  An LM step that can be one of the LAST (the previous accepted step changed the cost
+                                          by <= 1e-3 relative, or the iteration cap is reached with it) is solved to cg_relative_tolerance from the
+                                          start, as before.  Any other step is first solved LOOSELY: PCG stops once the estimated relative
+                                          energy-norm error of the step is below tau, with tau chosen so that tau x (rms step size, predicted from
+                                          the previous accepted step) <= pcg_forcing_tolerance radians.  (Estimate: Hestenes-Stiefel -- the squared
+                                          energy error is the sum of the LATER iterations' model decreases alpha_j r_j.z_j, extrapolated
+                                          geometrically from the last four; csrc/kernels.hpp cg_energy_stop.  Unlike a residual norm it bounds the
+                                          missing share of the step whatever the conditioning and the preconditioner.)  The loose step is
+                                          evaluated; it stands only if (a) it is an ordinary successful step (relative decrease > 0.25, cost change
+                                          and step norm more than 100 x above the function / parameter tolerances, valid model) and (b) tau x its
+                                          MEASURED rms size is within the bound.  Otherwise PCG CONTINUES from where it stopped -- to
+                                          cg_relative_tolerance for (a), to the tau the measured size asks for for (b); the solver state is
+                                          resumable and the iterates are bit for bit those of an uninterrupted solve at that tolerance -- and the
+                                          step and its cost are evaluated again.  So every decision that can end the solve, and the last accepted
+                                          step, are taken on the reference's exact step (estimator.cpp:300: SPARSE_NORMAL_CHOLESKY), and every
+                                          other iterate stays within pcg_forcing_tolerance (rms) of the one the exact step would have given.  Not
+                                          applied to disconnected graphs (their 1e-14 rule above stands) or to exact Cholesky steps.
+                                          0: every step at cg_relative_tolerance (rounds 1-3).  2 (a testing aid): every loose solve is continued
+                                          to cg_relative_tolerance whatever its evaluation says -- the solve must then reproduce pcg_forcing = 0
+                                          bit for bit, PCG iteration counts included (tests/test_gpu_round4.py). */
+  int32_t reserved0_;
+  double pcg_forcing_tolerance;        /* default 1e-8 rad: largest estimated rms deviation of an inexact step from the exact one -- two orders below
+                                          north_star's parity bar of 1e-6 rad (DESIGN.md section 6 has the measured trade: 1e-7 is 4 % faster on
+                                          the benchmark graph and flips a borderline termination on one MAGSAC test graph).  A loose iterate's
+                                          component along the gauge (all cameras rotated alike: the null space of J^T J, invisible to the energy
+                                          norm) is removed before the step is taken, as the exact step has none (kernels.hpp, k_gauge_part; for the
+                                          error types whose cost depends on R_j R_i^T alone, i.e. all but QUATERNION_NORM / ROTATION_MAT_FNORM). */
 } gsfm_rot_options;
 
 typedef enum {
@@ -205,6 +233,8 @@ typedef struct {
   int32_t num_pcg_collectives;    /*   ... of which inside PCG iterations: exactly one per LAUNCHED iteration (the all-gather of the A.p slices) */
   int32_t num_pcg_launched;       /* PCG iterations enqueued (chunks of cg_check_interval: the ones past convergence return at once, but a sharded
                                      problem's collective in them still runs); num_cg_iterations counts the effective ones */
+  int32_t num_forcing_refinements; /* forcing schedule: LM steps whose loose solve was continued to the tight tolerance after its trial evaluation */
+  int32_t num_inexact_steps;       /* forcing schedule: LM steps taken from a loose solve */
   int32_t reserved_;
 } gsfm_rot_summary;
 

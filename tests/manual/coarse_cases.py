@@ -14,7 +14,8 @@ def solve(n, ei, ej, rel, et, loss, init, coarse, cov6=None, iw=None, sigma=Fals
     if coarse is None: os.environ.pop("GSFM_PCG_COARSE", None)
     else: os.environ["GSFM_PCG_COARSE"] = coarse
     p = RotationProblem(n, ei, ej, rel, et, cov6=cov6, inlier_weight=iw); p.set_loss(loss)
-    out = p.solve_sigma_consensus(init, 3, 0.05) if sigma else p.solve(init)
+    # (pcg_forcing=0: this run compares two PRECONDITIONERS on the exact step; loose steps depend on the preconditioner by construction)
+    out = p.solve_sigma_consensus(init, 3, 0.05, pcg_forcing=0) if sigma else p.solve(init, pcg_forcing=0)
     p.close()
     return out
 

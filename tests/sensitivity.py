@@ -51,8 +51,26 @@ def ensemble_verdict(rot, ens):
     unperturbed run sits 6.7e-6 rad from all of them."""
     d = [_mean_dist(rot, r) for r, _ in ens]
     k = int(np.argmin(d))
-    nn = []
-    for i, (ri, _) in enumerate(ens):
-        nn.append(min(_mean_dist(ri, rj) for j, (rj, _) in enumerate(ens) if j != i))
-    return {"nearest": k, "nearest_dist": d[k], "nearest_iters": int(ens[k][1]["num_iterations"]), "dists": d, "member_nn": nn,
+    n = len(ens)
+    pair = [[0.0] * n for _ in range(n)]
+    for i in range(n):
+        for j in range(i + 1, n):
+            pair[i][j] = pair[j][i] = _mean_dist(ens[i][0], ens[j][0])
+    nn = [min(pair[i][j] for j in range(n) if j != i) for i in range(n)]
+    return {"nearest": k, "pair_dists": pair, "nearest_dist": d[k], "nearest_iters": int(ens[k][1]["num_iterations"]), "dists": d, "member_nn": nn,
             "iters": [int(s["num_iterations"]) for _, s in ens], "costs": [float(s["final_cost"]) for _, s in ens]}
+
+
+def ensemble_bar(v, cap=1e-5, floor=1e-6, same_iters=True):
+    """The parity bar for a device answer held against `ensemble_verdict`'s ensemble: max(floor, granularity of the NEAREST member's OWN
+    cluster), hard-capped at `cap`.  A cluster = the members that lie within `cap` * 10 of the nearest one and (`same_iters`: Madrid, where the
+    clusters go with the final iteration count) share its iteration count (the measured clusters are 4e-7..5e-6 rad wide and 2e-4 rad apart;
+    on the synthetic 150-camera graph all members reach one point within 1e-7 rad after 34..47 iterations, so there distance alone decides); its granularity = the nearest member's distance to its nearest
+    neighbour INSIDE the cluster.  A singleton cluster says nothing about its own width: that is a failure of the ensemble, not a bar --
+    the caller grows the ensemble (returns None).  So the bound can never silently become the distance BETWEEN clusters."""
+    k = v["nearest"]
+    ref = v["pair_dists"][k]
+    own = [d for j, d in enumerate(ref) if j != k and (not same_iters or v["iters"][j] == v["iters"][k]) and d <= 10 * cap]
+    if not own:
+        return None
+    return max(floor, min(cap, min(own)))

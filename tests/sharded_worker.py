@@ -39,15 +39,16 @@ def coarse_case(out, prefer_native):
     g = synth.make_graph(10000, 150000, 3, outlier_frac=0.1, local_window=300)
     loss = LF.MAGSACWeightBasedLoss(0.02)
     prob, part = sharding.make_sharded_problem(g, _abi.ANGLE_AXIS_COVARIANCE, loss=loss, prefer_native=prefer_native)
-    rot, summ = prob.solve(part.scatter(g["init_aa"]))
+    # (pcg_forcing=0 throughout: the ranks' aggregates follow the partition's order, i.e. this is preconditioner against preconditioner, on the exact step)
+    rot, summ = prob.solve(part.scatter(g["init_aa"]), pcg_forcing=0)
     n_ar = prob._comm.n_all_reduce
     os.environ["GSFM_PCG_COARSE"] = "0"
     plain, _ = sharding.make_sharded_problem(g, _abi.ANGLE_AXIS_COVARIANCE, loss=loss, prefer_native=prefer_native, part=part)
-    _, s_plain = plain.solve(part.scatter(g["init_aa"]))
+    _, s_plain = plain.solve(part.scatter(g["init_aa"]), pcg_forcing=0)
     os.environ.pop("GSFM_PCG_COARSE")
     if dist.get_rank() == 0:
         ref = RotationProblem(g["n_cams"], g["edge_i"], g["edge_j"], g["rel_aa"], _abi.ANGLE_AXIS_COVARIANCE, cov6=g["cov6"]); ref.set_loss(loss)
-        r1, s1 = ref.solve(g["init_aa"])
+        r1, s1 = ref.solve(g["init_aa"], pcg_forcing=0)
         np.savez(out, rot=part.gather(rot), ref_rot=r1, cost=summ["final_cost"], ref_cost=s1["final_cost"], iters=summ["num_iterations"], ref_iters=s1["num_iterations"],
                  cg=summ["num_cg_iterations"], ref_cg=s1["num_cg_iterations"], plain_cg=s_plain["num_cg_iterations"], n_ar=n_ar)
     dist.barrier()

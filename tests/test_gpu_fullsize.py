@@ -2,8 +2,8 @@
   C2  10k cams / 200k edges, Geman-McClure: full solve against the CPU oracle.
   C3  ETH3D-terrace stand-in: few tens of views, strongly anisotropic (COLMAP-like) covariances, MAGSAC.
   C4  14 scene-sized disconnected components solved as ONE problem (per-component gauge).
-  C5  100k cams / 10M edges: properties that do not need an oracle (gauge invariance, exact recovery of a
-      noise-free graph, linearity and symmetry of the normal mat-vec, checksum of checksums)."""
+  C5  100k cams / 10M edges: one full solve against the CPU oracle, and properties that do not need an oracle (gauge invariance,
+      exact recovery of a noise-free graph, linearity and symmetry of the normal mat-vec, checksum of checksums)."""
 import numpy as np
 import pytest
 
@@ -50,8 +50,10 @@ def test_c3_anisotropic_covariances_magsac_against_oracle(oracle):
     assert np.max(np.abs(a["s"] - b["s"]) / np.maximum(b["s"], 1e-30)) < 1e-10
     rd, sd = dev.solve(g["init_aa"])
     ro, so = ora.solve(g["init_aa"])
-    assert abs(sd["num_iterations"] - so["num_iterations"]) <= 1
-    assert abs(sd["final_cost"] - so["final_cost"]) <= 1e-5 * so["final_cost"]
+    print("C3: device %d it, oracle %d it, cost rel %.2e, mean dR %.2e rad" % (sd["num_iterations"], so["num_iterations"], abs(sd["final_cost"] - so["final_cost"]) / so["final_cost"],
+          synth.angular_distance(synth.align_rotations(rd, ro), ro).mean()))
+    assert sd["num_iterations"] == so["num_iterations"] and sd["termination"] == so["termination"]
+    assert abs(sd["final_cost"] - so["final_cost"]) <= 1e-9 * so["final_cost"]
     assert synth.angular_distance(synth.align_rotations(rd, ro), ro).mean() <= 1e-6
 
 
@@ -152,6 +154,29 @@ def test_c5_sweep_is_gauge_invariant_and_sums_its_edges(c5):
     b = dev.residuals(moved)
     assert np.max(np.abs(a["s"] - b["s"]) / np.maximum(a["s"], 1e-12)) < 1e-9
     assert abs(a["cost"] - b["cost"]) <= 1e-10 * a["cost"]
+
+
+def test_c5_full_solve_against_oracle(oracle, c5):
+    """The benchmark problem itself -- 100k cameras / 10M edges / 30 % outliers, ANGLE_AXIS_COVARIANCE + MAGSAC(0.02), default options (forcing
+    schedule included) -- against ONE solve of the CPU oracle (PCG to 1e-14; about 17 s on the GPU box's 16 usable cores): same LM iterations,
+    same termination, cost to 1e-9, rotations to north_star's 1e-6 rad (mean, after gauge alignment).  Also with the forcing schedule off."""
+    loss = LF.MAGSACWeightBasedLoss(0.02)
+    dev = _dev(c5, _abi.ANGLE_AXIS_COVARIANCE, loss)
+    ora = oracle.OracleProblem(c5["n_cams"], c5["edge_i"], c5["edge_j"], c5["rel_aa"], _abi.ANGLE_AXIS_COVARIANCE, cov6=c5["cov6"])
+    ora.set_loss(loss)
+    ro, so = ora.solve(c5["init_aa"])
+    for kw in (dict(), dict(pcg_forcing=0)):
+        rd, sd = dev.solve(c5["init_aa"], **kw)
+        d = synth.angular_distance(synth.align_rotations(rd, ro), ro)
+        print("C5 %s: device %d LM / %d PCG it (%d inexact steps, %d refined), oracle %d LM it; cost rel %.2e; dR mean %.2e max %.2e rad"
+              % (kw or "default", sd["num_iterations"], sd["num_cg_iterations"], sd["num_inexact_steps"], sd["num_forcing_refinements"], so["num_iterations"],
+                 abs(sd["final_cost"] - so["final_cost"]) / so["final_cost"], d.mean(), d.max()))
+        assert sd["num_iterations"] == so["num_iterations"] and sd["termination"] == so["termination"]
+        # cost: 1e-9 on the exact schedule; with loose early steps the last iterate differs from the oracle's by ~1e-8 rad, and it is not a
+        # stationary point (Ceres stops at function_tolerance 1e-6), so the cost follows linearly: 1e-7, a tenth of that tolerance
+        assert abs(sd["final_cost"] - so["final_cost"]) <= (1e-9 if kw else 1e-7) * so["final_cost"]
+        assert d.mean() <= 1e-6 and d.max() <= 1e-5
+        assert (sd["num_inexact_steps"] > 0) == (not kw)
 
 
 def test_c5_normal_matvec_is_linear_and_symmetric(c5):

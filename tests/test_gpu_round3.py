@@ -126,14 +126,17 @@ def test_column_sorted_solve_matches_the_oracle(oracle):
         dev = RotationProblem(g["n_cams"], g["edge_i"], g["edge_j"], g["rel_aa"], _abi.ANGLE_AXIS_COVARIANCE, cov6=g["cov6"])
     dev.set_loss(LF.MAGSACWeightBasedLoss(0.02))
     assert dev.matvec_bytes()[1] == 2
-    rd, sd = dev.solve(g["init_aa"], pcg_single_reduction=0)
     ora = oracle.OracleProblem(g["n_cams"], g["edge_i"], g["edge_j"], g["rel_aa"], _abi.ANGLE_AXIS_COVARIANCE, cov6=g["cov6"])
     ora.set_loss(LF.MAGSACWeightBasedLoss(0.02))
     ro, so = ora.solve(g["init_aa"])
-    assert sd["num_iterations"] == so["num_iterations"] and sd["termination"] == so["termination"]
-    assert abs(sd["final_cost"] - so["final_cost"]) <= 1e-9 * so["final_cost"]
-    d = synth.angular_distance(synth.align_rotations(rd, ro), ro)
-    assert d.mean() <= 1e-6, d.mean()       # the north-star bar (observed: orders of magnitude below)
+    # the exact schedule (every step at 1e-12) to 1e-9 in cost, as in round 3; the default schedule (loose early steps, round 4) lands ~1e-8 rad from
+    # it -- and the last iterate is not a stationary point (Ceres stops at function_tolerance 1e-6), so its cost follows linearly: 1e-7
+    for kw, cost_bar in ((dict(pcg_forcing=0), 1e-9), (dict(), 1e-7)):
+        rd, sd = dev.solve(g["init_aa"], pcg_single_reduction=0, **kw)
+        assert sd["num_iterations"] == so["num_iterations"] and sd["termination"] == so["termination"]
+        assert abs(sd["final_cost"] - so["final_cost"]) <= cost_bar * so["final_cost"]
+        d = synth.angular_distance(synth.align_rotations(rd, ro), ro)
+        assert d.mean() <= 1e-6, d.mean()       # the north-star bar (observed: orders of magnitude below)
 
 
 def test_edge_order_is_the_order_of_the_device_side_planes(oracle):

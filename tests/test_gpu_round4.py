@@ -1,0 +1,55 @@
+"""-m gpu: round 4 -- the forcing schedule of the PCG solves (gsfm_rot_options::pcg_forcing)."""
+import numpy as np
+import pytest
+
+from globalsfmpy_amd import _abi, synth
+from globalsfmpy_amd import loss_functions as LF
+
+pytestmark = pytest.mark.gpu
+
+
+def _problem(g, et, loss):
+    from globalsfmpy_amd.solver import RotationProblem
+    p = RotationProblem(g["n_cams"], g["edge_i"], g["edge_j"], g["rel_aa"], et, cov6=g["cov6"] if et == _abi.ANGLE_AXIS_COVARIANCE else None)
+    p.set_loss(loss)
+    return p
+
+
+@pytest.mark.parametrize("single_reduction", [0, 1])
+@pytest.mark.parametrize("n,e,et,loss", [(3000, 40000, _abi.ANGLE_AXIS_COVARIANCE, LF.MAGSACWeightBasedLoss(0.02)), (2000, 30000, _abi.ANGLE_AXIS, LF.HuberLoss(0.1)),
+                                         (1500, 20000, _abi.ROTATION_MAT_FNORM, LF.CauchyLoss(0.2))])
+def test_a_continued_solve_is_bit_for_bit_the_uninterrupted_one(n, e, et, loss, single_reduction):
+    """pcg_forcing = 2 stops every PCG solve at the loose criterion, evaluates the step, then CONTINUES the solve to the tight tolerance and
+    evaluates again.  The device state at a stop is resumable (kernels.hpp: CgScalars::done_seen, the mat-vec-entry decision of the
+    single-reduction recurrence), so the whole LM trajectory must equal the one with the schedule off: same bits, same PCG iteration counts."""
+    g = synth.make_graph(n, e, seed=31, outlier_frac=0.15)
+    p = _problem(g, et, loss)
+    kw = dict(dense_cholesky_max_cams=0, pcg_single_reduction=single_reduction)
+    r0, s0 = p.solve(g["init_aa"], pcg_forcing=0, **kw)
+    t0 = p.trace()
+    r2, s2 = p.solve(g["init_aa"], pcg_forcing=2, **kw)
+    t2 = p.trace()
+    assert s2["num_forcing_refinements"] > 0 and s2["num_inexact_steps"] == 0
+    assert np.array_equal(t0, t2), (t0[:, 7], t2[:, 7])
+    assert np.array_equal(r0, r2) and s0["final_cost"] == s2["final_cost"] and s0["num_cg_iterations"] == s2["num_cg_iterations"]
+
+
+@pytest.mark.parametrize("et,loss", [(_abi.ANGLE_AXIS_COVARIANCE, LF.MAGSACWeightBasedLoss(0.02)), (_abi.ANGLE_AXIS, LF.SoftLOneLoss(0.1)), (_abi.QUATERNION_COSINE, LF.HuberLoss(0.1))])
+def test_forcing_schedule_reaches_the_answer_of_the_exact_schedule(oracle, et, loss):
+    """Default schedule against pcg_forcing = 0 and against the oracle on a 4000-camera graph: same LM iterations, rotations two orders inside the
+    parity bar, no gauge drift (compared WITHOUT alignment: the loose steps' gauge component is removed), and fewer PCG iterations."""
+    g = synth.make_graph(4000, 60000, seed=44, outlier_frac=0.2)
+    p = _problem(g, et, loss)
+    r0, s0 = p.solve(g["init_aa"], pcg_forcing=0)
+    r1, s1 = p.solve(g["init_aa"])
+    d = synth.angular_distance(r1, r0)
+    print("et %d: %d -> %d PCG iterations (%d inexact steps, %d continued); rotations vs the exact schedule: mean %.2e max %.2e rad (no alignment)"
+          % (et, s0["num_cg_iterations"], s1["num_cg_iterations"], s1["num_inexact_steps"], s1["num_forcing_refinements"], d.mean(), d.max()))
+    assert s1["num_inexact_steps"] > 0 and s1["num_cg_iterations"] < s0["num_cg_iterations"]
+    assert s1["num_iterations"] == s0["num_iterations"] and s1["termination"] == s0["termination"]
+    assert d.mean() <= 1e-8 and d.max() <= 1e-6
+    ora = oracle.OracleProblem(g["n_cams"], g["edge_i"], g["edge_j"], g["rel_aa"], et, cov6=g["cov6"] if et == _abi.ANGLE_AXIS_COVARIANCE else None)
+    ora.set_loss(loss)
+    ro, so = ora.solve(g["init_aa"])
+    assert s1["num_iterations"] == so["num_iterations"]
+    assert synth.angular_distance(synth.align_rotations(r1, ro), ro).mean() <= 1e-6
