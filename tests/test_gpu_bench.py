@@ -19,7 +19,10 @@ def _json_line(stdout):
 
 
 def test_bench_single_gpu_contract_line():
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + SMALL, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    # (with the cpu_baseline leg: the oracle solves the same graph, so the line carries a device-vs-CPU comparison that is asserted below)
+    small = [a for a in SMALL]
+    small[small.index("--cpu-baseline") + 1] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + small + ["--cpu-single-cams", "0"], cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     out = _json_line(r.stdout)
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
@@ -31,6 +34,13 @@ def test_bench_single_gpu_contract_line():
     other = out["roofline_other"]
     assert {"k_lin", "k_cost_trial", "k_cost_full", "k_cost_s_only", "sigma_consensus_K6"} <= set(other)
     assert other["k_cost_full"]["kernel_ms"] >= other["k_cost_trial"]["kernel_ms"] * 0.9   # the stores cost something
+    # the CPU baseline solved the benchmark graph itself: it doubles as the parity check of the measured configuration (default PCG schedule)
+    cmp_ = out["cpu_baseline"]["device_vs_cpu"]
+    assert cmp_["mean_angular_difference_rad"] <= 1e-6 and cmp_["lm_iterations_device"] == cmp_["lm_iterations_cpu"], cmp_
+    # both schedules of the PCG tolerance are reported, `value` is the default one, and they agree
+    assert out["pcg_schedule"]["pcg_forcing"] == 1 and out["exact_schedule"]["pcg_forcing"] == 0
+    assert out["exact_schedule"]["default_schedule_vs_this"]["mean_angular_difference_rad"] <= 1e-6
+    assert out["exact_schedule"]["cg_iterations"] >= out["cg_iterations_per_solve"]
 
 
 def test_bench_two_ranks_on_one_gpu_over_gloo():
@@ -67,3 +77,19 @@ def test_bench_single_rank_over_native_rccl_prints_exactly_one_stdout_line():
     # the native communicator's callbacks only enqueue on the solver's stream: the PCG chunks are captured WITH their all-gathers and
     # replayed as hipGraphs by default, one collective per PCG iteration
     assert out["collectives_per_pcg_iteration"] == 1.0 and out["pcg_chunks_replayed_as_hipgraphs"] > 0
+    # ... measured AFTER a plain-launch pass (no hipGraph in a sharded solve), which is what the line falls back to should the captured variant hang
+    assert out["hipgraph_with_collectives"]["status"] == "ok" and out["hipgraph_with_collectives"]["same_final_cost"]
+    assert out["plain_launches"]["pcg_chunks_replayed_as_hipgraphs"] == 0 and out["plain_launches"]["value"] > 0
+
+
+def test_bench_falls_back_to_the_plain_launch_line_when_the_captured_variant_does_not_return():
+    """The watchdog of the hipGraph-with-collectives attempt, forced to fire (limit 1 ms): rank 0 still prints ONE line -- the plain-launch
+    measurement -- and the process ends with status 0 instead of 124 and no line (round-3 review)."""
+    env = dict(os.environ, GSFM_FORCE_SHARD="1", HSA_ENABLE_IPC_MODE_LEGACY="0", GSFM_BENCH_CAPTURE_WATCHDOG_S="0.001")
+    port = 29980 + os.getpid() % 9
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "1"] + SMALL + ["--sigma-pass", "0"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    out = _json_line(r.stdout)
+    assert "watchdog" in out["hipgraph_with_collectives"]["status"] and out["value"] > 0 and out["pcg_chunks_replayed_as_hipgraphs"] == 0
