@@ -279,20 +279,112 @@ class NativeComm(object):
             self._ctx = None
 
 
-def make_comm(width, prefer_native=True, group=None):
+class PeerComm(object):
+    """The two collectives as PEER STORES (csrc/gsfm_peer.hip): every rank's slice is written straight into a mailbox of every other rank
+    through hipIpcMemHandle-mapped pointers (over xGMI on a multi-GPU node) and a flag word tells the owner it has arrived -- two small
+    kernels on the solver's stream per collective, no collective-library launch inside the PCG loop, capturable into the PCG hipGraphs.
+    Calls that do not fit the mailbox (sized for the per-camera exchanges of the solve) go to `fallback` (NativeComm / TorchComm).
+    torch.distributed is used once, to exchange the IPC handles."""
+
+    def __init__(self, width, fallback, group=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist, self.fallback = torch, dist, fallback
+        self.rank, self.world, self.P = dist.get_rank(group), dist.get_world_size(group), int(width)
+
+        def all_ok(flag):
+            t = torch.tensor([1 if flag else 0], dtype=torch.int32, device="cuda" if dist.get_backend(group) == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+            return bool(t.item())
+
+        here = os.path.dirname(os.path.abspath(__file__))
+        lib, ctx, why = None, None, ""
+        try:
+            lib = C.CDLL(os.path.join(here, "libgsfm_peer.so"))
+            lib.gsfm_peer_last_error.restype = C.c_char_p
+            lib.gsfm_peer_create.restype = C.c_void_p
+            lib.gsfm_peer_create.argtypes = [C.c_int, C.c_int, C.c_size_t, C.c_char_p]
+            lib.gsfm_peer_connect.argtypes = [C.c_void_p, C.c_char_p]
+            lib.gsfm_peer_set_fallback.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+            lib.gsfm_peer_destroy.argtypes = [C.c_void_p]
+            lib.gsfm_peer_error.argtypes = [C.c_void_p]
+            lib.gsfm_peer_calls.argtypes = [C.c_void_p, C.c_int]
+            lib.gsfm_peer_calls.restype = C.c_long
+            nb = lib.gsfm_peer_handle_bytes()
+            handle = C.create_string_buffer(nb)
+            # gD slices (9 per camera) are the widest per-camera exchange; the PCG slot is 3 per camera + at most 8192 partial dot products
+            ctx = lib.gsfm_peer_create(self.rank, self.world, 9 * self.P + 16384, handle)
+            if not ctx:
+                why = lib.gsfm_peer_last_error().decode()
+        except OSError as e:
+            why = str(e)
+        if not all_ok(bool(ctx)):
+            if ctx:
+                lib.gsfm_peer_destroy(ctx)
+            raise RuntimeError("peer exchange unavailable on some rank%s" % (": " + why if why else ""))
+        handles = [None] * self.world
+        dist.all_gather_object(handles, handle.raw, group=group)
+        rc = lib.gsfm_peer_connect(ctx, b"".join(handles))
+        if not all_ok(rc == 0):
+            why = lib.gsfm_peer_last_error().decode() if rc else ""
+            lib.gsfm_peer_destroy(ctx)
+            raise RuntimeError("peer exchange: a mailbox could not be mapped%s" % (": " + why if why else " (on another rank)"))
+        fs = fallback.shard
+        lib.gsfm_peer_set_fallback(ctx, fs.ctx, C.cast(fs.all_gather, C.c_void_p), C.cast(fs.all_reduce_sum, C.c_void_p))
+        self._lib, self._ctx = lib, ctx
+        self.backend = "peer-store+" + fallback.backend
+        self.n_all_gather = self.n_all_reduce = -1
+        ag = C.cast(lib.gsfm_peer_all_gather, C.c_void_p).value
+        ar = C.cast(lib.gsfm_peer_all_reduce_sum, C.c_void_p).value
+        # capturable: every collective inside a PCG chunk fits the mailbox, i.e. is two plain kernel launches on the solver's stream
+        self.shard = _abi.Shard(rank=self.rank, world_size=self.world, slice_width=self.P, flags=_abi.SHARD_CAPTURABLE, ctx=ctx,
+                                all_gather=_abi.ALL_GATHER_FN(ag), all_reduce_sum=_abi.ALL_REDUCE_FN(ar))
+
+    def stream_handle(self):
+        return None
+
+    def calls(self):
+        """(collectives served by peer stores, collectives handed to the fallback)"""
+        return int(self._lib.gsfm_peer_calls(self._ctx, 0)), int(self._lib.gsfm_peer_calls(self._ctx, 1))
+
+    def error(self):
+        """True if a wait for a peer's flag ever ran into its bound (that solve's result is then invalid)."""
+        return bool(self._lib.gsfm_peer_error(self._ctx))
+
+    def close(self):
+        if self._ctx:
+            self.torch.cuda.synchronize()
+            self.dist.barrier()          # nobody unmaps a mailbox a peer may still be storing into
+            self._lib.gsfm_peer_destroy(self._ctx)
+            self._ctx = None
+        if hasattr(self.fallback, "close"):
+            self.fallback.close()
+
+
+def make_comm(width, prefer_native=True, group=None, exchange=None):
     """The two collectives for slices of `width` cameras (Partition.width): NativeComm when RCCL can be driven from C++ (backend nccl),
     else the torch.distributed callbacks."""
     import torch.distributed as dist
+    exchange = exchange or os.environ.get("GSFM_EXCHANGE", "collective")   # "peer": peer-store exchange (PeerComm) over the comm chosen below
+    comm = None
     if prefer_native and dist.get_backend(group) == "nccl" and os.environ.get("GSFM_NO_NATIVE_RCCL") is None:
         try:
-            return NativeComm(width, group)
+            comm = NativeComm(width, group)
         except Exception as e:  # noqa: BLE001
             import sys
             print("gsfm: native RCCL unavailable (%r); falling back to torch.distributed collectives" % (e,), file=sys.stderr)
-    return TorchComm(width, group)
+    if comm is None:
+        comm = TorchComm(width, group)
+    if exchange == "peer":
+        try:
+            return PeerComm(width, comm, group)
+        except Exception as e:  # noqa: BLE001  (every rank raises together: the failure is agreed on inside PeerComm)
+            import sys
+            print("gsfm: peer-store exchange unavailable (%r); using %s collectives" % (e, comm.backend), file=sys.stderr)
+    return comm
 
 
-def make_sharded_problem(graph, error_type, loss=None, prefer_native=True, group=None, part=None):
+def make_sharded_problem(graph, error_type, loss=None, prefer_native=True, group=None, part=None, exchange=None):
     """graph: dict from synth.make_graph (global, identical on every rank).  Partitions the cameras, builds this rank's share of the
     problem and returns (problem, partition); per-camera arrays enter and leave through partition.scatter / .gather."""
     import torch.distributed as dist
@@ -301,7 +393,7 @@ def make_sharded_problem(graph, error_type, loss=None, prefer_native=True, group
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     if part is None:
         part = partition_cameras(n, graph["edge_i"], graph["edge_j"], world)
-    comm = make_comm(part.width, prefer_native, group)
+    comm = make_comm(part.width, prefer_native, group, exchange)
     # (whether the GLOBAL graph is disconnected -- it decides the PCG tolerance -- is worked out inside gsfm_rot_problem_create from all
     # ranks' edges since round 3; the SHARD_DISCONNECTED flag is no longer needed here)
     ei, ej = part.relabel(graph["edge_i"]), part.relabel(graph["edge_j"])

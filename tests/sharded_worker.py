@@ -116,6 +116,9 @@ def main():
     if case == "disconnected":
         g = two_component_graph()
     prefer_native = len(sys.argv) > 3 and sys.argv[3] == "native"
+    exchange = "peer" if len(sys.argv) > 3 and sys.argv[3].startswith("peer") else None   # "peer": peer-store mailboxes (csrc/gsfm_peer.hip) over the chosen collectives
+    if exchange and sys.argv[3] == "peer-native":
+        prefer_native = True
     world = dist.get_world_size()
     if case == "isolated":   # hand-made partition: ranks 0..world-2 share the 1100 connected cameras, the last rank owns only isolated ones
         cuts = [int(v) for v in np.linspace(0, 1100, world)] + [g["n_cams"]]
@@ -137,7 +140,7 @@ def main():
         init = part.scatter(g["init_aa"])
         rot, summ = prob.solve(init, max_num_iterations=6)
     else:
-        prob, part = sharding.make_sharded_problem(g, _abi.ANGLE_AXIS_COVARIANCE, loss=MAGSACWeightBasedLoss(0.02), prefer_native=prefer_native, part=part)
+        prob, part = sharding.make_sharded_problem(g, _abi.ANGLE_AXIS_COVARIANCE, loss=MAGSACWeightBasedLoss(0.02), prefer_native=prefer_native, part=part, exchange=exchange)
         comm = prob._comm
         init = part.scatter(g["init_aa"])
         opts = {"pcg_hip_graph": int(os.environ["GSFM_TEST_PCG_GRAPH"])} if "GSFM_TEST_PCG_GRAPH" in os.environ else {}
@@ -147,7 +150,11 @@ def main():
         np.savez(out, rot=part.gather(rot), cost=summ["final_cost"], iters=summ["num_iterations"], cg=summ["num_cg_iterations"],
                  term=summ["termination"], backend=comm.backend, n_ag=comm.n_all_gather, n_ar=comm.n_all_reduce, sweep_ms=sweep_ms,
                  trace=prob.trace(), outer=summ["outer_iterations"], wchange=summ["last_weight_change"],
-                 graph_launches=summ["num_graph_launches"])
+                 graph_launches=summ["num_graph_launches"], peer_calls=(comm.calls() if hasattr(comm, "calls") else (0, 0)),
+                 peer_error=(comm.error() if hasattr(comm, "error") else False), pcg_collectives=summ["num_pcg_collectives"])
+    if hasattr(comm, "calls"):
+        prob.close()
+        comm.close()
     dist.barrier()
     dist.destroy_process_group()
 

@@ -198,3 +198,34 @@ def test_two_level_preconditioner_on_a_sharded_coherent_graph(tmp_path, world):
     assert int(res["iters"]) == int(res["ref_iters"]) and abs(int(res["cg"]) - int(res["ref_cg"])) <= 0.05 * int(res["ref_cg"]) + 2
     assert abs(float(res["cost"]) - float(res["ref_cost"])) <= 1e-9 * float(res["ref_cost"])
     assert synth.angular_distance(res["rot"], res["ref_rot"]).max() < 1e-8
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_peer_store_exchange_equals_the_host_staged_collectives_bit_for_bit(tmp_path, world):
+    """csrc/gsfm_peer.hip: every rank writes its slice into the other ranks' IPC-mapped mailboxes and a flag says it has arrived -- the
+    all-gather of every PCG iteration and of every linearisation, and the scalar all-reduces, without a collective-library call.  N processes
+    sharing the one GPU of the test box map each other's mailboxes exactly as N GPUs of a node would (hipIpcMemHandle); the solve must
+    reproduce the gloo path's rotations bit for bit (an all-gather moves bits; the scalar all-reduce adds the ranks' shares in rank order on every rank)."""
+    a = _launch(world, "gloo", str(tmp_path / ("peer%d.npz" % world)), mode="peer")
+    b = _launch(world, "gloo", str(tmp_path / ("gloo%d.npz" % world)))
+    assert str(a["backend"]) == "peer-store+gloo" and not bool(a["peer_error"])
+    served, fell_back = (int(v) for v in a["peer_calls"])
+    # (host-side count: a captured chunk's exchanges are counted once, at capture; nothing of the solve may need the fallback)
+    assert served > 0 and int(a["pcg_collectives"]) > 0 and fell_back <= 2, (served, fell_back)
+    assert int(a["cg"]) == int(b["cg"]) and int(a["iters"]) == int(b["iters"])
+    if world == 2:   # an all-gather moves bits and a two-term sum has one order: the whole solve is bit-identical
+        assert np.array_equal(a["rot"], b["rot"]) and float(a["cost"]) == float(b["cost"]) and np.array_equal(a["trace"], b["trace"])
+    else:            # the cost all-reduce: gloo adds the ranks' shares in its ring's order, the mailbox in rank order -- last-bit differences in the
+        #              costs, which the trust-region radius law feeds back into the steps
+        assert synth.angular_distance(a["rot"], b["rot"]).max() <= 1e-12 and abs(float(a["cost"]) - float(b["cost"])) <= 1e-13 * float(b["cost"])
+        assert np.allclose(a["trace"], b["trace"], rtol=1e-9, atol=0.0)
+    _compare(a, _reference())
+
+
+def test_peer_store_exchange_inside_the_captured_pcg_chunks(tmp_path):
+    """The two kernels of a peer-store collective take no per-call arguments (the sequence number lives on the device), so the chunks of PCG
+    iterations replay as hipGraphs WITH their exchanges: same bits as plain launches."""
+    a = _launch(2, "gloo", str(tmp_path / "peer_graph.npz"), mode="peer", extra_env={"GSFM_TEST_PCG_GRAPH": "1"})
+    b = _launch(2, "gloo", str(tmp_path / "peer_plain.npz"), mode="peer", extra_env={"GSFM_TEST_PCG_GRAPH": "0"})
+    assert int(a["graph_launches"]) > 0 and int(b["graph_launches"]) == 0 and not bool(a["peer_error"])
+    assert np.array_equal(a["rot"], b["rot"]) and int(a["cg"]) == int(b["cg"])
