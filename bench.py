@@ -318,14 +318,17 @@ def main():
     torch.cuda.synchronize()
     t_create = time.perf_counter() - t_create
 
+    prob_main = prob
+
     def barrier():
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed_solves(n_warm, n_steps, **opts):
+    def timed_solves(n_warm, n_steps, problem=None, **opts):
         """W untimed + exactly K timed solves bracketed by barrier + synchronize; returns (seconds, max over ranks; sweeps; last summary; last rotations)."""
+        prob = problem if problem is not None else prob_main
         summ_, rot_ = None, None
         for _ in range(n_warm):
             _, summ_ = prob.solve(init, verbose=args.verbose if rank == 0 else 0, **opts)
@@ -551,6 +554,46 @@ def main():
                                                 "same_final_cost": s_c["final_cost"] == out["final_cost"]}
             out["value"], out["ms_per_step"] = n_edges * sw_c / el_c, 1e3 * el_c / args.steps     # the library's default configuration
             out["pcg_chunks_replayed_as_hipgraphs"] = s_c["num_graph_launches"]
+    want_peer = os.environ.get("GSFM_BENCH_PEER", "1" if backend == "nccl" else "0") != "0"
+    if part is not None and world > 1 and want_peer:
+        # Third variant: the per-iteration all-gather as PEER STORES into IPC-mapped mailboxes (csrc/gsfm_peer.hip) instead of a collective-library
+        # call -- never run across GPUs before this launch either, so: own watchdog, accepted only if it reproduces the final cost, and `value`
+        # takes it only if it is faster.
+        import threading
+        limit = float(os.environ.get("GSFM_BENCH_CAPTURE_WATCHDOG_S", "300"))
+
+        def _fall_back_peer():
+            sys.stderr.write("bench.py rank %d: the peer-store variant did not finish within %.0f s: reporting what was measured before\n" % (rank, limit))
+            if rank == 0:
+                out["peer_store_exchange"] = {"status": "no result within %.0f s (watchdog)" % limit}
+                os.write(real_stdout, (json.dumps(out) + "\n").encode())
+            os._exit(0)
+        wd = threading.Timer(limit, _fall_back_peer)
+        wd.daemon = True
+        wd.start()
+        info = {"status": "unavailable"}
+        try:
+            prob_p, _ = sharding.make_sharded_problem(g, error_type, loss=loss_ctor(), part=part, exchange="peer")
+            if prob_p._comm.backend.startswith("peer-store"):
+                el_p, sw_p, s_p, _ = timed_solves(args.warmup, args.steps, problem=prob_p)
+                bad = prob_p._comm.error()
+                info = {"status": "ok" if not bad else "a wait for a peer's flag ran into its bound: result discarded", "backend": prob_p._comm.backend,
+                        "value": n_edges * sw_p / el_p, "ms_per_step": 1e3 * el_p / args.steps, "pcg_chunks_replayed_as_hipgraphs": s_p["num_graph_launches"],
+                        "final_cost": s_p["final_cost"], "lm_iterations": s_p["num_iterations"], "cg_iterations": s_p["num_cg_iterations"]}
+                if rank == 0:
+                    same = abs(s_p["final_cost"] - out["final_cost"]) <= 1e-12 * abs(out["final_cost"]) and s_p["num_iterations"] == out["lm_iterations"]
+                    info["reproduces_the_collective_run"] = bool(same)
+                    if same and not bad and info["value"] > out["value"]:
+                        out["value"], out["ms_per_step"] = info["value"], info["ms_per_step"]
+                        out["config"]["collectives"] = prob_p._comm.backend
+                        out["pcg_chunks_replayed_as_hipgraphs"] = info["pcg_chunks_replayed_as_hipgraphs"]
+            prob_p.close()
+            prob_p._comm.close()
+        except Exception as e:  # noqa: BLE001  (the extra variant never takes the line down with it)
+            info = {"status": "failed: %r" % (e,)}
+        wd.cancel()
+        if rank == 0:
+            out["peer_store_exchange"] = info
     if rank == 0:
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())

@@ -46,15 +46,17 @@ def test_bench_single_gpu_contract_line():
 def test_bench_two_ranks_on_one_gpu_over_gloo():
     """`python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2`: camera partition, sharded problem creation (with its
     agreement all-reduce), all-gathers inside PCG, max-over-ranks timing, rank 0's JSON line."""
-    env = dict(os.environ, GSFM_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, GSFM_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", GSFM_BENCH_PEER="1")   # (+ the peer-store variant, which nccl launches try by default)
     port = 29900 + os.getpid() % 90
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.path.join(ROOT, "bench.py"), "--gpus", "2"] + SMALL
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     out = _json_line(r.stdout)
-    assert out["n_gpus"] == 2 and out["value"] > 0 and out["config"]["parallelism"] == "camera-slice x2" and out["config"]["collectives"] == "gloo"
+    assert out["n_gpus"] == 2 and out["value"] > 0 and out["config"]["parallelism"] == "camera-slice x2" and out["config"]["collectives"] in ("gloo", "peer-store+gloo")
     assert out["collectives_per_pcg_iteration"] == 1.0 and out["collectives_per_solve"] > out["cg_iterations_per_solve"]   # exactly one collective per PCG iteration
+    ps = out["peer_store_exchange"]
+    assert ps["status"] == "ok" and ps["reproduces_the_collective_run"] and ps["backend"] == "peer-store+gloo" and ps["pcg_chunks_replayed_as_hipgraphs"] > 0, ps
     one = _json_line(subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + SMALL + ["--sigma-pass", "0"], cwd=ROOT, capture_output=True, text=True, timeout=900).stdout)
     assert out["lm_iterations"] == one["lm_iterations"] and out["residual_sweeps_per_solve"] == one["residual_sweeps_per_solve"]
     assert abs(out["final_cost"] - one["final_cost"]) <= 1e-6 * one["final_cost"]
