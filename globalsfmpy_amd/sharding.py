@@ -26,6 +26,8 @@ class Partition(object):
         self.n_pad = self.world * self.width
         self.new_id = new_id
         self.entries_per_rank = entries_per_rank
+        self.packed_components = False   # True: whole connected components per rank (pack_components); split_components of them had to be cut
+        self.split_components = 0
 
     def scatter(self, per_camera, fill=0.0):
         """(n_cams, ...) in the caller's numbering -> (n_pad, ...) in the problem's."""
@@ -58,11 +60,72 @@ def locality_order(n_cams, edge_i, edge_j):
     return order
 
 
-def partition_cameras(n_cams, edge_i, edge_j, world_size, order=None):
+def connected_components(n_cams, edge_i, edge_j):
+    """Component label per camera (cameras without an edge are their own component), labels 0..n_comp-1 in order of first appearance."""
+    from scipy.sparse import coo_matrix
+    from scipy.sparse.csgraph import connected_components as cc
+    ei, ej = np.asarray(edge_i, dtype=np.int64), np.asarray(edge_j, dtype=np.int64)
+    n_comp, lab = cc(coo_matrix((np.ones(ei.size, dtype=np.int8), (ei, ej)), shape=(n_cams, n_cams)), directed=False)
+    return int(n_comp), lab.astype(np.int64)
+
+
+def pack_components(n_cams, edge_i, edge_j, world_size, order, deg, max_imbalance=1.25):
+    """SURVEY 8(e), configuration C4 (several scenes batched as one disconnected graph): WHOLE connected components per rank, so that no edge is
+    cut -- every rank holds exactly its own edges instead of its own plus the cut ones, and its mat-vec gathers stay inside its slice --
+    balanced by directed entries with the longest-processing-time rule (pieces by decreasing size, each to the least loaded rank).  A scene
+    heavier than a rank's fair share (Trafalgar among the 1DSfM scenes on 8 GPUs) is first cut into that many contiguous runs of its locality
+    order, so only ITS edges can be cut.  Returns (per-rank camera lists, number of components that were split), or None when the graph is
+    connected (one component with edges) or the packing still leaves the busiest rank more than `max_imbalance` x the mean."""
+    n_comp, lab = connected_components(n_cams, edge_i, edge_j)
+    load = np.bincount(lab, weights=deg, minlength=n_comp)
+    with_edges = np.flatnonzero(load > 0)
+    if with_edges.size < 2:
+        return None
+    pos = np.empty(n_cams, dtype=np.int64)
+    pos[order] = np.arange(n_cams)
+    by_comp = np.lexsort((pos, lab))                       # cameras grouped by component, locality order inside
+    start = np.searchsorted(lab[by_comp], np.arange(n_comp + 1))
+    target = load.sum() / world_size
+    pieces, n_split = [], 0                               # (load, cameras)
+    for c in with_edges:
+        cams = by_comp[start[c]:start[c + 1]]
+        k = int(max(1, np.ceil(load[c] / target - 0.25)))
+        if k == 1:
+            pieces.append((float(load[c]), cams))
+            continue
+        n_split += 1
+        cs = np.cumsum(deg[cams])
+        cuts = [0] + [int(np.searchsorted(cs, load[c] * t / k, side="left")) + 1 for t in range(1, k)] + [cams.size]
+        for t in range(k):
+            lo, hi = min(cuts[t], cams.size), min(max(cuts[t + 1], cuts[t]), cams.size)
+            if hi > lo:
+                pieces.append((float(deg[cams[lo:hi]].sum()), cams[lo:hi]))
+    if len(pieces) < world_size:
+        return None
+    rank_load = np.zeros(world_size)
+    members = [[] for _ in range(world_size)]
+    for ld, cams in sorted(pieces, key=lambda p: -p[0]):
+        r = int(np.argmin(rank_load))
+        rank_load[r] += ld
+        members[r].append(cams)
+    if rank_load.max() > max_imbalance * rank_load.mean():
+        return None
+    # cameras without an edge: dealt out to even the camera counts (they cost nothing but a row of padding)
+    iso = by_comp[np.isin(lab[by_comp], np.flatnonzero(load == 0))]
+    counts = np.array([sum(c.size for c in m) for m in members])
+    for chunk in np.array_split(iso, max(1, min(iso.size, 4 * world_size))) if iso.size else []:
+        r = int(np.argmin(counts))
+        members[r].append(chunk)
+        counts[r] += chunk.size
+    return [np.concatenate(m) if m else np.empty(0, dtype=np.int64) for m in members], n_split
+
+
+def partition_cameras(n_cams, edge_i, edge_j, world_size, order=None, pack=True):
     """Contiguous slices of the locality ordering, cut so that every rank owns (nearly) the same number of directed entries
     (= block-CSR rows' worth of mat-vec work), every rank at least one camera.  In a spatially coherent view graph most
     neighbours of a rank's cameras then live on the same rank, so the gathers of the mat-vec stay inside its own slice; in a
-    uniformly random graph every balanced partition cuts (world-1)/world of the edges and only the balance matters."""
+    uniformly random graph every balanced partition cuts (world-1)/world of the edges and only the balance matters.
+    A DISCONNECTED graph with enough components is packed instead -- whole components per rank, no edge cut (pack_components)."""
     n_cams, world_size = int(n_cams), int(world_size)
     if world_size < 1 or n_cams < world_size:
         raise ValueError("need at least one camera per rank (%d cameras, %d ranks)" % (n_cams, world_size))
@@ -70,6 +133,18 @@ def partition_cameras(n_cams, edge_i, edge_j, world_size, order=None):
         order = locality_order(n_cams, edge_i, edge_j)
     order = np.asarray(order, dtype=np.int64)
     deg = np.bincount(np.asarray(edge_i, dtype=np.int64), minlength=n_cams) + np.bincount(np.asarray(edge_j, dtype=np.int64), minlength=n_cams)
+    if pack and world_size > 1:
+        packed = pack_components(n_cams, edge_i, edge_j, world_size, order, deg)
+        if packed is not None and all(m.size > 0 for m in packed[0]):
+            members, n_split = packed
+            width = max(m.size for m in members)
+            new_id = np.empty(n_cams, dtype=np.int64)
+            for r, m in enumerate(members):
+                new_id[m] = r * width + np.arange(m.size)
+            part = Partition(n_cams, world_size, width, new_id, [int(deg[m].sum()) for m in members])
+            part.packed_components, part.split_components = True, n_split
+            assert np.unique(new_id).size == n_cams
+            return part
     csum = np.cumsum(deg[order])
     total = int(csum[-1]) if n_cams else 0
     cuts = [0]

@@ -122,3 +122,40 @@ def test_partition_is_a_valid_relabelling_for_every_small_size():
             assert per_rank.min() >= 1 and per_rank.max() <= part.width, (world, n)
     with pytest.raises(ValueError):
         sharding.partition_cameras(3, [0, 1], [1, 2], 4)
+
+
+def test_disconnected_scenes_are_packed_whole_components_per_rank():
+    """BASELINE C4 (14 scenes as one disconnected graph): whole components per rank -- no edge is held by two ranks -- balanced by
+    directed entries; only a scene heavier than a rank's fair share is cut (into contiguous runs of its locality order); a connected graph
+    is never packed."""
+    from globalsfmpy_amd import sharding, synth
+    sizes = [227, 340, 394, 480, 530, 577, 677, 800, 970, 1100, 1300, 1500, 2100, 5288]       # scene sizes after performance.rst:78-92
+    gs = [synth.make_graph(n, 12 * n, seed=100 + k, outlier_frac=0.1) for k, n in enumerate(sizes)]
+    off = np.cumsum([0] + [g["n_cams"] for g in gs])
+    ei = np.concatenate([g["edge_i"].astype(np.int64) + o for g, o in zip(gs, off)])
+    ej = np.concatenate([g["edge_j"].astype(np.int64) + o for g, o in zip(gs, off)])
+    n = int(off[-1])
+    shuffle = np.random.default_rng(5).permutation(n)               # scene membership is not visible in the ids
+    ei, ej = shuffle[ei], shuffle[ej]
+    scene = np.empty(n, dtype=np.int64)
+    scene[shuffle] = np.repeat(np.arange(len(sizes)), sizes)
+    for world, expect_split in ((2, 0), (4, 1), (8, 2)):
+        part = sharding.partition_cameras(n, ei, ej, world)
+        assert part.packed_components and part.split_components <= expect_split, (world, part.split_components)
+        a, b = part.relabel(ei), part.relabel(ej)
+        cut = (a // part.width) != (b // part.width)
+        assert set(np.unique(scene[ei[cut]]).tolist()) <= {12, 13}      # only the heavy scenes (2100 / 5288 cameras) may have cut edges
+        held = sum(int(sharding.local_edge_mask(part, a, b, r).sum()) for r in range(world))
+        assert held == ei.size + int(cut.sum())                     # an uncut edge lives on exactly one rank
+        if part.split_components == 0:
+            assert not cut.any()
+        load = np.array(part.entries_per_rank, dtype=float)
+        assert load.max() <= 1.25 * load.mean() and load.sum() == 2 * ei.size
+        assert np.unique(part.new_id).size == n and part.new_id.max() < part.n_pad
+        # against the contiguous cut of the same graph: fewer cut edges (the scenes here are random graphs inside, so a scene that HAS to be split
+        # loses the share of its edges any balanced cut loses; real scenes are coherent and lose far less)
+        plain = sharding.partition_cameras(n, ei, ej, world, pack=False)
+        pa, pb = plain.relabel(ei), plain.relabel(ej)
+        assert cut.sum() <= ((pa // plain.width) != (pb // plain.width)).sum()
+    g = synth.make_graph(500, 4000, seed=1)
+    assert not sharding.partition_cameras(500, g["edge_i"], g["edge_j"], 4).packed_components
