@@ -10,7 +10,7 @@
 //   k_peer_pull   waits (system-scope acquire, bounded) until all `world` flags of its OWN mailbox carry the sequence number, then copies
 //                 the slots into the caller's buffer -- or, for the sum all-reduce, adds them in rank order (the same order on every rank:
 //                 bit-identical sums everywhere).
-// The sequence number is a device-resident counter advanced by k_peer_pull, so both kernels take no per-call arguments and a chunk of PCG
+// The sequence number is a device-resident counter advanced by the last workgroup of k_peer_pull, so both kernels take no per-call arguments and a chunk of PCG
 // iterations containing them replays as a hipGraph.  Buffers alternate with the call's parity: a rank can be at most one call ahead of a
 // peer (it needs that peer's flag to finish its own call), so the slot it overwrites was read two calls ago.
 // A call larger than the mailbox, or a communicator that could not map every peer, goes to the fallback callbacks (RCCL, or the
@@ -35,7 +35,7 @@ struct PeerDev {
   double* box[MAX_WORLD];            // mailbox base of every rank (own entry = local pointer)
   unsigned long long* flags[MAX_WORLD];   // flag words of every rank's mailbox: flags[p][r] = last call rank r has delivered to rank p
   unsigned long long* seq;           // local: calls completed
-  unsigned int* done_blocks;         // local: workgroups of the current push that have finished storing
+  unsigned int* done_blocks;         // local: [0] workgroups of the current push that have finished storing, [1] of the current pull that have finished reading
   int* error;                        // local, host-visible: 1 = a wait ran into its bound
 };
 
@@ -76,7 +76,14 @@ __global__ void __launch_bounds__(PEER_BLOCK) k_peer_pull(PeerDev d, double* dst
     }
   }
   __syncthreads();
-  if (!ok) { if (threadIdx.x == 0) *d.error = 1; return; }
+  if (!ok) {   // give up on this call (flagged for the host), but keep the call counter moving so that later calls line up again
+    if (threadIdx.x == 0) {
+      *d.error = 1;
+      const unsigned int n = __hip_atomic_fetch_add(d.done_blocks + 1, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+      if (n == gridDim.x - 1) { __hip_atomic_store(d.done_blocks + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); *d.seq = call; }
+    }
+    return;
+  }
   const unsigned long long stride = (unsigned long long)gridDim.x * PEER_BLOCK, i0 = (unsigned long long)blockIdx.x * PEER_BLOCK + threadIdx.x;
   if (mode == 0) {
     for (int p = 0; p < d.world; ++p) {
@@ -92,9 +99,13 @@ __global__ void __launch_bounds__(PEER_BLOCK) k_peer_pull(PeerDev d, double* dst
       dst[i] = acc;
     }
   }
+  // the last workgroup to finish advances the call counter (every workgroup has read it by then: it reads it before anything else)
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned int n = __hip_atomic_fetch_add(d.done_blocks + 1, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (n == gridDim.x - 1) { __hip_atomic_store(d.done_blocks + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); *d.seq = call; }
+  }
 }
-// (its own launch: every workgroup of k_peer_pull reads the counter at its start)
-__global__ void k_peer_advance(PeerDev d) { *d.seq = *d.seq + 1ull; }
 
 typedef int (*coll_fn)(void*, double*, size_t, void*);
 
@@ -134,7 +145,7 @@ void* gsfm_peer_create(int rank, int world, size_t cap_doubles, char* handle_out
   if (e != hipSuccess) { fail(std::string("mailbox allocation: ") + hipGetErrorString(e)); delete P; return nullptr; }
   bool ok = hipMemset(P->local, 0, P->bytes) == hipSuccess;
   ok = ok && hipMalloc((void**)&P->d_seq, sizeof(unsigned long long)) == hipSuccess && hipMemset(P->d_seq, 0, sizeof(unsigned long long)) == hipSuccess;
-  ok = ok && hipMalloc((void**)&P->d_done, sizeof(unsigned int)) == hipSuccess && hipMemset(P->d_done, 0, sizeof(unsigned int)) == hipSuccess;
+  ok = ok && hipMalloc((void**)&P->d_done, 2 * sizeof(unsigned int)) == hipSuccess && hipMemset(P->d_done, 0, 2 * sizeof(unsigned int)) == hipSuccess;
   ok = ok && hipHostMalloc((void**)&P->h_error, sizeof(int), hipHostMallocMapped) == hipSuccess;
   hipIpcMemHandle_t h;
   ok = ok && hipIpcGetMemHandle(&h, P->local) == hipSuccess;
@@ -185,7 +196,6 @@ static int peer_collective(Peer* P, double* buf, size_t count, void* stream, int
   const unsigned grid = (unsigned)((count + PEER_BLOCK - 1) / PEER_BLOCK) < 64u ? (unsigned)((count + PEER_BLOCK - 1) / PEER_BLOCK) : 64u;
   hipLaunchKernelGGL(k_peer_push, dim3(grid), dim3(PEER_BLOCK), 0, s, P->dev, src, (unsigned long long)count);
   hipLaunchKernelGGL(k_peer_pull, dim3(grid), dim3(PEER_BLOCK), 0, s, P->dev, buf, (unsigned long long)count, mode);
-  hipLaunchKernelGGL(k_peer_advance, dim3(1), dim3(1), 0, s, P->dev);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(std::string("peer exchange launch: ") + hipGetErrorString(e));
   return 0;

@@ -119,9 +119,8 @@ int lm_solve(gsfm_rot_problem* P, const gsfm_rot_options& o_in, gsfm_rot_summary
   bool last_successful = false, pcg_struggles = false;
   // Forcing schedule (gsfm_rot_options::pcg_forcing): steps far from convergence may deviate from the exact step by at most `eps_rad` (rms over the
   // cameras); off for disconnected graphs (their 1e-14 rule stands).
-  const double eps_rad = o.pcg_forcing_tolerance, refine_margin = 1e2, tau_max = 1e-2, sqrt_n = std::sqrt((double)std::max<uint32_t>(1, P->n_cams));
+  const double eps_rad = o.pcg_forcing_tolerance, tau_max = 1e-2, sqrt_n = std::sqrt((double)std::max<uint32_t>(1, P->n_cams));
   const bool forcing = o.pcg_forcing > 0 && P->n_components <= 1 && eps_rad > 0.0;
-  bool near_convergence = false;   // the last accepted step changed the cost by less than 1e-3 relative: every step from here on is exact from the start
   double pred_rms = -1.0;          // rms size of the last accepted step: the (conservative: steps shrink) prediction of the next one's
   while (true) {
     if (iteration >= o.max_num_iterations) return finish(GSFM_TERM_NO_CONVERGENCE);
@@ -133,10 +132,10 @@ int lm_solve(gsfm_rot_problem* P, const gsfm_rot_options& o_in, gsfm_rot_summary
     prep_valid = false;
     int cg = 0; double cg_rel = 0;
     bool dense_used = false;
-    // Forcing schedule: an LM step that cannot be one of the last is solved loosely -- to a relative (energy-norm) error tau chosen so that
-    // tau * |step|_rms <= eps_rad, with the step size predicted from the previous accepted step (first step: tau_max, corrected below).
-    const bool can_be_last = iteration >= o.max_num_iterations || near_convergence;
-    bool loose = forcing && !can_be_last;
+    // Forcing schedule: the step is solved loosely -- to a relative (energy-norm) error tau chosen so that tau * |step|_rms <= eps_rad, with the
+    // step size predicted from the previous accepted step (first step: tau_max, corrected below) -- unless it is the last one the iteration
+    // cap allows (that one is applied whatever it looks like: exact).
+    bool loose = forcing && iteration < o.max_num_iterations;
     double tau = pred_rms > 0.0 ? std::fmin(tau_max, eps_rad / pred_rms) : tau_max;
     if (tau <= 4.0 * o.cg_relative_tolerance) loose = false;
     bool use_pcg2 = false;
@@ -156,20 +155,31 @@ int lm_solve(gsfm_rot_problem* P, const gsfm_rot_options& o_in, gsfm_rot_summary
       if (int st = launch_cost(P, P->q_trial.p, SC_TRIAL)) return st;
       if (int st = read_scalars(P, h)) return st;
       for (int pass = 0; pass < 3 && !dense_used && loose && cg_rel > o.cg_relative_tolerance; ++pass) {
-        // The loose step has been evaluated.  It stands only if (a) the iteration is clearly an ordinary successful one -- anything that could
-        // end the solve or that the trust-region logic reacts to (a cost change within `refine_margin` of the function tolerance, a step near
-        // the parameter tolerance, a step that is not accepted, an invalid model) is decided on the exact step instead -- and (b) its estimated
-        // deviation from the exact step, tau * |step|_rms, is within eps_rad now that the step's size is known.  Otherwise PCG CONTINUES from
-        // where it stopped -- to the tight tolerance for (a), to the tau the measured step size asks for for (b): the same iterates as an
-        // uninterrupted solve at that tolerance -- and the step and its cost are evaluated again.
+        // The loose step has been evaluated.  Every decision the trust-region loop takes from it must be the one the exact step would give:
+        //  * termination (function / parameter tolerance): the decisive quantities -- cost change, step norm -- of the loose step are within
+        //    O(tau) of the exact step's (the model decrease even within O(tau^2)), so a value more than a factor two away from its threshold
+        //    decides (a terminating step is never applied: the answer is the same); inside that band PCG continues to the tight tolerance;
+        //  * acceptance: a relative decrease above 0.25 (the threshold is 1e-3) decides, anything else is settled on the exact step, as is an
+        //    invalid model;
+        //  * an accepted loose step must also be within eps_rad (rms, estimated: tau * |step|_rms) of the exact one now that its size is known,
+        //    otherwise PCG continues to the tau that size asks for.
+        // "Continues": from the state the stop left, i.e. the same iterates as an uninterrupted solve at the new tolerance.
         const double mcc = -0.5 * h[SC_STEP] + 0.5 * h[SC_STEP + 1] + 0.5 * h[SC_STEP + 2];
         const double cc = x_cost - h[SC_TRIAL], sn = std::sqrt(h[SC_STEP + 3]);
-        const bool ordinary = std::isfinite(mcc) && mcc > 0.0 && std::isfinite(h[SC_TRIAL]) && cc / mcc > std::fmax(o.min_relative_decrease, 0.25)
-                              && cc > refine_margin * o.function_tolerance * x_cost
-                              && sn > refine_margin * o.parameter_tolerance * (x_norm + o.parameter_tolerance);
-        const double tau_need = ordinary ? eps_rad / std::fmax(sn / sqrt_n, 1e-300) : 0.0;
-        if (ordinary && tau <= 1.5 * tau_need && o.pcg_forcing != 2) { sum->num_inexact_steps++; break; }
-        if (!ordinary || o.pcg_forcing == 2 || tau_need <= 4.0 * o.cg_relative_tolerance || pass == 2) { loose = false; tau = 0.0; } else tau = std::fmin(tau, tau_need);
+        const double pt = o.parameter_tolerance * (x_norm + o.parameter_tolerance), ft = o.function_tolerance * x_cost;
+        const bool valid_l = std::isfinite(mcc) && mcc > 0.0 && std::isfinite(h[SC_TRIAL]);
+        bool tight = !valid_l || o.pcg_forcing == 2;
+        double tau_need = tau;
+        if (!tight) {
+          if (sn <= 0.5 * pt || std::fabs(cc) <= 0.5 * ft) { sum->num_inexact_steps++; break; }            // terminates, as the exact step would
+          if (sn <= 2.0 * pt || std::fabs(cc) <= 2.0 * ft || cc / mcc <= std::fmax(o.min_relative_decrease, 0.25)) tight = true;
+          else {
+            tau_need = eps_rad / std::fmax(sn / sqrt_n, 1e-300);
+            if (tau <= 1.5 * tau_need) { sum->num_inexact_steps++; break; }
+            if (tau_need <= 4.0 * o.cg_relative_tolerance || pass == 2) tight = true;
+          }
+        }
+        if (tight) { loose = false; tau = 0.0; } else tau = std::fmin(tau, tau_need);
         if (int st = (use_pcg2 ? run_pcg2(P, o, o.cg_relative_tolerance, tau * tau, cg, &cg, &cg_rel) : run_pcg(P, o, o.cg_relative_tolerance, tau * tau, cg, &cg, &cg_rel))) return st;
         launch_step(P, loose);
         if (int st = launch_cost(P, P->q_trial.p, SC_TRIAL)) return st;
@@ -226,7 +236,6 @@ int lm_solve(gsfm_rot_problem* P, const gsfm_rot_options& o_in, gsfm_rot_summary
       gmax = h[SC_GMAX];
       sum->num_successful_steps++;
       last_successful = true;
-      if (std::fabs(cost_change) <= 1e-3 * cand_cost) near_convergence = true;
       pred_rms = step_norm / sqrt_n;
     } else {  // HandleUnsuccessfulStep
       radius /= decrease_factor; decrease_factor *= 2.0;

@@ -168,24 +168,23 @@ typedef struct {
                                           csrc/gsfm_rccl.cpp: RCCL collectives are stream-capturable) -- the default since round 3, 2 is the old
                                           explicit opt-in and means the same, GSFM_PCG_GRAPH_COLLECTIVES=0 in the environment switches it off;
                                           host-staged callbacks (gloo) keep plain launches.  0: plain launches everywhere. */
-  int32_t pcg_forcing;                 /* default 1: forcing schedule for the PCG solves -- steps far from convergence are solved only as accurately
-                                          as the answer needs.  An LM step that can be one of the LAST (the previous accepted step changed the cost
-                                          by <= 1e-3 relative, or the iteration cap is reached with it) is solved to cg_relative_tolerance from the
-                                          start, as before.  Any other step is first solved LOOSELY: PCG stops once the estimated relative
-                                          energy-norm error of the step is below tau, with tau chosen so that tau x (rms step size, predicted from
-                                          the previous accepted step) <= pcg_forcing_tolerance radians.  (Estimate: Hestenes-Stiefel -- the squared
-                                          energy error is the sum of the LATER iterations' model decreases alpha_j r_j.z_j, extrapolated
-                                          geometrically from the last four; csrc/kernels.hpp cg_energy_stop.  Unlike a residual norm it bounds the
-                                          missing share of the step whatever the conditioning and the preconditioner.)  The loose step is
-                                          evaluated; it stands only if (a) it is an ordinary successful step (relative decrease > 0.25, cost change
-                                          and step norm more than 100 x above the function / parameter tolerances, valid model) and (b) tau x its
-                                          MEASURED rms size is within the bound.  Otherwise PCG CONTINUES from where it stopped -- to
-                                          cg_relative_tolerance for (a), to the tau the measured size asks for for (b); the solver state is
-                                          resumable and the iterates are bit for bit those of an uninterrupted solve at that tolerance -- and the
-                                          step and its cost are evaluated again.  So every decision that can end the solve, and the last accepted
-                                          step, are taken on the reference's exact step (estimator.cpp:300: SPARSE_NORMAL_CHOLESKY), and every
-                                          other iterate stays within pcg_forcing_tolerance (rms) of the one the exact step would have given.  Not
-                                          applied to disconnected graphs (their 1e-14 rule above stands) or to exact Cholesky steps.
+  int32_t pcg_forcing;                 /* default 1: forcing schedule for the PCG solves -- an LM step is solved only as accurately as the answer
+                                          needs.  PCG first stops once the estimated relative energy-norm error of the step is below tau, with tau
+                                          chosen so that tau x (rms step size, predicted from the previous accepted step) <= pcg_forcing_tolerance
+                                          radians.  (Estimate: Hestenes-Stiefel -- the squared energy error is the sum of the LATER iterations' model
+                                          decreases alpha_j r_j.z_j, extrapolated geometrically from the last four; csrc/kernels.hpp cg_energy_stop.
+                                          Unlike a residual norm it bounds the missing share of the step whatever the conditioning and the
+                                          preconditioner.)  The loose step is evaluated, and every decision taken from it must be the exact step's:
+                                          a cost change or step norm more than a factor two away from the function / parameter tolerance decides
+                                          termination (those quantities agree with the exact step's to O(tau); a terminating step is never applied,
+                                          so the answer is the same), a relative decrease above 0.25 decides acceptance, and an accepted loose step
+                                          must be within pcg_forcing_tolerance (tau x its MEASURED rms size) of the exact one.  In every other case
+                                          -- too close to a threshold, a doubtful or invalid step, a step larger than predicted -- PCG CONTINUES from
+                                          where it stopped, to cg_relative_tolerance or to the tau the measured size asks for; the solver state is
+                                          resumable and the iterates are bit for bit those of an uninterrupted solve at that tolerance
+                                          (estimator.cpp:300's SPARSE_NORMAL_CHOLESKY is what cg_relative_tolerance stands in for).  The last step
+                                          an iteration cap allows is always solved tightly.  Not applied to disconnected graphs (their 1e-14 rule
+                                          above stands) or to exact Cholesky steps.
                                           0: every step at cg_relative_tolerance (rounds 1-3).  2 (a testing aid): every loose solve is continued
                                           to cg_relative_tolerance whatever its evaluation says -- the solve must then reproduce pcg_forcing = 0
                                           bit for bit, PCG iteration counts included (tests/test_gpu_round4.py). */

@@ -183,8 +183,10 @@ def test_random_graph_random_partition_equals_the_single_gpu_solve(tmp_path, wor
     res = _launch(world, "gloo", str(tmp_path / ("rand%d.npz" % seed)), case="random:%d" % seed)
     info = "n=%d e=%d et=%d %s slice sizes %s" % (int(res["n"]), int(res["e"]), int(res["et"]), str(res["loss"]), res["widths"].tolist())
     # (per-camera sums are bitwise those of one GPU; the PCG dot products add the same numbers in the partition's camera order, so an
-    # ill-conditioned step may need a few PCG iterations more or less: tests/manual/fuzz_sharded.sh, 7 of 25 random cases)
-    assert int(res["iters"]) == int(res["ref_iters"]) and abs(int(res["cg"]) - int(res["ref_cg"])) <= 0.02 * int(res["ref_cg"]) + 2, info
+    # ill-conditioned step may need a few PCG iterations more or less: tests/manual/fuzz_sharded.sh, 7 of 25 random cases.  Round 4: the loose
+    # solves of the forcing schedule stop on an ESTIMATE of the energy error extrapolated from the last four iterations, which moves by an
+    # iteration or two with the summation order -- per solve, and a solve is now 5-15 iterations instead of 30-150: 5 % + 4 instead of 2 % + 2)
+    assert int(res["iters"]) == int(res["ref_iters"]) and abs(int(res["cg"]) - int(res["ref_cg"])) <= 0.05 * int(res["ref_cg"]) + 4, info
     assert abs(float(res["cost"]) - float(res["ref_cost"])) <= 1e-8 * float(res["ref_cost"]), info
     assert synth.angular_distance(res["rot"], res["ref_rot"]).max() < (1e-4 if "MAGSAC" in str(res["loss"]) else 1e-6), info
 
