@@ -266,6 +266,8 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_dense_assemble_col(DenseArgs a, 
 #ifndef GSFM_COLLIN_THREADS
 #define GSFM_COLLIN_THREADS 256
 #endif
+// which instantiations of K2c hand BODY-frame row sums to the finishing kernel (the host asks the same question: solver_launch.hpp)
+__host__ __device__ constexpr bool col_lin_body_frame(int functor, bool fast) { return fast && functor == F_AA; }
 struct ColLinArgs {
   LinArgs lin;              // streams (qr, w, col, eid: all in position order), q, loss, rho_ext, sigma, h0..h2 (out); row_base
   ColLayoutDev L;
@@ -274,6 +276,7 @@ struct ColLinArgs {
 template <int F, int WM, int LM, bool FAST>
 __device__ __forceinline__ void lin_col_body(const ColLinArgs& a) {
   constexpr int RB = GSFM_COL_RB, SUB = GSFM_COL_SUB, T = GSFM_COLLIN_THREADS, RPL = RB / T;
+  constexpr bool BODY = col_lin_body_frame(F, FAST);
   __shared__ double slots[9][SUB];
   __shared__ double2 qrow[2][RB];
   __shared__ uint32_t wtot[RPL][T / 64];
@@ -312,12 +315,20 @@ __device__ __forceinline__ void lin_col_body(const ColLinArgs& a) {
       const uint32_t d = sc * SUB + k * T + t;
       const uint32_t cr = mt[k].x, pm = col_slot(mt[k].y);
       double g3[3] = {0, 0, 0}, G6[6] = {0, 0, 0, 0, 0, 0}, B6[6] = {0, 0, 0, 0, 0, 0};
-      if (cr != GSFM_COL_PAD) {
+      if constexpr (BODY) {   // body-frame evaluation (kernels.hpp, lin_entry_body_aa): the slots carry (gb, B), the finishing kernel rotates the row sums
+        if (cr != GSFM_COL_PAD) {
+          const uint32_t rl = col_rowl(mt[k].y);
+          const double2 k0 = qrow[0][rl], k1 = qrow[1][rl];
+          lin_entry_body_aa<WM, LM>(a.lin, d, cr, Quat{k0.x, k0.y, k1.x, k1.y}, qm[k], S[k], g3, B6);
+        }
+#pragma unroll
+        for (int c = 0; c < 6; ++c) G6[c] = B6[c];
+      } else if (cr != GSFM_COL_PAD) {
         const uint32_t rl = col_rowl(mt[k].y);
         const double2 k0 = qrow[0][rl], k1 = qrow[1][rl];
         const Quat qk{k0.x, k0.y, k1.x, k1.y};
         lin_entry_eval<F, WM, LM, FAST>(a.lin, d, cr, qk, qm[k], S[k], g3, G6);
-        // body frame: B = R_k^T G R_k
+        // body frame: B = R_k^T G R_k  (the BODY instantiations produce B directly)
         double R[9], Tm[9];
         qmat(qk, R);
 #pragma unroll
@@ -371,10 +382,14 @@ __device__ __forceinline__ void lin_col_body(const ColLinArgs& a) {
 // Registers at the compiler's choice (~200-250: two waves per SIMD, two workgroups per CU): asking for three waves spills the eighteen
 // row accumulators (76 B of scratch per lane) and costs 1010 us against 785 at C5.
 template <int F, int WM, int LM, bool FAST>
-__global__ void __launch_bounds__(GSFM_COLLIN_THREADS) k_lin_col(ColLinArgs a) { lin_col_body<F, WM, LM, FAST>(a); }
+#ifndef GSFM_K2C_ATTR
+#define GSFM_K2C_ATTR
+#endif
+__global__ void __launch_bounds__(GSFM_COLLIN_THREADS) GSFM_K2C_ATTR k_lin_col(ColLinArgs a) { lin_col_body<F, WM, LM, FAST>(a); }
 
 // gD[k] = sum_{c < NCH} part[block(k) * NCH + c][k mod RB]  (nine values per camera)
-__global__ void __launch_bounds__(GSFM_BLOCK) k_lin_col_finish(uint32_t n_rows, uint32_t row_base, uint32_t nch, uint32_t n_wg, const double* __restrict__ part, double* __restrict__ gD) {
+// q != null: the partial sums are in the rows' body frames (sum gb, sum B): g = R_k sum gb, D = R_k (sum B) R_k^T
+__global__ void __launch_bounds__(GSFM_BLOCK) k_lin_col_finish(uint32_t n_rows, uint32_t row_base, uint32_t nch, uint32_t n_wg, const double* __restrict__ part, double* __restrict__ gD, const double2* __restrict__ q) {
   const uint32_t row = blockIdx.x * GSFM_BLOCK + threadIdx.x;
   if (row >= n_rows) return;
   const uint32_t blk = row / GSFM_COL_RB, r = row % GSFM_COL_RB;
@@ -386,6 +401,19 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_lin_col_finish(uint32_t n_rows, 
     for (int x = 0; x < 9; ++x) v[x] += part[(size_t)x * plane + o];
   }
   double* out = gD + 9 * (size_t)(row_base + row);
+  if (q) {
+    double R[9], T[9];
+    qmat(load_q(q, row_base + row), R);
+    const double g0 = v[0], g1 = v[1], g2 = v[2];
+    v[0] = R[0] * g0 + R[1] * g1 + R[2] * g2; v[1] = R[3] * g0 + R[4] * g1 + R[5] * g2; v[2] = R[6] * g0 + R[7] * g1 + R[8] * g2;
+    const double S[9] = {v[3], v[4], v[5], v[4], v[6], v[7], v[5], v[7], v[8]};
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) T[3 * r + c] = R[3 * r] * S[c] + R[3 * r + 1] * S[3 + c] + R[3 * r + 2] * S[6 + c];   // R S
+    v[3] = T[0] * R[0] + T[1] * R[1] + T[2] * R[2]; v[4] = T[0] * R[3] + T[1] * R[4] + T[2] * R[5]; v[5] = T[0] * R[6] + T[1] * R[7] + T[2] * R[8];
+    v[6] = T[3] * R[3] + T[4] * R[4] + T[5] * R[5]; v[7] = T[3] * R[6] + T[4] * R[7] + T[5] * R[8]; v[8] = T[6] * R[6] + T[7] * R[7] + T[8] * R[8];
+  }
 #pragma unroll
   for (int x = 0; x < 9; ++x) out[x] = v[x];
 }

@@ -890,6 +890,37 @@ __device__ __forceinline__ void lin_entry_eval(const LinArgs& a, uint32_t d, uin
     G6[0] = d00; G6[1] = d01; G6[2] = d02; G6[3] = d11; G6[4] = d12; G6[5] = d22;
   }
 }
+// The same entry in the BODY frame (K2c's fast path, angle-axis family): with E = Exp(e) = R_j R_i^T R_ij^T one has J_l^-1(e)^T = J_l^-1(e) E and
+// R_ij R_i = E^T R_j, so the first camera's Jacobian -J_l^-1(e)^T R_ij, taken to its body frame, is -J_l^-1(e) R_j -- the NEGATIVE of the
+// second camera's body-frame Jacobian A = W J_l^-1(e) R_j.  One formula serves both roles (no R_ij matrix, no role-dependent branch), the block
+// B = rho' A^T A comes out in the body frame K3c wants (no R_k^T G R_k afterwards), and the row sums are rotated ONCE per row by the finishing
+// kernel: g_k = R_k sum(gb), D_k = R_k (sum B) R_k^T.  ~57 multiply-adds fewer per entry than lin_entry_eval<FAST> + the conjugation.
+template <int WM, int LM>
+__device__ __forceinline__ void lin_entry_body_aa(const LinArgs& a, uint32_t d, uint32_t cr, const Quat& qk, const Quat& qm, LinStreams S, double* gb3, double* B6) {
+  const Quat qr{S.r0.x, S.r0.y, S.r1.x, S.r1.y};
+  const bool row_is_second = (cr >> 31) != 0;
+  const Quat qi = row_is_second ? qm : qk, qj = row_is_second ? qk : qm;
+  const Quat qe = qmul(qmul(qj, qconj(qi)), qconj(qr));
+  double e[3], s, th, r[3];
+  quat_log(qe, e, &s, &th);
+  if (WM == W_SCALAR && a.sigma.on) {   // sigma consensus: e is the unit-weight residual
+    S.W.l00 = sigma_weight(a.sigma, e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
+    __builtin_nontemporal_store(S.W.l00, a.ws_rw + d);
+  }
+  apply_w_vec<WM>(S.W, e, r);
+  double Jm[9], Rj[9], JR[9], A[9];
+  jlinv_matrix(e, jlinv_coeff(th, s, fabs(qe.w)), Jm);
+  qmat(qj, Rj);
+  mat3_mul(Jm, Rj, JR);
+  apply_w_mat<WM>(S.W, JR, A);
+  const double rho1 = loss_rho1<LM>(a.loss, r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+  const double sg = row_is_second ? rho1 : -rho1;
+#pragma unroll
+  for (int x = 0; x < 3; ++x) gb3[x] = sg * (A[x] * r[0] + A[3 + x] * r[1] + A[6 + x] * r[2]);
+  B6[0] = rho1 * (A[0] * A[0] + A[3] * A[3] + A[6] * A[6]); B6[1] = rho1 * (A[0] * A[1] + A[3] * A[4] + A[6] * A[7]);
+  B6[2] = rho1 * (A[0] * A[2] + A[3] * A[5] + A[6] * A[8]); B6[3] = rho1 * (A[1] * A[1] + A[4] * A[4] + A[7] * A[7]);
+  B6[4] = rho1 * (A[1] * A[2] + A[4] * A[5] + A[7] * A[8]); B6[5] = rho1 * (A[2] * A[2] + A[5] * A[5] + A[8] * A[8]);
+}
 template <int F, int WM, int LM>
 __device__ __forceinline__ void lin_rows_fast(const LinArgs& a) {
   const uint32_t G = a.G;

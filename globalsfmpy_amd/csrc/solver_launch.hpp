@@ -293,7 +293,10 @@ int launch_lin(gsfm_rot_problem* P, const double2* q) {
     ColLinArgs ca{};
     ca.lin = a; ca.L = P->cs.dev(); ca.part = P->cs.part.p;
     if (dispatch<ColLinArgs, ColLinLauncher>(P, ca, (int)P->cs.n_wg)) return fail(GSFM_ERR_UNSUPPORTED, "no kernel for this error type");
-    hipLaunchKernelGGL(k_lin_col_finish, dim3(grid_for(P->n_rows)), dim3(GSFM_BLOCK), 0, P->stream, P->n_rows, P->own_begin, P->cs.nch, P->cs.n_wg, (const double*)P->cs.part.p, P->gD.p);
+    // (the fast path of the angle-axis family sums in the rows' body frames: the finishing kernel rotates -- same predicate as ColLinLauncher's choice)
+    const bool body = col_lin_body_frame(P->functor, loss_mode(P) != LM_PROGRAM && !a.rho_ext && k2_fast_enabled());
+    hipLaunchKernelGGL(k_lin_col_finish, dim3(grid_for(P->n_rows)), dim3(GSFM_BLOCK), 0, P->stream, P->n_rows, P->own_begin, P->cs.nch, P->cs.n_wg, (const double*)P->cs.part.p, P->gD.p,
+                       body ? q : (const double2*)nullptr);
   } else if (dispatch<LinArgs, LinLauncher>(P, a, grid_for((size_t)P->n_rows * P->G))) return fail(GSFM_ERR_UNSUPPORTED, "no kernel for this error type");
   P->timer.end(tk);
   P->have_lin = true;
