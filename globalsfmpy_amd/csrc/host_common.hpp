@@ -6,6 +6,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <exception>
+#include <stdexcept>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -75,12 +77,21 @@ int host_threads() {
   return (int)std::max<long>(1, std::min<long>(n, 16));
 }
 // body(t, T) on T threads (T - 1 spawned + the caller)
+// An exception in any thread (std::bad_alloc of a per-thread table, say) is carried to the caller after ALL threads have been joined: thrown
+// from a std::thread body it would call std::terminate, and thrown on the caller with joinable threads alive the vector's destructor would.
 template <typename F> void parallel_run(int T, F body) {
   if (T <= 1) { body(0, 1); return; }
+  std::vector<std::exception_ptr> err((size_t)T);
   std::vector<std::thread> th;
-  for (int t = 1; t < T; ++t) th.emplace_back([&body, t, T] { body(t, T); });
-  body(0, T);
+  struct Joiner { std::vector<std::thread>& v; ~Joiner() { for (auto& x : v) if (x.joinable()) x.join(); } } joiner{th};
+  auto guarded = [&body, &err, T](int t) { try { body(t, T); } catch (...) { err[(size_t)t] = std::current_exception(); } };
+  try {
+    for (int t = 1; t < T; ++t) th.emplace_back(guarded, t);
+  } catch (...) { err[0] = std::current_exception(); }   // (std::system_error: no more threads -- the ones started are joined below, their ranges stay undone)
+  if (!err[0]) guarded(0);
   for (auto& x : th) x.join();
+  if ((int)th.size() != T - 1 && !err[0]) err[0] = std::make_exception_ptr(std::runtime_error("could not start the host threads of the structure build"));
+  for (auto& e : err) if (e) std::rethrow_exception(e);
 }
 
 // counts[k + 1] += number of items with key(u) == k, u in [0, n): per-thread histograms over contiguous item ranges, summed in thread order
@@ -297,6 +308,7 @@ struct gsfm_rot_problem {
   DevBuf<double> sigma_table, sigma_sum;   // nu = 3 table; [0] = sum |w - w_old| over this rank's cost edges
 
   bool have_lin = false;
+  bool fast_lin_ok = true;   // the loss's rho'' is <= 0 for every s (decided from leaf kind AND parameter signs in prepare_loss): K2's alpha = 0 fast path applies
   int graph_launches = 0;
   int n_collectives = 0, n_pcg_collectives = 0, n_pcg_launched = 0;   // issued (or replayed from a graph) since the solve started
   std::vector<double> trace;

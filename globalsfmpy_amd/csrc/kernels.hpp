@@ -664,6 +664,7 @@ struct LinArgs {
   double* h4;                  // H22
   double* gD;                  // 9 per camera: g(3), D sym(6: d00 d01 d02 d11 d12 d22)
   int lap;                     // 1: Laplacian form, planes h0..h2 hold the symmetric edge weight B (see lin_rows)
+  int fast_ok;                 // host decision: the alpha = 0 fast path may be taken (kind and parameter signs of the loss checked in prepare_loss)
   SigmaDev sigma;              // sigma consensus: compute the weight of every directed entry from its unit-weight residual, store it
   double* ws_rw;               //   into the weight plane (= ws, writable) and use it
 };

@@ -164,6 +164,7 @@ __device__ __forceinline__ Rho3 loss_leaf_simple(const DevLossNode& n, double s)
 
 // rho only (trial-cost sweeps never need the derivatives): the MAGSAC value is one table lookup.
 __device__ __forceinline__ double loss_magsac_value(const DevLossNode& n, double sq) {
+#pragma clang fp contract(off)   // the same rounding as loss_magsac3().r0 (the sigma-consensus form of the first cost sweep uses that one): x_cost and the trial costs agree to the bit
   const double ssm2 = n.aux[1];
   if (sq > n.aux[6]) sq = n.aux[6];
   long x = (long)rint(1000.0 * sq / ssm2);     // same expression as the full evaluation: same table cell

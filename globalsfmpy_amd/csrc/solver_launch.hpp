@@ -45,13 +45,17 @@ bool k2_fast_enabled() {
   const char* e = getenv("GSFM_K2_FAST");
   return !(e && *e && atoi(e) <= 0);
 }
+// ... and the loss must really have rho'' <= 0 everywhere: true for the cheap leaves with ordinary parameters, but e.g. Geman-McClure with a
+// negative sigma^2 has rho'' > 0 (t = s / a^2 + g2 < 0), where the reference applies the Corrector in full (round-3 advisor).  Decided per
+// problem in prepare_loss (gsfm_rot_problem::fast_lin_ok); the launchers take the conjunction through LinArgs::fast_ok.
+bool k2_fast_path(const gsfm_rot_problem* P) { return k2_fast_enabled() && P->fast_lin_ok; }
 template <int F, int W, int L> struct LinLauncher {
   static void go(const LinArgs& a, int grid, hipStream_t s) {
     if constexpr (F == F_AA || F == F_QCOS) {   // functors of R_j R_i^T only: the Laplacian form exists (lin_rows)
       if (a.lap) {
         if constexpr (L != LM_PROGRAM) {
           // (a host-callback loss may have rho'' > 0: the general path applies the Corrector in full)
-          if (!a.rho_ext && k2_fast_enabled()) hipLaunchKernelGGL((k_lin_fast<F, W, L>), dim3(grid), dim3(GSFM_BLOCK), 0, s, a);
+          if (!a.rho_ext && a.fast_ok) hipLaunchKernelGGL((k_lin_fast<F, W, L>), dim3(grid), dim3(GSFM_BLOCK), 0, s, a);
           else hipLaunchKernelGGL((k_lin3<F, W, L, true>), dim3(grid), dim3(GSFM_BLOCK), 0, s, a);
         } else hipLaunchKernelGGL((k_lin<F, W, L, true>), dim3(grid), dim3(GSFM_BLOCK), 0, s, a);
         return;
@@ -66,7 +70,7 @@ template <int F, int W, int L> struct ColLinLauncher {   // K2c (column-sorted l
     if constexpr (F == F_AA || F == F_QCOS) {
       const dim3 g(grid), b(GSFM_COLLIN_THREADS);
       if constexpr (L != LM_PROGRAM) {
-        if (!a.lin.rho_ext && k2_fast_enabled()) hipLaunchKernelGGL((k_lin_col<F, W, L, true>), g, b, 0, s, a);
+        if (!a.lin.rho_ext && a.lin.fast_ok) hipLaunchKernelGGL((k_lin_col<F, W, L, true>), g, b, 0, s, a);
         else hipLaunchKernelGGL((k_lin_col<F, W, L, false>), g, b, 0, s, a);
       } else hipLaunchKernelGGL((k_lin_col<F, W, L, false>), g, b, 0, s, a);
     }
@@ -151,6 +155,16 @@ int prepare_loss(gsfm_rot_problem* P, const gsfm_loss_node* prog, int n) {
     }
   }
   if (n > 0 && (nr != 1 || na != 1)) return fail(GSFM_ERR_INVALID_ARG, "loss program does not reduce to one value");
+  // K2's fast path assumes rho'' <= 0 for every s (Ceres' Corrector then always takes its alpha = 0 branch).  That is a property of the leaf
+  // kind AND of its parameters: Geman-McClure, rho'' = -g2^2 / (a^2 t^3) with t = s / a^2 + g2, turns positive for a negative sigma^2 (g2);
+  // a MAGSAC weight loss with a negative sigma flips the sign of rho' and rho''.  Anything doubtful takes the general path (full Corrector).
+  P->fast_lin_ok = true;
+  if (n == 1) {
+    const gsfm_loss_node& s0 = prog[0];
+    if (s0.kind == GSFM_LOSS_GEMAN_MCCLURE && !(s0.p[1] > 0.0 && s0.p[0] != 0.0)) P->fast_lin_ok = false;
+    if (s0.kind == GSFM_LOSS_MAGSAC && !(s0.p[0] > 0.0)) P->fast_lin_ok = false;
+    if ((s0.kind == GSFM_LOSS_TUKEY || s0.kind == GSFM_LOSS_SOFT_L1 || s0.kind == GSFM_LOSS_HUBER) && !(s0.p[0] != 0.0)) P->fast_lin_ok = false;
+  }
   P->h_loss = L;
   if (!P->d_loss.p && P->d_loss.alloc(1) != hipSuccess) return fail(GSFM_ERR_HIP, "alloc loss");
   HIPCHK(hipMemcpy(P->d_loss.p, &P->h_loss, sizeof(DevLoss), hipMemcpyHostToDevice));
@@ -283,7 +297,7 @@ int launch_lin(gsfm_rot_problem* P, const double2* q) {
   LinArgs a{};
   a.n_rows = P->n_rows; a.row_base = P->own_begin; a.G = P->G; a.row_ptr = P->row_ptr.p; a.col = P->col.p; a.eid = P->dir.eid.p;
   a.qr0 = P->dir.qr0.p; a.qr1 = P->dir.qr1.p; a.w0 = P->dir.w0.p; a.w1 = P->dir.w1.p; a.w2 = P->dir.w2.p; a.ws = P->dir.ws.p; a.ws_rw = P->dir.ws.p;
-  a.q = q; a.loss = P->d_loss.p; a.rho_ext = P->cb ? P->rho_ext.p : nullptr;
+  a.q = q; a.loss = P->d_loss.p; a.rho_ext = P->cb ? P->rho_ext.p : nullptr; a.fast_ok = k2_fast_path(P) ? 1 : 0;
   if (P->sigma_pending_lin) { a.sigma = P->sigma; a.sigma.on = 1; P->sigma_pending_lin = false; }
   if (!P->lap && !P->h3.p && (P->h3.alloc(P->dir.n) != hipSuccess || P->h4.alloc(P->dir.n) != hipSuccess)) return fail(GSFM_ERR_HIP, "allocating the general normal-equation blocks failed");
   a.h0 = P->h0.p; a.h1 = P->h1.p; a.h2 = P->h2.p; a.h3 = P->h3.p; a.h4 = P->h4.p; a.gD = P->gD.p; a.lap = P->lap;
@@ -294,7 +308,7 @@ int launch_lin(gsfm_rot_problem* P, const double2* q) {
     ca.lin = a; ca.L = P->cs.dev(); ca.part = P->cs.part.p;
     if (dispatch<ColLinArgs, ColLinLauncher>(P, ca, (int)P->cs.n_wg)) return fail(GSFM_ERR_UNSUPPORTED, "no kernel for this error type");
     // (the fast path of the angle-axis family sums in the rows' body frames: the finishing kernel rotates -- same predicate as ColLinLauncher's choice)
-    const bool body = col_lin_body_frame(P->functor, loss_mode(P) != LM_PROGRAM && !a.rho_ext && k2_fast_enabled());
+    const bool body = col_lin_body_frame(P->functor, loss_mode(P) != LM_PROGRAM && !a.rho_ext && a.fast_ok);
     hipLaunchKernelGGL(k_lin_col_finish, dim3(grid_for(P->n_rows)), dim3(GSFM_BLOCK), 0, P->stream, P->n_rows, P->own_begin, P->cs.nch, P->cs.n_wg, (const double*)P->cs.part.p, P->gD.p,
                        body ? q : (const double2*)nullptr);
   } else if (dispatch<LinArgs, LinLauncher>(P, a, grid_for((size_t)P->n_rows * P->G))) return fail(GSFM_ERR_UNSUPPORTED, "no kernel for this error type");
