@@ -48,7 +48,7 @@ class Options(C.Structure):
         ("cg_check_interval", C.c_int32), ("verbose", C.c_int32),
         ("pcg_single_reduction", C.c_int32), ("cg_stall_iterations", C.c_int32),
         ("dense_cholesky_max_cams", C.c_int32), ("pcg_hip_graph", C.c_int32),
-        ("pcg_forcing", C.c_int32), ("reserved0_", C.c_int32), ("pcg_forcing_tolerance", C.c_double),
+        ("pcg_forcing", C.c_int32), ("dense_cholesky_auto_cams", C.c_int32), ("pcg_forcing_tolerance", C.c_double),
     ]
 
 

@@ -116,7 +116,17 @@ int lm_solve(gsfm_rot_problem* P, const gsfm_rot_options& o_in, gsfm_rot_summary
   record(x_cost, 0, 0, 0, 0);
   if (!std::isfinite(x_cost)) return finish(GSFM_TERM_FAILURE);
   if (gmax <= o.gradient_tolerance) return finish(GSFM_TERM_GRADIENT_TOLERANCE);
-  bool last_successful = false, pcg_struggles = false;
+  bool last_successful = false, pcg_struggles = false, pcg_dearer_than_cholesky = false;
+  // What one exact step (assemble + factorise + both substitutions, one hipGraph replay) takes on MI355X as a function of 3N: measured
+  // (tools/bench_chol.hip, profiles/r03_bench_chol.txt: 1182 -> 0.45 ms, 2400 -> 1.33, 4500 -> 3.27, 9000 -> 13.5), log-log interpolated.
+  auto dense_cost_ms = [](double n3) {
+    static const double pts[5][2] = {{600.0, 0.20}, {1182.0, 0.45}, {2400.0, 1.33}, {4500.0, 3.27}, {9000.0, 13.5}};
+    int k = 0;
+    while (k < 3 && n3 > pts[k + 1][0]) ++k;
+    const double t = std::log(n3 / pts[k][0]) / std::log(pts[k + 1][0] / pts[k][0]);
+    return pts[k][1] * std::pow(pts[k + 1][1] / pts[k][1], t);
+  };
+  double cg_ms_before = 0.0;
   // Forcing schedule (gsfm_rot_options::pcg_forcing): steps far from convergence may deviate from the exact step by at most `eps_rad` (rms over the
   // cameras); off for disconnected graphs (their 1e-14 rule stands).
   const double eps_rad = o.pcg_forcing_tolerance, tau_max = 1e-2, sqrt_n = std::sqrt((double)std::max<uint32_t>(1, P->n_cams));
@@ -141,8 +151,11 @@ int lm_solve(gsfm_rot_problem* P, const gsfm_rot_options& o_in, gsfm_rot_summary
     bool use_pcg2 = false;
     // dense_cholesky_max_cams > 0: exact Cholesky steps for graphs up to that size; < 0: up to |value| cameras, but only
     // once a PCG solve of this run has needed more than 150 iterations (2.5 ms of factorisation beats that many mat-vecs)
+    // dense_cholesky_auto_cams: graphs beyond dense_cholesky_max_cams and up to this size switch to exact steps from the moment a PCG-solved
+    // step has cost more GPU time than a factorisation of their size is known to take (dense_cost_ms below): sticky for the rest of the solve.
     const int64_t dense_cap = o.dense_cholesky_max_cams > 0 ? o.dense_cholesky_max_cams : -(int64_t)o.dense_cholesky_max_cams;
-    if (!P->sharded && dense_cap > 0 && (int64_t)P->n_cams <= dense_cap && (o.dense_cholesky_max_cams > 0 || pcg_struggles)) {
+    const bool dense_auto = o.dense_cholesky_max_cams > 0 && (int64_t)P->n_cams > dense_cap && (int64_t)P->n_cams <= (int64_t)o.dense_cholesky_auto_cams && pcg_dearer_than_cholesky;
+    if (!P->sharded && ((dense_cap > 0 && (int64_t)P->n_cams <= dense_cap && (o.dense_cholesky_max_cams > 0 || pcg_struggles)) || dense_auto)) {
       if (int st = run_dense(P, &dense_used)) return st;
     }
     for (int attempt = 0; attempt < 2; ++attempt) {
@@ -193,6 +206,11 @@ int lm_solve(gsfm_rot_problem* P, const gsfm_rot_options& o_in, gsfm_rot_summary
       if (info == 0) { sum->num_dense_solves++; break; }
       dense_used = false;   // not positive definite to working precision: the step just evaluated is meaningless, PCG solves it again
     }
+    if (!dense_used && !P->sharded && (int64_t)P->n_cams <= (int64_t)o.dense_cholesky_auto_cams) {   // GPU time of this step's linear solve (HIP events, resolved by the read-back above)
+      const double step_ms = P->timer.acc[T_CG] - cg_ms_before;
+      if (step_ms > 1.25 * dense_cost_ms(3.0 * P->n_cams)) pcg_dearer_than_cholesky = true;
+    }
+    cg_ms_before = P->timer.acc[T_CG];
     // (a loose solve's count is projected to the tight tolerance -- PCG converges about linearly in the logarithm -- before it is held against the 150)
     if ((loose && tau > 0.0 ? cg * std::log(o.cg_relative_tolerance) / std::log(std::fmin(0.5, tau)) : (double)cg) > 150.0) pcg_struggles = true;
     if (o.verbose && !dense_used && !loose && cg >= o.max_cg_iterations && cg_rel > o.cg_relative_tolerance)

@@ -188,7 +188,13 @@ typedef struct {
                                           0: every step at cg_relative_tolerance (rounds 1-3).  2 (a testing aid): every loose solve is continued
                                           to cg_relative_tolerance whatever its evaluation says -- the solve must then reproduce pcg_forcing = 0
                                           bit for bit, PCG iteration counts included (tests/test_gpu_round4.py). */
-  int32_t reserved0_;
+  int32_t dense_cholesky_auto_cams;    /* default 5333 (the largest matrix the exact step supports; 0 = off): graphs with more than
+                                          dense_cholesky_max_cams and at most this many cameras start on PCG and switch to exact Cholesky steps --
+                                          what the reference does for every graph, estimator.cpp:300 -- from the moment one PCG-solved step has
+                                          cost more GPU time (HIP events) than 1.25 x the factorisation of their size is measured to take on
+                                          MI355X (0.45 ms at 394 cameras, 1.33 at 800, 3.27 at 1500, 13.5 at 3000; tools/bench_chol.hip).  Easy
+                                          graphs (a few dozen PCG iterations per step) never switch; Madrid-like ones (hundreds) do after their
+                                          first step.  Ignored for sharded problems and when dense_cholesky_max_cams < 0. */
   double pcg_forcing_tolerance;        /* default 1e-8 rad: largest estimated rms deviation of an inexact step from the exact one -- two orders below
                                           north_star's parity bar of 1e-6 rad (DESIGN.md section 6 has the measured trade: 1e-7 is 4 % faster on
                                           the benchmark graph and flips a borderline termination on one MAGSAC test graph).  A loose iterate's

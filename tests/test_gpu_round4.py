@@ -68,3 +68,28 @@ def test_fast_linearisation_path_is_refused_for_a_loss_whose_second_derivative_t
     scale = np.abs(b["gradient"]).max()
     assert np.abs(a["gradient"] - b["gradient"]).max() <= 1e-9 * scale
     assert np.abs(a["diag_blocks"] - b["diag_blocks"]).max() <= 1e-9 * np.abs(b["diag_blocks"]).max()
+
+
+def test_exact_steps_take_over_where_pcg_costs_more_than_a_factorisation(oracle):
+    """dense_cholesky_auto_cams (default 5333): a graph beyond dense_cholesky_max_cams starts on PCG and switches to exact Cholesky steps -- the
+    reference's own linear solver, estimator.cpp:300 -- once a PCG-solved step has cost more GPU time than a factorisation of its size takes.
+    A spatially coherent 800-camera graph (hundreds of block-Jacobi iterations per step) switches after its first step; a uniformly random one
+    (two dozen iterations) never does; both agree with the oracle, and asking for PCG only (dense_cholesky_max_cams = 0) is respected."""
+    hard = synth.make_graph(800, 4800, seed=8, outlier_frac=0.1, local_window=16)     # a chain-like graph: 150-270 block-Jacobi iterations per step
+    easy = synth.make_graph(1500, 45000, seed=9, outlier_frac=0.1)
+    for g, switches in ((hard, True), (easy, False)):
+        p = _problem(g, _abi.ANGLE_AXIS, LF.HuberLoss(0.1))
+        r, s = p.solve(g["init_aa"])
+        rp, sp = p.solve(g["init_aa"], dense_cholesky_max_cams=0)
+        print("%s: %d LM iterations, %d exact steps, %d PCG iterations (PCG only: %d)" % ("coherent" if switches else "random", s["num_iterations"], s["num_dense_solves"],
+              s["num_cg_iterations"], sp["num_cg_iterations"]))
+        assert sp["num_dense_solves"] == 0
+        if switches:
+            assert 0 < s["num_dense_solves"] < s["num_iterations"] and s["num_cg_iterations"] < sp["num_cg_iterations"]
+        else:
+            assert s["num_dense_solves"] == 0
+        ora = oracle.OracleProblem(g["n_cams"], g["edge_i"], g["edge_j"], g["rel_aa"], _abi.ANGLE_AXIS)
+        ora.set_loss(LF.HuberLoss(0.1))
+        ro, so = ora.solve(g["init_aa"])
+        assert s["num_iterations"] == so["num_iterations"]
+        assert synth.angular_distance(synth.align_rotations(r, ro), ro).mean() <= 1e-6
