@@ -488,8 +488,8 @@ def main():
                              directed_entries_per_launch=int(nd), launches_per_solve=summ["num_cg_iterations"]),
         }
         out["pcg_schedule"] = {"pcg_forcing": 1, "pcg_forcing_tolerance_rad": 1e-8, "inexact_steps_per_solve": summ["num_inexact_steps"], "continued_solves_per_solve": summ["num_forcing_refinements"],
-                               "what": "LM steps far from convergence are solved loosely (estimated deviation from the exact step <= 1e-8 rad rms), every step that can be one of "
-                                       "the last at cg_relative_tolerance 1e-12 (include/gsfm_rot.h: pcg_forcing)"}
+                               "what": "every LM step is solved loosely first (estimated deviation from the exact step <= 1e-8 rad rms); decisions are taken from it only when "
+                                       "a factor two away from their thresholds, otherwise PCG continues towards cg_relative_tolerance 1e-12 (include/gsfm_rot.h: pcg_forcing)"}
         if exact is not None:
             out["exact_schedule"] = exact
         if tree is not None:

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""profiles/r03_pmc_traffic.json from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs) over tools/r03_k3_probe.py.
+"""profiles/rNN_pmc_traffic.json from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs) over tools/r04_pmc_probe.py (round 3: r03_k3_probe.py).
 usage: make_pmc_traffic.py <fetch.db> <write.db> <out.json>
 HBM bytes per launch: fetch = 2 x FETCH_SIZE x 1024 (gfx950 correction for wide coalesced reads, MI355X_MICROARCH.md section HBM),
 write = WRITE_SIZE x 1024 (uncalibrated).  The json carries the sha of the kernel sources it was measured on: bench.py reports `traffic`
@@ -26,7 +26,7 @@ KEYS = [("k_matvec", ["k_mv_col(", "k_matvec<"]), ("k_matvec_finish", ["k_mv_col
 def main():
     import bench
     f, w = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
-    out = {"_comment": "HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in separate runs of tools/r03_k3_probe.py: the C5 problem, a few launches "
+    out = {"_comment": "HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in separate runs of the round's probe script (tools/r04_pmc_probe.py): the C5 problem, a few launches "
                        "of every hot kernel); fetch = 2 x FETCH_SIZE x 1024 (gfx950 correction), write = WRITE_SIZE x 1024 (uncalibrated)",
            "workload": {"cams": 100000, "edges": 10000000}, "kernel_source_sha16": bench.kernel_source_sha16(), "kernels": {}}
     for key, pats in KEYS:
