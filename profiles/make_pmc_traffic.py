@@ -19,8 +19,9 @@ def per_kernel(db, counter):
     return {r[0]: {"calls": r[1], "avg": r[2], "dur_us": r[3] / 1e3} for r in rows}
 
 
-KEYS = [("k_matvec", ["k_mv_col(", "k_matvec<"]), ("k_matvec_finish", ["k_mv_col_finish"]), ("k_lin", ["k_lin_col<", "k_lin_fast<", "k_lin3<", "k_lin<"]),
-        ("k_cost", ["k_cost<0, 2, 2, false>", "k_cost_direct<0, 2, 2, false>"])]
+KEYS = [("k_matvec", ["k_mv_col(", "k_matvec<"]), ("k_matvec_finish", ["k_mv_col_finish"]), ("k_lin", ["k_lin_col<0, 2, 2, true>", "k_lin_col<", "k_lin_fast<", "k_lin3<", "k_lin<"]),
+        ("k_cost", ["k_cost<0, 2, 2, false>", "k_cost_direct<0, 2, 2, false>"]), ("k_cost_full", ["k_cost<0, 2, 2, true>"]), ("k_cost_unit_weights", ["k_cost<0, 0, 1, false>"]),
+        ("k_lin_unit_weights", ["k_lin_col<0, 0, 1, true>"]), ("k_lin_scalar_weights", ["k_lin_col<0, 1, 1, true>"])]
 
 
 def main():
@@ -30,8 +31,10 @@ def main():
                        "of every hot kernel); fetch = 2 x FETCH_SIZE x 1024 (gfx950 correction), write = WRITE_SIZE x 1024 (uncalibrated)",
            "workload": {"cams": 100000, "edges": 10000000}, "kernel_source_sha16": bench.kernel_source_sha16(), "kernels": {}}
     for key, pats in KEYS:
-        for name in f:
-            if any(p in name for p in pats) and f[name]["avg"] * 2048 > 1e5:
+        # (patterns in order of preference: the probe of round 4 also launches other specialisations of the same kernels)
+        hits = [name for p in pats for name in f if p in name and f[name]["avg"] * 2048 > 1e5]
+        for name in hits[:1]:
+            if True:
                 wb = w.get(name, {"avg": 0.0})["avg"] * 1024.0
                 out[key] = {"fetch_bytes": int(2.0 * f[name]["avg"] * 1024.0), "write_bytes": int(wb), "kernel": name[:120], "launches_profiled": f[name]["calls"],
                             "mean_duration_us_profiled": round(f[name]["dur_us"], 1)}
