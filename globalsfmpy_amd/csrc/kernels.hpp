@@ -664,6 +664,7 @@ struct LinArgs {
   double* h4;                  // H22
   double* gD;                  // 9 per camera: g(3), D sym(6: d00 d01 d02 d11 d12 d22)
   int lap;                     // 1: Laplacian form, planes h0..h2 hold the symmetric edge weight B (see lin_rows)
+  const double* go;            // non-null: the launch is predicated -- it does nothing unless *go != 0 (device-side LM control: the step was accepted)
   int fast_ok;                 // host decision: the alpha = 0 fast path may be taken (kind and parameter signs of the loss checked in prepare_loss)
   SigmaDev sigma;              // sigma consensus: compute the weight of every directed entry from its unit-weight residual, store it
   double* ws_rw;               //   into the weight plane (= ws, writable) and use it
@@ -679,6 +680,7 @@ struct LinArgs {
 // Jacobian, and K3 streams 52 B per entry instead of 76; the rotation by the row's R_k is nine FMAs K3 has room for.
 template <int F, int WM, int LM, bool LAP>
 __device__ __forceinline__ void lin_rows(const LinArgs& a) {
+  if (a.go && *a.go == 0.0) return;
   constexpr int R = ResDim<F>::R;
   const uint32_t G = a.G;
   const uint32_t t = blockIdx.x * GSFM_BLOCK + threadIdx.x;
@@ -924,6 +926,7 @@ __device__ __forceinline__ void lin_entry_body_aa(const LinArgs& a, uint32_t d, 
 }
 template <int F, int WM, int LM>
 __device__ __forceinline__ void lin_rows_fast(const LinArgs& a) {
+  if (a.go && *a.go == 0.0) return;
   const uint32_t G = a.G;
   const uint32_t t = blockIdx.x * GSFM_BLOCK + threadIdx.x;
   const uint32_t row = t / G, lane = t % G;
@@ -1097,6 +1100,7 @@ struct PrepArgs {
   int init_scale;         // 1 at iteration 0
   int jacobi_scaling;
   double radius, min_diag, max_diag;
+  const double* radius_dev;  // non-null: the trust-region radius is read from here (device-side LM control) instead of `radius`
   double* Mblk;           // 6: D + Lambda
   double* Minv;           // 6
   double* Lam;            // 6: damping block in eta space
@@ -1139,7 +1143,7 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_cam_prep(PrepArgs a) {
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       const double s2 = sc[c] * sc[c];
-      lam[c] = fmin(fmax(s2 * dd[c], a.min_diag), a.max_diag) / (a.radius * s2);
+      lam[c] = fmin(fmax(s2 * dd[c], a.min_diag), a.max_diag) / ((a.radius_dev ? *a.radius_dev : a.radius) * s2);
     }
     // Lambda_eta = Tinv^T diag(lam) Tinv
     double L[6];
@@ -2117,6 +2121,73 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_dense_assemble(DenseArgs a) {
     }
     for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) atomicAdd(dense_elem(a.A, 3 * row + r, 3 * m + c), H[3 * r + c]);
   }
+}
+
+
+// ------------------------------------------------------------------------------------------
+// Device-side Levenberg-Marquardt control for EXACT steps (latency regime: Madrid-sized graphs, one Cholesky step per iteration).  The
+// decisions of TrustRegionMinimizer the host loop takes between two synchronisations -- step validity, the two tolerance tests, acceptance,
+// the radius law -- are taken by one lane from the scalars the step and cost kernels left on the device; the kernels of the accept path (state
+// copy, linearisation) are predicated on its verdict and the damping is rebuilt from the radius it wrote, so a whole LM iteration is
+// enqueued without a host decision and read back ONCE (solver_lm.hpp).  Same formulas, same operation order as the host loop: the two
+// controls produce bit-identical trajectories (tests/test_gpu_round4.py).
+// ------------------------------------------------------------------------------------------
+enum { CT_RADIUS = 0, CT_DF = 1, CT_XCOST = 2, CT_XNORM = 3, CT_GMAX = 4, CT_ACCEPT = 5, CT_TERM = 6 /* -1: go on */, CT_NINVALID = 7, CT_VALID = 8,
+       CT_CAND = 9, CT_CC = 10, CT_MCC = 11, CT_STEPN = 12, CT_DENSE_FAIL = 13, CT_NONFINITE = 14, CT_N = 16 };
+struct LmOpts { double function_tolerance, gradient_tolerance, parameter_tolerance, min_relative_decrease, max_radius, min_radius; };
+__device__ __forceinline__ double lm_cube(double t) { return t * t * t; }
+__global__ void k_lm_set(double* ctl, double radius, double df, double x_cost, double x_norm, double gmax, double n_invalid) {
+  ctl[CT_RADIUS] = radius; ctl[CT_DF] = df; ctl[CT_XCOST] = x_cost; ctl[CT_XNORM] = x_norm; ctl[CT_GMAX] = gmax; ctl[CT_NINVALID] = n_invalid;
+  ctl[CT_ACCEPT] = 0.0; ctl[CT_TERM] = -1.0; ctl[CT_DENSE_FAIL] = 0.0; ctl[CT_NONFINITE] = 0.0;
+}
+// scal: SC_STEP.. = eta.g, eta.r, eta^T Lam eta, |delta|^2, |x_trial|^2 ; trial cost ; dense status.  (indices passed in: the enum lives on the host side)
+__global__ void k_lm_decide(LmOpts o, const double* scal, int sc_step, int sc_trial, int sc_info, double* ctl) {
+  ctl[CT_ACCEPT] = 0.0; ctl[CT_TERM] = -1.0; ctl[CT_DENSE_FAIL] = 0.0; ctl[CT_VALID] = 0.0;
+  int info;
+  __builtin_memcpy(&info, scal + sc_info, sizeof(int));
+  if (info != 0) { ctl[CT_DENSE_FAIL] = 1.0; return; }   // the factor broke down: the step is meaningless, the host solves it again by PCG
+  const double eta_g = scal[sc_step], eta_r = scal[sc_step + 1], eta_L = scal[sc_step + 2];
+  const double mcc = -0.5 * eta_g + 0.5 * eta_r + 0.5 * eta_L;
+  ctl[CT_MCC] = mcc;
+  double radius = ctl[CT_RADIUS], df = ctl[CT_DF];
+  if (!(isfinite(mcc) && mcc > 0.0)) {   // HandleInvalidStep
+    const double ni = ctl[CT_NINVALID] + 1.0;
+    ctl[CT_NINVALID] = ni;
+    if (ni >= 5.0) { ctl[CT_TERM] = 4.0; return; }
+    ctl[CT_RADIUS] = radius / df; ctl[CT_DF] = df * 2.0;
+    return;
+  }
+  ctl[CT_VALID] = 1.0; ctl[CT_NINVALID] = 0.0;
+  double cand = scal[sc_trial];
+  if (!isfinite(cand)) { cand = 1.7976931348623157e308; ctl[CT_NONFINITE] = 1.0; }
+  const double x_cost = ctl[CT_XCOST], x_norm = ctl[CT_XNORM];
+  const double step_norm = sqrt(scal[sc_step + 3]), cost_change = x_cost - cand, rel_dec = cost_change / mcc;
+  ctl[CT_CAND] = cand; ctl[CT_CC] = cost_change; ctl[CT_STEPN] = step_norm;
+  if (step_norm <= o.parameter_tolerance * (x_norm + o.parameter_tolerance)) { ctl[CT_TERM] = 2.0; return; }
+  if (fabs(cost_change) <= o.function_tolerance * x_cost) { ctl[CT_TERM] = 0.0; return; }
+  if (rel_dec > o.min_relative_decrease) {   // HandleSuccessfulStep
+    ctl[CT_ACCEPT] = 1.0;
+    ctl[CT_XNORM] = sqrt(scal[sc_step + 4]); ctl[CT_XCOST] = cand;
+    radius = radius / fmax(1.0 / 3.0, 1.0 - lm_cube(2.0 * rel_dec - 1.0));
+    ctl[CT_RADIUS] = fmin(o.max_radius, radius); ctl[CT_DF] = 2.0;
+  } else { ctl[CT_RADIUS] = radius / df; ctl[CT_DF] = df * 2.0; }
+}
+// accepted: x <- x_trial, q <- q_trial (copies, not pointer swaps: captured graphs hold the addresses)
+__global__ void __launch_bounds__(GSFM_BLOCK) k_lm_accept(const double* ctl, uint32_t n, int param_dim, double* x, const double* x_trial, double2* q, const double2* q_trial) {
+  if (ctl[CT_ACCEPT] == 0.0) return;
+  const uint32_t k = blockIdx.x * GSFM_BLOCK + threadIdx.x;
+  if (k >= n) return;
+  for (int c = 0; c < param_dim; ++c) x[(size_t)param_dim * k + c] = x_trial[(size_t)param_dim * k + c];
+  q[2 * (size_t)k] = q_trial[2 * (size_t)k]; q[2 * (size_t)k + 1] = q_trial[2 * (size_t)k + 1];
+}
+// after the (predicated) linearisation and the damping rebuild: the gradient test of an accepted step, the radius floor
+__global__ void k_lm_after(LmOpts o, const double* scal, int sc_gmax, double* ctl) {
+  if (ctl[CT_TERM] >= 0.0 || ctl[CT_DENSE_FAIL] != 0.0) return;
+  if (ctl[CT_ACCEPT] != 0.0) {
+    ctl[CT_GMAX] = scal[sc_gmax];
+    if (ctl[CT_GMAX] <= o.gradient_tolerance) { ctl[CT_TERM] = 1.0; return; }
+  }
+  if (ctl[CT_RADIUS] <= o.min_radius) ctl[CT_TERM] = 4.0;
 }
 
 }  // namespace gsfm

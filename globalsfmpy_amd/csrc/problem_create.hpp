@@ -557,7 +557,7 @@ static gsfm_status problem_create_impl(uint32_t n_cams, uint64_t n_edges, const 
   }
   ok &= P->part_a.alloc(P->nb_cam) == hipSuccess; ok &= P->part_b.alloc(P->nb_cam) == hipSuccess;
   ok &= P->part_cam.alloc((size_t)5 * P->nb_cam) == hipSuccess; ok &= P->part_gauge.alloc((size_t)9 * P->nb_cam) == hipSuccess; ok &= P->part_cost.alloc((size_t)2 * P->nb_cost) == hipSuccess;
-  ok &= P->scal.alloc(SC_N, true) == hipSuccess; ok &= P->cgsc.alloc(1, true) == hipSuccess;
+  ok &= P->scal.alloc(SC_ALL, true) == hipSuccess; ok &= P->cgsc.alloc(1, true) == hipSuccess;
   {  // fused mat-vec of the single-reduction PCG: one row group (256 / G rows) per workgroup unless that leaves too many partials
     const size_t rows_per_group = GSFM_BLOCK / P->G, groups = (P->n_rows + rows_per_group - 1) / rows_per_group;
     size_t max_partials = GSFM_MV_MAX_PARTIALS;

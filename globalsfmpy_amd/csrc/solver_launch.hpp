@@ -186,7 +186,8 @@ int all_reduce(gsfm_rot_problem* P, double* buf, size_t count) {
 }
 
 // ---- launches -----------------------------------------------------------------------------
-enum { SC_COST = 0, SC_GMAX = 1, SC_STEP = 2 /* ..6 */, SC_XNORM2 = 7, SC_TRIAL = 8, SC_DENSE_INFO = 15 /* an int: status of the Cholesky factorisation */, SC_N = 16 };
+enum { SC_COST = 0, SC_GMAX = 1, SC_STEP = 2 /* ..6 */, SC_XNORM2 = 7, SC_TRIAL = 8, SC_DENSE_INFO = 15 /* an int: status of the Cholesky factorisation */, SC_N = 16,
+       SC_CTL = 16 /* .. 31: the device-side LM control block (kernels.hpp, CT_*), read back together with the scalars */, SC_ALL = 32 };
 enum { T_LIN = 0, T_SWEEP = 1, T_CG = 2 };
 
 void launch_cache(gsfm_rot_problem* P, const double* x, double2* q) {
@@ -258,7 +259,7 @@ int refresh_external_rho(gsfm_rot_problem* P, const double2* q) {
 // optional per-edge outputs of K1 (device pointers, problem edge order)
 struct CostOutputs { double2* srho = nullptr; double2* rho12 = nullptr; double* rho1 = nullptr; double* r = nullptr; };
 
-int launch_lin(gsfm_rot_problem* P, const double2* q);
+int launch_lin(gsfm_rot_problem* P, const double2* q, const double* go = nullptr);
 
 // K1: cost at quaternion cache q -> scal[slot] (all-reduced when sharded)
 int launch_cost(gsfm_rot_problem* P, const double2* q, int slot, const CostOutputs& out = CostOutputs()) {
@@ -292,12 +293,12 @@ int launch_cost(gsfm_rot_problem* P, const double2* q, int slot, const CostOutpu
 }
 
 // K2: linearise at q -> gD (all-gathered), H blocks
-int launch_lin(gsfm_rot_problem* P, const double2* q) {
+int launch_lin(gsfm_rot_problem* P, const double2* q, const double* go) {
   if (P->cb) { if (int st = refresh_external_rho(P, q)) return st; }
   LinArgs a{};
   a.n_rows = P->n_rows; a.row_base = P->own_begin; a.G = P->G; a.row_ptr = P->row_ptr.p; a.col = P->col.p; a.eid = P->dir.eid.p;
   a.qr0 = P->dir.qr0.p; a.qr1 = P->dir.qr1.p; a.w0 = P->dir.w0.p; a.w1 = P->dir.w1.p; a.w2 = P->dir.w2.p; a.ws = P->dir.ws.p; a.ws_rw = P->dir.ws.p;
-  a.q = q; a.loss = P->d_loss.p; a.rho_ext = P->cb ? P->rho_ext.p : nullptr; a.fast_ok = k2_fast_path(P) ? 1 : 0;
+  a.q = q; a.loss = P->d_loss.p; a.rho_ext = P->cb ? P->rho_ext.p : nullptr; a.fast_ok = k2_fast_path(P) ? 1 : 0; a.go = go;
   if (P->sigma_pending_lin) { a.sigma = P->sigma; a.sigma.on = 1; P->sigma_pending_lin = false; }
   if (!P->lap && !P->h3.p && (P->h3.alloc(P->dir.n) != hipSuccess || P->h4.alloc(P->dir.n) != hipSuccess)) return fail(GSFM_ERR_HIP, "allocating the general normal-equation blocks failed");
   a.h0 = P->h0.p; a.h1 = P->h1.p; a.h2 = P->h2.p; a.h3 = P->h3.p; a.h4 = P->h4.p; a.gD = P->gD.p; a.lap = P->lap;
@@ -317,8 +318,9 @@ int launch_lin(gsfm_rot_problem* P, const double2* q) {
   return all_gather(P, P->gD.p, (size_t)P->shard.slice_width * 9);
 }
 
-void launch_prep(gsfm_rot_problem* P, const gsfm_rot_options& o, double radius, bool init_scale) {
+void launch_prep(gsfm_rot_problem* P, const gsfm_rot_options& o, double radius, bool init_scale, const double* radius_dev = nullptr) {
   PrepArgs a{};
+  a.radius_dev = radius_dev;
   a.n = P->n_cams; a.param_dim = P->param_dim; a.x = P->x.p; a.gD = P->gD.p; a.scale = P->scale.p;
   a.init_scale = init_scale; a.jacobi_scaling = o.jacobi_scaling; a.radius = radius; a.min_diag = o.min_lm_diagonal; a.max_diag = o.max_lm_diagonal;
   a.Mblk = P->Mblk.p; a.Minv = P->Minv.p; a.Lam = P->Lam.p; a.Tinv = P->Tinv.p; a.b = P->b.p; a.gmax_partials = P->part_cam.p;

@@ -127,6 +127,10 @@ int lm_solve(gsfm_rot_problem* P, const gsfm_rot_options& o_in, gsfm_rot_summary
     return pts[k][1] * std::pow(pts[k + 1][1] / pts[k][1], t);
   };
   double cg_ms_before = 0.0;
+  // LM control on the device for exact steps (GSFM_LM_DEVICE_CONTROL=0: the host loop, for A/B and for the bit-identity test): unsharded
+  // problems with a native loss on the row-major layout -- the linearisation of the accept path must be enqueueable without the host
+  static const bool device_control_env = [] { const char* e = getenv("GSFM_LM_DEVICE_CONTROL"); return !(e && *e && atoi(e) == 0); }();
+  const bool device_control = device_control_env && o.lm_device_control != 0 && !P->sharded && !P->cb && !P->cs.active;
   // Forcing schedule (gsfm_rot_options::pcg_forcing): steps far from convergence may deviate from the exact step by at most `eps_rad` (rms over the
   // cameras); off for disconnected graphs (their 1e-14 rule stands).
   const double eps_rad = o.pcg_forcing_tolerance, tau_max = 1e-2, sqrt_n = std::sqrt((double)std::max<uint32_t>(1, P->n_cams));
@@ -141,7 +145,7 @@ int lm_solve(gsfm_rot_problem* P, const gsfm_rot_options& o_in, gsfm_rot_summary
     if (!prep_valid) launch_prep(P, o, radius, false);
     prep_valid = false;
     int cg = 0; double cg_rel = 0;
-    bool dense_used = false;
+    bool dense_used = false, handled_on_device = false;
     // Forcing schedule: the step is solved loosely -- to a relative (energy-norm) error tau chosen so that tau * |step|_rms <= eps_rad, with the
     // step size predicted from the previous accepted step (first step: tau_max, corrected below) -- unless it is the last one the iteration
     // cap allows (that one is applied whatever it looks like: exact).
@@ -166,6 +170,56 @@ int lm_solve(gsfm_rot_problem* P, const gsfm_rot_options& o_in, gsfm_rot_summary
       }
       launch_step(P, !dense_used && loose);
       if (int st = launch_cost(P, P->q_trial.p, SC_TRIAL)) return st;
+      if (dense_used && device_control) {
+        // Exact step: the trust-region decisions are taken on the device (kernels.hpp, k_lm_decide), the accept path is enqueued predicated on
+        // them, the damping is rebuilt from the radius they leave -- the whole LM iteration without a host decision, ONE read-back.
+        double* ctl = P->scal.p + SC_CTL;
+        const LmOpts lo{o.function_tolerance, o.gradient_tolerance, o.parameter_tolerance, o.min_relative_decrease, o.max_trust_region_radius, o.min_trust_region_radius};
+        hipLaunchKernelGGL(k_lm_set, dim3(1), dim3(1), 0, P->stream, ctl, radius, decrease_factor, x_cost, x_norm, gmax, (double)num_invalid);
+        hipLaunchKernelGGL(k_lm_decide, dim3(1), dim3(1), 0, P->stream, lo, (const double*)P->scal.p, (int)SC_STEP, (int)SC_TRIAL, (int)SC_DENSE_INFO, ctl);
+        hipLaunchKernelGGL(k_lm_accept, dim3(P->nb_cam), dim3(GSFM_BLOCK), 0, P->stream, (const double*)ctl, P->n_cams, P->param_dim, P->x.p, (const double*)P->x_trial.p, P->q.p, (const double2*)P->q_trial.p);
+        if (int st = launch_lin(P, P->q.p, ctl + CT_ACCEPT)) return st;
+        launch_prep(P, o, radius, false, ctl + CT_RADIUS);
+        hipLaunchKernelGGL(k_lm_after, dim3(1), dim3(1), 0, P->stream, lo, (const double*)P->scal.p, (int)SC_GMAX, ctl);
+        double hc[SC_ALL];
+        if (int st = read_back(P, hc, P->scal.p, SC_ALL * sizeof(double), "read scalars + LM control")) return st;
+        std::memcpy(h, hc, sizeof(h));
+        const double* c = hc + SC_CTL;
+        if (c[CT_DENSE_FAIL] == 0.0) {
+          sum->num_dense_solves++;
+          sum->num_residual_sweeps++;
+          num_invalid = (int)c[CT_NINVALID];
+          prep_valid = true;                                 // (rebuilt on the device with the radius decided there)
+          if (c[CT_VALID] == 0.0) {                          // HandleInvalidStep
+            if (c[CT_TERM] == 4.0) return finish(GSFM_TERM_FAILURE);
+            radius = c[CT_RADIUS]; decrease_factor = c[CT_DF];
+            sum->num_unsuccessful_steps++;
+            record(x_cost, 0, 0, 0, 0);
+            handled_on_device = true;
+            break;
+          }
+          if (c[CT_NONFINITE] != 0.0) sum->nonfinite = 1;
+          const double step_norm = c[CT_STEPN], cost_change = c[CT_CC], rel_dec = c[CT_CC] / c[CT_MCC];
+          if (sum->iters_to_1e6 < 0 && std::fabs(cost_change) <= 1e-6 * x_cost) sum->iters_to_1e6 = iteration;
+          if (c[CT_TERM] == 2.0) { record(x_cost, cost_change, step_norm, rel_dec, 0); return finish(GSFM_TERM_PARAMETER_TOLERANCE); }
+          if (c[CT_TERM] == 0.0) { record(x_cost, cost_change, step_norm, rel_dec, 0); return finish(GSFM_TERM_FUNCTION_TOLERANCE); }
+          radius = c[CT_RADIUS]; decrease_factor = c[CT_DF];
+          if (c[CT_ACCEPT] != 0.0) {
+            x_norm = c[CT_XNORM]; x_cost = c[CT_XCOST]; gmax = c[CT_GMAX];
+            sum->num_residual_sweeps++; sum->num_linearizations++;
+            sum->num_successful_steps++;
+            last_successful = true;
+            pred_rms = step_norm / sqrt_n;
+          } else sum->num_unsuccessful_steps++;
+          record(x_cost, cost_change, step_norm, rel_dec, 0);
+          handled_on_device = true;
+          break;
+        }
+        // the factorisation met a non-positive pivot: nothing was decided (the control block is untouched apart from its flags, the
+        // linearisation did not run, the damping was rebuilt from the unchanged radius); PCG solves the step again, host control
+        dense_used = false;
+        continue;
+      }
       if (int st = read_scalars(P, h)) return st;
       for (int pass = 0; pass < 3 && !dense_used && loose && cg_rel > o.cg_relative_tolerance; ++pass) {
         // The loose step has been evaluated.  Every decision the trust-region loop takes from it must be the one the exact step would give:
@@ -206,6 +260,7 @@ int lm_solve(gsfm_rot_problem* P, const gsfm_rot_options& o_in, gsfm_rot_summary
       if (info == 0) { sum->num_dense_solves++; break; }
       dense_used = false;   // not positive definite to working precision: the step just evaluated is meaningless, PCG solves it again
     }
+    if (handled_on_device) { cg_ms_before = P->timer.acc[T_CG]; continue; }
     if (!dense_used && !P->sharded && (int64_t)P->n_cams <= (int64_t)o.dense_cholesky_auto_cams) {   // GPU time of this step's linear solve (HIP events, resolved by the read-back above)
       const double step_ms = P->timer.acc[T_CG] - cg_ms_before;
       if (step_ms > 1.25 * dense_cost_ms(3.0 * P->n_cams)) pcg_dearer_than_cholesky = true;
@@ -245,7 +300,7 @@ int lm_solve(gsfm_rot_problem* P, const gsfm_rot_options& o_in, gsfm_rot_summary
       x_cost = cand_cost;  // Ceres re-evaluates at the accepted point: same value
       if (int st = launch_lin(P, P->q.p)) return st;
       sum->num_residual_sweeps++; sum->num_linearizations++;
-      radius = radius / std::fmax(1.0 / 3.0, 1.0 - std::pow(2.0 * rel_dec - 1.0, 3));
+      { const double t = 2.0 * rel_dec - 1.0; radius = radius / std::fmax(1.0 / 3.0, 1.0 - t * t * t); }   // (t * t * t, as k_lm_decide: one rounding sequence for both controls)
       radius = std::fmin(o.max_trust_region_radius, radius);
       decrease_factor = 2.0;
       launch_prep(P, o, radius, false);

@@ -201,6 +201,14 @@ typedef struct {
                                           component along the gauge (all cameras rotated alike: the null space of J^T J, invisible to the energy
                                           norm) is removed before the step is taken, as the exact step has none (kernels.hpp, k_gauge_part; for the
                                           error types whose cost depends on R_j R_i^T alone, i.e. all but QUATERNION_NORM / ROTATION_MAT_FNORM). */
+  int32_t lm_device_control;           /* default 1: for EXACT (Cholesky) steps of unsharded problems with a native loss the trust-region decisions
+                                          of an LM iteration -- step validity, function / parameter tolerance, acceptance, the radius law -- are
+                                          taken by a one-lane kernel from the scalars the step and cost kernels left on the device; the accept path
+                                          (state copy, linearisation) is enqueued predicated on its verdict and the damping is rebuilt from the
+                                          radius it wrote, so an iteration costs ONE host read-back instead of two and no host decision sits between
+                                          its kernels.  Same formulas in the same order as the host loop: bit-identical trajectories
+                                          (tests/test_gpu_round4.py).  0: the host loop everywhere. */
+  int32_t reserved1_;
 } gsfm_rot_options;
 
 typedef enum {

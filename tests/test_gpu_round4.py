@@ -93,3 +93,24 @@ def test_exact_steps_take_over_where_pcg_costs_more_than_a_factorisation(oracle)
         ro, so = ora.solve(g["init_aa"])
         assert s["num_iterations"] == so["num_iterations"]
         assert synth.angular_distance(synth.align_rotations(r, ro), ro).mean() <= 1e-6
+
+
+@pytest.mark.parametrize("et,loss", [(_abi.ANGLE_AXIS_COVARIANCE, LF.MAGSACWeightBasedLoss(0.02)), (_abi.ANGLE_AXIS, LF.SoftLOneLoss(0.1)), (_abi.QUATERNION_COSINE, LF.HuberLoss(0.1)),
+                                     (_abi.ROTATION_MAT_FNORM, LF.CauchyLoss(0.3))])
+def test_lm_control_on_the_device_follows_the_host_loop_bit_for_bit(et, loss):
+    """Exact steps (300 cameras): the one-lane control kernel takes the trust-region decisions from the device scalars and the accept path runs
+    predicated on it (lm_device_control = 1, one read-back per iteration) -- the same formulas in the same order as the host loop, hence the same
+    trace (cost, cost change, gradient norm, step norm, relative decrease, radius per iteration), rotations and summary, rejected steps included."""
+    g = synth.make_graph(300, 3000, seed=77, outlier_frac=0.25)
+    p = _problem(g, et, loss)
+    init = g["init_aa"] + 0.3 * np.random.default_rng(1).standard_normal(g["init_aa"].shape)   # a far start: rejected and invalid steps happen
+    out = []
+    for dc in (0, 1):
+        r, s = p.solve(init, lm_device_control=dc)
+        out.append((r, s, p.trace()))
+    (r0, s0, t0), (r1, s1, t1) = out
+    assert s0["num_dense_solves"] == s0["num_iterations"] > 0
+    assert np.array_equal(t0, t1), (t0[:, :3], t1[:, :3])
+    assert np.array_equal(r0, r1)
+    for k in ("num_iterations", "num_successful_steps", "num_unsuccessful_steps", "termination", "final_cost", "num_residual_sweeps", "num_linearizations", "iters_to_1e6", "final_radius"):
+        assert s0[k] == s1[k], k
