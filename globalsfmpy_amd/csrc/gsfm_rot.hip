@@ -49,6 +49,7 @@ void gsfm_rot_problem_destroy(gsfm_rot_problem* P) {
   if (P->dense_graph) (void)hipGraphExecDestroy(P->dense_graph);
   if (P->own_stream && P->stream) (void)hipStreamDestroy(P->stream);
   if (P->pin) (void)hipHostFree(P->pin);
+  if (P->rec_host) (void)hipHostFree(P->rec_host);
   delete P;
 }
 

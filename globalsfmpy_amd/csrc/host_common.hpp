@@ -308,6 +308,8 @@ struct gsfm_rot_problem {
   DevBuf<double> sigma_table, sigma_sum;   // nu = 3 table; [0] = sum |w - w_old| over this rank's cost edges
 
   bool have_lin = false;
+  double* rec_host = nullptr;            // LM control on the device: ring of four per-iteration records in mapped host memory ((CT_N + 1) doubles each; the host polls the stamp)
+  double* rec_dev = nullptr;             //   ... and its device address
   bool fast_lin_ok = true;   // the loss's rho'' is <= 0 for every s (decided from leaf kind AND parameter signs in prepare_loss): K2's alpha = 0 fast path applies
   int graph_launches = 0;
   int n_collectives = 0, n_pcg_collectives = 0, n_pcg_launched = 0;   // issued (or replayed from a graph) since the solve started

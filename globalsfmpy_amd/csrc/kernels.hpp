@@ -2133,16 +2133,21 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_dense_assemble(DenseArgs a) {
 // controls produce bit-identical trajectories (tests/test_gpu_round4.py).
 // ------------------------------------------------------------------------------------------
 enum { CT_RADIUS = 0, CT_DF = 1, CT_XCOST = 2, CT_XNORM = 3, CT_GMAX = 4, CT_ACCEPT = 5, CT_TERM = 6 /* -1: go on */, CT_NINVALID = 7, CT_VALID = 8,
-       CT_CAND = 9, CT_CC = 10, CT_MCC = 11, CT_STEPN = 12, CT_DENSE_FAIL = 13, CT_NONFINITE = 14, CT_N = 16 };
+       CT_CAND = 9, CT_CC = 10, CT_MCC = 11, CT_STEPN = 12, CT_DENSE_FAIL = 13, CT_NONFINITE = 14, CT_SKIPPED = 15 /* this iteration was enqueued ahead of a verdict that ended the run: nothing was decided */, CT_N = 16 };
 struct LmOpts { double function_tolerance, gradient_tolerance, parameter_tolerance, min_relative_decrease, max_radius, min_radius; };
 __device__ __forceinline__ double lm_cube(double t) { return t * t * t; }
 __global__ void k_lm_set(double* ctl, double radius, double df, double x_cost, double x_norm, double gmax, double n_invalid) {
   ctl[CT_RADIUS] = radius; ctl[CT_DF] = df; ctl[CT_XCOST] = x_cost; ctl[CT_XNORM] = x_norm; ctl[CT_GMAX] = gmax; ctl[CT_NINVALID] = n_invalid;
-  ctl[CT_ACCEPT] = 0.0; ctl[CT_TERM] = -1.0; ctl[CT_DENSE_FAIL] = 0.0; ctl[CT_NONFINITE] = 0.0;
+  ctl[CT_ACCEPT] = 0.0; ctl[CT_TERM] = -1.0; ctl[CT_DENSE_FAIL] = 0.0; ctl[CT_NONFINITE] = 0.0; ctl[CT_SKIPPED] = 0.0;
 }
 // scal: SC_STEP.. = eta.g, eta.r, eta^T Lam eta, |delta|^2, |x_trial|^2 ; trial cost ; dense status.  (indices passed in: the enum lives on the host side)
+// The control block is authoritative between host interventions (k_lm_set): iteration k + 1 may be enqueued before the host has read
+// iteration k's verdict, so a verdict that ends the run of exact steps -- a termination, a factor that broke down -- must stop every later
+// decision: such an iteration is marked SKIPPED, accepts nothing and leaves the block alone.
 __global__ void k_lm_decide(LmOpts o, const double* scal, int sc_step, int sc_trial, int sc_info, double* ctl) {
-  ctl[CT_ACCEPT] = 0.0; ctl[CT_TERM] = -1.0; ctl[CT_DENSE_FAIL] = 0.0; ctl[CT_VALID] = 0.0;
+  ctl[CT_ACCEPT] = 0.0;
+  if (ctl[CT_TERM] >= 0.0 || ctl[CT_DENSE_FAIL] != 0.0) { ctl[CT_SKIPPED] = 1.0; return; }
+  ctl[CT_SKIPPED] = 0.0; ctl[CT_VALID] = 0.0; ctl[CT_NONFINITE] = 0.0;
   int info;
   __builtin_memcpy(&info, scal + sc_info, sizeof(int));
   if (info != 0) { ctl[CT_DENSE_FAIL] = 1.0; return; }   // the factor broke down: the step is meaningless, the host solves it again by PCG
@@ -2181,13 +2186,25 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_lm_accept(const double* ctl, uin
   q[2 * (size_t)k] = q_trial[2 * (size_t)k]; q[2 * (size_t)k + 1] = q_trial[2 * (size_t)k + 1];
 }
 // after the (predicated) linearisation and the damping rebuild: the gradient test of an accepted step, the radius floor
-__global__ void k_lm_after(LmOpts o, const double* scal, int sc_gmax, double* ctl) {
-  if (ctl[CT_TERM] >= 0.0 || ctl[CT_DENSE_FAIL] != 0.0) return;
-  if (ctl[CT_ACCEPT] != 0.0) {
-    ctl[CT_GMAX] = scal[sc_gmax];
-    if (ctl[CT_GMAX] <= o.gradient_tolerance) { ctl[CT_TERM] = 1.0; return; }
+// ... and the iteration's record for the host: the control block as this iteration left it, in its slot of a ring (the host reads it from a
+// side stream while the next iteration is already running).  `gterm`: the gradient / radius verdicts are kept apart from CT_TERM in the record
+// (the host loop takes them at the top of the NEXT iteration, after recording this one) but halt later decisions just the same.
+// `rec` is host memory mapped into the device (the host polls the record's last word instead of synchronising a stream: a cross-stream event
+// costs tens of microseconds per iteration, more than the gap it was meant to close); `stamp` = the LM iteration, written last, system scope.
+__global__ void k_lm_after(LmOpts o, const double* scal, int sc_gmax, double* ctl, double* rec, double stamp) {
+  if (ctl[CT_SKIPPED] != 0.0) return;
+  double term_next = -1.0;
+  if (ctl[CT_TERM] < 0.0 && ctl[CT_DENSE_FAIL] == 0.0) {
+    if (ctl[CT_ACCEPT] != 0.0) {
+      ctl[CT_GMAX] = scal[sc_gmax];
+      if (ctl[CT_GMAX] <= o.gradient_tolerance) term_next = 1.0;
+    }
+    if (term_next < 0.0 && ctl[CT_RADIUS] <= o.min_radius) term_next = 4.0;
   }
-  if (ctl[CT_RADIUS] <= o.min_radius) ctl[CT_TERM] = 4.0;
+  for (int k = 0; k < CT_N; ++k) rec[k] = ctl[k];
+  __threadfence_system();
+  __hip_atomic_store(rec + CT_N, stamp, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (term_next >= 0.0) ctl[CT_TERM] = term_next;   // (after the copy: the record shows the iteration's own verdict)
 }
 
 }  // namespace gsfm

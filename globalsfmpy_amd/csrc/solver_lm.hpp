@@ -92,7 +92,9 @@ int lm_solve(gsfm_rot_problem* P, const gsfm_rot_options& o_in, gsfm_rot_summary
     if (o.verbose) fprintf(stderr, "[gsfm] it %3d cost %.12e dcost %.3e |g| %.3e |dx| %.3e rho %.3e radius %.3e cg %d\n",
                            iteration, cost, dc, gmax, sn, rd, radius, cg);
   };
+  bool spec_enqueued = false, exact_pipeline_used = false;   // LM control on the device: an exact iteration is already in flight / the pipeline ran at all
   auto finish = [&](int term) {
+    if (spec_enqueued || exact_pipeline_used) { (void)hipStreamSynchronize(P->stream); P->timer.resolve(); spec_enqueued = false; }   // (whatever was enqueued ahead skips itself; the phase timers need the sync)
     sum->termination = term; sum->num_iterations = iteration; sum->final_cost = x_cost; sum->final_gradient_max_norm = gmax;
     sum->final_radius = radius; sum->t_total_ms = now_ms() - t0;
     sum->num_graph_launches = P->graph_launches;
@@ -130,6 +132,7 @@ int lm_solve(gsfm_rot_problem* P, const gsfm_rot_options& o_in, gsfm_rot_summary
   // LM control on the device for exact steps (GSFM_LM_DEVICE_CONTROL=0: the host loop, for A/B and for the bit-identity test): unsharded
   // problems with a native loss on the row-major layout -- the linearisation of the accept path must be enqueueable without the host
   static const bool device_control_env = [] { const char* e = getenv("GSFM_LM_DEVICE_CONTROL"); return !(e && *e && atoi(e) == 0); }();
+  bool exact_pipeline_broken = false;   // exact steps turned out impossible (size, memory)
   const bool device_control = device_control_env && o.lm_device_control != 0 && !P->sharded && !P->cb && !P->cs.active;
   // Forcing schedule (gsfm_rot_options::pcg_forcing): steps far from convergence may deviate from the exact step by at most `eps_rad` (rms over the
   // cameras); off for disconnected graphs (their 1e-14 rule stands).
@@ -145,7 +148,7 @@ int lm_solve(gsfm_rot_problem* P, const gsfm_rot_options& o_in, gsfm_rot_summary
     if (!prep_valid) launch_prep(P, o, radius, false);
     prep_valid = false;
     int cg = 0; double cg_rel = 0;
-    bool dense_used = false, handled_on_device = false;
+    bool dense_used = false;
     // Forcing schedule: the step is solved loosely -- to a relative (energy-norm) error tau chosen so that tau * |step|_rms <= eps_rad, with the
     // step size predicted from the previous accepted step (first step: tau_max, corrected below) -- unless it is the last one the iteration
     // cap allows (that one is applied whatever it looks like: exact).
@@ -159,7 +162,102 @@ int lm_solve(gsfm_rot_problem* P, const gsfm_rot_options& o_in, gsfm_rot_summary
     // step has cost more GPU time than a factorisation of their size is known to take (dense_cost_ms below): sticky for the rest of the solve.
     const int64_t dense_cap = o.dense_cholesky_max_cams > 0 ? o.dense_cholesky_max_cams : -(int64_t)o.dense_cholesky_max_cams;
     const bool dense_auto = o.dense_cholesky_max_cams > 0 && (int64_t)P->n_cams > dense_cap && (int64_t)P->n_cams <= (int64_t)o.dense_cholesky_auto_cams && pcg_dearer_than_cholesky;
-    if (!P->sharded && ((dense_cap > 0 && (int64_t)P->n_cams <= dense_cap && (o.dense_cholesky_max_cams > 0 || pcg_struggles)) || dense_auto)) {
+    const bool exact_now = !P->sharded && ((dense_cap > 0 && (int64_t)P->n_cams <= dense_cap && (o.dense_cholesky_max_cams > 0 || pcg_struggles)) || dense_auto);
+    if (exact_now && device_control && !exact_pipeline_broken) {
+      // Exact step with the trust-region decisions on the device (kernels.hpp, k_lm_decide): the whole LM iteration -- factorisation, step,
+      // trial cost, decision, predicated accept path, damping for the next step -- is enqueued without a host decision, and iteration k + 1
+      // is enqueued BEFORE iteration k's record is read (from a side stream), so the GPU never waits for the host between two exact steps.
+      // An iteration enqueued ahead of a verdict that ends the run (termination, broken factor) decides nothing (CT_SKIPPED).
+      double* ctl = P->scal.p + SC_CTL;
+      const LmOpts lo{o.function_tolerance, o.gradient_tolerance, o.parameter_tolerance, o.min_relative_decrease, o.max_trust_region_radius, o.min_trust_region_radius};
+      constexpr int REC = CT_N + 1;
+      if (!P->rec_host) {
+        if (hipHostMalloc((void**)&P->rec_host, 4 * REC * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+            hipHostGetDevicePointer((void**)&P->rec_dev, P->rec_host, 0) != hipSuccess) { (void)hipGetLastError(); return fail(GSFM_ERR_HIP, "mapped record of the LM control"); }
+      }
+      auto enqueue_exact = [&](int it) -> int {   // 0: enqueued, 1: no exact step possible (size, memory), < 0: error
+        bool used = false;
+        if (int st = run_dense(P, &used)) return -st;
+        if (!used) return 1;
+        launch_step(P);
+        if (int st = launch_cost(P, P->q_trial.p, SC_TRIAL)) return -st;
+        hipLaunchKernelGGL(k_lm_decide, dim3(1), dim3(1), 0, P->stream, lo, (const double*)P->scal.p, (int)SC_STEP, (int)SC_TRIAL, (int)SC_DENSE_INFO, ctl);
+        hipLaunchKernelGGL(k_lm_accept, dim3(P->nb_cam), dim3(GSFM_BLOCK), 0, P->stream, (const double*)ctl, P->n_cams, P->param_dim, P->x.p, (const double*)P->x_trial.p, P->q.p, (const double2*)P->q_trial.p);
+        if (int st = launch_lin(P, P->q.p, ctl + CT_ACCEPT)) return -st;
+        launch_prep(P, o, radius, false, ctl + CT_RADIUS);
+        P->rec_host[REC * (it & 3) + CT_N] = -1.0;   // (the slot's previous user, iteration it - 4, was read long ago)
+        hipLaunchKernelGGL(k_lm_after, dim3(1), dim3(1), 0, P->stream, lo, (const double*)P->scal.p, (int)SC_GMAX, ctl, P->rec_dev + REC * (it & 3), (double)it);
+        return 0;
+      };
+      int eq = 0;
+      exact_pipeline_used = true;
+      if (!spec_enqueued) {
+        hipLaunchKernelGGL(k_lm_set, dim3(1), dim3(1), 0, P->stream, ctl, radius, decrease_factor, x_cost, x_norm, gmax, (double)num_invalid);
+        eq = enqueue_exact(iteration);
+        if (eq < 0) return -eq;
+      }
+      if (eq == 1) exact_pipeline_broken = true;   // (falls through to the generic path below: PCG)
+      else {
+        spec_enqueued = false;
+        static const bool ahead = [] { const char* e = getenv("GSFM_LM_ENQUEUE_AHEAD"); return !(e && *e && atoi(e) == 0); }();
+        if (ahead && iteration + 1 <= o.max_num_iterations) {
+          const int e2 = enqueue_exact(iteration + 1);
+          if (e2 < 0) return -e2;
+          spec_enqueued = e2 == 0;
+        }
+        double c[CT_N];
+        {   // this iteration's record: poll its stamp in mapped host memory (the main stream may already be running the next iteration)
+          volatile double* slot = P->rec_host + REC * (iteration & 3);
+          const double t_poll = now_ms();
+          bool seen = false;
+          for (long spin = 0; !(seen = slot[CT_N] == (double)iteration); ++spin) {
+            if ((spin & 0x3ff) == 0x3ff && now_ms() - t_poll > 20000.0) break;   // (20 s: something is badly wrong)
+            __builtin_ia32_pause();
+          }
+          if (!seen) {   // fall back to the stream: an error on it surfaces here
+            if (int st = sync_check(P, "LM control: record")) return st;
+            if (slot[CT_N] != (double)iteration) return fail(GSFM_ERR_HIP, "LM control: the record of an iteration never arrived");
+          }
+          std::atomic_thread_fence(std::memory_order_acquire);
+          for (int k = 0; k < CT_N; ++k) c[k] = slot[k];
+        }
+        prep_valid = true;                                 // (rebuilt on the device with the radius decided there)
+        if (c[CT_DENSE_FAIL] != 0.0) {
+          // the factorisation met a non-positive pivot: nothing was decided, the linearisation did not run, the damping was rebuilt from the
+          // unchanged radius, whatever was enqueued ahead is skipping itself; PCG solves this step again under host control
+          if (int st = sync_check(P, "LM control: drain")) return st;
+          spec_enqueued = false;
+        } else {
+          sum->num_dense_solves++;
+          sum->num_residual_sweeps++;
+          num_invalid = (int)c[CT_NINVALID];
+          auto leave = [&](int term) { return finish(term); };
+          if (c[CT_VALID] == 0.0) {                          // HandleInvalidStep
+            if (c[CT_TERM] == 4.0) return leave(GSFM_TERM_FAILURE);
+            radius = c[CT_RADIUS]; decrease_factor = c[CT_DF];
+            sum->num_unsuccessful_steps++;
+            record(x_cost, 0, 0, 0, 0);
+            continue;
+          }
+          if (c[CT_NONFINITE] != 0.0) sum->nonfinite = 1;
+          const double step_norm = c[CT_STEPN], cost_change = c[CT_CC], rel_dec = c[CT_CC] / c[CT_MCC];
+          if (sum->iters_to_1e6 < 0 && std::fabs(cost_change) <= 1e-6 * x_cost) sum->iters_to_1e6 = iteration;
+          if (c[CT_TERM] == 2.0) { record(x_cost, cost_change, step_norm, rel_dec, 0); return leave(GSFM_TERM_PARAMETER_TOLERANCE); }
+          if (c[CT_TERM] == 0.0) { record(x_cost, cost_change, step_norm, rel_dec, 0); return leave(GSFM_TERM_FUNCTION_TOLERANCE); }
+          radius = c[CT_RADIUS]; decrease_factor = c[CT_DF];
+          if (c[CT_ACCEPT] != 0.0) {
+            x_norm = c[CT_XNORM]; x_cost = c[CT_XCOST]; gmax = c[CT_GMAX];
+            sum->num_residual_sweeps++; sum->num_linearizations++;
+            sum->num_successful_steps++;
+            last_successful = true;
+            pred_rms = step_norm / sqrt_n;
+          } else sum->num_unsuccessful_steps++;
+          record(x_cost, cost_change, step_norm, rel_dec, 0);
+          continue;
+        }
+      }
+    }
+    if (exact_now && !exact_pipeline_broken && !(device_control)) {
       if (int st = run_dense(P, &dense_used)) return st;
     }
     for (int attempt = 0; attempt < 2; ++attempt) {
@@ -170,56 +268,6 @@ int lm_solve(gsfm_rot_problem* P, const gsfm_rot_options& o_in, gsfm_rot_summary
       }
       launch_step(P, !dense_used && loose);
       if (int st = launch_cost(P, P->q_trial.p, SC_TRIAL)) return st;
-      if (dense_used && device_control) {
-        // Exact step: the trust-region decisions are taken on the device (kernels.hpp, k_lm_decide), the accept path is enqueued predicated on
-        // them, the damping is rebuilt from the radius they leave -- the whole LM iteration without a host decision, ONE read-back.
-        double* ctl = P->scal.p + SC_CTL;
-        const LmOpts lo{o.function_tolerance, o.gradient_tolerance, o.parameter_tolerance, o.min_relative_decrease, o.max_trust_region_radius, o.min_trust_region_radius};
-        hipLaunchKernelGGL(k_lm_set, dim3(1), dim3(1), 0, P->stream, ctl, radius, decrease_factor, x_cost, x_norm, gmax, (double)num_invalid);
-        hipLaunchKernelGGL(k_lm_decide, dim3(1), dim3(1), 0, P->stream, lo, (const double*)P->scal.p, (int)SC_STEP, (int)SC_TRIAL, (int)SC_DENSE_INFO, ctl);
-        hipLaunchKernelGGL(k_lm_accept, dim3(P->nb_cam), dim3(GSFM_BLOCK), 0, P->stream, (const double*)ctl, P->n_cams, P->param_dim, P->x.p, (const double*)P->x_trial.p, P->q.p, (const double2*)P->q_trial.p);
-        if (int st = launch_lin(P, P->q.p, ctl + CT_ACCEPT)) return st;
-        launch_prep(P, o, radius, false, ctl + CT_RADIUS);
-        hipLaunchKernelGGL(k_lm_after, dim3(1), dim3(1), 0, P->stream, lo, (const double*)P->scal.p, (int)SC_GMAX, ctl);
-        double hc[SC_ALL];
-        if (int st = read_back(P, hc, P->scal.p, SC_ALL * sizeof(double), "read scalars + LM control")) return st;
-        std::memcpy(h, hc, sizeof(h));
-        const double* c = hc + SC_CTL;
-        if (c[CT_DENSE_FAIL] == 0.0) {
-          sum->num_dense_solves++;
-          sum->num_residual_sweeps++;
-          num_invalid = (int)c[CT_NINVALID];
-          prep_valid = true;                                 // (rebuilt on the device with the radius decided there)
-          if (c[CT_VALID] == 0.0) {                          // HandleInvalidStep
-            if (c[CT_TERM] == 4.0) return finish(GSFM_TERM_FAILURE);
-            radius = c[CT_RADIUS]; decrease_factor = c[CT_DF];
-            sum->num_unsuccessful_steps++;
-            record(x_cost, 0, 0, 0, 0);
-            handled_on_device = true;
-            break;
-          }
-          if (c[CT_NONFINITE] != 0.0) sum->nonfinite = 1;
-          const double step_norm = c[CT_STEPN], cost_change = c[CT_CC], rel_dec = c[CT_CC] / c[CT_MCC];
-          if (sum->iters_to_1e6 < 0 && std::fabs(cost_change) <= 1e-6 * x_cost) sum->iters_to_1e6 = iteration;
-          if (c[CT_TERM] == 2.0) { record(x_cost, cost_change, step_norm, rel_dec, 0); return finish(GSFM_TERM_PARAMETER_TOLERANCE); }
-          if (c[CT_TERM] == 0.0) { record(x_cost, cost_change, step_norm, rel_dec, 0); return finish(GSFM_TERM_FUNCTION_TOLERANCE); }
-          radius = c[CT_RADIUS]; decrease_factor = c[CT_DF];
-          if (c[CT_ACCEPT] != 0.0) {
-            x_norm = c[CT_XNORM]; x_cost = c[CT_XCOST]; gmax = c[CT_GMAX];
-            sum->num_residual_sweeps++; sum->num_linearizations++;
-            sum->num_successful_steps++;
-            last_successful = true;
-            pred_rms = step_norm / sqrt_n;
-          } else sum->num_unsuccessful_steps++;
-          record(x_cost, cost_change, step_norm, rel_dec, 0);
-          handled_on_device = true;
-          break;
-        }
-        // the factorisation met a non-positive pivot: nothing was decided (the control block is untouched apart from its flags, the
-        // linearisation did not run, the damping was rebuilt from the unchanged radius); PCG solves the step again, host control
-        dense_used = false;
-        continue;
-      }
       if (int st = read_scalars(P, h)) return st;
       for (int pass = 0; pass < 3 && !dense_used && loose && cg_rel > o.cg_relative_tolerance; ++pass) {
         // The loose step has been evaluated.  Every decision the trust-region loop takes from it must be the one the exact step would give:
@@ -260,7 +308,6 @@ int lm_solve(gsfm_rot_problem* P, const gsfm_rot_options& o_in, gsfm_rot_summary
       if (info == 0) { sum->num_dense_solves++; break; }
       dense_used = false;   // not positive definite to working precision: the step just evaluated is meaningless, PCG solves it again
     }
-    if (handled_on_device) { cg_ms_before = P->timer.acc[T_CG]; continue; }
     if (!dense_used && !P->sharded && (int64_t)P->n_cams <= (int64_t)o.dense_cholesky_auto_cams) {   // GPU time of this step's linear solve (HIP events, resolved by the read-back above)
       const double step_ms = P->timer.acc[T_CG] - cg_ms_before;
       if (step_ms > 1.25 * dense_cost_ms(3.0 * P->n_cams)) pcg_dearer_than_cholesky = true;
