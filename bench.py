@@ -507,10 +507,10 @@ def main():
                                                                    ": residual, row Jacobian, robust weight rho', gradient, diagonal blocks, edge blocks; once per accepted LM step "
                                                                    "(fast path: losses with rho'' <= 0, see kernels.hpp lin_entry_eval)",
                               traffic=pmc_bytes("k_lin"), frac_on_survey_8d_bytes=(168.0 * e_local + 72.0 * n_cams) / (kt["k_lin"] * 1e-3) / 1e9 / HBM_PEAK_GBPS),
-                "k_cost_trial": k1_entry(variants["trial_cost"], 0.0, "K1 k_cost<FULL=false>: residual + rho VALUE, block-reduced; the solver's trial-cost sweep (no rho', no per-edge store)", "k_cost"),
-                "k_cost_reweight": k1_entry(variants["rho1_only"], 8.0, "K1 k_cost<FULL=true>, the reweight sweep as SURVEY 8(d) defines it: residual, loss, rho' stored per edge "
+                "k_cost_trial": k1_entry(variants["trial_cost"], 0.0, "K1 k_cost<MODE 0>: residual + rho VALUE, block-reduced; the solver's trial-cost sweep (no rho', no per-edge store)", "k_cost"),
+                "k_cost_reweight": k1_entry(variants["rho1_only"], 8.0, "K1 k_cost<MODE 2>, the reweight sweep as SURVEY 8(d) defines it (own lean instantiation since round 4): residual, loss, rho' stored per edge "
                                                                         "(problem edge order, coalesced non-temporal stores)", "k_cost_reweight"),
-                "k_cost_full": k1_entry(variants["full_reweight"], 32.0, "K1 k_cost<FULL=true>: residual, s, (rho, rho', rho'') stored per edge in the problem's edge order "
+                "k_cost_full": k1_entry(variants["full_reweight"], 32.0, "K1 k_cost<MODE 1>: residual, s, (rho, rho', rho'') stored per edge in the problem's edge order "
                                                                          "(what gsfm_rot_residuals runs; the caller's order is restored at the C-ABI boundary)", "k_cost_full"),
                 "k_cost_s_only": k1_entry(variants["s_only"], 8.0, "K1 s-only mode: s stored per edge (pass 1 of host-callback losses)", "k_cost_s_only"),
             }

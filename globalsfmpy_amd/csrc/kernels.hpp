@@ -491,9 +491,10 @@ struct CostArgs {
 // are 16-byte coalesced, non-temporal loads; both camera quaternions come from LDS.  Measured (tools/bench_cost*.hip, C5): streams only
 // 137 us; + all arithmetic 138-152 us (hidden); direct global gathers 181 us; these 2-D LDS tiles 160 us.
 // One edge of K1: residual, s, loss, optional per-edge outputs; returns the edge's 1/2 rho (0 in s_only mode).
-template <int F, int WM, int LM, bool FULL>
+template <int F, int WM, int LM, int MODE>
 __device__ __forceinline__ double cost_edge(const CostArgs& a, uint32_t e, const Quat& qi, const Quat& qj, const Quat& qr, EdgeW W, double& dw_acc) {
   constexpr int R = ResDim<F>::R;
+  constexpr bool FULL = MODE == 1;   // MODE 0: cost only (trial sweeps); 1: every optional output, sigma consensus, host-callback rho; 2: the reweight sweep (rho' stored)
   double r[R];
   if (FULL && F == F_AA && WM == W_SCALAR && a.sigma.on) {
     const double w_old = W.l00;
@@ -510,7 +511,12 @@ __device__ __forceinline__ double cost_edge(const CostArgs& a, uint32_t e, const
   double s = 0.0;
 #pragma unroll
   for (int k = 0; k < R; ++k) s += r[k] * r[k];
-  if (!FULL) return 0.5 * loss_value<LM>(a.loss, s);
+  if (MODE == 0) return 0.5 * loss_value<LM>(a.loss, s);
+  if (MODE == 2) {   // SURVEY 8(d)'s reweight sweep and nothing else: residual, loss, rho' out (8 B, coalesced, non-temporal), no run-time option in the way
+    const Rho3 rho = loss_eval<LM>(a.loss, s);
+    __builtin_nontemporal_store(rho.r1, a.rho1_out + e);
+    return 0.5 * rho.r0;
+  }
   if (a.s_only) { __builtin_nontemporal_store(s, a.s_out + e); return 0.0; }
   Rho3 rho;
   if (a.rho_ext) { const size_t o = 3 * (size_t)a.eid[e]; rho.r0 = a.rho_ext[o]; rho.r1 = a.rho_ext[o + 1]; rho.r2 = a.rho_ext[o + 2]; }
@@ -525,7 +531,7 @@ __device__ __forceinline__ double cost_edge(const CostArgs& a, uint32_t e, const
   return 0.5 * rho.r0;
 }
 
-template <int F, int WM, int LM, bool FULL>
+template <int F, int WM, int LM, int MODE>
 __global__ void __launch_bounds__(GSFM_TILE_THREADS) k_cost(CostArgs a) {
   __shared__ double2 qi_xy[GSFM_CAMBLOCK], qi_zw[GSFM_CAMBLOCK], qj_xy[GSFM_CAMBLOCK], qj_zw[GSFM_CAMBLOCK];
   __shared__ double lds[GSFM_TILE_THREADS / 64 + 1];
@@ -560,7 +566,7 @@ __global__ void __launch_bounds__(GSFM_TILE_THREADS) k_cost(CostArgs a) {
       const Quat qr{r0[u].x, r0[u].y, r1[u].x, r1[u].y};
       const double2 i0 = qi_xy[ij[u].x], i1 = qi_zw[ij[u].x], j0 = qj_xy[ij[u].y], j1 = qj_zw[ij[u].y];
       const Quat qi{i0.x, i0.y, i1.x, i1.y}, qj{j0.x, j0.y, j1.x, j1.y};
-      acc += cost_edge<F, WM, LM, FULL>(a, e, qi, qj, qr, Wm[u], dw);
+      acc += cost_edge<F, WM, LM, MODE>(a, e, qi, qj, qr, Wm[u], dw);
     }
   }
   // deterministic block reduction (fixed tree per wave, fixed order over the 16 waves)
@@ -572,7 +578,7 @@ __global__ void __launch_bounds__(GSFM_TILE_THREADS) k_cost(CostArgs a) {
     for (int k = 0; k < GSFM_TILE_THREADS / 64; ++k) t += lds[k];
     a.partials[blockIdx.x] = t;
   }
-  if (FULL) {   // sum |w - w_old| of the sigma mode (zero otherwise)
+  if (MODE == 1) {   // sum |w - w_old| of the sigma mode (zero otherwise)
     dw = wave_sum(dw);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = dw;
@@ -589,7 +595,7 @@ __global__ void __launch_bounds__(GSFM_TILE_THREADS) k_cost(CostArgs a) {
 // 128 KiB fill -- many cameras at a fixed degree (edges per tile = degree * 2048^2 / cameras), or one rank's share of a
 // sharded problem.  Same edge order (so a chunk's gathers fall into few 64 KiB windows of q), `idx` holds GLOBAL camera
 // indices, the quaternions are gathered through L1/L2; 256 lanes per workgroup, no LDS, so the occupancy is VGPR-bound.
-template <int F, int WM, int LM, bool FULL>
+template <int F, int WM, int LM, int MODE>
 __global__ void __launch_bounds__(GSFM_BLOCK) k_cost_direct(CostArgs a) {
   __shared__ double lds[GSFM_BLOCK / 64 + 1];
   const CostTile tile = a.tiles[blockIdx.x];
@@ -600,7 +606,7 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_cost_direct(CostArgs a) {
     EdgeW W = load_w<WM>(a.w0, a.w1, a.w2, a.ws, e);
     if (WM == W_SCALAR && a.unit_w) W.l00 = 1.0;
     const Quat qi = load_q(a.q, ij.x), qj = load_q(a.q, ij.y);
-    acc += cost_edge<F, WM, LM, FULL>(a, e, qi, qj, Quat{r0.x, r0.y, r1.x, r1.y}, W, dw);
+    acc += cost_edge<F, WM, LM, MODE>(a, e, qi, qj, Quat{r0.x, r0.y, r1.x, r1.y}, W, dw);
   }
   acc = wave_sum(acc);
   if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = acc;
@@ -610,7 +616,7 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_cost_direct(CostArgs a) {
     for (int k = 0; k < GSFM_BLOCK / 64; ++k) t += lds[k];
     a.partials[blockIdx.x] = t;
   }
-  if (FULL) {
+  if (MODE == 1) {
     dw = wave_sum(dw);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = dw;

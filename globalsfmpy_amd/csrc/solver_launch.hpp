@@ -31,13 +31,17 @@ int dispatch(const gsfm_rot_problem* P, const ArgsT& args, int grid) {
 template <int F, int W, int L> struct CostLauncher {
   static void go(const CostArgs& a, int grid, hipStream_t s) {
     const bool full = a.s_only || a.rho_ext || a.srho_out || a.rho12_out || a.rho1_out || a.r_out || a.sigma.on;
+    // the reweight sweep proper (rho' out and nothing else asked for) has its own lean instantiation
+    const bool reweight = a.rho1_out && !(a.s_only || a.rho_ext || a.srho_out || a.rho12_out || a.r_out || a.sigma.on);
     if (a.direct) {
-      if (full) hipLaunchKernelGGL((k_cost_direct<F, W, L, true>), dim3(grid), dim3(GSFM_BLOCK), 0, s, a);
-      else hipLaunchKernelGGL((k_cost_direct<F, W, L, false>), dim3(grid), dim3(GSFM_BLOCK), 0, s, a);
+      if (reweight) hipLaunchKernelGGL((k_cost_direct<F, W, L, 2>), dim3(grid), dim3(GSFM_BLOCK), 0, s, a);
+      else if (full) hipLaunchKernelGGL((k_cost_direct<F, W, L, 1>), dim3(grid), dim3(GSFM_BLOCK), 0, s, a);
+      else hipLaunchKernelGGL((k_cost_direct<F, W, L, 0>), dim3(grid), dim3(GSFM_BLOCK), 0, s, a);
       return;
     }
-    if (full) hipLaunchKernelGGL((k_cost<F, W, L, true>), dim3(grid), dim3(GSFM_TILE_THREADS), 0, s, a);
-    else hipLaunchKernelGGL((k_cost<F, W, L, false>), dim3(grid), dim3(GSFM_TILE_THREADS), 0, s, a);
+    if (reweight) hipLaunchKernelGGL((k_cost<F, W, L, 2>), dim3(grid), dim3(GSFM_TILE_THREADS), 0, s, a);
+    else if (full) hipLaunchKernelGGL((k_cost<F, W, L, 1>), dim3(grid), dim3(GSFM_TILE_THREADS), 0, s, a);
+    else hipLaunchKernelGGL((k_cost<F, W, L, 0>), dim3(grid), dim3(GSFM_TILE_THREADS), 0, s, a);
   }
 };
 // K2: GSFM_K2_FAST=0 switches the fast path (losses with rho'' <= 0) off, for A/B measurements.  Read at every launch.

@@ -1,0 +1,8 @@
+import sys; sys.path.insert(0, "/root/repo")
+from globalsfmpy_amd import _abi, synth
+from globalsfmpy_amd.loss_functions import MAGSACWeightBasedLoss
+from globalsfmpy_amd.solver import RotationProblem
+g = synth.make_graph(100000, 10000000, 2023, outlier_frac=0.3)
+p = RotationProblem(g["n_cams"], g["edge_i"], g["edge_j"], g["rel_aa"], _abi.ANGLE_AXIS_COVARIANCE, cov6=g["cov6"])
+p.set_loss(MAGSACWeightBasedLoss(0.02))
+for _ in range(3): print({k: round(1e3 * v, 1) for k, v in p.time_sweep_variants(g["init_aa"], reps=10).items()})
