@@ -195,7 +195,8 @@ typedef struct {
                                           MI355X (0.45 ms at 394 cameras, 1.33 at 800, 3.27 at 1500, 13.5 at 3000; tools/bench_chol.hip).  Easy
                                           graphs (a few dozen PCG iterations per step) never switch; Madrid-like ones (hundreds) do after their
                                           first step.  Ignored for sharded problems and when dense_cholesky_max_cams < 0. */
-  double pcg_forcing_tolerance;        /* default 1e-8 rad: largest estimated rms deviation of an inexact step from the exact one -- two orders below
+  double pcg_forcing_tolerance;        /* default 1e-8 rad: largest estimated rms deviation of an inexact step from the exact one (or 5e-6 x the squared
+                                          rms step size in radians, whichever is larger: a Gauss-Newton step of several degrees carries a far larger linearisation error) -- two orders below
                                           north_star's parity bar of 1e-6 rad (DESIGN.md section 6 has the measured trade: 1e-7 is 4 % faster on
                                           the benchmark graph and flips a borderline termination on one MAGSAC test graph).  A loose iterate's
                                           component along the gauge (all cameras rotated alike: the null space of J^T J, invisible to the energy
