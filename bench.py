@@ -531,6 +531,19 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args, loss_ctor, error_type, rot_cmp, summ)
     else:
         out = None
+    # From here on the line is armed: the variants below have never run across GPUs, and a GPU fault in one of them would end the process
+    # from inside the runtime (abort()) -- a C-level handler then writes the plain-launch line measured above and leaves with status 0.
+    crash_lib = None
+    if part is not None:
+        try:
+            import ctypes
+            crash_lib = ctypes.CDLL(os.path.join(ROOT, "globalsfmpy_amd", "libgsfm_peer.so"))
+            line0 = (json.dumps(dict(out, after_the_plain_run="a later variant ended the process: this is the plain-launch measurement")) + "\n").encode() if rank == 0 else b""
+            crash_lib.gsfm_crash_line_arm(ctypes.c_int(real_stdout if rank == 0 else -1), line0, ctypes.c_size_t(len(line0)))
+        except OSError:
+            crash_lib = None
+        if os.environ.get("GSFM_BENCH_TEST_CRASH") == "1":   # (test hook: what a GPU fault does)
+            os.abort()
     if sharded_capture:
         # The library's default for the native communicator: PCG chunks replayed as hipGraphs WITH their all-gathers.  Tried only now that the
         # plain-launch line exists; if it does not come back in time, rank 0 prints that line and every rank leaves with status 0.
@@ -594,6 +607,8 @@ def main():
         wd.cancel()
         if rank == 0:
             out["peer_store_exchange"] = info
+    if crash_lib is not None:
+        crash_lib.gsfm_crash_line_disarm()
     if rank == 0:
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
