@@ -144,7 +144,9 @@ int lm_solve(gsfm_rot_problem* P, const gsfm_rot_options& o_in, gsfm_rot_summary
   // graph: 683 -> ~500 PCG iterations, the final answer ~1e-9 rad (mean) from the exact schedule (profiles/r04_forcing_floor.txt).
   // GSFM_FORCING_KAPPA overrides (0 = absolute bound only).
   static const double kappa = [] { const char* e = getenv("GSFM_FORCING_KAPPA"); return e && *e ? atof(e) : 5e-6; }();
-  const bool forcing = o.pcg_forcing > 0 && P->n_components <= 1 && eps_rad > 0.0;
+  // (not for QUATERNION_NORM: that functor canonicalises the sign of two quaternions separately, quat.hpp:135-142 -- a DISCONTINUOUS residual, where a
+  // 1e-8 rad difference in an iterate flips signs the exact schedule does not flip; tests/manual/fuzz_forcing.py found it)
+  const bool forcing = o.pcg_forcing > 0 && P->n_components <= 1 && eps_rad > 0.0 && P->functor != F_QNORM;
   double pred_rms = -1.0;          // rms size of the last accepted step: the (conservative: steps shrink) prediction of the next one's
   while (true) {
     if (iteration >= o.max_num_iterations) return finish(GSFM_TERM_NO_CONVERGENCE);

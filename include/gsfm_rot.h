@@ -184,7 +184,8 @@ typedef struct {
                                           resumable and the iterates are bit for bit those of an uninterrupted solve at that tolerance
                                           (estimator.cpp:300's SPARSE_NORMAL_CHOLESKY is what cg_relative_tolerance stands in for).  The last step
                                           an iteration cap allows is always solved tightly.  Not applied to disconnected graphs (their 1e-14 rule
-                                          above stands) or to exact Cholesky steps.
+                                          above stands), to exact Cholesky steps, or to QUATERNION_NORM (a discontinuous residual: its sign
+                                          canonicalisation flips under differences the schedule allows).
                                           0: every step at cg_relative_tolerance (rounds 1-3).  2 (a testing aid): every loose solve is continued
                                           to cg_relative_tolerance whatever its evaluation says -- the solve must then reproduce pcg_forcing = 0
                                           bit for bit, PCG iteration counts included (tests/test_gpu_round4.py). */
