@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <cfloat>
 #include "../../include/gsfm_rot.h"
+#include "devmath.hpp"
 
 namespace gsfm {
 
@@ -171,7 +172,7 @@ __device__ __forceinline__ double loss_magsac_value(const DevLossNode& n, double
   if (x > (long)n.table_len - 1) x = (long)n.table_len - 1;
   // nu = 3: table[x] = Gamma(1, x/1000) = exp(-x/1000); evaluating it beats a second random gather (the
   // arithmetic of this kernel is hidden behind the streams). Same quantised x, value within 1 ulp of the table.
-  const double tv = (n.nu == 3) ? exp(-1e-3 * (double)x) : n.table[x];
+  const double tv = (n.nu == 3) ? exp_sc(-1e-3 * (double)x) : n.table[x];
   const double weight = n.aux[4] * (tv - n.aux[7]);
   return n.inverse ? 1.0 / weight : n.aux[5] - weight;
 }
@@ -191,7 +192,7 @@ __device__ __forceinline__ Rho3 loss_magsac3(const DevLossNode& n, double sq) {
   bool zero_derivative = false;
   if (sq > n.aux[6]) { sq = n.aux[6]; zero_derivative = true; }
   const long x = (long)rint(1000.0 * sq / n.aux[1]);   // Python round(): half to even
-  const double e = exp(-1e-3 * (double)x);
+  const double e = exp_sc(-1e-3 * (double)x);
   Rho3 o;
   o.r0 = n.aux[5] - n.aux[4] * (e - n.aux[7]);
   o.r1 = n.rho1_scale * e;
@@ -209,7 +210,7 @@ __device__ __forceinline__ Rho3 loss_magsac3(const DevLossNode& n, double sq) {
 __device__ __forceinline__ double loss_magsac3_rho1(const DevLossNode& n, double sq) {
   if (sq > n.aux[6]) return 0.00001;
   const long x = (long)rint(1000.0 * sq / n.aux[1]);
-  const double r1 = n.rho1_scale * exp(-1e-3 * (double)x);
+  const double r1 = n.rho1_scale * exp_sc(-1e-3 * (double)x);
   return r1 == 0.0 ? 0.00001 : r1;
 }
 

@@ -12,6 +12,7 @@
 // EigenQuaternionParameterization) and is applied in O(N) camera kernels.
 #pragma once
 #include <hip/hip_runtime.h>
+#include "devmath.hpp"
 
 namespace gsfm {
 
@@ -63,7 +64,11 @@ __device__ __forceinline__ void quat_log(const Quat& q, double* e, double* s_out
     // division is ~25 instructions more per edge for a result that differs in the last ulp or two)
     const double rs = rsqrt(s2);
     const double s = s2 * rs;
-    const double two_theta = 2.0 * ((q.w < 0.0) ? atan2(-s, -q.w) : atan2(s, q.w));
+    // ceres takes atan2(-s, -w) for w < 0 and atan2(s, w) otherwise.  atan2 is odd in its first argument bit for bit, so both are
+    // +-atan2(s, |w|): ONE evaluation.  (Written as the two-way select, the compiler emitted two inline copies of atan2 under divergent
+    // exec masks -- the sign of w is arbitrary under the double cover, so almost every wavefront ran both.)
+    const double half = atan2_q1(s, fabs(q.w));
+    const double two_theta = 2.0 * ((q.w < 0.0) ? -half : half);
     const double k = two_theta * rs;
     e[0] = q.x * k; e[1] = q.y * k; e[2] = q.z * k;
     *s_out = s; *theta_out = two_theta;
