@@ -30,7 +30,10 @@ namespace gsfm {
 #endif
 #define GSFM_COL_PAD 0xffffffffu   // column value of a padding position (zero block, reads camera 0)
 
-struct ColWg { uint32_t first_sub, n_sub, row0, pad; };   // sub-chunk range; first row of the block (local to the owned rows)
+// One workgroup's task: a range of sub-chunks of one row block; `row0` = first row of the block (local to the owned rows); `part` = where its
+// partial row sums go (block * nch + chunk: what the finishing kernels index by).  The array is in LAUNCH order, which is not the order of
+// `part`: the tasks of a block have unequal sizes and the large ones of all blocks are launched first (problem_create.hpp, build_colsort).
+struct ColWg { uint32_t first_sub, n_sub, row0, part; };
 struct ColLayoutDev {
   const ColWg* wg;
   const uint2* meta;        // per position p of a sub-chunk: .x = neighbour camera | role << 31 (GSFM_COL_PAD = padding);
@@ -127,7 +130,7 @@ __device__ __forceinline__ void mv_col_body(const ColMatvecArgs& a, Stop stop_af
       for (uint32_t t = s1 - cnt[k]; t < s1; ++t) { y0 += slots[buf][k][0][t]; y1 += slots[buf][k][1][t]; y2 += slots[buf][k][2][t]; }
     }
   }
-  const size_t o = (size_t)blockIdx.x * RB + r, plane = (size_t)a.L.n_wg * RB;
+  const size_t o = (size_t)w.part * RB + r, plane = (size_t)a.L.n_wg * RB;
   a.part[o] = y0; a.part[plane + o] = y1; a.part[2 * plane + o] = y2;
 }
 __global__ void __launch_bounds__(GSFM_COL_RB) k_mv_col(ColMatvecArgs a) {
@@ -266,6 +269,9 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_dense_assemble_col(DenseArgs a, 
 #ifndef GSFM_COLLIN_THREADS
 #define GSFM_COLLIN_THREADS 256
 #endif
+#ifndef GSFM_K2C_PIPE
+#define GSFM_K2C_PIPE 1
+#endif
 // which instantiations of K2c hand BODY-frame row sums to the finishing kernel (the host asks the same question: solver_launch.hpp)
 __host__ __device__ constexpr bool col_lin_body_frame(int functor, bool fast) { return fast && functor == F_AA; }
 struct ColLinArgs {
@@ -282,6 +288,7 @@ __device__ __forceinline__ void lin_col_body(const ColLinArgs& a) {
   __shared__ uint32_t wtot[RPL][T / 64];
   const ColWg w = a.L.wg[blockIdx.x];
   const uint32_t t = threadIdx.x;
+  const LossView<LM> lv = loss_view<LM>(a.lin.loss);   // (before the first store: scalar loads, see loss_dev.hpp)
   for (uint32_t r = t; r < RB; r += T) {
     const uint32_t k = min(a.lin.row_base + w.row0 + r, a.lin.row_base + a.lin.n_rows - 1);   // (a ragged last block re-reads its last row)
     qrow[0][r] = a.lin.q[2 * (size_t)k]; qrow[1][r] = a.lin.q[2 * (size_t)k + 1];
@@ -292,24 +299,34 @@ __device__ __forceinline__ void lin_col_body(const ColLinArgs& a) {
 #pragma unroll
     for (int c = 0; c < 9; ++c) acc[j][c] = 0.0;
   __syncthreads();
+  // Software pipeline over the sub-chunks (round 4): the records and streams of sub-chunk s + 1 are requested BEFORE sub-chunk s is
+  // evaluated and its neighbour quaternions before the row phase, so the HBM round trips run behind the ~1 100 VALU instructions of the
+  // evaluation, the LDS row phase and the two barriers instead of in front of them.  The registers for it (2 x 24 per lane) are the ones
+  // the scalar-register transcendentals freed (devmath.hpp; 228 -> 169 without the pipeline).  -DGSFM_K2C_PIPE=0: the round-3 form, both
+  // trips of ONE sub-chunk requested together (two dependent round trips per sub-chunk, nothing in flight during the evaluation).
+  constexpr int K = SUB / T;
+  static_assert(K == RPL, "one record per owned row");
+  uint2 mt[K];
+  LinStreams S[K];
+  Quat qm[K];
+  auto request = [&](uint32_t s, uint2* m, LinStreams* St) {   // (past the end: the last sub-chunk again, discarded)
+    const uint32_t sc = w.first_sub + min(s, w.n_sub - 1);
+#pragma unroll
+    for (int k = 0; k < K; ++k) m[k] = col_load_meta(a.L.meta + (sc * SUB + k * T + t));
+#pragma unroll
+    for (int k = 0; k < K; ++k) St[k] = lin_load_streams<WM>(a.lin, sc * SUB + k * T + t);
+  };
+  auto gather = [&](const uint2* m, Quat* q) {   // (padding positions read camera 0; nothing of it is used)
+#pragma unroll
+    for (int k = 0; k < K; ++k) q[k] = load_q(a.lin.q, m[k].x == GSFM_COL_PAD ? 0u : (m[k].x & 0x7fffffffu));
+  };
+  if (w.n_sub) { request(0, mt, S); gather(mt, qm); }
   for (uint32_t s = 0; s < w.n_sub; ++s) {
     const uint32_t sc = w.first_sub + s;
-    // The kernel is latency-bound (VALU ~20 % busy): both trips of the sub-chunk are requested together -- the two 8-byte records first,
-    // then, as soon as they are there, both trips' streams and neighbour quaternions -- so a sub-chunk pays two dependent memory round
-    // trips instead of four.  (Padding positions read camera 0 and their own, valid, stream slots; nothing of it is used.)  Requesting the
-    // NEXT sub-chunk's records ahead as well was measured and dropped: 793 us against 745 for the row-major K2 on the same box.
-    constexpr int K = SUB / T;
-    uint2 mt[K];
-#pragma unroll
-    for (int k = 0; k < K; ++k) mt[k] = col_load_meta(a.L.meta + (sc * SUB + k * T + t));
-    LinStreams S[K];
-    Quat qm[K];
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-      const uint32_t d = sc * SUB + k * T + t;
-      S[k] = lin_load_streams<WM>(a.lin, d);
-      qm[k] = load_q(a.lin.q, mt[k].x == GSFM_COL_PAD ? 0u : (mt[k].x & 0x7fffffffu));
-    }
+    uint2 mtn[K];
+    LinStreams Sn[K];
+    Quat qmn[K];
+    if (GSFM_K2C_PIPE) request(s + 1, mtn, Sn);
 #pragma unroll
     for (int k = 0; k < K; ++k) {
       const uint32_t d = sc * SUB + k * T + t;
@@ -319,7 +336,7 @@ __device__ __forceinline__ void lin_col_body(const ColLinArgs& a) {
         if (cr != GSFM_COL_PAD) {
           const uint32_t rl = col_rowl(mt[k].y);
           const double2 k0 = qrow[0][rl], k1 = qrow[1][rl];
-          lin_entry_body_aa<WM, LM>(a.lin, d, cr, Quat{k0.x, k0.y, k1.x, k1.y}, qm[k], S[k], g3, B6);
+          lin_entry_body_aa<WM, LM>(a.lin, lv, d, cr, Quat{k0.x, k0.y, k1.x, k1.y}, qm[k], S[k], g3, B6);
         }
 #pragma unroll
         for (int c = 0; c < 6; ++c) G6[c] = B6[c];
@@ -327,7 +344,7 @@ __device__ __forceinline__ void lin_col_body(const ColLinArgs& a) {
         const uint32_t rl = col_rowl(mt[k].y);
         const double2 k0 = qrow[0][rl], k1 = qrow[1][rl];
         const Quat qk{k0.x, k0.y, k1.x, k1.y};
-        lin_entry_eval<F, WM, LM, FAST>(a.lin, d, cr, qk, qm[k], S[k], g3, G6);
+        lin_entry_eval<F, WM, LM, FAST>(a.lin, lv, d, cr, qk, qm[k], S[k], g3, G6);
         // body frame: B = R_k^T G R_k  (the BODY instantiations produce B directly)
         double R[9], Tm[9];
         qmat(qk, R);
@@ -349,7 +366,6 @@ __device__ __forceinline__ void lin_col_body(const ColLinArgs& a) {
       for (int c = 0; c < 6; ++c) slots[3 + c][pm] = G6[c];
     }
     // slot ranges of rows t + j * T: the rows' counts ride in the records of positions t + j * T, i.e. in mt[j] (K == RPL)
-    static_assert(K == RPL, "one record per owned row");
     uint32_t cnt[RPL], inc[RPL];
 #pragma unroll
     for (int j = 0; j < RPL; ++j) {
@@ -357,24 +373,37 @@ __device__ __forceinline__ void lin_col_body(const ColLinArgs& a) {
       inc[j] = wave_incl_scan(cnt[j]);
       if ((t & 63u) == 63u) wtot[j][t >> 6] = inc[j];
     }
+    if (GSFM_K2C_PIPE) gather(mtn, qmn);   // the next sub-chunk's neighbour quaternions travel during the row phase
     __syncthreads();
-    uint32_t carry = 0;
+    uint32_t carry = 0, s0[RPL], nmax = 0;
 #pragma unroll
     for (int j = 0; j < RPL; ++j) {
       uint32_t s1 = carry + inc[j];
       for (uint32_t v = 0; v < T / 64; ++v) { const uint32_t wt = wtot[j][v]; if (v < (t >> 6)) s1 += wt; carry += wt; }
-      const uint32_t s0 = s1 - cnt[j];
-      for (uint32_t u = s0; u < s1; ++u) {
+      s0[j] = s1 - cnt[j];
+      nmax = max(nmax, cnt[j]);
+    }
+    // the rows of a lane side by side (their LDS reads are independent: one latency per step instead of one per row and step); every row
+    // still adds its slots in slot order
+    for (uint32_t u = 0; u < nmax; ++u) {
 #pragma unroll
-        for (int c = 0; c < 9; ++c) acc[j][c] += slots[c][u];
+      for (int j = 0; j < RPL; ++j) {
+        if (u < cnt[j]) {
+#pragma unroll
+          for (int c = 0; c < 9; ++c) acc[j][c] += slots[c][s0[j] + u];
+        }
       }
     }
     __syncthreads();
+    if (GSFM_K2C_PIPE) {
+#pragma unroll
+      for (int k = 0; k < K; ++k) { mt[k] = mtn[k]; S[k] = Sn[k]; qm[k] = qmn[k]; }
+    } else if (s + 1 < w.n_sub) { request(s + 1, mt, S); gather(mt, qm); }
   }
   const size_t plane = (size_t)a.L.n_wg * RB;
 #pragma unroll
   for (int j = 0; j < RPL; ++j) {
-    const size_t o = (size_t)blockIdx.x * RB + t + j * T;
+    const size_t o = (size_t)w.part * RB + t + j * T;
 #pragma unroll
     for (int c = 0; c < 9; ++c) a.part[(size_t)c * plane + o] = acc[j][c];
   }

@@ -492,7 +492,7 @@ struct CostArgs {
 // 137 us; + all arithmetic 138-152 us (hidden); direct global gathers 181 us; these 2-D LDS tiles 160 us.
 // One edge of K1: residual, s, loss, optional per-edge outputs; returns the edge's 1/2 rho (0 in s_only mode).
 template <int F, int WM, int LM, int MODE>
-__device__ __forceinline__ double cost_edge(const CostArgs& a, uint32_t e, const Quat& qi, const Quat& qj, const Quat& qr, EdgeW W, double& dw_acc) {
+__device__ __forceinline__ double cost_edge(const CostArgs& a, const LossView<LM>& lv, uint32_t e, const Quat& qi, const Quat& qj, const Quat& qr, EdgeW W, double& dw_acc) {
   constexpr int R = ResDim<F>::R;
   constexpr bool FULL = MODE == 1;   // MODE 0: cost only (trial sweeps); 1: every optional output, sigma consensus, host-callback rho; 2: the reweight sweep (rho' stored)
   double r[R];
@@ -511,16 +511,16 @@ __device__ __forceinline__ double cost_edge(const CostArgs& a, uint32_t e, const
   double s = 0.0;
 #pragma unroll
   for (int k = 0; k < R; ++k) s += r[k] * r[k];
-  if (MODE == 0) return 0.5 * loss_value<LM>(a.loss, s);
+  if (MODE == 0) return 0.5 * loss_value<LM>(lv, s);
   if (MODE == 2) {   // SURVEY 8(d)'s reweight sweep and nothing else: residual, loss, rho' out (8 B, coalesced, non-temporal), no run-time option in the way
-    const Rho3 rho = loss_eval<LM>(a.loss, s);
+    const Rho3 rho = loss_eval<LM>(lv, s);
     __builtin_nontemporal_store(rho.r1, a.rho1_out + e);
     return 0.5 * rho.r0;
   }
   if (a.s_only) { __builtin_nontemporal_store(s, a.s_out + e); return 0.0; }
   Rho3 rho;
   if (a.rho_ext) { const size_t o = 3 * (size_t)a.eid[e]; rho.r0 = a.rho_ext[o]; rho.r1 = a.rho_ext[o + 1]; rho.r2 = a.rho_ext[o + 2]; }
-  else rho = loss_eval<LM>(a.loss, s);
+  else rho = loss_eval<LM>(lv, s);
   if (a.srho_out) nt_store2(a.srho_out + e, s, rho.r0);
   if (a.rho12_out) nt_store2(a.rho12_out + e, rho.r1, rho.r2);
   if (a.rho1_out) __builtin_nontemporal_store(rho.r1, a.rho1_out + e);
@@ -536,6 +536,7 @@ __global__ void __launch_bounds__(GSFM_TILE_THREADS) k_cost(CostArgs a) {
   __shared__ double2 qi_xy[GSFM_CAMBLOCK], qi_zw[GSFM_CAMBLOCK], qj_xy[GSFM_CAMBLOCK], qj_zw[GSFM_CAMBLOCK];
   __shared__ double lds[GSFM_TILE_THREADS / 64 + 1];
   const CostTile tile = a.tiles[blockIdx.x];
+  const LossView<LM> lv = loss_view<LM>(a.loss);   // (before the first store: scalar loads, see loss_dev.hpp)
   {
     const uint32_t bi = tile.ib * GSFM_CAMBLOCK, bj = tile.jb * GSFM_CAMBLOCK;
     const uint32_t ci = min((uint32_t)GSFM_CAMBLOCK, a.n_cams - bi), cj = min((uint32_t)GSFM_CAMBLOCK, a.n_cams - bj);
@@ -566,7 +567,7 @@ __global__ void __launch_bounds__(GSFM_TILE_THREADS) k_cost(CostArgs a) {
       const Quat qr{r0[u].x, r0[u].y, r1[u].x, r1[u].y};
       const double2 i0 = qi_xy[ij[u].x], i1 = qi_zw[ij[u].x], j0 = qj_xy[ij[u].y], j1 = qj_zw[ij[u].y];
       const Quat qi{i0.x, i0.y, i1.x, i1.y}, qj{j0.x, j0.y, j1.x, j1.y};
-      acc += cost_edge<F, WM, LM, MODE>(a, e, qi, qj, qr, Wm[u], dw);
+      acc += cost_edge<F, WM, LM, MODE>(a, lv, e, qi, qj, qr, Wm[u], dw);
     }
   }
   // deterministic block reduction (fixed tree per wave, fixed order over the 16 waves)
@@ -599,6 +600,7 @@ template <int F, int WM, int LM, int MODE>
 __global__ void __launch_bounds__(GSFM_BLOCK) k_cost_direct(CostArgs a) {
   __shared__ double lds[GSFM_BLOCK / 64 + 1];
   const CostTile tile = a.tiles[blockIdx.x];
+  const LossView<LM> lv = loss_view<LM>(a.loss);
   double acc = 0.0, dw = 0.0;
   for (uint32_t e = tile.begin + threadIdx.x; e < tile.end; e += GSFM_BLOCK) {
     const uint2 ij = a.idx[e];
@@ -606,7 +608,7 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_cost_direct(CostArgs a) {
     EdgeW W = load_w<WM>(a.w0, a.w1, a.w2, a.ws, e);
     if (WM == W_SCALAR && a.unit_w) W.l00 = 1.0;
     const Quat qi = load_q(a.q, ij.x), qj = load_q(a.q, ij.y);
-    acc += cost_edge<F, WM, LM, MODE>(a, e, qi, qj, Quat{r0.x, r0.y, r1.x, r1.y}, W, dw);
+    acc += cost_edge<F, WM, LM, MODE>(a, lv, e, qi, qj, Quat{r0.x, r0.y, r1.x, r1.y}, W, dw);
   }
   acc = wave_sum(acc);
   if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = acc;
@@ -687,6 +689,7 @@ struct LinArgs {
 template <int F, int WM, int LM, bool LAP>
 __device__ __forceinline__ void lin_rows(const LinArgs& a) {
   if (a.go && *a.go == 0.0) return;
+  const LossView<LM> lv = loss_view<LM>(a.loss);   // (before the first store: scalar loads, see loss_dev.hpp)
   constexpr int R = ResDim<F>::R;
   const uint32_t G = a.G;
   const uint32_t t = blockIdx.x * GSFM_BLOCK + threadIdx.x;
@@ -726,7 +729,7 @@ __device__ __forceinline__ void lin_rows(const LinArgs& a) {
       for (int c = 0; c < R; ++c) s += r[c] * r[c];
       Rho3 rho;
       if (a.rho_ext) { const size_t o = 3 * (size_t)a.eid[d]; rho.r0 = a.rho_ext[o]; rho.r1 = a.rho_ext[o + 1]; rho.r2 = a.rho_ext[o + 2]; }
-      else rho = loss_eval<LM>(a.loss, s);
+      else rho = loss_eval<LM>(lv, s);
       robustify<R>(rho, s, r, Ai, Aj);
       const double* Ar = row_is_second ? Aj : Ai;  // Jacobian of the row camera
       const double* Ac = row_is_second ? Ai : Aj;  // Jacobian of the neighbour (dead code when LAP)
@@ -806,7 +809,7 @@ __device__ __forceinline__ void edge_lin_row(const Quat& qk, const Quat& qm, con
   if (F == F_AA) {
     const Quat qe = qmul(qmul(qj, qconj(qi)), qconj(qr));
     double e[3], s, th;
-    quat_log(qe, e, &s, &th);
+    quat_log<true>(qe, e, &s, &th);
     if (WM == W_SCALAR && sg.on) {   // sigma consensus: e is the unit-weight residual
       W.l00 = sigma_weight(sg, e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
       __builtin_nontemporal_store(W.l00, ws_slot);
@@ -844,13 +847,13 @@ __device__ __forceinline__ void edge_lin_row(const Quat& qk, const Quat& qm, con
 // g (3) and G = J_k^T J_k (6: 00 01 02 11 12 22) of one directed entry, Corrector applied.  FAST: the rho'' <= 0 path above; otherwise the
 // general one (both Jacobians, full Corrector, host-callback rho) restricted to the row camera's block -- the Laplacian form needs no more.
 template <int F, int WM, int LM, bool FAST>
-__device__ __forceinline__ void lin_entry_eval(const LinArgs& a, uint32_t d, uint32_t cr, const Quat& qk, const Quat& qm, LinStreams S, double* g3, double* G6) {
+__device__ __forceinline__ void lin_entry_eval(const LinArgs& a, const LossView<LM>& lv, uint32_t d, uint32_t cr, const Quat& qk, const Quat& qm, LinStreams S, double* g3, double* G6) {
   const Quat qr{S.r0.x, S.r0.y, S.r1.x, S.r1.y};
   const bool row_is_second = (cr >> 31) != 0;
   if (FAST) {
     double r[3], Ar[9];
     edge_lin_row<F, WM>(qk, qm, qr, S.W, row_is_second, a.sigma, a.ws_rw + d, r, Ar);
-    const double rho1 = loss_rho1<LM>(a.loss, r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+    const double rho1 = loss_rho1<LM>(lv, r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
 #pragma unroll
     for (int x = 0; x < 3; ++x) g3[x] = rho1 * (Ar[x] * r[0] + Ar[3 + x] * r[1] + Ar[6 + x] * r[2]);
     G6[0] = rho1 * (Ar[0] * Ar[0] + Ar[3] * Ar[3] + Ar[6] * Ar[6]); G6[1] = rho1 * (Ar[0] * Ar[1] + Ar[3] * Ar[4] + Ar[6] * Ar[7]);
@@ -880,7 +883,7 @@ __device__ __forceinline__ void lin_entry_eval(const LinArgs& a, uint32_t d, uin
     for (int c = 0; c < R; ++c) s += r[c] * r[c];
     Rho3 rho;
     if (a.rho_ext) { const size_t o = 3 * (size_t)a.eid[d]; rho.r0 = a.rho_ext[o]; rho.r1 = a.rho_ext[o + 1]; rho.r2 = a.rho_ext[o + 2]; }
-    else rho = loss_eval<LM>(a.loss, s);
+    else rho = loss_eval<LM>(lv, s);
     robustify<R>(rho, s, r, Ai, Aj);
     const double* Ar = row_is_second ? Aj : Ai;
 #pragma unroll
@@ -904,14 +907,17 @@ __device__ __forceinline__ void lin_entry_eval(const LinArgs& a, uint32_t d, uin
 // second camera's body-frame Jacobian A = W J_l^-1(e) R_j.  One formula serves both roles (no R_ij matrix, no role-dependent branch), the block
 // B = rho' A^T A comes out in the body frame K3c wants (no R_k^T G R_k afterwards), and the row sums are rotated ONCE per row by the finishing
 // kernel: g_k = R_k sum(gb), D_k = R_k (sum B) R_k^T.  ~57 multiply-adds fewer per entry than lin_entry_eval<FAST> + the conjugation.
+#ifndef GSFM_K2C_SC
+#define GSFM_K2C_SC true   // K2c's transcendental coefficients in scalar registers (frees ~60 VGPRs; A/B: -DGSFM_K2C_SC=false)
+#endif
 template <int WM, int LM>
-__device__ __forceinline__ void lin_entry_body_aa(const LinArgs& a, uint32_t d, uint32_t cr, const Quat& qk, const Quat& qm, LinStreams S, double* gb3, double* B6) {
+__device__ __forceinline__ void lin_entry_body_aa(const LinArgs& a, const LossView<LM>& lv, uint32_t d, uint32_t cr, const Quat& qk, const Quat& qm, LinStreams S, double* gb3, double* B6) {
   const Quat qr{S.r0.x, S.r0.y, S.r1.x, S.r1.y};
   const bool row_is_second = (cr >> 31) != 0;
   const Quat qi = row_is_second ? qm : qk, qj = row_is_second ? qk : qm;
   const Quat qe = qmul(qmul(qj, qconj(qi)), qconj(qr));
   double e[3], s, th, r[3];
-  quat_log(qe, e, &s, &th);
+  quat_log<GSFM_K2C_SC>(qe, e, &s, &th);
   if (WM == W_SCALAR && a.sigma.on) {   // sigma consensus: e is the unit-weight residual
     S.W.l00 = sigma_weight(a.sigma, e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
     __builtin_nontemporal_store(S.W.l00, a.ws_rw + d);
@@ -922,7 +928,7 @@ __device__ __forceinline__ void lin_entry_body_aa(const LinArgs& a, uint32_t d, 
   qmat(qj, Rj);
   mat3_mul(Jm, Rj, JR);
   apply_w_mat<WM>(S.W, JR, A);
-  const double rho1 = loss_rho1<LM>(a.loss, r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+  const double rho1 = loss_rho1<LM, GSFM_K2C_SC>(lv, r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
   const double sg = row_is_second ? rho1 : -rho1;
 #pragma unroll
   for (int x = 0; x < 3; ++x) gb3[x] = sg * (A[x] * r[0] + A[3 + x] * r[1] + A[6 + x] * r[2]);
@@ -933,6 +939,7 @@ __device__ __forceinline__ void lin_entry_body_aa(const LinArgs& a, uint32_t d, 
 template <int F, int WM, int LM>
 __device__ __forceinline__ void lin_rows_fast(const LinArgs& a) {
   if (a.go && *a.go == 0.0) return;
+  const LossView<LM> lv = loss_view<LM>(a.loss);   // (before the first store: scalar loads, see loss_dev.hpp)
   const uint32_t G = a.G;
   const uint32_t t = blockIdx.x * GSFM_BLOCK + threadIdx.x;
   const uint32_t row = t / G, lane = t % G;
@@ -941,14 +948,16 @@ __device__ __forceinline__ void lin_rows_fast(const LinArgs& a) {
   if (live) {
     const Quat qk = load_q(a.q, a.row_base + row);
     const uint32_t end = a.row_ptr[row + 1];
-    // (a software-pipelined form of this loop -- next trip's streams and gather in flight during the evaluation -- was measured and dropped:
-    // 705-719 us against 710 at C5; at three waves per SIMD it spills and takes 1430)
+    // (a software-pipelined form of this loop -- next trip's column and streams requested before the current trip is evaluated, its
+    // neighbour quaternion after the block stores -- was measured twice and dropped: round 3, 705-719 us against 710 at C5; round 4, with
+    // the loss leaf in scalar registers and three waves per SIMD without spills, 404-455 us against 411-456 on the 100k / 10M ANGLE_AXIS
+    // problem (profiles/r04b_roll_ab.txt): three to five waves per SIMD already hide the round trips of this loop)
     for (uint32_t d = a.row_ptr[row] + lane; d < end; d += G) {
       const uint32_t cr = __builtin_nontemporal_load(a.col + d);
       const LinStreams S = lin_load_streams<WM>(a, d);
       const Quat qm = load_q(a.q, cr & 0x7fffffffu);
       double g3[3], G6[6];
-      lin_entry_eval<F, WM, LM, true>(a, d, cr, qk, qm, S, g3, G6);
+      lin_entry_eval<F, WM, LM, true>(a, lv, d, cr, qk, qm, S, g3, G6);
 #pragma unroll
       for (int c = 0; c < 3; ++c) acc[c] += g3[c];
 #pragma unroll

@@ -172,7 +172,7 @@ __device__ __forceinline__ double loss_magsac_value(const DevLossNode& n, double
   if (x > (long)n.table_len - 1) x = (long)n.table_len - 1;
   // nu = 3: table[x] = Gamma(1, x/1000) = exp(-x/1000); evaluating it beats a second random gather (the
   // arithmetic of this kernel is hidden behind the streams). Same quantised x, value within 1 ulp of the table.
-  const double tv = (n.nu == 3) ? exp_sc(-1e-3 * (double)x) : n.table[x];
+  const double tv = (n.nu == 3) ? exp(-1e-3 * (double)x) : n.table[x];
   const double weight = n.aux[4] * (tv - n.aux[7]);
   return n.inverse ? 1.0 / weight : n.aux[5] - weight;
 }
@@ -192,7 +192,7 @@ __device__ __forceinline__ Rho3 loss_magsac3(const DevLossNode& n, double sq) {
   bool zero_derivative = false;
   if (sq > n.aux[6]) { sq = n.aux[6]; zero_derivative = true; }
   const long x = (long)rint(1000.0 * sq / n.aux[1]);   // Python round(): half to even
-  const double e = exp_sc(-1e-3 * (double)x);
+  const double e = exp(-1e-3 * (double)x);
   Rho3 o;
   o.r0 = n.aux[5] - n.aux[4] * (e - n.aux[7]);
   o.r1 = n.rho1_scale * e;
@@ -207,10 +207,12 @@ __device__ __forceinline__ Rho3 loss_magsac3(const DevLossNode& n, double sq) {
 // needs nothing but sqrt(rho').  nu = 3: weight'(s) = -C 2 exp(-s / 2 sigma^2) / (2 sigma^3) on the quantised s (loss_functions.py:
 // 304-321): the table cell x comes from the same exact division as in loss_magsac, exp(-x / 1000) IS the table value
 // Gamma(1, x / 1000), and the constant factor is one host-precomputed product instead of a division per edge.
+// SC: the exponential with its coefficients in scalar registers (devmath.hpp: the same bits, ~25 vector registers fewer).
+template <bool SC>
 __device__ __forceinline__ double loss_magsac3_rho1(const DevLossNode& n, double sq) {
   if (sq > n.aux[6]) return 0.00001;
   const long x = (long)rint(1000.0 * sq / n.aux[1]);
-  const double r1 = n.rho1_scale * exp_sc(-1e-3 * (double)x);
+  const double r1 = n.rho1_scale * (SC ? exp_sc(-1e-3 * (double)x) : exp(-1e-3 * (double)x));
   return r1 == 0.0 ? 0.00001 : r1;
 }
 
@@ -256,12 +258,39 @@ __device__ __forceinline__ double loss_value(const DevLoss* __restrict__ loss, d
   return loss_eval<LM>(loss, s).r0;  // the unused derivatives are dead code for the simple leaves
 }
 
-// K2's fast path (see lin_rows_fast): only for LM_SIMPLE / LM_MAGSAC
+// What a kernel keeps of the loss after its prologue.  For the single-leaf specialisations a COPY of the leaf, taken before the kernel's
+// first global store: the compiler then reads the fields it needs with scalar loads and they stay in SGPRs.  Read through the pointer
+// INSIDE a kernel that also stores (K2, K2c, the K1 modes with per-edge outputs), the same fields were per-lane vector loads from a uniform
+// address (scalar loads are not coherent with the kernel's own stores, so the compiler may not use them), each followed by
+// s_waitcnt vmcnt(0) -- a wait for everything the lane had in flight, twice per entry in the MAGSAC leaf (cut test, then cell and scale).
+// The general program keeps the pointer (its node loop is the slow path anyway).
+template <int LM> struct LossView { const DevLoss* p; DevLossNode n; };
 template <int LM>
-__device__ __forceinline__ double loss_rho1(const DevLoss* __restrict__ loss, double s) {
-  if (LM == LM_MAGSAC) return loss_magsac3_rho1(loss->nodes[0], s);
-  return loss_leaf_simple(loss->nodes[0], s).r1;
+__device__ __forceinline__ LossView<LM> loss_view(const DevLoss* __restrict__ p) {
+  LossView<LM> v;
+  v.p = p;
+  if (LM != LM_PROGRAM) v.n = p->nodes[0];
+  return v;
 }
+template <int LM>
+__device__ __forceinline__ Rho3 loss_eval(const LossView<LM>& v, double s) {
+  if (LM == LM_SIMPLE) return loss_leaf_simple(v.n, s);
+  if (LM == LM_MAGSAC) return loss_magsac3(v.n, s);
+  return loss_eval_program(v.p, s);
+}
+template <int LM>
+__device__ __forceinline__ double loss_value(const LossView<LM>& v, double s) {
+  if (LM == LM_MAGSAC) return loss_magsac_value(v.n, s);
+  return loss_eval<LM>(v, s).r0;
+}
+// K2's fast path (see lin_rows_fast): only for LM_SIMPLE / LM_MAGSAC
+template <int LM, bool SC = true>
+__device__ __forceinline__ double loss_rho1(const LossView<LM>& v, double s) {
+  if (LM == LM_MAGSAC) return loss_magsac3_rho1<SC>(v.n, s);
+  return loss_leaf_simple(v.n, s).r1;
+}
+template <int LM, bool SC = true>
+__device__ __forceinline__ double loss_rho1(const DevLoss* __restrict__ loss, double s) { return loss_rho1<LM, SC>(loss_view<LM>(loss), s); }
 
 // Ceres Corrector (corrector.cc 1.14): residual scaling and the alpha term.
 struct Corrector { double sqrt_rho1, residual_scaling, alpha_sq_norm; };

@@ -141,6 +141,7 @@ int build_colsort(gsfm_rot_problem* P, const std::vector<uint32_t>& rp, hvec<uin
   hvec<uint2> h_meta(n_pos);
   hvec<uint16_t> h_kcnt(n_pos);
   std::vector<ColWg> h_wg((size_t)nblk * C.nch);
+  const bool graded = C.nch > 1 && !(getenv("GSFM_COL_EVEN") && atoi(getenv("GSFM_COL_EVEN")) > 0);
   parallel_run(std::max(1, std::min<int>(n_threads, (int)nblk)), [&](int t, int T) {
     std::vector<std::pair<uint64_t, uint32_t>> ent;   // (camera << 16 | local row, d): a repeated camera pair is ordered by d
     std::vector<uint32_t> cnt(RB + 1), fill(RB), chist;
@@ -163,9 +164,20 @@ int build_colsort(gsfm_rot_problem* P, const std::vector<uint32_t>& rp, hvec<uin
         for (uint32_t r = r0; r < r1; ++r) for (uint32_t d = rp[r]; d < rp[r + 1]; ++d) ent.emplace_back(((uint64_t)(col[d] & 0x7fffffffu) << 16) | (r - r0), d);
         std::sort(ent.begin(), ent.end());
       }
+      // The tasks of a block: its sub-chunks cut into nch ranges of DECREASING size (1.5 x the mean down to 0.5 x), launched chunk-major --
+      // the large tasks of all blocks first, the small ones last.  Equal tasks fill the chip in whole rounds (K2c: 2 x 256 resident
+      // workgroups, 1764 equal tasks = 3.45 rounds, the last one half empty; measured as a saw-tooth in the task count: 616 us at 1960
+      // tasks, 645 at 2156, 612 at 2548: profiles/r04b_wgs_sweep.txt); with graded sizes the tail is as long as the SMALLEST task.
+      // GSFM_COL_EVEN=1: equal sizes (the round-3 dealing).
       for (uint32_t c = 0; c < C.nch; ++c) {
-        const size_t lo = ns * c / C.nch, hi = ns * (c + 1) / C.nch;
-        h_wg[(size_t)b * C.nch + c] = ColWg{(uint32_t)(sub_off[b] + lo), (uint32_t)(hi - lo), r0, 0};
+        size_t lo, hi;
+        if (graded && ns >= 4 * (size_t)C.nch) {
+          // cumulative weight of chunks 0 .. c-1 with w_c = 1.5 - c / (nch - 1), total nch
+          auto cum = [&](uint32_t k) { return 1.5 * k - 0.5 * (double)k * (k - 1) / (double)(C.nch - 1); };
+          lo = (size_t)std::llround((double)ns * cum(c) / (double)C.nch); hi = (size_t)std::llround((double)ns * cum(c + 1) / (double)C.nch);
+          if (c + 1 == C.nch) hi = ns;
+        } else { lo = ns * c / C.nch; hi = ns * (c + 1) / C.nch; }
+        h_wg[(size_t)c * nblk + b] = ColWg{(uint32_t)(sub_off[b] + lo), (uint32_t)(hi - lo), r0, b * C.nch + c};
       }
       for (size_t s = 0; s < ns; ++s) {
         const size_t lo = s * SUB, hi = std::min(ne, lo + SUB), base = (sub_off[b] + s) * SUB;

@@ -57,6 +57,9 @@ __device__ __forceinline__ Quat aa_to_quat(double a0, double a1, double a2) {
 
 // Quaternion -> angle-axis (ceres::QuaternionToAngleAxis semantics: result angle in (-pi, pi]).
 // Also returns theta^2 = |e|^2 and (|w|, s = |v|) for the Jacobian coefficient below.
+// SC: atan2 with its coefficients in scalar registers (devmath.hpp; same bits) -- for kernels whose vector registers are the constraint
+// (the linearisations); the sweeps are bound by instruction issue and keep the library's form (measured: profiles/r04b_*).
+template <bool SC = false>
 __device__ __forceinline__ void quat_log(const Quat& q, double* e, double* s_out, double* theta_out) {
   const double s2 = q.x * q.x + q.y * q.y + q.z * q.z;
   if (s2 > 0.0) {
@@ -67,7 +70,7 @@ __device__ __forceinline__ void quat_log(const Quat& q, double* e, double* s_out
     // ceres takes atan2(-s, -w) for w < 0 and atan2(s, w) otherwise.  atan2 is odd in its first argument bit for bit, so both are
     // +-atan2(s, |w|): ONE evaluation.  (Written as the two-way select, the compiler emitted two inline copies of atan2 under divergent
     // exec masks -- the sign of w is arbitrary under the double cover, so almost every wavefront ran both.)
-    const double half = atan2_q1(s, fabs(q.w));
+    const double half = SC ? atan2_q1(s, fabs(q.w)) : atan2(s, fabs(q.w));
     const double two_theta = 2.0 * ((q.w < 0.0) ? -half : half);
     const double k = two_theta * rs;
     e[0] = q.x * k; e[1] = q.y * k; e[2] = q.z * k;
