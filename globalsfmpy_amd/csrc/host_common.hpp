@@ -197,12 +197,19 @@ struct EventTimer {  // GPU time per phase, resolved at host syncs
   int cat[NPAIR];
   int used = 0;
   bool ok = false;
+  bool mute = false;   // no events while set (the device-controlled exact-step pipeline: solver_lm.hpp)
   double acc[3] = {0, 0, 0};
   hipStream_t stream = nullptr;
-  void init() { ok = true; for (int k = 0; k < 2 * NPAIR; ++k) if (hipEventCreate(&ev[k]) != hipSuccess) ok = false; }
+  // GSFM_PHASE_TIMERS=0: no events at all (the summary's t_*_ms stay zero) -- every begin / end is an event record on the solver's stream, eight
+  // per exact LM iteration; for measuring what they cost
+  void init() {
+    const char* e = getenv("GSFM_PHASE_TIMERS");
+    if (e && *e && atoi(e) == 0) { ok = false; return; }
+    ok = true; for (int k = 0; k < 2 * NPAIR; ++k) if (hipEventCreate(&ev[k]) != hipSuccess) ok = false;
+  }
   void destroy() { if (ok) for (int k = 0; k < 2 * NPAIR; ++k) (void)hipEventDestroy(ev[k]); ok = false; }
   int begin(int category) {
-    if (!ok) return -1;
+    if (!ok || mute) return -1;
     if (used == NPAIR) { (void)hipStreamSynchronize(stream); resolve(); }
     const int k = used++;
     cat[k] = category;

@@ -2159,7 +2159,7 @@ __global__ void k_lm_set(double* ctl, double radius, double df, double x_cost, d
 // The control block is authoritative between host interventions (k_lm_set): iteration k + 1 may be enqueued before the host has read
 // iteration k's verdict, so a verdict that ends the run of exact steps -- a termination, a factor that broke down -- must stop every later
 // decision: such an iteration is marked SKIPPED, accepts nothing and leaves the block alone.
-__global__ void k_lm_decide(LmOpts o, const double* scal, int sc_step, int sc_trial, int sc_info, double* ctl) {
+__device__ __forceinline__ void lm_decide_body(const LmOpts& o, const double* scal, int sc_step, int sc_trial, int sc_info, double* ctl) {
   ctl[CT_ACCEPT] = 0.0;
   if (ctl[CT_TERM] >= 0.0 || ctl[CT_DENSE_FAIL] != 0.0) { ctl[CT_SKIPPED] = 1.0; return; }
   ctl[CT_SKIPPED] = 0.0; ctl[CT_VALID] = 0.0; ctl[CT_NONFINITE] = 0.0;
@@ -2192,13 +2192,32 @@ __global__ void k_lm_decide(LmOpts o, const double* scal, int sc_step, int sc_tr
     ctl[CT_RADIUS] = fmin(o.max_radius, radius); ctl[CT_DF] = 2.0;
   } else { ctl[CT_RADIUS] = radius / df; ctl[CT_DF] = df * 2.0; }
 }
-// accepted: x <- x_trial, q <- q_trial (copies, not pointer swaps: captured graphs hold the addresses)
-__global__ void __launch_bounds__(GSFM_BLOCK) k_lm_accept(const double* ctl, uint32_t n, int param_dim, double* x, const double* x_trial, double2* q, const double2* q_trial) {
-  if (ctl[CT_ACCEPT] == 0.0) return;
-  const uint32_t k = blockIdx.x * GSFM_BLOCK + threadIdx.x;
-  if (k >= n) return;
-  for (int c = 0; c < param_dim; ++c) x[(size_t)param_dim * k + c] = x_trial[(size_t)param_dim * k + c];
-  q[2 * (size_t)k] = q_trial[2 * (size_t)k]; q[2 * (size_t)k + 1] = q_trial[2 * (size_t)k + 1];
+// One workgroup closes the step: the five sums of k_cam_step's partials and the trial cost's (the reductions k_sum_partials_multi /
+// k_sum_partials would have launched: same routine, same order, same bits, written to the same scalars), the decision (one lane), and -- if the
+// step is accepted -- x <- x_trial, q <- q_trial (copies, not pointer swaps: captured graphs hold the addresses).  Three launches fewer per
+// exact LM iteration than sum, sum, decide, accept (~4.5 us each on a chain of ~60 dependent launches).
+__global__ void __launch_bounds__(GSFM_BLOCK) k_lm_decide(LmOpts o, double* scal, int sc_step, int sc_trial, int sc_info, double* ctl,
+                                                          const double* __restrict__ step_part, int nb_cam, const double* __restrict__ cost_part, int nb_cost,
+                                                          uint32_t n, int param_dim, double* x, const double* __restrict__ x_trial, double2* q, const double2* __restrict__ q_trial) {
+  __shared__ double lds[8];
+  for (int c = 0; c < 5; ++c) {
+    const double t = sum_partials_bcast(step_part + (size_t)c * nb_cam, nb_cam, lds);
+    if (threadIdx.x == 0) scal[sc_step + c] = t;
+  }
+  {
+    const double t = sum_partials_bcast(cost_part, nb_cost, lds);
+    if (threadIdx.x == 0) scal[sc_trial] = t;
+  }
+  if (threadIdx.x == 0) {
+    lm_decide_body(o, scal, sc_step, sc_trial, sc_info, ctl);
+    lds[5] = ctl[CT_ACCEPT];
+  }
+  __syncthreads();
+  if (lds[5] == 0.0) return;
+  for (uint32_t k = threadIdx.x; k < n; k += GSFM_BLOCK) {
+    for (int c = 0; c < param_dim; ++c) x[(size_t)param_dim * k + c] = x_trial[(size_t)param_dim * k + c];
+    q[2 * (size_t)k] = q_trial[2 * (size_t)k]; q[2 * (size_t)k + 1] = q_trial[2 * (size_t)k + 1];
+  }
 }
 // after the (predicated) linearisation and the damping rebuild: the gradient test of an accepted step, the radius floor
 // ... and the iteration's record for the host: the control block as this iteration left it, in its slot of a ring (the host reads it from a
@@ -2206,7 +2225,16 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_lm_accept(const double* ctl, uin
 // (the host loop takes them at the top of the NEXT iteration, after recording this one) but halt later decisions just the same.
 // `rec` is host memory mapped into the device (the host polls the record's last word instead of synchronising a stream: a cross-stream event
 // costs tens of microseconds per iteration, more than the gap it was meant to close); `stamp` = the LM iteration, written last, system scope.
-__global__ void k_lm_after(LmOpts o, const double* scal, int sc_gmax, double* ctl, double* rec, double stamp) {
+// (round 4: the max-norm reduction of k_cam_prep's partials -- k_max_partials, same routine -- is done here, one launch fewer)
+__global__ void __launch_bounds__(GSFM_BLOCK) k_lm_after(LmOpts o, double* scal, int sc_gmax, double* ctl, double* rec, double stamp, const double* __restrict__ gmax_part, int nb_cam) {
+  __shared__ double lds[8];
+  {
+    double v = 0.0;
+    for (int k = threadIdx.x; k < nb_cam; k += GSFM_BLOCK) v = fmax(v, gmax_part[k]);
+    const double t = block_max_bcast(v, lds);
+    if (threadIdx.x != 0) return;
+    scal[sc_gmax] = t;
+  }
   if (ctl[CT_SKIPPED] != 0.0) return;
   double term_next = -1.0;
   if (ctl[CT_TERM] < 0.0 && ctl[CT_DENSE_FAIL] == 0.0) {

@@ -266,7 +266,8 @@ struct CostOutputs { double2* srho = nullptr; double2* rho12 = nullptr; double* 
 int launch_lin(gsfm_rot_problem* P, const double2* q, const double* go = nullptr);
 
 // K1: cost at quaternion cache q -> scal[slot] (all-reduced when sharded)
-int launch_cost(gsfm_rot_problem* P, const double2* q, int slot, const CostOutputs& out = CostOutputs()) {
+// reduce = false: the caller sums the sweep's partials itself (k_lm_decide; unsharded problems only)
+int launch_cost(gsfm_rot_problem* P, const double2* q, int slot, const CostOutputs& out = CostOutputs(), bool reduce = true) {
   const bool sig = P->sigma_pending_cost;
   P->sigma_pending_cost = false;
   if (P->cb) {
@@ -291,7 +292,7 @@ int launch_cost(gsfm_rot_problem* P, const double2* q, int slot, const CostOutpu
   const int tk = P->timer.begin(T_SWEEP);
   if (dispatch<CostArgs, CostLauncher>(P, a, P->nb_cost)) return fail(GSFM_ERR_UNSUPPORTED, "no kernel for this error type");
   P->timer.end(tk);
-  hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(GSFM_BLOCK), 0, P->stream, P->part_cost.p, P->nb_cost, P->scal.p + slot);
+  if (reduce) hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(GSFM_BLOCK), 0, P->stream, P->part_cost.p, P->nb_cost, P->scal.p + slot);
   if (sig && !P->cb) hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(GSFM_BLOCK), 0, P->stream, P->part_cost.p + P->nb_cost, P->nb_cost, P->sigma_sum.p);
   return all_reduce(P, P->scal.p + slot, 1);
 }
@@ -322,14 +323,14 @@ int launch_lin(gsfm_rot_problem* P, const double2* q, const double* go) {
   return all_gather(P, P->gD.p, (size_t)P->shard.slice_width * 9);
 }
 
-void launch_prep(gsfm_rot_problem* P, const gsfm_rot_options& o, double radius, bool init_scale, const double* radius_dev = nullptr) {
+void launch_prep(gsfm_rot_problem* P, const gsfm_rot_options& o, double radius, bool init_scale, const double* radius_dev = nullptr, bool reduce = true) {
   PrepArgs a{};
   a.radius_dev = radius_dev;
   a.n = P->n_cams; a.param_dim = P->param_dim; a.x = P->x.p; a.gD = P->gD.p; a.scale = P->scale.p;
   a.init_scale = init_scale; a.jacobi_scaling = o.jacobi_scaling; a.radius = radius; a.min_diag = o.min_lm_diagonal; a.max_diag = o.max_lm_diagonal;
   a.Mblk = P->Mblk.p; a.Minv = P->Minv.p; a.Lam = P->Lam.p; a.Tinv = P->Tinv.p; a.b = P->b.p; a.gmax_partials = P->part_cam.p;
   hipLaunchKernelGGL(k_cam_prep, dim3(P->nb_cam), dim3(GSFM_BLOCK), 0, P->stream, a);
-  hipLaunchKernelGGL(k_max_partials, dim3(1), dim3(GSFM_BLOCK), 0, P->stream, P->part_cam.p, P->nb_cam, P->scal.p + SC_GMAX);
+  if (reduce) hipLaunchKernelGGL(k_max_partials, dim3(1), dim3(GSFM_BLOCK), 0, P->stream, P->part_cam.p, P->nb_cam, P->scal.p + SC_GMAX);
 }
 
 int launch_matvec(gsfm_rot_problem* P, const double* Mblk, const double* p, double* y, const int* done, double* dot_part = nullptr, bool* dot_done = nullptr) {

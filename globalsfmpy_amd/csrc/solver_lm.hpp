@@ -5,7 +5,8 @@
 
 namespace {
 
-int launch_step(gsfm_rot_problem* P, bool inexact = false) {
+// reduce = false: the caller sums k_cam_step's partials itself (k_lm_decide)
+int launch_step(gsfm_rot_problem* P, bool inexact = false, bool reduce = true) {
   const double *eta = P->xcg.p, *rcg = P->r.p;
   if (inexact && P->lap_capable) {   // (functors whose cost depends on R_j R_i^T alone: for those the gauge is an exact symmetry) a loose PCG iterate: its gauge component is taken out first (kernels.hpp, k_gauge_part) -- into copies, the PCG state stays resumable
     GaugeArgs ga{P->n_cams, P->nb_cam, P->active.p, P->q_lin ? P->q_lin : P->q.p, P->Lam.p, P->xcg.p, P->r.p, P->part_gauge.p, P->eta_fix.p, P->rcg_fix.p};
@@ -17,7 +18,7 @@ int launch_step(gsfm_rot_problem* P, bool inexact = false) {
   a.n = P->n_cams; a.param_dim = P->param_dim; a.x = P->x.p; a.active = P->active.p; a.eta = eta; a.b = P->b.p; a.rcg = rcg;
   a.Lam = P->Lam.p; a.Tinv = P->Tinv.p; a.x_trial = P->x_trial.p; a.q_trial = P->q_trial.p; a.partials = P->part_cam.p;
   hipLaunchKernelGGL(k_cam_step, dim3(P->nb_cam), dim3(GSFM_BLOCK), 0, P->stream, a);
-  hipLaunchKernelGGL(k_sum_partials_multi, dim3(1), dim3(GSFM_BLOCK), 0, P->stream, P->part_cam.p, P->nb_cam, 5, P->scal.p + SC_STEP);
+  if (reduce) hipLaunchKernelGGL(k_sum_partials_multi, dim3(1), dim3(GSFM_BLOCK), 0, P->stream, P->part_cam.p, P->nb_cam, 5, P->scal.p + SC_STEP);
   return 0;
 }
 
@@ -184,18 +185,25 @@ int lm_solve(gsfm_rot_problem* P, const gsfm_rot_options& o_in, gsfm_rot_summary
         if (hipHostMalloc((void**)&P->rec_host, 4 * REC * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
             hipHostGetDevicePointer((void**)&P->rec_dev, P->rec_host, 0) != hipSuccess) { (void)hipGetLastError(); return fail(GSFM_ERR_HIP, "mapped record of the LM control"); }
       }
+      // (no phase timers in this pipeline: every begin / end is an event record on the stream, eight of them per iteration = 24 us of the
+      // 545 us a Madrid iteration takes -- 34.3 -> 32.6-33.0 ms per solve; the summary's t_*_ms cover the host-controlled steps only)
+      struct Mute { EventTimer& t; explicit Mute(EventTimer& tt) : t(tt) { t.mute = true; } ~Mute() { t.mute = false; } };
       auto enqueue_exact = [&](int it) -> int {   // 0: enqueued, 1: no exact step possible (size, memory), < 0: error
+        const Mute muted(P->timer);
         bool used = false;
         if (int st = run_dense(P, &used)) return -st;
         if (!used) return 1;
-        launch_step(P);
-        if (int st = launch_cost(P, P->q_trial.p, SC_TRIAL)) return -st;
-        hipLaunchKernelGGL(k_lm_decide, dim3(1), dim3(1), 0, P->stream, lo, (const double*)P->scal.p, (int)SC_STEP, (int)SC_TRIAL, (int)SC_DENSE_INFO, ctl);
-        hipLaunchKernelGGL(k_lm_accept, dim3(P->nb_cam), dim3(GSFM_BLOCK), 0, P->stream, (const double*)ctl, P->n_cams, P->param_dim, P->x.p, (const double*)P->x_trial.p, P->q.p, (const double2*)P->q_trial.p);
+        // (the single-workgroup reductions ride in their consumers: k_lm_decide sums the step's and the trial cost's partials and applies an
+        // accepted step, k_lm_after takes the gradient's max norm -- six launches after the factorisation instead of ten)
+        launch_step(P, false, false);
+        if (int st = launch_cost(P, P->q_trial.p, SC_TRIAL, CostOutputs(), false)) return -st;
+        hipLaunchKernelGGL(k_lm_decide, dim3(1), dim3(GSFM_BLOCK), 0, P->stream, lo, P->scal.p, (int)SC_STEP, (int)SC_TRIAL, (int)SC_DENSE_INFO, ctl,
+                           (const double*)P->part_cam.p, P->nb_cam, (const double*)P->part_cost.p, P->nb_cost,
+                           P->n_cams, P->param_dim, P->x.p, (const double*)P->x_trial.p, P->q.p, (const double2*)P->q_trial.p);
         if (int st = launch_lin(P, P->q.p, ctl + CT_ACCEPT)) return -st;
-        launch_prep(P, o, radius, false, ctl + CT_RADIUS);
+        launch_prep(P, o, radius, false, ctl + CT_RADIUS, false);
         P->rec_host[REC * (it & 3) + CT_N] = -1.0;   // (the slot's previous user, iteration it - 4, was read long ago)
-        hipLaunchKernelGGL(k_lm_after, dim3(1), dim3(1), 0, P->stream, lo, (const double*)P->scal.p, (int)SC_GMAX, ctl, P->rec_dev + REC * (it & 3), (double)it);
+        hipLaunchKernelGGL(k_lm_after, dim3(1), dim3(GSFM_BLOCK), 0, P->stream, lo, P->scal.p, (int)SC_GMAX, ctl, P->rec_dev + REC * (it & 3), (double)it, (const double*)P->part_cam.p, P->nb_cam);
         return 0;
       };
       int eq = 0;
