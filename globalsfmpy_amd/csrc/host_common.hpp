@@ -198,18 +198,22 @@ struct EventTimer {  // GPU time per phase, resolved at host syncs
   int used = 0;
   bool ok = false;
   bool mute = false;   // no events while set (the device-controlled exact-step pipeline: solver_lm.hpp)
+  bool mute_all = false;   // the problem is too small to afford them (apply_rule)
   double acc[3] = {0, 0, 0};
   hipStream_t stream = nullptr;
-  // GSFM_PHASE_TIMERS=0: no events at all (the summary's t_*_ms stay zero) -- every begin / end is an event record on the solver's stream, eight
-  // per exact LM iteration; for measuring what they cost
-  void init() {
+  // Every begin / end is an event record on the solver's stream (~3 us each, ten to twelve per LM iteration).  Problems whose kernels take
+  // hundreds of microseconds do not notice; in the latency regime they are 11 % of a solve (10k cameras / 200k edges: 3.69 -> 3.29 ms;
+  // Madrid 34.3 -> 32.6 ms).  Rule (apply_rule, at problem creation): timers from 2 M directed entries on; below, the summary's t_*_ms
+  // stay zero.  GSFM_PHASE_TIMERS=1 / 0 forces them on / off.
+  void init() { ok = true; for (int k = 0; k < 2 * NPAIR; ++k) if (hipEventCreate(&ev[k]) != hipSuccess) ok = false; }
+  void apply_rule(size_t directed_entries) {
     const char* e = getenv("GSFM_PHASE_TIMERS");
-    if (e && *e && atoi(e) == 0) { ok = false; return; }
-    ok = true; for (int k = 0; k < 2 * NPAIR; ++k) if (hipEventCreate(&ev[k]) != hipSuccess) ok = false;
+    const bool want = e && *e ? atoi(e) != 0 : directed_entries >= (size_t)2000000;
+    if (!want) mute_all = true;
   }
   void destroy() { if (ok) for (int k = 0; k < 2 * NPAIR; ++k) (void)hipEventDestroy(ev[k]); ok = false; }
   int begin(int category) {
-    if (!ok || mute) return -1;
+    if (!ok || mute || mute_all) return -1;
     if (used == NPAIR) { (void)hipStreamSynchronize(stream); resolve(); }
     const int k = used++;
     cat[k] = category;
@@ -275,7 +279,7 @@ struct gsfm_rot_problem {
   bool coarse_adaptive = false;     // use it only once a block-Jacobi PCG solve of the run has needed more than 150 iterations
   DevBuf<double> coarseA, coarseAinv, coarse_rc, coarse_xc, coarse_scale, coarse_part;
   std::vector<double> h_coarse, h_coarse_inv;
-  void* pin = nullptr;              // 256 B of pinned host memory: staging for the small read-backs of the solve loop (read_back)
+  void* pin = nullptr;              // 512 B of pinned host memory: [0, 256) staging for the small read-backs of the solve loop (read_back), [256, 264) the deferred gradient norm (lm_solve)
   DevBuf<double> denseA, denseL, dense_x;
   hipGraphExec_t dense_graph = nullptr;   // zero + assemble + blocked Cholesky + solve, captured once
   bool dense_graph_lap = false;           // form of the blocks the captured assemble kernel expects

@@ -293,7 +293,7 @@ static gsfm_status problem_create_impl(uint32_t n_cams, uint64_t n_edges, const 
     P->n_pad = shard->slice_width * shard->world_size;
   } else { P->own_begin = 0; P->own_end = n_cams; P->n_pad = n_cams; P->shard.slice_width = n_cams; P->shard.world_size = 1; }
   P->n_rows = P->own_end - P->own_begin;
-  if (hipHostMalloc(&P->pin, 256, hipHostMallocDefault) != hipSuccess) { P->pin = nullptr; (void)hipGetLastError(); }   // (read_back then copies to pageable memory)
+  if (hipHostMalloc(&P->pin, 512, hipHostMallocDefault) != hipSuccess) { P->pin = nullptr; (void)hipGetLastError(); }   // (read_back then copies to pageable memory)
 
   // ---- host-side structure: directed entries by row (counting sort), cost-owned edges ----
   const uint32_t *edge_i = edge_i_in, *edge_j = edge_j_in;
@@ -502,6 +502,7 @@ static gsfm_status problem_create_impl(uint32_t n_cams, uint64_t n_edges, const 
   P->h_cost_eid = cost_eid;
 
   lap("cost tiles");
+  P->timer.apply_rule(nd);
   {  // K2c / K3c, the column-sorted layout of the directed entries: for large graphs whose rows offer the gathers no locality -- i.e. where
      // neither the relabelling nor the two-level preconditioner (both for spatially coherent graphs) applies.  GSFM_K3_COLSORT=0/1 overrides.
     const char* env = getenv("GSFM_K3_COLSORT");

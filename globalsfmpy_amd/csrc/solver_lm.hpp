@@ -94,7 +94,22 @@ int lm_solve(gsfm_rot_problem* P, const gsfm_rot_options& o_in, gsfm_rot_summary
                            iteration, cost, dc, gmax, sn, rd, radius, cg);
   };
   bool spec_enqueued = false, exact_pipeline_used = false;   // LM control on the device: an exact iteration is already in flight / the pipeline ran at all
+  // Host-controlled steps: the gradient's max norm of an accepted point is not waited for.  Its only consumer is the gradient-tolerance test at
+  // the top of the NEXT iteration, so it is copied to pinned memory behind the damping rebuild and read at that iteration's first host
+  // synchronisation (the PCG's first look, or the trial cost's) -- one read-back + idle GPU (25-35 us) fewer per accepted step; if the test then
+  // fires, the linear solve that was started is discarded (nothing of it had been applied) and the run ends where it would have.  The trace row of
+  // the accepting iteration gets its |g| when it arrives.  GSFM_DEFER_GMAX=0, verbose runs: the round-3 read-back.
+  static const bool defer_env = [] { const char* e = getenv("GSFM_DEFER_GMAX"); return !(e && *e && atoi(e) == 0); }();
+  const bool defer_gmax = defer_env && P->pin && !o.verbose;
+  bool gmax_deferred = false;
+  size_t gmax_trace_slot = 0;
+  volatile double* const gmax_pin = P->pin ? (volatile double*)((char*)P->pin + 256) : nullptr;
+  auto take_gmax = [&]() {   // (call behind a synchronisation of the stream)
+    gmax = *gmax_pin; gmax_deferred = false;
+    if (gmax_trace_slot < P->trace.size()) P->trace[gmax_trace_slot] = gmax;
+  };
   auto finish = [&](int term) {
+    if (gmax_deferred) { (void)hipStreamSynchronize(P->stream); P->timer.resolve(); take_gmax(); }
     if (spec_enqueued || exact_pipeline_used) { (void)hipStreamSynchronize(P->stream); P->timer.resolve(); spec_enqueued = false; }   // (whatever was enqueued ahead skips itself; the phase timers need the sync)
     sum->termination = term; sum->num_iterations = iteration; sum->final_cost = x_cost; sum->final_gradient_max_norm = gmax;
     sum->final_radius = radius; sum->t_total_ms = now_ms() - t0;
@@ -129,7 +144,6 @@ int lm_solve(gsfm_rot_problem* P, const gsfm_rot_options& o_in, gsfm_rot_summary
     const double t = std::log(n3 / pts[k][0]) / std::log(pts[k + 1][0] / pts[k][0]);
     return pts[k][1] * std::pow(pts[k + 1][1] / pts[k][1], t);
   };
-  double cg_ms_before = 0.0;
   // LM control on the device for exact steps (GSFM_LM_DEVICE_CONTROL=0: the host loop, for A/B and for the bit-identity test): unsharded
   // problems with a native loss on the row-major layout -- the linearisation of the accept path must be enqueueable without the host
   static const bool device_control_env = [] { const char* e = getenv("GSFM_LM_DEVICE_CONTROL"); return !(e && *e && atoi(e) == 0); }();
@@ -151,13 +165,16 @@ int lm_solve(gsfm_rot_problem* P, const gsfm_rot_options& o_in, gsfm_rot_summary
   double pred_rms = -1.0;          // rms size of the last accepted step: the (conservative: steps shrink) prediction of the next one's
   while (true) {
     if (iteration >= o.max_num_iterations) return finish(GSFM_TERM_NO_CONVERGENCE);
-    if (last_successful && gmax <= o.gradient_tolerance) return finish(GSFM_TERM_GRADIENT_TOLERANCE);
-    if (radius <= o.min_trust_region_radius) return finish(GSFM_TERM_FAILURE);
+    if (last_successful && !gmax_deferred && gmax <= o.gradient_tolerance) return finish(GSFM_TERM_GRADIENT_TOLERANCE);
+    if (radius <= o.min_trust_region_radius) {
+      if (gmax_deferred) { if (int st = sync_check(P, "gradient norm")) return st; take_gmax(); if (gmax <= o.gradient_tolerance) return finish(GSFM_TERM_GRADIENT_TOLERANCE); }
+      return finish(GSFM_TERM_FAILURE);
+    }
     ++iteration;
     last_successful = false;
     if (!prep_valid) launch_prep(P, o, radius, false);
     prep_valid = false;
-    int cg = 0; double cg_rel = 0;
+    int cg = 0; double cg_rel = 0, pcg_wall_ms = 0.0;
     bool dense_used = false;
     // Forcing schedule: the step is solved loosely -- to a relative (energy-norm) error tau chosen so that tau * |step|_rms <= eps_rad, with the
     // step size predicted from the previous accepted step (first step: tau_max, corrected below) -- unless it is the last one the iteration
@@ -173,6 +190,11 @@ int lm_solve(gsfm_rot_problem* P, const gsfm_rot_options& o_in, gsfm_rot_summary
     const int64_t dense_cap = o.dense_cholesky_max_cams > 0 ? o.dense_cholesky_max_cams : -(int64_t)o.dense_cholesky_max_cams;
     const bool dense_auto = o.dense_cholesky_max_cams > 0 && (int64_t)P->n_cams > dense_cap && (int64_t)P->n_cams <= (int64_t)o.dense_cholesky_auto_cams && pcg_dearer_than_cholesky;
     const bool exact_now = !P->sharded && ((dense_cap > 0 && (int64_t)P->n_cams <= dense_cap && (o.dense_cholesky_max_cams > 0 || pcg_struggles)) || dense_auto);
+    if (gmax_deferred && exact_now) {   // (exact steps do not pass a synchronisation before they need it)
+      if (int st = sync_check(P, "gradient norm")) return st;
+      take_gmax();
+      if (gmax <= o.gradient_tolerance) { --iteration; return finish(GSFM_TERM_GRADIENT_TOLERANCE); }
+    }
     if (exact_now && device_control && !exact_pipeline_broken) {
       // Exact step with the trust-region decisions on the device (kernels.hpp, k_lm_decide): the whole LM iteration -- factorisation, step,
       // trial cost, decision, predicated accept path, damping for the next step -- is enqueued without a host decision, and iteration k + 1
@@ -281,7 +303,13 @@ int lm_solve(gsfm_rot_problem* P, const gsfm_rot_options& o_in, gsfm_rot_summary
       if (!dense_used) {
         if (int st = coarse_build(P, pcg_struggles)) return st;
         use_pcg2 = P->coarse_n == 0 && use_single_reduction(P, o);
+        const double t_pcg = now_ms();
         if (int st = (use_pcg2 ? run_pcg2(P, o, o.cg_relative_tolerance, loose ? tau * tau : 0.0, -1, &cg, &cg_rel) : run_pcg(P, o, o.cg_relative_tolerance, loose ? tau * tau : 0.0, -1, &cg, &cg_rel))) return st;
+        pcg_wall_ms += now_ms() - t_pcg;   // (run_pcg returns behind its last read-back: the solve's elapsed time, round trips included)
+        if (gmax_deferred) {
+          take_gmax();
+          if (gmax <= o.gradient_tolerance) { --iteration; return finish(GSFM_TERM_GRADIENT_TOLERANCE); }   // (this iteration never began)
+        }
       }
       launch_step(P, !dense_used && loose);
       if (int st = launch_cost(P, P->q_trial.p, SC_TRIAL)) return st;
@@ -312,7 +340,9 @@ int lm_solve(gsfm_rot_problem* P, const gsfm_rot_options& o_in, gsfm_rot_summary
           }
         }
         if (tight) { loose = false; tau = 0.0; } else tau = std::fmin(tau, tau_need);
+        const double t_pcg = now_ms();
         if (int st = (use_pcg2 ? run_pcg2(P, o, o.cg_relative_tolerance, tau * tau, cg, &cg, &cg_rel) : run_pcg(P, o, o.cg_relative_tolerance, tau * tau, cg, &cg, &cg_rel))) return st;
+        pcg_wall_ms += now_ms() - t_pcg;
         launch_step(P, loose);
         if (int st = launch_cost(P, P->q_trial.p, SC_TRIAL)) return st;
         if (int st = read_scalars(P, h)) return st;
@@ -325,11 +355,9 @@ int lm_solve(gsfm_rot_problem* P, const gsfm_rot_options& o_in, gsfm_rot_summary
       if (info == 0) { sum->num_dense_solves++; break; }
       dense_used = false;   // not positive definite to working precision: the step just evaluated is meaningless, PCG solves it again
     }
-    if (!dense_used && !P->sharded && (int64_t)P->n_cams <= (int64_t)o.dense_cholesky_auto_cams) {   // GPU time of this step's linear solve (HIP events, resolved by the read-back above)
-      const double step_ms = P->timer.acc[T_CG] - cg_ms_before;
-      if (step_ms > 1.25 * dense_cost_ms(3.0 * P->n_cams)) pcg_dearer_than_cholesky = true;
+    if (!dense_used && !P->sharded && (int64_t)P->n_cams <= (int64_t)o.dense_cholesky_auto_cams) {   // what this step's linear solve took (elapsed: graphs of this size carry no phase timers)
+      if (pcg_wall_ms > 1.25 * dense_cost_ms(3.0 * P->n_cams)) pcg_dearer_than_cholesky = true;
     }
-    cg_ms_before = P->timer.acc[T_CG];
     // (a loose solve's count is projected to the tight tolerance -- PCG converges about linearly in the logarithm -- before it is held against the 150)
     if ((loose && tau > 0.0 ? cg * std::log(o.cg_relative_tolerance) / std::log(std::fmin(0.5, tau)) : (double)cg) > 150.0) pcg_struggles = true;
     if (o.verbose && !dense_used && !loose && cg >= o.max_cg_iterations && cg_rel > o.cg_relative_tolerance)
@@ -369,8 +397,14 @@ int lm_solve(gsfm_rot_problem* P, const gsfm_rot_options& o_in, gsfm_rot_summary
       decrease_factor = 2.0;
       launch_prep(P, o, radius, false);
       prep_valid = true;
-      if (int st = read_scalars(P, h)) return st;
-      gmax = h[SC_GMAX];
+      if (defer_gmax) {
+        HIPCHK(hipMemcpyAsync((void*)gmax_pin, P->scal.p + SC_GMAX, sizeof(double), hipMemcpyDeviceToHost, P->stream));
+        gmax_deferred = true;
+        gmax_trace_slot = P->trace.size() + 3;   // (column 3 of the row record() appends below)
+      } else {
+        if (int st = read_scalars(P, h)) return st;
+        gmax = h[SC_GMAX];
+      }
       sum->num_successful_steps++;
       last_successful = true;
       pred_rms = step_norm / sqrt_n;
