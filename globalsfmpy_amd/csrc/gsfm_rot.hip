@@ -50,6 +50,7 @@ void gsfm_rot_problem_destroy(gsfm_rot_problem* P) {
   if (P->own_stream && P->stream) (void)hipStreamDestroy(P->stream);
   if (P->pin) (void)hipHostFree(P->pin);
   if (P->rec_host) (void)hipHostFree(P->rec_host);
+  if (P->mail_host) (void)hipHostFree(P->mail_host);
   delete P;
 }
 

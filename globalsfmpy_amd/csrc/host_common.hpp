@@ -321,6 +321,11 @@ struct gsfm_rot_problem {
   bool have_lin = false;
   double* rec_host = nullptr;            // LM control on the device: ring of four per-iteration records in mapped host memory ((CT_N + 1) doubles each; the host polls the stamp)
   double* rec_dev = nullptr;             //   ... and its device address
+  double* mail_host = nullptr;           // PCG status mailbox (k_pcg_mail): GSFM_MAIL_WORDS + 1 doubles of mapped host memory, its device address, the device-resident
+  double* mail_dev = nullptr;            //   count of posts and the count the host expects next; mail_state: 0 not tried, 1 usable, -1 unavailable
+  DevBuf<double> mail_count;
+  double mail_expected = 0.0;
+  int mail_state = 0;
   bool fast_lin_ok = true;   // the loss's rho'' is <= 0 for every s (decided from leaf kind AND parameter signs in prepare_loss): K2's alpha = 0 fast path applies
   int graph_launches = 0;
   int n_collectives = 0, n_pcg_collectives = 0, n_pcg_launched = 0;   // issued (or replayed from a graph) since the solve started

@@ -1818,6 +1818,19 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_coarse_assemble(CoarseAsmArgs a)
 // bit-identical scalars and no finalize launch or atomics are needed.
 // ------------------------------------------------------------------------------------------
 #define GSFM_MV_MAX_PARTIALS 8192   // the fused mat-vec runs `reps` row groups per workgroup so that its delta partials stay below this
+// The PCG's status for the host WITHOUT a stream synchronisation: the last node of a chunk copies the scalar block into mapped host memory and
+// stamps it with a device-resident count of such posts (system-scope release); the host polls the stamp.  A read-back costs a blit kernel, the
+// return of hipStreamSynchronize and the next launch's way to the GPU -- 14 + 4 + 25 us of idle GPU per look in the latency regime (10k
+// cameras / 200k edges: 16 looks per solve, a quarter of the PCG time).  No per-call kernel argument: the node is part of the captured chunk.
+#define GSFM_MAIL_WORDS 32
+__global__ void k_pcg_mail(const double* __restrict__ sc, int nwords, double* mail, double* counter) {
+  for (int k = 0; k < nwords; ++k) mail[k] = sc[k];
+  const double c = *counter + 1.0;
+  *counter = c;
+  __threadfence_system();
+  __hip_atomic_store(mail + GSFM_MAIL_WORDS, c, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 struct Cg2Scalars {
   double gamma[2];   // parity-indexed gamma_i
   double alpha[2];

@@ -92,6 +92,44 @@ bool graph_collectives_ok(const gsfm_rot_problem* P, const gsfm_rot_options& o) 
   return !(e && *e && atoi(e) == 0);
 }
 
+// ---- the PCG's status without a stream synchronisation (kernels.hpp, k_pcg_mail) -----------------------------------------------------------
+// mail_usable: allocates on first use (mapped, coherent host memory + the device counter); GSFM_PCG_MAILBOX=0 keeps the read-backs.
+bool mail_usable(gsfm_rot_problem* P) {
+  if (P->mail_state == 0) {
+    static const bool off = [] { const char* e = getenv("GSFM_PCG_MAILBOX"); return e && *e && atoi(e) == 0; }();
+    P->mail_state = -1;
+    if (!off && hipHostMalloc((void**)&P->mail_host, (GSFM_MAIL_WORDS + 1) * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) {
+      std::memset(P->mail_host, 0, (GSFM_MAIL_WORDS + 1) * sizeof(double));
+      if (hipHostGetDevicePointer((void**)&P->mail_dev, P->mail_host, 0) == hipSuccess && P->mail_count.alloc(1, true) == hipSuccess) { P->mail_expected = 0.0; P->mail_state = 1; }
+    }
+    if (P->mail_state < 0) { (void)hipGetLastError(); if (P->mail_host) { (void)hipHostFree(P->mail_host); P->mail_host = nullptr; } }
+  }
+  return P->mail_state > 0;
+}
+// enqueue (or capture) the post of `bytes` of the scalar block at sc
+void mail_post(gsfm_rot_problem* P, const void* sc, size_t bytes) {
+  static_assert(sizeof(CgScalars) % 8 == 0 && sizeof(Cg2Scalars) % 8 == 0 && sizeof(CgScalars) <= 8 * GSFM_MAIL_WORDS && sizeof(Cg2Scalars) <= 8 * GSFM_MAIL_WORDS, "scalar blocks fit the mailbox");
+  hipLaunchKernelGGL(k_pcg_mail, dim3(1), dim3(1), 0, P->stream, (const double*)sc, (int)(bytes / 8), P->mail_dev, P->mail_count.p);
+}
+// wait for post number mail_expected and take `bytes` of it.  The wait is bounded: after 20 s the stream is synchronised, which surfaces a device
+// error if there was one.
+int mail_wait(gsfm_rot_problem* P, void* dst, size_t bytes) {
+  volatile double* stamp = P->mail_host + GSFM_MAIL_WORDS;
+  const double t0 = now_ms();
+  bool seen = false;
+  for (long spin = 0; !(seen = *stamp == P->mail_expected); ++spin) {
+    if ((spin & 0x3ff) == 0x3ff && now_ms() - t0 > 20000.0) break;
+    __builtin_ia32_pause();
+  }
+  if (!seen) {
+    if (int st = sync_check(P, "pcg status")) return st;
+    if (*stamp != P->mail_expected) return fail(GSFM_ERR_HIP, "the PCG status of a chunk never arrived");
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
+  std::memcpy(dst, (const void*)P->mail_host, bytes);
+  return 0;
+}
+
 // block-Jacobi PCG on (J^T J + Lambda) eta = -g to the relative residual `tol` -- or, etol2 > 0 (a loose solve of the forcing schedule), until the
 // estimated relative energy-norm error squared falls below etol2 (kernels.hpp, cg_energy_stop); returns iterations.  resume_iters >= 0: continue the solve
 // that stopped after that many iterations (at a looser tolerance) instead of starting one -- the device state is exactly what the stopping
@@ -141,8 +179,10 @@ int run_pcg(gsfm_rot_problem* P, const gsfm_rot_options& o, double tol, double e
     a.par ^= 1;
     return 0;
   };
-  auto enqueue_chunk = [&]() -> int {  // `chunk` iterations; leaves a.par where it found it when chunk is even
+  const bool mail = mail_usable(P);
+  auto enqueue_chunk = [&]() -> int {  // `chunk` iterations (+ the status post); leaves a.par where it found it when chunk is even
     for (int c = 0; c < chunk; ++c) if (int st = enqueue_iter()) return st;
+    if (mail) mail_post(P, P->cgsc.p, sizeof(CgScalars));
     return 0;
   };
   // The chunk between two host checks as one hipGraph launch: 4 * chunk dependent kernels whose arguments never change.
@@ -182,9 +222,10 @@ int run_pcg(gsfm_rot_problem* P, const gsfm_rot_options& o, double tol, double e
       if (graph) { HIPCHK(hipGraphLaunch(G.exec, P->stream)); P->graph_launches++; P->n_collectives += G.collectives; P->n_pcg_collectives += G.collectives; }
       else if (int st = enqueue_chunk()) return st;
       launched += chunk; P->n_pcg_launched += chunk;
+      if (mail) P->mail_expected += 1.0;
     }
     P->timer.end(tk);
-    if (int st = read_back(P, &h, P->cgsc.p, sizeof(h), "pcg")) return st;
+    if (int st = mail ? mail_wait(P, &h, sizeof(h)) : read_back(P, &h, P->cgsc.p, sizeof(h), "pcg")) return st;
     if (h.done || launched >= o.max_cg_iterations + chunk) break;
     // Fewer host round trips: extrapolate the average convergence factor so far to the tolerance and enqueue that many
     // chunks before looking again (kernels past convergence return at their first instruction, so overshoot is cheap).
@@ -267,6 +308,7 @@ int run_pcg2(gsfm_rot_problem* P, const gsfm_rot_options& o, double tol, double 
     for (int k = 0; k < 2; ++k) { if (int st = enqueue_iter()) return st; ++launched; P->n_pcg_launched++; }
     P->timer.end(tk);
   }
+  const bool mail = mail_usable(P);
   auto& G = P->pcg2_graph;
   bool graph = o.pcg_hip_graph && (!P->sharded || graph_collectives_ok(P, o)) && chunk % 2 == 0 && !G.unusable && !P->pcg_graph.unusable;
   if (graph && (!G.exec || G.max_iters != c.max_iters || G.chunk != chunk || G.lap != P->lin_is_lap)) {
@@ -276,6 +318,7 @@ int run_pcg2(gsfm_rot_problem* P, const gsfm_rot_options& o, double tol, double 
       int st = 0;
       const int c0 = P->n_collectives, p0 = P->n_pcg_collectives;
       for (int k = 0; k < chunk && st == 0; ++k) st = enqueue_iter();
+      if (mail && st == 0) mail_post(P, P->cg2sc.p, sizeof(Cg2Scalars));
       const hipError_t e = hipStreamEndCapture(P->stream, &captured);
       G.collectives = P->n_collectives - c0;
       P->n_collectives = c0; P->n_pcg_collectives = p0;
@@ -291,11 +334,12 @@ int run_pcg2(gsfm_rot_problem* P, const gsfm_rot_options& o, double tol, double 
     const int tk = P->timer.begin(T_CG);
     for (int cc = 0; cc < chunks; ++cc) {
       if (graph) { HIPCHK(hipGraphLaunch(G.exec, P->stream)); P->graph_launches++; P->n_collectives += G.collectives; P->n_pcg_collectives += G.collectives; }
-      else { for (int k = 0; k < chunk; ++k) if (int st = enqueue_iter()) return st; }
+      else { for (int k = 0; k < chunk; ++k) if (int st = enqueue_iter()) return st; if (mail) mail_post(P, P->cg2sc.p, sizeof(Cg2Scalars)); }
       launched += chunk; P->n_pcg_launched += chunk;
+      if (mail) P->mail_expected += 1.0;
     }
     P->timer.end(tk);
-    if (int st = read_back(P, &h, P->cg2sc.p, sizeof(h), "pcg")) return st;
+    if (int st = mail ? mail_wait(P, &h, sizeof(h)) : read_back(P, &h, P->cg2sc.p, sizeof(h), "pcg")) return st;
     if (h.done || launched >= o.max_cg_iterations + chunk + 2) break;
     chunks = 1;   // same look-ahead as run_pcg: extrapolate the convergence factor, enqueue that many chunks before looking again
     if (!(etol2 > 0.0) && h.iters > 0 && h.last_rel > 0.0 && h.last_rel < 1.0 && tol > 0.0 && tol < h.last_rel) {
