@@ -22,7 +22,16 @@ int launch_step(gsfm_rot_problem* P, bool inexact = false, bool reduce = true) {
   return 0;
 }
 
+// The scalar block of the LM loop (trial cost, step sums, gradient norm): through the mailbox the PCG's status takes (solver_pcg.hpp) where
+// there is one -- a one-lane kernel behind the sweep's reduction and a polled stamp instead of a blit, a stream synchronisation and the way
+// back -- otherwise a read-back.
 int read_scalars(gsfm_rot_problem* P, double* h) {
+  static_assert(SC_N <= GSFM_MAIL_WORDS, "the scalar block fits the mailbox");
+  if (mail_usable(P)) {
+    mail_post(P, P->scal.p, SC_N * sizeof(double));
+    P->mail_expected += 1.0;
+    return mail_wait(P, h, SC_N * sizeof(double));
+  }
   return read_back(P, h, P->scal.p, SC_N * sizeof(double), "read scalars");
 }
 
@@ -109,7 +118,7 @@ int lm_solve(gsfm_rot_problem* P, const gsfm_rot_options& o_in, gsfm_rot_summary
     if (gmax_trace_slot < P->trace.size()) P->trace[gmax_trace_slot] = gmax;
   };
   auto finish = [&](int term) {
-    if (gmax_deferred) { (void)hipStreamSynchronize(P->stream); P->timer.resolve(); take_gmax(); }
+    if (gmax_deferred || P->timer.used) { (void)hipStreamSynchronize(P->stream); P->timer.resolve(); if (gmax_deferred) take_gmax(); }   // (the mailbox reads leave the phase timers' events unresolved)
     if (spec_enqueued || exact_pipeline_used) { (void)hipStreamSynchronize(P->stream); P->timer.resolve(); spec_enqueued = false; }   // (whatever was enqueued ahead skips itself; the phase timers need the sync)
     sum->termination = term; sum->num_iterations = iteration; sum->final_cost = x_cost; sum->final_gradient_max_norm = gmax;
     sum->final_radius = radius; sum->t_total_ms = now_ms() - t0;
