@@ -281,6 +281,18 @@ struct gsfm_rot_problem {
   std::vector<double> h_coarse, h_coarse_inv;
   void* pin = nullptr;              // 512 B of pinned host memory: [0, 256) staging for the small read-backs of the solve loop (read_back), [256, 264) the deferred gradient norm (lm_solve)
   DevBuf<double> denseA, denseL, dense_x;
+  // One exact LM iteration under device control as ONE graph (solver_lm.hpp, enqueue_exact): factorisation, step, trial cost, decision,
+  // predicated accept path, damping, record.  Valid for the loss, options and block form it was captured with.
+  struct IterGraph {
+    hipGraphExec_t exec = nullptr;
+    bool unusable = false, lap = false;
+    int plain_runs = 0;           // iterations enqueued plainly so far (the first one allocates: it cannot be captured)
+    uint64_t loss_epoch = 0;
+    const void* x_ptr = nullptr;   // the state buffer its kernels address (host-controlled steps swap x and x_trial)
+    double key[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // the by-value options its kernels froze (tolerances, radius bounds, damping clamps, Jacobi scaling)
+    void reset() { if (exec) (void)hipGraphExecDestroy(exec); exec = nullptr; plain_runs = 0; }
+  } iter_graph;
+  uint64_t loss_epoch = 0;                // bumped whenever the loss (and with it the choice of kernels) changes
   hipGraphExec_t dense_graph = nullptr;   // zero + assemble + blocked Cholesky + solve, captured once
   bool dense_graph_lap = false;           // form of the blocks the captured assemble kernel expects
   int nb_mv = 1, mv_reps = 1;

@@ -2164,7 +2164,10 @@ enum { CT_RADIUS = 0, CT_DF = 1, CT_XCOST = 2, CT_XNORM = 3, CT_GMAX = 4, CT_ACC
        CT_CAND = 9, CT_CC = 10, CT_MCC = 11, CT_STEPN = 12, CT_DENSE_FAIL = 13, CT_NONFINITE = 14, CT_SKIPPED = 15 /* this iteration was enqueued ahead of a verdict that ended the run: nothing was decided */, CT_N = 16 };
 struct LmOpts { double function_tolerance, gradient_tolerance, parameter_tolerance, min_relative_decrease, max_radius, min_radius; };
 __device__ __forceinline__ double lm_cube(double t) { return t * t * t; }
-__global__ void k_lm_set(double* ctl, double radius, double df, double x_cost, double x_norm, double gmax, double n_invalid) {
+// `it_dev`: the number of the LM iteration the next k_lm_after stamps its record with -- on the device, so that no kernel of an iteration takes a
+// per-iteration argument and the whole iteration replays as one hipGraph (solver_lm.hpp)
+__global__ void k_lm_set(double* ctl, double radius, double df, double x_cost, double x_norm, double gmax, double n_invalid, double* it_dev, double iteration) {
+  *it_dev = iteration;
   ctl[CT_RADIUS] = radius; ctl[CT_DF] = df; ctl[CT_XCOST] = x_cost; ctl[CT_XNORM] = x_norm; ctl[CT_GMAX] = gmax; ctl[CT_NINVALID] = n_invalid;
   ctl[CT_ACCEPT] = 0.0; ctl[CT_TERM] = -1.0; ctl[CT_DENSE_FAIL] = 0.0; ctl[CT_NONFINITE] = 0.0; ctl[CT_SKIPPED] = 0.0;
 }
@@ -2239,7 +2242,7 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_lm_decide(LmOpts o, double* scal
 // `rec` is host memory mapped into the device (the host polls the record's last word instead of synchronising a stream: a cross-stream event
 // costs tens of microseconds per iteration, more than the gap it was meant to close); `stamp` = the LM iteration, written last, system scope.
 // (round 4: the max-norm reduction of k_cam_prep's partials -- k_max_partials, same routine -- is done here, one launch fewer)
-__global__ void __launch_bounds__(GSFM_BLOCK) k_lm_after(LmOpts o, double* scal, int sc_gmax, double* ctl, double* rec, double stamp, const double* __restrict__ gmax_part, int nb_cam) {
+__global__ void __launch_bounds__(GSFM_BLOCK) k_lm_after(LmOpts o, double* scal, int sc_gmax, double* ctl, double* rec_ring, int rec_stride, double* it_dev, const double* __restrict__ gmax_part, int nb_cam) {
   __shared__ double lds[8];
   {
     double v = 0.0;
@@ -2249,6 +2252,9 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_lm_after(LmOpts o, double* scal,
     scal[sc_gmax] = t;
   }
   if (ctl[CT_SKIPPED] != 0.0) return;
+  const double stamp = *it_dev;                                  // this iteration's number; the next one's is one more
+  double* const rec = rec_ring + (size_t)rec_stride * ((int)stamp & 3);
+  *it_dev = stamp + 1.0;
   double term_next = -1.0;
   if (ctl[CT_TERM] < 0.0 && ctl[CT_DENSE_FAIL] == 0.0) {
     if (ctl[CT_ACCEPT] != 0.0) {

@@ -7,7 +7,8 @@ namespace {
 // Exact step for small graphs: dense Cholesky of (J^T J + Lambda) in the left-tangent space (dense_kernels.hpp).  Enqueues only: the
 // factorisation's status lands in the scalar block (SC_DENSE_INFO) and is read together with the trial cost, one host synchronisation
 // later; a non-positive pivot makes the caller solve the step again by PCG.  *used = false if nothing was enqueued (size, memory).
-int run_dense(gsfm_rot_problem* P, bool* used) {
+// plain = true: enqueue the kernels themselves (the caller is capturing them into a graph of its own: solver_lm.hpp, the LM iteration graph)
+int run_dense(gsfm_rot_problem* P, bool* used, bool plain = false) {
   *used = false;
   const uint32_t n = 3 * P->n_cams, T = (n + GSFM_CB - 1) / GSFM_CB;
   if (T > GSFM_DENSE_MAX_T) return 0;
@@ -90,6 +91,12 @@ int run_dense(gsfm_rot_problem* P, bool* used) {
     }
     // (exact solve: the PCG residual term of the model decrease is zero -- k_dense_assemble cleared it)
   };
+  if (plain) {
+    if (!P->denseA.p) return 0;   // (nothing may be allocated under a capture)
+    enqueue();
+    *used = true;
+    return 0;
+  }
   const int tk = P->timer.begin(T_CG);
   if (P->dense_graph && P->dense_graph_lap != P->lin_is_lap) { (void)hipGraphExecDestroy(P->dense_graph); P->dense_graph = nullptr; }
   if (!P->dense_graph && !P->pcg_graph.unusable) {   // one launch per 32 columns: replay them as one graph

@@ -103,6 +103,7 @@ int read_back(gsfm_rot_problem* P, void* dst, const void* src_dev, size_t bytes,
 // ---- loss preparation ---------------------------------------------------------------------
 int prepare_loss(gsfm_rot_problem* P, const gsfm_loss_node* prog, int n) {
   if (n < 0 || n > GSFM_LOSS_MAX_NODES) return fail(GSFM_ERR_INVALID_ARG, "loss program length out of range");
+  P->loss_epoch++;   // (captured LM iterations froze the kernels the old loss selected)
   DevLoss L;
   std::memset(&L, 0, sizeof(L));
   L.n = n;

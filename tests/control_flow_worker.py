@@ -41,6 +41,13 @@ def main(out):
     os.environ["GSFM_K3_COLSORT"] = "1"
     g = synth.make_graph(2500, 120000, seed=31, outlier_frac=0.25)
     run("colsort", g, _abi.ANGLE_AXIS_COVARIANCE, LF.MAGSACWeightBasedLoss(0.02), g["init_aa"], pcg_forcing=0, **pcg)
+    os.environ.pop("GSFM_K3_COLSORT", None)
+    # (e) exact Cholesky steps under device control (small graphs): a plain run, and one whose first factorisations break down (trust region
+    # of 1e20: no damping, the gauge null space stays) so that PCG steps under host control sit between exact ones
+    g = synth.make_graph(300, 6000, seed=9, outlier_frac=0.2)
+    run("exact_steps", g, _abi.ANGLE_AXIS_COVARIANCE, LF.MAGSACWeightBasedLoss(0.02), g["init_aa"])
+    g = synth.make_graph(60, 400, 3, outlier_frac=0.1)
+    run("broken_factor", g, _abi.ANGLE_AXIS, LF.HuberLoss(0.1), g["init_aa"], cov=False, initial_trust_region_radius=1e20, max_trust_region_radius=1e20, pcg_forcing=0)
     np.savez(out, **res)
 
 

@@ -11,7 +11,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 WORKER = os.path.join(ROOT, "tests", "control_flow_worker.py")
-CASES = ("magsac", "exact_data", "far", "colsort")
+CASES = ("magsac", "exact_data", "far", "colsort", "exact_steps", "broken_factor")
 
 
 def _run(tmp_path, tag, **env):
@@ -29,7 +29,8 @@ def test_host_control_variants_are_bit_identical(tmp_path):
     assert int(base["exact_data_sum"][1]) == 1, base["exact_data_sum"]
     assert base["far_sum"][6] >= 1
     variants = {"no_mailbox": dict(GSFM_PCG_MAILBOX=0), "gmax_read_back": dict(GSFM_DEFER_GMAX=0), "timers_on": dict(GSFM_PHASE_TIMERS=1),
-                "round3_control": dict(GSFM_PCG_MAILBOX=0, GSFM_DEFER_GMAX=0, GSFM_PHASE_TIMERS=1)}
+                "round3_control": dict(GSFM_PCG_MAILBOX=0, GSFM_DEFER_GMAX=0, GSFM_PHASE_TIMERS=1),
+                "iteration_graph": dict(GSFM_LM_ITER_GRAPH=1)}   # (exact steps: the whole LM iteration replayed as one hipGraph)
     for tag, env in variants.items():
         v = _run(tmp_path, tag, **env)
         for c in CASES:
@@ -45,5 +46,5 @@ def test_graded_task_sizes_change_the_answer_only_by_rounding(tmp_path):
     a, b = base["colsort_sum"], even["colsort_sum"]
     assert a[0] == b[0] and a[1] == b[1] and abs(a[2] - b[2]) <= 1e-11 * abs(b[2])
     assert np.abs(base["colsort_rot"] - even["colsort_rot"]).max() <= 1e-9
-    for c in ("magsac", "exact_data", "far"):   # (row-major layout: nothing to deal)
+    for c in ("magsac", "exact_data", "far", "exact_steps", "broken_factor"):   # (row-major layout: nothing to deal)
         assert np.array_equal(base[c + "_rot"], even[c + "_rot"])
