@@ -141,7 +141,9 @@ int build_colsort(gsfm_rot_problem* P, const std::vector<uint32_t>& rp, hvec<uin
   hvec<uint2> h_meta(n_pos);
   hvec<uint16_t> h_kcnt(n_pos);
   std::vector<ColWg> h_wg((size_t)nblk * C.nch);
-  const bool graded = C.nch > 1 && !(getenv("GSFM_COL_EVEN") && atoi(getenv("GSFM_COL_EVEN")) > 0);
+  // (graded only where the tasks outnumber the chip's resident workgroups several times over -- K2c holds 512, K3c 1024: with a single round,
+  // as on one rank's share of a sharded problem (400 tasks), the kernel takes as long as its LARGEST task, and grading made K3c 33 -> 40 us there)
+  const bool graded = C.nch > 1 && (size_t)nblk * C.nch >= 1280 && !(getenv("GSFM_COL_EVEN") && atoi(getenv("GSFM_COL_EVEN")) > 0);
   parallel_run(std::max(1, std::min<int>(n_threads, (int)nblk)), [&](int t, int T) {
     std::vector<std::pair<uint64_t, uint32_t>> ent;   // (camera << 16 | local row, d): a repeated camera pair is ordered by d
     std::vector<uint32_t> cnt(RB + 1), fill(RB), chist;
