@@ -192,7 +192,7 @@ typedef struct {
   int32_t dense_cholesky_auto_cams;    /* default 5333 (the largest matrix the exact step supports; 0 = off): graphs with more than
                                           dense_cholesky_max_cams and at most this many cameras start on PCG and switch to exact Cholesky steps --
                                           what the reference does for every graph, estimator.cpp:300 -- from the moment one PCG-solved step has
-                                          cost more GPU time (HIP events) than 1.25 x the factorisation of their size is measured to take on
+                                          cost more time (elapsed, host clock around the solve) than 1.25 x the factorisation of their size is measured to take on
                                           MI355X (0.45 ms at 394 cameras, 1.33 at 800, 3.27 at 1500, 13.5 at 3000; tools/bench_chol.hip).  Easy
                                           graphs (a few dozen PCG iterations per step) never switch; Madrid-like ones (hundreds) do after their
                                           first step.  Ignored for sharded problems and when dense_cholesky_max_cams < 0. */
@@ -239,7 +239,10 @@ typedef struct {
   double final_radius;
   double last_weight_change;      /* sigma-consensus: last mean |w - w_prev| */
   double t_total_ms;              /* host wall time of the call (uploads of the 3N rotations included) */
-  double t_linearize_ms;          /* GPU time (HIP events) in the linearise kernel */
+  double t_linearize_ms;          /* GPU time (HIP events) in the linearise kernel.  The three phase times are taken only for problems of
+                                     2 M directed entries or more and never inside the device-controlled exact-step pipeline (an event
+                                     record costs ~3 us on the stream: 11 % of a 10k-camera solve); otherwise they stay 0.
+                                     GSFM_PHASE_TIMERS=1 / 0 in the environment forces them on / off */
   double t_sweep_ms;              /* GPU time in the residual+reweight cost sweep */
   double t_cg_ms;                 /* GPU time in PCG kernels (and dense solves) */
   int32_t num_dense_solves;       /* LM steps solved by the dense Cholesky path */
