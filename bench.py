@@ -137,7 +137,7 @@ def small_graph_timings(args):
     out = {}
     cores = pyoracle.usable_cores()
 
-    def best(p, x0, oracle_args=None):
+    def best(p, x0, oracle_args=None, comps=None):   # comps: camera ranges of the connected components (each has its own gauge)
         ts, s = [], None
         rd, _ = p.solve(x0)
         for _ in range(3):
@@ -154,7 +154,12 @@ def small_graph_timings(args):
             r["cpu_oracle_ms"] = 1e3 * (time.perf_counter() - t)
             r["cpu_oracle_cores"] = cores
             r["cpu_oracle_lm_iterations"] = so["num_iterations"]
-            r["device_vs_cpu_mean_rad"] = float(synth.angular_distance(synth.align_rotations(rd, ro), ro).mean())
+            if comps is None:
+                r["device_vs_cpu_mean_rad"] = float(synth.angular_distance(synth.align_rotations(rd, ro), ro).mean())
+            else:
+                d = np.concatenate([synth.angular_distance(synth.align_rotations(rd[a:b], ro[a:b]), ro[a:b]) for a, b in comps])
+                r["device_vs_cpu_mean_rad"] = float(d.mean())
+                r["device_vs_cpu_max_rad"] = float(d.max())
         return r
 
     g = synth.make_graph(10000, 200000, 11, outlier_frac=0.1)
@@ -209,6 +214,20 @@ def small_graph_timings(args):
             p = RotationProblem(len(ids), ei, ej, m["rel_aa"], _abi.ANGLE_AXIS)
             p.set_loss(LF.SoftLOneLoss(0.1))
             out["C1_madrid_softl1_EstimateRotations_default"] = best(p, x0, (len(ids), ei, ej, m["rel_aa"], _abi.ANGLE_AXIS, None, LF.SoftLOneLoss(0.1)))
+            p.close()
+            # C4: the 14 1DSfM scenes as ONE disconnected problem (the construction of tests/test_gpu_fullsize.py: the real Madrid graph + thirteen
+            # synthetic graphs with the scenes' camera counts, Trafalgar's 5 288 included; Huber(0.1), trace-weighted covariances)
+            sizes = [577, 227, 450, 553, 332, 328, 2152, 1084, 572, 789, 836, 437, 5288]
+            scenes = [synth.make_graph(n, 12 * n, seed=400 + k, outlier_frac=0.1) for k, n in enumerate(sizes)]
+            scenes.insert(2, {"n_cams": len(ids), "edge_i": ei, "edge_j": ej, "rel_aa": m["rel_aa"], "cov6": c6, "init_aa": x0})
+            offs = np.cumsum([0] + [g4["n_cams"] for g4 in scenes])
+            ei4 = np.concatenate([g4["edge_i"] + o for o, g4 in zip(offs, scenes)]).astype(np.uint32)
+            ej4 = np.concatenate([g4["edge_j"] + o for o, g4 in zip(offs, scenes)]).astype(np.uint32)
+            rel4 = np.concatenate([g4["rel_aa"] for g4 in scenes]); cov4 = np.concatenate([g4["cov6"] for g4 in scenes]); init4 = np.concatenate([g4["init_aa"] for g4 in scenes])
+            p = RotationProblem(int(offs[-1]), ei4, ej4, rel4, _abi.ANGLE_AXIS_COVTRACE, cov6=cov4)
+            p.set_loss(LF.HuberLoss(0.1))
+            out["C4_14_scenes_%d_cams_%d_edges_one_disconnected_problem" % (int(offs[-1]), len(ei4))] = best(p, init4, (int(offs[-1]), ei4, ej4, rel4, _abi.ANGLE_AXIS_COVTRACE, cov4, LF.HuberLoss(0.1)),
+                                                                                                          comps=[(int(a), int(b)) for a, b in zip(offs[:-1], offs[1:])])
             p.close()
         except Exception as e:  # noqa: BLE001  (the extra keys never take the headline down with them)
             out["C1_madrid_error"] = repr(e)
