@@ -23,8 +23,12 @@
 
 namespace gsfm {
 
-#define GSFM_COL_RB 512    // rows per block = positions per sub-chunk = lanes of a K3c workgroup
+#ifndef GSFM_COL_RB
+#define GSFM_COL_RB 512    // rows per block = positions per sub-chunk = lanes of a K3c workgroup (512 or 1024: -DGSFM_COL_RB=1024 -DGSFM_COLLIN_THREADS=512)
+#endif
 #define GSFM_COL_SUB GSFM_COL_RB
+#define GSFM_COL_SLOT_BITS (GSFM_COL_RB == 1024 ? 10 : 9)   // bits of a slot / a row inside its block; a row's count in a sub-chunk needs one more (0 .. SUB)
+static_assert(GSFM_COL_RB == (1 << GSFM_COL_SLOT_BITS), "row blocks of 512 or 1024 rows");
 #ifndef GSFM_COL_EPL
 #define GSFM_COL_EPL 1     // K3c: sub-chunks in flight per iteration (entries per lane); -DGSFM_COL_EPL=n: 1 measured best in the product (2: +4..9 %, 3: +8 %)
 #endif
@@ -48,9 +52,11 @@ struct ColLayoutDev {
   uint32_t cbits, cmax;
   uint32_t n_wg, nch;
 };
-__device__ __forceinline__ uint32_t col_slot(uint32_t y) { return y & 0x3ffu; }
-__device__ __forceinline__ uint32_t col_rowcount(uint32_t y) { return (y >> 10) & 0x3ffu; }
-__device__ __forceinline__ uint32_t col_rowl(uint32_t y) { return y >> 20; }
+// the record's second word: slot (SLOT_BITS) | count of row p (SLOT_BITS + 1) | row of the entry inside its block (SLOT_BITS)
+__host__ __device__ constexpr uint32_t col_pack(uint32_t slot, uint32_t rowcount, uint32_t rowl) { return slot | (rowcount << GSFM_COL_SLOT_BITS) | (rowl << (2 * GSFM_COL_SLOT_BITS + 1)); }
+__host__ __device__ __forceinline__ uint32_t col_slot(uint32_t y) { return y & ((1u << GSFM_COL_SLOT_BITS) - 1u); }
+__host__ __device__ __forceinline__ uint32_t col_rowcount(uint32_t y) { return (y >> GSFM_COL_SLOT_BITS) & ((2u << GSFM_COL_SLOT_BITS) - 1u); }
+__host__ __device__ __forceinline__ uint32_t col_rowl(uint32_t y) { return y >> (2 * GSFM_COL_SLOT_BITS + 1); }
 // inclusive prefix sum over the 64 lanes of a wavefront: DPP row shifts inside the rows of 16 lanes, then the two row broadcasts (six VALU
 // instructions, no LDS traffic)
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x) {
@@ -91,7 +97,7 @@ __device__ __forceinline__ void mv_col_body(const ColMatvecArgs& a, Stop stop_af
   const uint32_t r = threadIdx.x, wave = r >> 6;
   double y0 = 0.0, y1 = 0.0, y2 = 0.0;
   uint32_t m[EPL], pos[EPL]; double2 A[EPL], B[EPL], C[EPL];
-  const uint32_t cmask = (1u << a.L.cbits) - 1u, cshift = a.L.cbits + 9u, cmax = a.L.cmax;
+  const uint32_t cmask = (1u << a.L.cbits) - 1u, cshift = a.L.cbits + GSFM_COL_SLOT_BITS, cmax = a.L.cmax;
   auto request = [&](uint32_t s) {   // the streams of sub-chunks s .. s + EPL - 1 of this workgroup (past its end: the last one again, discarded)
 #pragma unroll
     for (int k = 0; k < EPL; ++k) {
@@ -108,7 +114,7 @@ __device__ __forceinline__ void mv_col_body(const ColMatvecArgs& a, Stop stop_af
     uint32_t cnt[EPL], inc[EPL];
 #pragma unroll
     for (int k = 0; k < EPL; ++k) {
-      const uint32_t cam = (m[k] & cmask) == cmask ? 0u : (m[k] & cmask), pm = (m[k] >> a.L.cbits) & 0x1ffu;
+      const uint32_t cam = (m[k] & cmask) == cmask ? 0u : (m[k] & cmask), pm = (m[k] >> a.L.cbits) & ((1u << GSFM_COL_SLOT_BITS) - 1u);
       const double* um = a.u + 3 * (size_t)cam;
       const double u0 = um[0], u1 = um[1], u2 = um[2];
       slots[buf][k][0][pm] = A[k].x * u0 + A[k].y * u1 + B[k].x * u2;

@@ -116,10 +116,10 @@ int build_colsort(gsfm_rot_problem* P, const std::vector<uint32_t>& rp, hvec<uin
   constexpr uint32_t RB = GSFM_COL_RB, SUB = GSFM_COL_SUB;
   auto& C = P->cs;
   const uint32_t n_rows = P->n_rows, nblk = (n_rows + RB - 1) / RB;
-  if (nblk == 0 || P->n_cams >= (1u << 22) - 1u) return 0;
+  if (nblk == 0 || P->n_cams >= (1u << (31 - GSFM_COL_SLOT_BITS)) - 1u) return 0;   // (camera | slot | count in one 32-bit word: 2^22 cameras at 512 rows per block)
   uint32_t cbits = 1;
   while (((1u << cbits) - 1u) <= P->n_cams) ++cbits;   // cameras 0 .. n_cams - 1 and the all-ones padding value
-  const uint32_t cmax = cbits <= 19 ? (1u << (23 - cbits)) - 1u : 0u, kpad = (1u << cbits) - 1u;
+  const uint32_t cmax = cbits + GSFM_COL_SLOT_BITS <= 28 ? (1u << (32 - GSFM_COL_SLOT_BITS - cbits)) - 1u : 0u, kpad = (1u << cbits) - 1u;   // (RB = 512: counts up to 2^(23 - cbits) - 1 in the word, as before)
   std::vector<size_t> sub_off((size_t)nblk + 1, 0);
   for (uint32_t b = 0; b < nblk; ++b) {
     const size_t ne = rp[std::min(n_rows, (b + 1) * RB)] - rp[b * RB];
@@ -143,7 +143,7 @@ int build_colsort(gsfm_rot_problem* P, const std::vector<uint32_t>& rp, hvec<uin
   std::vector<ColWg> h_wg((size_t)nblk * C.nch);
   // (graded only where the tasks outnumber the chip's resident workgroups several times over -- K2c holds 512, K3c 1024: with a single round,
   // as on one rank's share of a sharded problem (400 tasks), the kernel takes as long as its LARGEST task, and grading made K3c 33 -> 40 us there)
-  const bool graded = C.nch > 1 && (size_t)nblk * C.nch >= 1280 && !(getenv("GSFM_COL_EVEN") && atoi(getenv("GSFM_COL_EVEN")) > 0);
+  const bool graded = C.nch > 1 && (size_t)nblk * C.nch >= (size_t)(GSFM_COL_RB == 512 ? 1280 : 640) && !(getenv("GSFM_COL_EVEN") && atoi(getenv("GSFM_COL_EVEN")) > 0);
   parallel_run(std::max(1, std::min<int>(n_threads, (int)nblk)), [&](int t, int T) {
     std::vector<std::pair<uint64_t, uint32_t>> ent;   // (camera << 16 | local row, d): a repeated camera pair is ordered by d
     std::vector<uint32_t> cnt(RB + 1), fill(RB), chist;
@@ -190,13 +190,12 @@ int build_colsort(gsfm_rot_problem* P, const std::vector<uint32_t>& rp, hvec<uin
         uint32_t pad_slot = (uint32_t)(hi - lo);
         for (size_t e = lo; e < lo + SUB; ++e) {
           const size_t o = base + (e - lo);
-          const uint32_t p = (uint32_t)(e - lo), rows_here = (cnt[p + 1] - cnt[p]) << 10;   // position p also carries the slot count of ROW p
+          const uint32_t p = (uint32_t)(e - lo), rc = cnt[p + 1] - cnt[p];   // position p also carries the slot count of ROW p
           if (e < hi) {
             const uint32_t rl = (uint32_t)(ent[e].first & 0xffff), d = ent[e].second;
-            h_col[o] = col[d]; h_eid[o] = deid[d]; h_meta[o] = make_uint2(col[d], fill[rl]++ | rows_here | (rl << 20));
-          } else { h_col[o] = GSFM_COL_PAD; h_eid[o] = 0; h_meta[o] = make_uint2(GSFM_COL_PAD, pad_slot++ | rows_here); }   // zero block, a slot no row reads
-          const uint32_t rc = rows_here >> 10;
-          h_kcol[o] = (h_meta[o].x == GSFM_COL_PAD ? kpad : (h_meta[o].x & 0x7fffffffu)) | ((h_meta[o].y & 0x1ffu) << cbits) | (std::min(rc, cmax) << (cbits + 9));
+            h_col[o] = col[d]; h_eid[o] = deid[d]; h_meta[o] = make_uint2(col[d], col_pack(fill[rl]++, rc, rl));
+          } else { h_col[o] = GSFM_COL_PAD; h_eid[o] = 0; h_meta[o] = make_uint2(GSFM_COL_PAD, col_pack(pad_slot++, rc, 0)); }   // zero block, a slot no row reads
+          h_kcol[o] = (h_meta[o].x == GSFM_COL_PAD ? kpad : (h_meta[o].x & 0x7fffffffu)) | (col_slot(h_meta[o].y) << cbits) | (std::min(rc, cmax) << (cbits + GSFM_COL_SLOT_BITS));
           h_kcnt[o] = (uint16_t)rc;
         }
       }
