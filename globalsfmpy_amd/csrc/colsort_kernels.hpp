@@ -139,7 +139,79 @@ __device__ __forceinline__ void mv_col_body(const ColMatvecArgs& a, Stop stop_af
   const size_t o = (size_t)w.part * RB + r, plane = (size_t)a.L.n_wg * RB;
   a.part[o] = y0; a.part[plane + o] = y1; a.part[2 * plane + o] = y2;
 }
-__global__ void __launch_bounds__(GSFM_COL_RB) k_mv_col(ColMatvecArgs a) {
+// The same product with FEWER lanes than positions: T lanes, K = RB / T positions per lane and sub-chunk, lane t owns rows t, t + T, ... (like K2c).
+// Smaller workgroups = more, smaller barrier groups per CU.  -DGSFM_K3C_THREADS=256; measured against the 512-lane form in profiles/r04b_k3c_threads_ab.txt.
+#ifndef GSFM_K3C_THREADS
+#define GSFM_K3C_THREADS GSFM_COL_RB
+#endif
+template <typename Stop>
+__device__ __forceinline__ void mv_col_body_k(const ColMatvecArgs& a, Stop stop_after_request) {
+  constexpr int RB = GSFM_COL_RB, T = GSFM_K3C_THREADS, K = RB / T;
+  static_assert(T >= GSFM_BLOCK && RB % T == 0, "k_mv_col_cg re-sums the gamma partials with the 256-lane kernels' tree");
+  __shared__ double slots[2][3][RB];
+  __shared__ uint32_t wtot[2][K][T / 64];
+  const ColWg w = a.L.wg[blockIdx.x];
+  const uint32_t r = threadIdx.x, wave = r >> 6;
+  double y[K][3];
+#pragma unroll
+  for (int j = 0; j < K; ++j) y[j][0] = y[j][1] = y[j][2] = 0.0;
+  uint32_t m[K], pos[K]; double2 A[K], B[K], C[K];
+  const uint32_t cmask = (1u << a.L.cbits) - 1u, cshift = a.L.cbits + GSFM_COL_SLOT_BITS, cmax = a.L.cmax;
+  auto request = [&](uint32_t s) {
+    const uint32_t sc = w.first_sub + min(s, w.n_sub - 1);
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const size_t e = (size_t)sc * RB + (size_t)k * T + r;
+      m[k] = __builtin_nontemporal_load(a.L.kcol + e); pos[k] = (uint32_t)e;
+      A[k] = nt_load2(a.b0 + e); B[k] = nt_load2(a.b1 + e); C[k] = nt_load2(a.b2 + e);
+    }
+  };
+  if (w.n_sub) request(0);
+  if (stop_after_request()) return;
+  int buf = 0;
+  for (uint32_t s = 0; s < w.n_sub; ++s, buf ^= 1) {
+    uint32_t cnt[K], inc[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const uint32_t cam = (m[k] & cmask) == cmask ? 0u : (m[k] & cmask), pm = (m[k] >> a.L.cbits) & ((1u << GSFM_COL_SLOT_BITS) - 1u);
+      const double* um = a.u + 3 * (size_t)cam;
+      const double u0 = um[0], u1 = um[1], u2 = um[2];
+      slots[buf][0][pm] = A[k].x * u0 + A[k].y * u1 + B[k].x * u2;
+      slots[buf][1][pm] = A[k].y * u0 + B[k].y * u1 + C[k].x * u2;
+      slots[buf][2][pm] = B[k].x * u0 + C[k].x * u1 + C[k].y * u2;
+      uint32_t c = m[k] >> cshift;                      // the count of ROW k * T + r rides at position k * T + r
+      if (c == cmax) c = a.L.kcnt[pos[k]];
+      cnt[k] = c;
+      inc[k] = wave_incl_scan(c);
+      if ((r & 63u) == 63u) wtot[buf][k][wave] = inc[k];
+    }
+    if (s + 1 < w.n_sub) request(s + 1);
+    __syncthreads();
+    uint32_t carry = 0, s0[K], nmax = 0;
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      uint32_t s1 = carry + inc[j];
+      for (uint32_t v = 0; v < T / 64; ++v) { const uint32_t wt = wtot[buf][j][v]; if (v < wave) s1 += wt; carry += wt; }
+      s0[j] = s1 - cnt[j];
+      nmax = max(nmax, cnt[j]);
+    }
+    for (uint32_t t = 0; t < nmax; ++t) {
+#pragma unroll
+      for (int j = 0; j < K; ++j)
+        if (t < cnt[j]) { y[j][0] += slots[buf][0][s0[j] + t]; y[j][1] += slots[buf][1][s0[j] + t]; y[j][2] += slots[buf][2][s0[j] + t]; }
+    }
+  }
+  const size_t plane = (size_t)a.L.n_wg * RB;
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    const size_t o = (size_t)w.part * RB + (size_t)j * T + r;
+    a.part[o] = y[j][0]; a.part[plane + o] = y[j][1]; a.part[2 * plane + o] = y[j][2];
+  }
+}
+#if GSFM_K3C_THREADS != GSFM_COL_RB
+#define mv_col_body mv_col_body_k
+#endif
+__global__ void __launch_bounds__(GSFM_K3C_THREADS) k_mv_col(ColMatvecArgs a) {
   if (a.done && *a.done) return;
   mv_col_body(a, [] { return false; });
 }
@@ -147,7 +219,7 @@ __global__ void __launch_bounds__(GSFM_COL_RB) k_mv_col(ColMatvecArgs a) {
 // workgroup re-sums the gamma partials in the order and with the reduction tree of the 256-lane kernels, so all of them, and the vector
 // kernel that follows, see bit-identical scalars -- then the rows.  The delta partials come from k_mv_col_finish (dot_part).
 struct ColMatvecCgArgs { ColMatvecArgs mv; Cg2Args cg; };
-__global__ void __launch_bounds__(GSFM_COL_RB) k_mv_col_cg(ColMatvecCgArgs aa) {
+__global__ void __launch_bounds__(GSFM_K3C_THREADS) k_mv_col_cg(ColMatvecCgArgs aa) {
   __shared__ double lds[4];
   const Cg2Args& c = aa.cg;
   mv_col_body(aa.mv, [&]() -> bool {
