@@ -56,7 +56,7 @@ def kernel_source_sha16():
     import hashlib
     h = hashlib.sha256()
     d = os.path.join(ROOT, "globalsfmpy_amd", "csrc")
-    for f in ("kernels.hpp", "colsort_kernels.hpp", "loss_dev.hpp", "so3_dev.hpp"):
+    for f in ("kernels.hpp", "colsort_kernels.hpp", "loss_dev.hpp", "so3_dev.hpp", "devmath.hpp"):
         h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
 
