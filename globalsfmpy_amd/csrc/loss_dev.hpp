@@ -267,7 +267,7 @@ __device__ __forceinline__ double loss_value(const DevLoss* __restrict__ loss, d
 template <int LM> struct LossView { const DevLoss* p; DevLossNode n; };
 template <int LM>
 __device__ __forceinline__ LossView<LM> loss_view(const DevLoss* __restrict__ p) {
-  LossView<LM> v;
+  LossView<LM> v{};   // (the general program never reads the copy)
   v.p = p;
   if (LM != LM_PROGRAM) v.n = p->nodes[0];
   return v;
