@@ -166,6 +166,10 @@ int lm_solve(gsfm_rot_problem* P, const gsfm_rot_options& o_in, gsfm_rot_summary
   // from convergence, a linear solve to 1e-8 rad would be wasted on it; the deviation allowed, kappa |step|^2, stays orders below that error
   // (a 14-degree step: tau 1.2e-6 instead of 4e-8; below 2.6 degrees the absolute bound is the tighter one).  Tree start of the benchmark
   // graph: 683 -> ~500 PCG iterations, the final answer ~1e-9 rad (mean) from the exact schedule (profiles/r04_forcing_floor.txt).
+  // Larger floors were swept at the end of the round (profiles/r04b_kappa_sweep.txt: 5e-5 / 1e-4 / 3e-4 -> tree start 437 / 378 / 350 iterations,
+  // 97 / 85 / 80 ms, C5 36 / 35 / 34 iterations, the same two misses among 40 random graphs up to 1e-4) and NOT adopted: at 1e-4 the suite's own
+  // forcing pass loses a 172-iteration trajectory (trust region creeping up, steps above 0.6 degrees for dozens of iterations: the deviations of
+  // consecutive steps add up faster than the slow convergence contracts them -- 5e-4 rad from the oracle, where 5e-6 follows it).
   // GSFM_FORCING_KAPPA overrides (0 = absolute bound only).
   static const double kappa = [] { const char* e = getenv("GSFM_FORCING_KAPPA"); return e && *e ? atof(e) : 5e-6; }();
   // (not for QUATERNION_NORM: that functor canonicalises the sign of two quaternions separately, quat.hpp:135-142 -- a DISCONTINUOUS residual, where a
