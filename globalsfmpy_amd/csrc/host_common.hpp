@@ -270,7 +270,6 @@ struct gsfm_rot_problem {
   DevBuf<double> x, x_trial, aa_io, active, scale, gD, Mblk, Minv, Lam, Tinv, b, D6;
   DevBuf<double2> q, q_trial;
   DevBuf<double> xcg, r, z, p, Ap, s_dir, part_g2, part_d2;
-  DevBuf<double> eta_fix, rcg_fix;   // forcing schedule: a loose step with its gauge component removed, and the residual that goes with it (launch_step)
   DevBuf<double> w_gather;   // sharded single-reduction PCG: per rank [slice of A u | delta partials of its rows] (run_pcg2)
   uint32_t w_tail = 0;
   DevBuf<Cg2Scalars> cg2sc;

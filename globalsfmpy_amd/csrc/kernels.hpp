@@ -1210,7 +1210,7 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_max_partials(const double* __res
 // from an inexact step the same way -- w = (sum R^T Lam R)^-1 sum R^T Lam eta, eta_k -= R_k w -- and keep the PCG residual consistent
 // (r += Lam R_k w; J^T J R w = 0), so that the model decrease computed from (eta, r) stays exact for the corrected step.
 // Out of place (eta_out, rcg_out): the PCG state itself must stay what the stopping iteration left, so that the solve can be continued.
-struct GaugeArgs { uint32_t n; int nb; const double* active; const double2* q; const double* Lam; const double* eta; const double* rcg; double* part; /* [9][nb] */ double* eta_out; double* rcg_out; };
+struct GaugeArgs { uint32_t n; int nb; const double* active; const double2* q; const double* Lam; const double* eta; const double* rcg; double* part; /* [9][nb] */ };
 __global__ void __launch_bounds__(GSFM_BLOCK) k_gauge_part(GaugeArgs a) {
   __shared__ double lds[8];
   double v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -1239,30 +1239,30 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_gauge_part(GaugeArgs a) {
     if (threadIdx.x == 0) a.part[(size_t)c * a.nb + blockIdx.x] = t;
   }
 }
-__global__ void __launch_bounds__(GSFM_BLOCK) k_gauge_apply(GaugeArgs a) {
-  __shared__ double lds[8];
+// w = A^-1 s from the nine sums of k_gauge_part (every block: same partials, same order, same bits); a singular A (no damping at all) leaves
+// the step alone.  All lanes of the workgroup must call it (block reductions).
+__device__ __forceinline__ void gauge_solve(const double* __restrict__ part, int nb, double* lds, double* w) {
   double S[9];
 #pragma unroll
-  for (int c = 0; c < 9; ++c) S[c] = sum_partials_bcast(a.part + (size_t)c * a.nb, a.nb, lds);   // (every block: same partials, same order, same bits)
-  // w = A^-1 s, A symmetric (S[3..8]) by cofactors; a singular A (no damping at all) leaves the step alone
+  for (int c = 0; c < 9; ++c) S[c] = sum_partials_bcast(part + (size_t)c * nb, nb, lds);
   const double a00 = S[3], a01 = S[4], a02 = S[5], a11 = S[6], a12 = S[7], a22 = S[8];
   const double c00 = a11 * a22 - a12 * a12, c01 = a02 * a12 - a01 * a22, c02 = a01 * a12 - a02 * a11;
   const double det = a00 * c00 + a01 * c01 + a02 * c02;
   const bool ok = fabs(det) > 0.0;
   const double c11 = a00 * a22 - a02 * a02, c12 = a01 * a02 - a00 * a12, c22 = a00 * a11 - a01 * a01, id = ok ? 1.0 / det : 0.0;
-  const double w0 = id * (c00 * S[0] + c01 * S[1] + c02 * S[2]), w1 = id * (c01 * S[0] + c11 * S[1] + c12 * S[2]), w2 = id * (c02 * S[0] + c12 * S[1] + c22 * S[2]);
-  const uint32_t k = blockIdx.x * GSFM_BLOCK + threadIdx.x;
-  if (k < a.n) {
-    double d[3] = {0.0, 0.0, 0.0}, ld[3] = {0.0, 0.0, 0.0};
-    if (a.active[k] != 0.0) {
-      double R[9];
-      qmat(load_q(a.q, k), R);
-      d[0] = R[0] * w0 + R[1] * w1 + R[2] * w2; d[1] = R[3] * w0 + R[4] * w1 + R[5] * w2; d[2] = R[6] * w0 + R[7] * w1 + R[8] * w2;
-      sym3_mulvec(a.Lam + 6 * (size_t)k, d, ld);
-    }
-#pragma unroll
-    for (int c = 0; c < 3; ++c) { a.eta_out[3 * (size_t)k + c] = a.eta[3 * (size_t)k + c] - d[c]; a.rcg_out[3 * (size_t)k + c] = a.rcg[3 * (size_t)k + c] + ld[c]; }
+  w[0] = id * (c00 * S[0] + c01 * S[1] + c02 * S[2]); w[1] = id * (c01 * S[0] + c11 * S[1] + c12 * S[2]); w[2] = id * (c02 * S[0] + c12 * S[1] + c22 * S[2]);
+}
+// the correction of camera k: eta_k - R_k w and rcg_k + Lam_k R_k w (inactive cameras: unchanged)
+__device__ __forceinline__ void gauge_correct(const double* w, bool active, const double2* __restrict__ q, const double* __restrict__ Lam, uint32_t k, const double* eta_in, const double* rcg_in, double* e, double* rc) {
+  double d[3] = {0.0, 0.0, 0.0}, ld[3] = {0.0, 0.0, 0.0};
+  if (active) {
+    double R[9];
+    qmat(load_q(q, k), R);
+    d[0] = R[0] * w[0] + R[1] * w[1] + R[2] * w[2]; d[1] = R[3] * w[0] + R[4] * w[1] + R[5] * w[2]; d[2] = R[6] * w[0] + R[7] * w[1] + R[8] * w[2];
+    sym3_mulvec(Lam + 6 * (size_t)k, d, ld);
   }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) { e[c] = eta_in[3 * (size_t)k + c] - d[c]; rc[c] = rcg_in[3 * (size_t)k + c] + ld[c]; }
 }
 
 struct StepArgs {
@@ -1278,6 +1278,9 @@ struct StepArgs {
   double* x_trial;
   double2* q_trial;
   double* partials;       // 5 * gridDim.x : eta.g, eta.rcg, eta^T Lam eta, |x - x_trial|^2, |x_trial|^2
+  // a loose PCG iterate (forcing schedule): the nine sums of k_gauge_part; the gauge component is taken out of eta and the residual corrected
+  // on the fly (round 4: the kernel that wrote the corrected copies is gone -- one launch fewer per loose step; the PCG state stays untouched)
+  const double* gauge_part; int gauge_nb; const double2* gauge_q;
 };
 // delta = Tinv eta; x_trial = Plus(x, delta); scalars for the model cost change and the
 // parameter-tolerance test (TrustRegionMinimizer::ComputeCandidatePointAndEvaluateCost).
@@ -1285,16 +1288,19 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_cam_step(StepArgs a) {
   __shared__ double lds[8];
   double v[5] = {0, 0, 0, 0, 0};
   const uint32_t k = blockIdx.x * GSFM_BLOCK + threadIdx.x;
+  double gw[3] = {0.0, 0.0, 0.0};
+  if (a.gauge_part) gauge_solve(a.gauge_part, a.gauge_nb, lds, gw);
   if (k < a.n) {
     const size_t k3 = 3 * (size_t)k;
-    const double e[3] = {a.eta[k3], a.eta[k3 + 1], a.eta[k3 + 2]};
+    double e[3] = {a.eta[k3], a.eta[k3 + 1], a.eta[k3 + 2]}, rc[3] = {a.rcg[k3], a.rcg[k3 + 1], a.rcg[k3 + 2]};
+    if (a.gauge_part) gauge_correct(gw, a.active[k] != 0.0, a.gauge_q, a.Lam, k, a.eta, a.rcg, e, rc);
     const double* Ti = a.Tinv + 9 * (size_t)k;
     const double d[3] = {Ti[0] * e[0] + Ti[1] * e[1] + Ti[2] * e[2], Ti[3] * e[0] + Ti[4] * e[1] + Ti[5] * e[2],
                          Ti[6] * e[0] + Ti[7] * e[1] + Ti[8] * e[2]};
     double le[3];
     sym3_mulvec(a.Lam + 6 * (size_t)k, e, le);
     v[0] = -(e[0] * a.b[k3] + e[1] * a.b[k3 + 1] + e[2] * a.b[k3 + 2]);
-    v[1] = e[0] * a.rcg[k3] + e[1] * a.rcg[k3 + 1] + e[2] * a.rcg[k3 + 2];
+    v[1] = e[0] * rc[0] + e[1] * rc[1] + e[2] * rc[2];
     v[2] = e[0] * le[0] + e[1] * le[1] + e[2] * le[2];
     const double act = a.active[k];
     Quat qt;
@@ -1825,6 +1831,24 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_coarse_assemble(CoarseAsmArgs a)
 #define GSFM_MAIL_WORDS 32
 __global__ void k_pcg_mail(const double* __restrict__ sc, int nwords, double* mail, double* counter) {
   for (int k = 0; k < nwords; ++k) mail[k] = sc[k];
+  const double c = *counter + 1.0;
+  *counter = c;
+  __threadfence_system();
+  __hip_atomic_store(mail + GSFM_MAIL_WORDS, c, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// The LM loop's look at a trial point in ONE launch: the step's five sums and the trial cost's (the reductions k_sum_partials_multi /
+// k_sum_partials would have launched: same routine, same order, same bits, written to the same scalars), then the scalar block's post.
+__global__ void __launch_bounds__(GSFM_BLOCK) k_trial_post(double* scal, int sc_step, int sc_trial, const double* __restrict__ step_part, int nb_cam,
+                                                           const double* __restrict__ cost_part, int nb_cost, int nwords, double* mail, double* counter) {
+  __shared__ double lds[8];
+  for (int c = 0; c < 5; ++c) {
+    const double t = sum_partials_bcast(step_part + (size_t)c * nb_cam, nb_cam, lds);
+    if (threadIdx.x == 0) scal[sc_step + c] = t;
+  }
+  const double t = sum_partials_bcast(cost_part, nb_cost, lds);
+  if (threadIdx.x != 0) return;
+  scal[sc_trial] = t;
+  for (int k = 0; k < nwords; ++k) mail[k] = scal[k];
   const double c = *counter + 1.0;
   *counter = c;
   __threadfence_system();

@@ -7,15 +7,14 @@ namespace {
 
 // reduce = false: the caller sums k_cam_step's partials itself (k_lm_decide)
 int launch_step(gsfm_rot_problem* P, bool inexact = false, bool reduce = true) {
-  const double *eta = P->xcg.p, *rcg = P->r.p;
-  if (inexact && P->lap_capable) {   // (functors whose cost depends on R_j R_i^T alone: for those the gauge is an exact symmetry) a loose PCG iterate: its gauge component is taken out first (kernels.hpp, k_gauge_part) -- into copies, the PCG state stays resumable
-    GaugeArgs ga{P->n_cams, P->nb_cam, P->active.p, P->q_lin ? P->q_lin : P->q.p, P->Lam.p, P->xcg.p, P->r.p, P->part_gauge.p, P->eta_fix.p, P->rcg_fix.p};
-    hipLaunchKernelGGL(k_gauge_part, dim3(P->nb_cam), dim3(GSFM_BLOCK), 0, P->stream, ga);
-    hipLaunchKernelGGL(k_gauge_apply, dim3(P->nb_cam), dim3(GSFM_BLOCK), 0, P->stream, ga);
-    eta = P->eta_fix.p; rcg = P->rcg_fix.p;
-  }
   StepArgs a{};
-  a.n = P->n_cams; a.param_dim = P->param_dim; a.x = P->x.p; a.active = P->active.p; a.eta = eta; a.b = P->b.p; a.rcg = rcg;
+  if (inexact && P->lap_capable) {   // (functors whose cost depends on R_j R_i^T alone: for those the gauge is an exact symmetry) a loose PCG iterate: its gauge component is taken out first (kernels.hpp, k_gauge_part) -- inside k_cam_step, the PCG state stays resumable
+    const double2* gq = P->q_lin ? P->q_lin : P->q.p;
+    GaugeArgs ga{P->n_cams, P->nb_cam, P->active.p, gq, P->Lam.p, P->xcg.p, P->r.p, P->part_gauge.p};
+    hipLaunchKernelGGL(k_gauge_part, dim3(P->nb_cam), dim3(GSFM_BLOCK), 0, P->stream, ga);
+    a.gauge_part = P->part_gauge.p; a.gauge_nb = P->nb_cam; a.gauge_q = gq;
+  }
+  a.n = P->n_cams; a.param_dim = P->param_dim; a.x = P->x.p; a.active = P->active.p; a.eta = P->xcg.p; a.b = P->b.p; a.rcg = P->r.p;
   a.Lam = P->Lam.p; a.Tinv = P->Tinv.p; a.x_trial = P->x_trial.p; a.q_trial = P->q_trial.p; a.partials = P->part_cam.p;
   hipLaunchKernelGGL(k_cam_step, dim3(P->nb_cam), dim3(GSFM_BLOCK), 0, P->stream, a);
   if (reduce) hipLaunchKernelGGL(k_sum_partials_multi, dim3(1), dim3(GSFM_BLOCK), 0, P->stream, P->part_cam.p, P->nb_cam, 5, P->scal.p + SC_STEP);
@@ -35,6 +34,22 @@ int read_scalars(gsfm_rot_problem* P, double* h) {
   return read_back(P, h, P->scal.p, SC_N * sizeof(double), "read scalars");
 }
 
+
+// The trial point of a host-controlled step: step, cost sweep and the look at the scalars.  With the mailbox (unsharded, native loss) the
+// three single-workgroup kernels behind the sweep -- two reductions and the post -- are one (k_trial_post).
+int evaluate_trial(gsfm_rot_problem* P, bool inexact, double* h) {
+  if (!P->sharded && !P->cb && !P->sigma_pending_cost && mail_usable(P)) {
+    launch_step(P, inexact, false);
+    if (int st = launch_cost(P, P->q_trial.p, SC_TRIAL, CostOutputs(), false)) return st;
+    hipLaunchKernelGGL(k_trial_post, dim3(1), dim3(GSFM_BLOCK), 0, P->stream, P->scal.p, (int)SC_STEP, (int)SC_TRIAL, (const double*)P->part_cam.p, P->nb_cam,
+                       (const double*)P->part_cost.p, P->nb_cost, (int)SC_N, P->mail_dev, P->mail_count.p);
+    P->mail_expected += 1.0;
+    return mail_wait(P, h, SC_N * sizeof(double));
+  }
+  launch_step(P, inexact);
+  if (int st = launch_cost(P, P->q_trial.p, SC_TRIAL)) return st;
+  return read_scalars(P, h);
+}
 
 // Per-camera host arrays (rotations, gradient, mat-vec operands) enter and leave in the caller's numbering.
 const double* to_internal(gsfm_rot_problem* P, const double* ext, int width) {
@@ -359,9 +374,7 @@ int lm_solve(gsfm_rot_problem* P, const gsfm_rot_options& o_in, gsfm_rot_summary
           if (gmax <= o.gradient_tolerance) { --iteration; return finish(GSFM_TERM_GRADIENT_TOLERANCE); }   // (this iteration never began)
         }
       }
-      launch_step(P, !dense_used && loose);
-      if (int st = launch_cost(P, P->q_trial.p, SC_TRIAL)) return st;
-      if (int st = read_scalars(P, h)) return st;
+      if (int st = evaluate_trial(P, !dense_used && loose, h)) return st;
       for (int pass = 0; pass < 3 && !dense_used && loose && cg_rel > o.cg_relative_tolerance; ++pass) {
         // The loose step has been evaluated.  Every decision the trust-region loop takes from it must be the one the exact step would give:
         //  * termination (function / parameter tolerance): the decisive quantities -- cost change, step norm -- of the loose step are within
@@ -391,9 +404,7 @@ int lm_solve(gsfm_rot_problem* P, const gsfm_rot_options& o_in, gsfm_rot_summary
         const double t_pcg = now_ms();
         if (int st = (use_pcg2 ? run_pcg2(P, o, o.cg_relative_tolerance, tau * tau, cg, &cg, &cg_rel) : run_pcg(P, o, o.cg_relative_tolerance, tau * tau, cg, &cg, &cg_rel))) return st;
         pcg_wall_ms += now_ms() - t_pcg;
-        launch_step(P, loose);
-        if (int st = launch_cost(P, P->q_trial.p, SC_TRIAL)) return st;
-        if (int st = read_scalars(P, h)) return st;
+        if (int st = evaluate_trial(P, loose, h)) return st;
         sum->num_forcing_refinements++;
         if (!loose) break;
       }
