@@ -551,14 +551,18 @@ def main():
     else:
         out = None
     # From here on the line is armed: the variants below have never run across GPUs, and a GPU fault in one of them would end the process
-    # from inside the runtime (abort()) -- a C-level handler then writes the plain-launch line measured above and leaves with status 0.
+    # from inside the runtime (abort()) -- a C-level handler then writes the plain-launch line measured above, with a `crashed_variant` field carrying the signal number, and leaves.
     crash_lib = None
     if part is not None:
         try:
             import ctypes
-            crash_lib = ctypes.CDLL(os.path.join(ROOT, "globalsfmpy_amd", "libgsfm_peer.so"))
-            line0 = (json.dumps(dict(out, after_the_plain_run="a later variant ended the process: this is the plain-launch measurement")) + "\n").encode() if rank == 0 else b""
-            crash_lib.gsfm_crash_line_arm(ctypes.c_int(real_stdout if rank == 0 else -1), line0, ctypes.c_size_t(len(line0)))
+            crash_lib = ctypes.CDLL(os.path.join(ROOT, "globalsfmpy_amd", "libgsfm_benchguard.so"))   # (bench-only code: csrc/bench_guard.c)
+            # the line says that -- and by which signal -- a later variant died: the handler patches the two digits of "signal": 00
+            marker = '"signal": 00'
+            line0 = (json.dumps(dict(out, crashed_variant={"what": "a variant tried AFTER the plain-launch measurement (captured collectives / peer stores) ended the process; "
+                                                                  "`value` is the plain-launch measurement", "signal": 0})).replace('"signal": 0}', marker + "}") + "\n").encode() if rank == 0 else b""
+            off = line0.find(marker.encode()) + len(marker) - 2 if rank == 0 else 0
+            crash_lib.gsfm_crash_line_arm(ctypes.c_int(real_stdout if rank == 0 else -1), line0, ctypes.c_size_t(len(line0)), ctypes.c_size_t(max(off, 0)))
         except OSError:
             crash_lib = None
         if os.environ.get("GSFM_BENCH_TEST_CRASH") == "1":   # (test hook: what a GPU fault does)

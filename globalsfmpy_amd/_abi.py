@@ -69,7 +69,8 @@ class Summary(C.Structure):
         ("num_dense_solves", C.c_int32), ("num_graph_launches", C.c_int32),
         ("num_collectives", C.c_int32), ("num_pcg_collectives", C.c_int32),
         ("num_pcg_launched", C.c_int32), ("num_forcing_refinements", C.c_int32),
-        ("num_inexact_steps", C.c_int32), ("reserved_", C.c_int32),
+        ("num_inexact_steps", C.c_int32), ("num_pcg_capped_steps", C.c_int32),
+        ("worst_accepted_cg_residual", C.c_double), ("num_forcing_restarts", C.c_int32), ("reserved_", C.c_int32),
     ]
 
     def as_dict(self):
@@ -181,7 +182,7 @@ def load_library():
             "globalsfmpy_amd: %s not found. The HIP extension is the product and has no CPU fallback; "
             "build it with `python -c 'import __graft_entry__ as g; g.build()'`." % LIB_PATH)
     lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
-    if lib.gsfm_rot_abi_version() != 3:
+    if lib.gsfm_rot_abi_version() != 4:
         raise ImportError("globalsfmpy_amd: ABI version mismatch in %s" % LIB_PATH)
     lib.gsfm_last_error.restype = C.c_char_p
     lib.gsfm_rot_options_default.argtypes = [C.POINTER(Options)]

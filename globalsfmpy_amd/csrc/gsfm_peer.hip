@@ -15,6 +15,11 @@
 // peer (it needs that peer's flag to finish its own call), so the slot it overwrites was read two calls ago.
 // A call larger than the mailbox, or a communicator that could not map every peer, goes to the fallback callbacks (RCCL, or the
 // torch.distributed ones): the choice is the caller's (sharding.make_comm(..., exchange="peer")).
+// A wait that runs into its bound (a peer that never delivers) is an ERROR of the solve it happens in and the end of the peer path for this
+// communicator: the flag is looked at on entry of every call -- the first call that sees it returns non-zero (the solver then returns
+// GSFM_ERR_COMM; a rank whose waits all succeeded meets the same bound one call later, because the failed rank has stopped storing) -- and every
+// later call goes to the fallback callbacks, call by call.  gsfm_peer_error_take() lets the host layer fail a solve whose LAST calls timed
+// out (inside a replayed hipGraph no callback runs on the host).
 // Built with hipcc --offload-arch=gfx950 into libgsfm_peer.so.  Tested without a multi-GPU node: N processes sharing one GPU exchange
 // IPC handles the same way (tests/test_gpu_sharded.py: bitwise equality with the host-staged path at 2 / 3 / 8 ranks).
 #include <hip/hip_runtime.h>
@@ -118,6 +123,7 @@ struct Peer {
   unsigned int* d_done = nullptr;
   int* h_error = nullptr;            // pinned
   bool connected = false;
+  bool reported = false;             // the time-out has been returned to the solver (or taken by the host layer) once
   void* fb_ctx = nullptr; coll_fn fb_gather = nullptr, fb_reduce = nullptr;
   long n_peer = 0, n_fallback = 0;
 };
@@ -139,10 +145,11 @@ void* gsfm_peer_create(int rank, int world, size_t cap_doubles, char* handle_out
   P->flag_off = 2 * (size_t)world * cap_doubles * sizeof(double);
   P->bytes = P->flag_off + (size_t)world * sizeof(unsigned long long);
   // fine-grained (system-coherent, not cached across kernels) device memory: peers store into it and the local kernels poll it
+  // (no coarse-grained hipMalloc fallback: in such memory a system-scope poll may never see a peer's store -- every call would time out; the
+  // caller falls back to the collective communicator instead, sharding.make_comm)
   hipError_t e = hipExtMallocWithFlags(&P->local, P->bytes, hipDeviceMallocUncached);
   if (e != hipSuccess) { (void)hipGetLastError(); e = hipExtMallocWithFlags(&P->local, P->bytes, hipDeviceMallocFinegrained); }
-  if (e != hipSuccess) { (void)hipGetLastError(); e = hipMalloc(&P->local, P->bytes); }
-  if (e != hipSuccess) { fail(std::string("mailbox allocation: ") + hipGetErrorString(e)); delete P; return nullptr; }
+  if (e != hipSuccess) { (void)hipGetLastError(); fail(std::string("fine-grained mailbox allocation: ") + hipGetErrorString(e)); delete P; return nullptr; }
   bool ok = hipMemset(P->local, 0, P->bytes) == hipSuccess;
   ok = ok && hipMalloc((void**)&P->d_seq, sizeof(unsigned long long)) == hipSuccess && hipMemset(P->d_seq, 0, sizeof(unsigned long long)) == hipSuccess;
   ok = ok && hipMalloc((void**)&P->d_done, 2 * sizeof(unsigned int)) == hipSuccess && hipMemset(P->d_done, 0, 2 * sizeof(unsigned int)) == hipSuccess;
@@ -184,7 +191,12 @@ void gsfm_peer_set_fallback(void* ctx, void* fb_ctx, void* all_gather_fn, void* 
 
 static int peer_collective(Peer* P, double* buf, size_t count, void* stream, int mode) {
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (!P->connected || count > P->dev.cap) {
+  const bool broken = *static_cast<volatile int*>(P->h_error) != 0;
+  if (broken && !P->reported) {
+    P->reported = true;
+    return fail("peer exchange: a wait for a peer's slice ran into its 5 s bound in an earlier call of this solve -- its result is invalid; this communicator uses its fallback collectives from now on");
+  }
+  if (!P->connected || count > P->dev.cap || broken) {
     coll_fn f = mode ? P->fb_reduce : P->fb_gather;
     if (!f) return fail("peer exchange: the call does not fit the mailbox and there is no fallback");
     P->n_fallback++;
@@ -205,6 +217,16 @@ int gsfm_peer_all_reduce_sum(void* ctx, double* buf, size_t count, void* stream)
 
 // 1 if a wait ever ran into its bound (the data of that call is then garbage: the caller must treat the solve as failed)
 int gsfm_peer_error(void* ctx) { return *static_cast<Peer*>(ctx)->h_error; }
+// 1 exactly once per communicator: a time-out has happened and no collective call has returned it to the solver yet (call behind a
+// synchronisation of the solver's stream, i.e. after a solve)
+int gsfm_peer_error_take(void* ctx) {
+  Peer* P = static_cast<Peer*>(ctx);
+  if (*static_cast<volatile int*>(P->h_error) == 0 || P->reported) return 0;
+  P->reported = true;
+  return 1;
+}
+// test hook: behave as if a wait had timed out
+void gsfm_peer_inject_error(void* ctx) { *static_cast<Peer*>(ctx)->h_error = 1; }
 long gsfm_peer_calls(void* ctx, int fallback) { Peer* P = static_cast<Peer*>(ctx); return fallback ? P->n_fallback : P->n_peer; }
 
 void gsfm_peer_destroy(void* ctx) {
@@ -220,31 +242,3 @@ void gsfm_peer_destroy(void* ctx) {
 }
 
 }  // extern "C"
-
-// ---- bench.py's safety net ---------------------------------------------------------------------------------------------------------
-// The multi-rank variants bench.py tries after its plain-launch measurement (captured collectives, peer stores) have never run across
-// GPUs; a GPU memory fault in one of them ends the process through abort() inside the HSA runtime, from where no Python handler runs.
-// gsfm_crash_line_arm() keeps the already measured JSON line and makes SIGABRT / SIGSEGV / SIGBUS / SIGFPE write it to `fd` and leave
-// with status 0 (async-signal-safe: write + _exit only); gsfm_crash_line_disarm() restores the default dispositions.
-#include <csignal>
-#include <unistd.h>
-namespace {
-char g_crash_line[1 << 16];
-volatile size_t g_crash_len = 0;
-volatile int g_crash_fd = -1;
-void crash_handler(int) {
-  if (g_crash_fd >= 0 && g_crash_len) { ssize_t r = write(g_crash_fd, g_crash_line, g_crash_len); (void)r; }
-  _exit(0);
-}
-}  // namespace
-extern "C" int gsfm_crash_line_arm(int fd, const char* line, size_t len) {
-  if (len >= sizeof(g_crash_line)) return 1;
-  std::memcpy(g_crash_line, line, len);
-  g_crash_len = len; g_crash_fd = fd;
-  for (int sig : {SIGABRT, SIGSEGV, SIGBUS, SIGFPE}) std::signal(sig, crash_handler);
-  return 0;
-}
-extern "C" void gsfm_crash_line_disarm(void) {
-  for (int sig : {SIGABRT, SIGSEGV, SIGBUS, SIGFPE}) std::signal(sig, SIG_DFL);
-  g_crash_fd = -1; g_crash_len = 0;
-}

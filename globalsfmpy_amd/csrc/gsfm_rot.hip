@@ -21,7 +21,7 @@ void gsfm_rot_options_default(gsfm_rot_options* o) {
   o->function_tolerance = 1e-6; o->gradient_tolerance = 1e-10; o->parameter_tolerance = 1e-8;
   o->initial_trust_region_radius = 1e4; o->max_trust_region_radius = 1e16; o->min_trust_region_radius = 1e-32;
   o->min_relative_decrease = 1e-3; o->min_lm_diagonal = 1e-6; o->max_lm_diagonal = 1e32;
-  o->jacobi_scaling = 1; o->max_cg_iterations = 1000; o->cg_relative_tolerance = 1e-12; o->cg_check_interval = 8; o->verbose = 0; o->pcg_single_reduction = -1; o->cg_stall_iterations = 0; o->dense_cholesky_max_cams = 512; o->pcg_hip_graph = 1;
+  o->jacobi_scaling = 1; o->max_cg_iterations = 20000; o->cg_relative_tolerance = 1e-12; o->cg_check_interval = 8; o->verbose = 0; o->pcg_single_reduction = -1; o->cg_stall_iterations = 0; o->dense_cholesky_max_cams = 512; o->pcg_hip_graph = 1;
   o->pcg_forcing = 1; o->pcg_forcing_tolerance = 1e-8; o->dense_cholesky_auto_cams = 5333; o->lm_device_control = 1;
 }
 
@@ -107,8 +107,23 @@ gsfm_status gsfm_rot_solve(gsfm_rot_problem* P, double* rot, const gsfm_rot_opti
   gsfm_rot_summary local; if (!summary) summary = &local;
   const double t0 = now_ms();
   if (int st = upload_state(P, rot)) return (gsfm_status)st;
-  if (int st = lm_solve(P, o, summary)) return (gsfm_status)st;
-  if (int st = download_state(P, rot)) return (gsfm_status)st;
+  int st = lm_solve(P, o, summary);
+  if (st == GSFM_INTERNAL_RESTART) {
+    // The forcing schedule gave up on this trajectory after inexact steps had been applied (solver_lm.hpp, the contraction gate): the solve is
+    // redone from the caller's rotations -- still untouched in `rot` -- with every step exact; what the abandoned attempt spent stays on the bill.
+    const gsfm_rot_summary spent = *summary;
+    gsfm_rot_options o2 = o;
+    o2.pcg_forcing = 0;
+    if (o.verbose) fprintf(stderr, "[gsfm] forcing schedule abandoned after %d LM iterations (steps stopped contracting): restarting with exact steps\n", spent.num_iterations);
+    if (int st2 = upload_state(P, rot)) return (gsfm_status)st2;
+    st = lm_solve(P, o2, summary);
+    summary->num_forcing_restarts = 1;
+    summary->num_cg_iterations += spent.num_cg_iterations; summary->num_residual_sweeps += spent.num_residual_sweeps; summary->num_linearizations += spent.num_linearizations;
+    summary->num_graph_launches += spent.num_graph_launches; summary->num_collectives += spent.num_collectives; summary->num_pcg_collectives += spent.num_pcg_collectives;
+    summary->num_pcg_launched += spent.num_pcg_launched; summary->t_linearize_ms += spent.t_linearize_ms; summary->t_sweep_ms += spent.t_sweep_ms; summary->t_cg_ms += spent.t_cg_ms;
+  }
+  if (st) return (gsfm_status)st;
+  if (int st2 = download_state(P, rot)) return (gsfm_status)st2;
   summary->t_total_ms = now_ms() - t0;
   return GSFM_OK;
 }
@@ -174,6 +189,9 @@ gsfm_status gsfm_rot_solve_sigma_consensus(gsfm_rot_problem* P, double* rot, int
       total.num_dense_solves += summary->num_dense_solves; total.num_graph_launches += summary->num_graph_launches;
       total.num_collectives += summary->num_collectives; total.num_pcg_collectives += summary->num_pcg_collectives; total.num_pcg_launched += summary->num_pcg_launched;
       total.t_linearize_ms += summary->t_linearize_ms; total.t_sweep_ms += summary->t_sweep_ms; total.t_cg_ms += summary->t_cg_ms;
+      total.num_forcing_refinements += summary->num_forcing_refinements; total.num_inexact_steps += summary->num_inexact_steps;
+      total.num_pcg_capped_steps += summary->num_pcg_capped_steps; total.num_forcing_restarts += summary->num_forcing_restarts;
+      total.worst_accepted_cg_residual = std::fmax(total.worst_accepted_cg_residual, summary->worst_accepted_cg_residual);
     }
     total.last_weight_change = avg;
     if (avg <= 1e-7) break;  // :448

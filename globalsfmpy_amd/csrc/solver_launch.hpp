@@ -177,16 +177,23 @@ int prepare_loss(gsfm_rot_problem* P, const gsfm_loss_node* prog, int n) {
 }
 
 // ---- collectives --------------------------------------------------------------------------
+// A failing callback also drops the captured PCG chunks: they hold whatever kernels the communicator enqueued when they were captured (the peer-store
+// exchange's, say), and a communicator that has just failed may answer differently from now on (csrc/gsfm_peer.hip: its fallback collectives) --
+// the next solve captures afresh, through the callbacks.
+int comm_failed(gsfm_rot_problem* P, const char* what) {
+  P->pcg_graph.reset(); P->pcg2_graph.reset();
+  return fail(GSFM_ERR_COMM, what);
+}
 int all_gather(gsfm_rot_problem* P, double* buf, size_t count_per_rank) {
   if (!P->sharded) return 0;
   P->n_collectives++;
-  if (P->shard.all_gather(P->shard.ctx, buf, count_per_rank, (void*)P->stream) != 0) return fail(GSFM_ERR_COMM, "all_gather callback failed");
+  if (P->shard.all_gather(P->shard.ctx, buf, count_per_rank, (void*)P->stream) != 0) return comm_failed(P, "all_gather callback failed");
   return 0;
 }
 int all_reduce(gsfm_rot_problem* P, double* buf, size_t count) {
   if (!P->sharded) return 0;
   P->n_collectives++;
-  if (P->shard.all_reduce_sum(P->shard.ctx, buf, count, (void*)P->stream) != 0) return fail(GSFM_ERR_COMM, "all_reduce callback failed");
+  if (P->shard.all_reduce_sum(P->shard.ctx, buf, count, (void*)P->stream) != 0) return comm_failed(P, "all_reduce callback failed");
   return 0;
 }
 

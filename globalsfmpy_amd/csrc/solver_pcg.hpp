@@ -130,6 +130,17 @@ int mail_wait(gsfm_rot_problem* P, void* dst, size_t bytes) {
   return 0;
 }
 
+// A struggling solve: past its first 1000 iterations PCG goes on only while the relative residual still halves within 512 iterations (looked at
+// when the host looks: the scalars are replicated, every rank of a sharded problem decides alike).  A solve that stops here -- or at
+// max_cg_iterations -- above its tolerance is reported by lm_solve (num_pcg_capped_steps), never taken silently.
+struct PcgStagnation {
+  double mark_rel = 1.0; int mark_it = 0;
+  bool stop(int iters, double rel) {
+    if (rel < 0.5 * mark_rel) { mark_rel = rel; mark_it = iters; return false; }
+    return iters >= 1000 && iters - mark_it >= 512;
+  }
+};
+
 // block-Jacobi PCG on (J^T J + Lambda) eta = -g to the relative residual `tol` -- or, etol2 > 0 (a loose solve of the forcing schedule), until the
 // estimated relative energy-norm error squared falls below etol2 (kernels.hpp, cg_energy_stop); returns iterations.  resume_iters >= 0: continue the solve
 // that stopped after that many iterations (at a looser tolerance) instead of starting one -- the device state is exactly what the stopping
@@ -206,6 +217,7 @@ int run_pcg(gsfm_rot_problem* P, const gsfm_rot_options& o, double tol, double e
     if (!G.exec) { (void)hipGetLastError(); G.unusable = true; graph = false; }  // e.g. a stream that cannot be captured: plain launches
   }
   int launched = 0, chunks = 1;
+  PcgStagnation stagnation;
   if (resume) {   // the parity of the iteration that follows the stop; a captured chunk starts at parity 0
     launched = resume_iters;
     if (resume_iters & 1) {
@@ -226,7 +238,7 @@ int run_pcg(gsfm_rot_problem* P, const gsfm_rot_options& o, double tol, double e
     }
     P->timer.end(tk);
     if (int st = mail ? mail_wait(P, &h, sizeof(h)) : read_back(P, &h, P->cgsc.p, sizeof(h), "pcg")) return st;
-    if (h.done || launched >= o.max_cg_iterations + chunk) break;
+    if (h.done || launched >= o.max_cg_iterations + chunk || stagnation.stop(h.iters, h.last_rel)) break;
     // Fewer host round trips: extrapolate the average convergence factor so far to the tolerance and enqueue that many
     // chunks before looking again (kernels past convergence return at their first instruction, so overshoot is cheap).
     chunks = 1;
@@ -330,6 +342,7 @@ int run_pcg2(gsfm_rot_problem* P, const gsfm_rot_options& o, double tol, double 
     if (!G.exec) { (void)hipGetLastError(); G.unusable = true; graph = false; }
   }
   int chunks = 1;
+  PcgStagnation stagnation;
   while (true) {
     const int tk = P->timer.begin(T_CG);
     for (int cc = 0; cc < chunks; ++cc) {
@@ -340,7 +353,7 @@ int run_pcg2(gsfm_rot_problem* P, const gsfm_rot_options& o, double tol, double 
     }
     P->timer.end(tk);
     if (int st = mail ? mail_wait(P, &h, sizeof(h)) : read_back(P, &h, P->cg2sc.p, sizeof(h), "pcg")) return st;
-    if (h.done || launched >= o.max_cg_iterations + chunk + 2) break;
+    if (h.done || launched >= o.max_cg_iterations + chunk + 2 || stagnation.stop(h.iters, h.last_rel)) break;
     chunks = 1;   // same look-ahead as run_pcg: extrapolate the convergence factor, enqueue that many chunks before looking again
     if (!(etol2 > 0.0) && h.iters > 0 && h.last_rel > 0.0 && h.last_rel < 1.0 && tol > 0.0 && tol < h.last_rel) {
       const double per_iter = std::log(h.last_rel) / h.iters;

@@ -152,6 +152,8 @@ py::dict summary_dict(const gsfm_rot_summary& s) {
   d["num_edges_used"] = s.num_edges_used; d["last_weight_change"] = s.last_weight_change;
   d["num_dense_solves"] = s.num_dense_solves; d["num_linearizations"] = s.num_linearizations;
   d["t_linearize_ms"] = s.t_linearize_ms; d["t_sweep_ms"] = s.t_sweep_ms; d["t_cg_ms"] = s.t_cg_ms;
+  d["num_inexact_steps"] = s.num_inexact_steps; d["num_forcing_refinements"] = s.num_forcing_refinements; d["num_forcing_restarts"] = s.num_forcing_restarts;
+  d["num_pcg_capped_steps"] = s.num_pcg_capped_steps; d["worst_accepted_cg_residual"] = s.worst_accepted_cg_residual;
   return d;
 }
 

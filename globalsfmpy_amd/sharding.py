@@ -383,12 +383,20 @@ class PeerComm(object):
             lib.gsfm_peer_set_fallback.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
             lib.gsfm_peer_destroy.argtypes = [C.c_void_p]
             lib.gsfm_peer_error.argtypes = [C.c_void_p]
+            lib.gsfm_peer_error_take.argtypes = [C.c_void_p]
+            lib.gsfm_peer_inject_error.argtypes = [C.c_void_p]
             lib.gsfm_peer_calls.argtypes = [C.c_void_p, C.c_int]
             lib.gsfm_peer_calls.restype = C.c_long
             nb = lib.gsfm_peer_handle_bytes()
             handle = C.create_string_buffer(nb)
             # gD slices (9 per camera) are the widest per-camera exchange; the PCG slot is 3 per camera + at most 8192 partial dot products
-            ctx = lib.gsfm_peer_create(self.rank, self.world, 9 * self.P + 16384, handle)
+            cap = 9 * self.P + 16384
+            # SHARD_CAPTURABLE below is a promise about the calls INSIDE a PCG chunk: the all-gather of the A.p slices (3 per camera) with, in the
+            # single-reduction recurrence, the rank's partial dot products in its tail (8 per block of 256 cameras: problem_create.hpp, w_tail).
+            # They fit the mailbox by construction -- checked here, so that no in-chunk call can reach a host-staged fallback under capture
+            # (round-4 advisor); everything wider (the coarse matrix, once per LM step) is issued outside the chunks.
+            assert 3 * self.P + 8 * ((self.P + 255) // 256) <= cap
+            ctx = lib.gsfm_peer_create(self.rank, self.world, cap, handle)
             if not ctx:
                 why = lib.gsfm_peer_last_error().decode()
         except OSError as e:
@@ -423,8 +431,14 @@ class PeerComm(object):
         return int(self._lib.gsfm_peer_calls(self._ctx, 0)), int(self._lib.gsfm_peer_calls(self._ctx, 1))
 
     def error(self):
-        """True if a wait for a peer's flag ever ran into its bound (that solve's result is then invalid)."""
+        """True if a wait for a peer's flag ever ran into its bound (that solve's result is then invalid; every later call of this
+        communicator goes to the fallback collectives)."""
         return bool(self._lib.gsfm_peer_error(self._ctx))
+
+    def take_error(self):
+        """True exactly once: a wait timed out and no collective call has returned the failure to the solver yet (the time-out happened in the
+        last calls of a solve, or inside a replayed hipGraph).  RotationProblem checks it after every library call and raises."""
+        return bool(self._lib.gsfm_peer_error_take(self._ctx))
 
     def close(self):
         if self._ctx:

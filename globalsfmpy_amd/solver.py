@@ -45,6 +45,12 @@ class ProblemBase(object):
         self._reraise_callback_error()
         if st != 0:
             raise SolverError("%s failed with status %d: %s" % (what, st, self._last_error()))
+        comm = getattr(self, "_comm", None)
+        if comm is not None and hasattr(comm, "take_error") and comm.take_error():
+            # (peer-store exchange: a wait for a peer's slice timed out in the last calls of this solve -- what it returned is not a result;
+            # the captured PCG chunks still hold the peer kernels: set_stream drops them, the next solve captures the fallback's)
+            self._lib.gsfm_rot_set_stream(self._h, C.c_void_p(comm.stream_handle() or 0))
+            raise SolverError("%s: the peer-store exchange timed out waiting for a peer; the result is invalid (later solves use the fallback collectives)" % what)
 
     def _last_error(self):
         return ""

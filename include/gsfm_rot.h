@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define GSFM_ROT_ABI_VERSION 3
+#define GSFM_ROT_ABI_VERSION 4
 
 typedef enum {
   GSFM_OK = 0,
@@ -117,7 +117,11 @@ typedef struct {
   double min_lm_diagonal;              /* 1e-6  */
   double max_lm_diagonal;              /* 1e32  */
   int32_t jacobi_scaling;              /* 1     */
-  int32_t max_cg_iterations;           /* PCG replaces CHOLMOD: iteration cap per LM step (default 1000) */
+  int32_t max_cg_iterations;           /* PCG replaces CHOLMOD: iteration cap per LM step (default 20000, the oracle's; 1000 until round 4).  Beyond its
+                                          first 1000 iterations a solve goes on only while the relative residual still halves within 512 iterations.
+                                          A solve that ends ABOVE cg_relative_tolerance either way is not the reference's exact step
+                                          (estimator.cpp:300): graphs of at most dense_cholesky_auto_cams cameras hand that step, and the rest of the
+                                          run, to the factorisation; larger ones evaluate it and say so in gsfm_rot_summary::num_pcg_capped_steps */
   double cg_relative_tolerance;        /* stop when sqrt(r.M^-1 r / b.M^-1 b) <= tol. Default 1e-12, the stand-in for the
                                           reference's exact sparse Cholesky: every parity claim is made at this value.
                                           Looser values are a documented trade: on the C5 graph
@@ -253,6 +257,16 @@ typedef struct {
                                      problem's collective in them still runs); num_cg_iterations counts the effective ones */
   int32_t num_forcing_refinements; /* forcing schedule: LM steps whose loose solve was continued to the tight tolerance after its trial evaluation */
   int32_t num_inexact_steps;       /* forcing schedule: LM steps taken from a loose solve */
+  int32_t num_pcg_capped_steps;    /* (ABI v4) LM steps whose PCG solve ended at max_cg_iterations (or on cg_stall_iterations) ABOVE cg_relative_tolerance
+                                      and were evaluated all the same: such a step is NOT the reference's exact Cholesky step (estimator.cpp:300).
+                                      0 on every run whose parity claim holds; non-zero = the answer may differ from the reference's beyond the
+                                      PCG tolerance (raise max_cg_iterations, or use the exact step: dense_cholesky_max_cams) */
+  double worst_accepted_cg_residual; /* (ABI v4) largest relative residual sqrt(r.M^-1 r / b.M^-1 b) of a TIGHT PCG solve whose step was evaluated
+                                      (<= cg_relative_tolerance unless num_pcg_capped_steps > 0); loose solves of the forcing schedule are
+                                      counted by num_inexact_steps instead */
+  int32_t num_forcing_restarts;    /* (ABI v4) 1 if the forcing schedule was abandoned mid-run and the solve was REDONE from the initial rotations
+                                      with every step exact (the trajectory turned out not to contract fast enough for inexact steps to be
+                                      forgotten, see pcg_forcing); the counters and times above include the abandoned attempt */
   int32_t reserved_;
 } gsfm_rot_summary;
 

@@ -8,7 +8,7 @@ random error type, loss, outlier share, degree, coherent or random topology; the
   beyond-PCG neither, and the EXACT schedule itself is more than 1e-6 rad from the oracle: block-Jacobi PCG runs into its iteration cap on
              these systems (far starts under the MAGSAC loss: weights spanning 1e-5 .. 5e4), no schedule reproduces the reference there;
   MISMATCH   anything else (printed with both traces' cost changes).
-usage: python tests/manual/fuzz_forcing.py [trials] [seed]"""
+usage: python tests/manual/fuzz_forcing.py [trials] [seed] [dense]"""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -28,36 +28,54 @@ def random_loss(rng, et):
     return [LF.HuberLoss(a), LF.SoftLOneLoss(a), LF.CauchyLoss(a), LF.GemanMcClureLoss(a, 1.0), LF.TrivialLoss(), LF.TukeyLoss(max(a, 0.3))][int(rng.integers(0, 6))]
 
 
-def run(trials=40, seed=1, with_oracle=True):
+def cases(trials, seed, only=(), dense=False):
+    """The seeded sequence of trials: (t, graph, error type, loss, init, coherent?) -- trial t of a seed is the same problem whatever `only` skips.
+    dense: 600-2500 cameras of mean degree 100-300 instead of 600-6000 of degree 8-60 -- the regime of the benchmark graph (degree 200), where the
+    linear systems are well conditioned and the schedule stays ON under every loss (round 5)."""
     rng = np.random.default_rng(seed)
-    tally = {"same": 0, "within-bar": 0, "MISMATCH": 0}
-    saved = []
-    only = [int(v) for v in os.environ.get("FUZZ_ONLY", "").split(",") if v]
-    np.set_printoptions(linewidth=250, precision=4)
     for t in range(trials):
-        n = int(rng.integers(600, 6000))
-        deg = float(rng.uniform(8, 60))
+        n = int(rng.integers(600, 2500 if dense else 6000))
+        deg = float(rng.uniform(100, 300) if dense else rng.uniform(8, 60))
         e = int(n * deg / 2)
         kw = {}
         if rng.random() < 0.4:
             kw["local_window"] = int(max(2 * deg + 4, rng.uniform(0.02, 0.3) * n))
-        g = synth.make_graph(n, e, int(rng.integers(1, 1 << 30)), outlier_frac=float(rng.uniform(0.0, 0.35)), **kw)
+        gseed, outl = int(rng.integers(1, 1 << 30)), float(rng.uniform(0.0, 0.35))
         et = ETS[int(rng.integers(0, len(ETS)))]
         loss = random_loss(rng, et)
-        init = g["init_aa"] if rng.random() < 0.7 else g["init_aa"] + float(rng.uniform(0.05, 0.3)) * rng.standard_normal(g["init_aa"].shape)
+        far = rng.random() >= 0.7
+        far_scale = float(rng.uniform(0.05, 0.3)) if far else 0.0
+        # (the far start's noise is drawn from the same stream: the graph must exist even for a skipped trial, its size decides how much is drawn)
         if only and t not in only:
+            if far:
+                rng.standard_normal((n, 3))
             continue
+        g = synth.make_graph(n, e, gseed, outlier_frac=outl, **kw)
+        init = g["init_aa"] + far_scale * rng.standard_normal(g["init_aa"].shape) if far else g["init_aa"]
+        yield t, g, et, loss, init, bool(kw)
+
+
+def run(trials=40, seed=1, with_oracle=True, only=None, dense=False, oracle_every=4):
+    """The DEFAULT options against pcg_forcing = 0 (everything else default, the exact-step rescue of struggling PCG solves included)."""
+    tally = {"same": 0, "within-bar": 0, "MISMATCH": 0}
+    saved, schedule = [], {"kept": 0, "restarted": 0, "never loose": 0}
+    if only is None:
+        only = [int(v) for v in os.environ.get("FUZZ_ONLY", "").split(",") if v]
+    np.set_printoptions(linewidth=250, precision=4)
+    for t, g, et, loss, init, coherent in cases(trials, seed, only, dense):
+        n, e, kw = g["n_cams"], len(g["edge_i"]), coherent
         p = RotationProblem(g["n_cams"], g["edge_i"], g["edge_j"], g["rel_aa"], et, cov6=g["cov6"], inlier_weight=g["inlier_weight"])
         p.set_loss(loss)
-        r0, s0 = p.solve(init, pcg_forcing=0, dense_cholesky_auto_cams=0)
+        r0, s0 = p.solve(init, pcg_forcing=0)
         t0 = p.trace()
-        r1, s1 = p.solve(init, dense_cholesky_auto_cams=0)
+        r1, s1 = p.solve(init)
         t1 = p.trace()
+        schedule["restarted" if s1["num_forcing_restarts"] else "kept" if s1["num_inexact_steps"] else "never loose"] += 1
         d = synth.angular_distance(synth.align_rotations(r1, r0), r0)
         same_it = s0["num_iterations"] == s1["num_iterations"] and s0["termination"] == s1["termination"]
         verdict = "same" if same_it and d.mean() <= 1e-7 else "within-bar" if same_it and d.mean() <= 1e-6 else "MISMATCH"
         extra = ""
-        if with_oracle and t % 4 == 0:
+        if with_oracle and t % oracle_every == 0:
             from oracle import pyoracle
             o = pyoracle.OracleProblem(g["n_cams"], g["edge_i"], g["edge_j"], g["rel_aa"], et, cov6=g["cov6"], inlier_weight=g["inlier_weight"])
             o.set_loss(loss)
@@ -66,9 +84,11 @@ def run(trials=40, seed=1, with_oracle=True):
             extra = "  | oracle: %d it, default schedule %.1e rad from it" % (so["num_iterations"], do.mean())
         tally[verdict] += 1
         saved.append(1.0 - s1["num_cg_iterations"] / max(1, s0["num_cg_iterations"]))
-        print("trial %3d n=%4d e=%6d %-8s et=%d %-24s LM %2d/%2d PCG %5d -> %5d  dR mean %.1e max %.1e  %s%s" % (
+        flags = "%s%s%s" % (" restarted" if s1["num_forcing_restarts"] else "", " dense:%d" % s1["num_dense_solves"] if s1["num_dense_solves"] else "",
+                            " CAPPED:%d(%.0e)" % (s1["num_pcg_capped_steps"], s1["worst_accepted_cg_residual"]) if s1["num_pcg_capped_steps"] else "")
+        print("trial %3d n=%4d e=%6d %-8s et=%d %-24s LM %2d/%2d PCG %5d -> %5d (%d inexact)%s  dR mean %.1e max %.1e  %s%s" % (
             t, n, e, "coherent" if kw else "random", et, type(loss).__name__, s0["num_iterations"], s1["num_iterations"], s0["num_cg_iterations"], s1["num_cg_iterations"],
-            d.mean(), d.max(), verdict, extra), flush=True)
+            s1["num_inexact_steps"], flags, d.mean(), d.max(), verdict, extra), flush=True)
         if only:
             print("exact schedule   [it, cost, dcost, |g|, |dx|, rel_dec, radius, cg]"); print(t0)
             print("default schedule"); print(t1)
@@ -89,7 +109,7 @@ def run(trials=40, seed=1, with_oracle=True):
                   % ([int(x[1]["num_iterations"]) for x in runs], spread, d_or))
             d_ex = float(synth.angular_distance(synth.align_rotations(r0, runs[0][0]), runs[0][0]).mean())
             print("      the EXACT schedule is %.1e rad from the oracle (%d vs %d LM iterations, %d PCG iterations over %d steps, cap %d per step)"
-                  % (d_ex, s0["num_iterations"], runs[0][1]["num_iterations"], s0["num_cg_iterations"], s0["num_iterations"], 1000))
+                  % (d_ex, s0["num_iterations"], runs[0][1]["num_iterations"], s0["num_cg_iterations"], s0["num_iterations"], 20000))
             if spread >= 0.1 * d.mean():
                 verdict = "ill-posed"
             elif d_ex > 1e-6:
@@ -100,9 +120,9 @@ def run(trials=40, seed=1, with_oracle=True):
             print("      exact schedule, relative cost changes:", ["%.1e" % (abs(r[2]) / max(r[1], 1e-300)) for r in t0[1:]])
             print("      default schedule                     :", ["%.1e" % (abs(r[2]) / max(r[1], 1e-300)) for r in t1[1:]])
         p.close()
-    print("forcing fuzz: %s; PCG iterations saved: median %.0f %%" % (tally, 100 * float(np.median(saved))))
+    print("forcing fuzz (%s graphs, seed %d): %s; schedule: %s; PCG iterations saved: median %.0f %%" % ("dense" if dense else "sparse", seed, tally, schedule, 100 * float(np.median(saved)) if saved else 0.0))
     return tally["MISMATCH"]
 
 
-if __name__ == "__main__":
-    sys.exit(min(1, run(int(sys.argv[1]) if len(sys.argv) > 1 else 40, int(sys.argv[2]) if len(sys.argv) > 2 else 1)))
+if __name__ == "__main__":   # usage: fuzz_forcing.py [trials] [seed] [dense]
+    sys.exit(min(1, run(int(sys.argv[1]) if len(sys.argv) > 1 else 40, int(sys.argv[2]) if len(sys.argv) > 2 else 1, dense=len(sys.argv) > 3 and sys.argv[3] == "dense")))

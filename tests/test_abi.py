@@ -27,7 +27,7 @@ def test_library_exports_every_declared_entry_point():
     assert len(names) >= 18
     for n in names:
         assert hasattr(lib, n), "libgsfm_rot.so does not export %s" % n
-    assert lib.gsfm_rot_abi_version() == 3
+    assert lib.gsfm_rot_abi_version() == 4
 
 
 def test_struct_layout_matches_header_defaults():
