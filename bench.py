@@ -144,7 +144,8 @@ def small_graph_timings(args):
             t = time.perf_counter()
             rd, s = p.solve(x0)
             ts.append(time.perf_counter() - t)
-        r = {"ms": 1e3 * min(ts), "lm_iterations": s["num_iterations"], "cg_iterations": s["num_cg_iterations"], "dense_cholesky_steps": s["num_dense_solves"]}
+        r = {"ms": 1e3 * min(ts), "lm_iterations": s["num_iterations"], "cg_iterations": s["num_cg_iterations"], "dense_cholesky_steps": s["num_dense_solves"],
+             "inexact_steps": s["num_inexact_steps"], "forcing_restarts": s["num_forcing_restarts"], "pcg_capped_steps": s["num_pcg_capped_steps"]}
         if oracle_args is not None and args.cpu_baseline:   # the same solve by the CPU oracle on all usable cores, beside it
             n, ei, ej, rel, et, c6, loss = oracle_args
             o = pyoracle.OracleProblem(n, ei, ej, rel, et, cov6=c6)
@@ -409,7 +410,8 @@ def main():
                 "residual_sweeps": st["num_residual_sweeps"], "termination": st["termination_name"], "final_cost": st["final_cost"],
                 "mean_angular_error_vs_ground_truth_deg": float(np.rad2deg(e1.mean())),
                 "mean_difference_to_the_noise_init_solution_rad": float(dd.mean()), "host_tree_build_s": t_tree,
-                "inexact_steps": st["num_inexact_steps"], "continued_solves": st["num_forcing_refinements"],
+                "inexact_steps": st["num_inexact_steps"], "continued_solves": st["num_forcing_refinements"], "forcing_restarts": st["num_forcing_restarts"],
+                "pcg_capped_steps": st["num_pcg_capped_steps"],
                 "exact_schedule": {"pcg_forcing": 0, "ms_per_solve": 1e3 * dt_tree_x, "lm_iterations": stx["num_iterations"], "cg_iterations": stx["num_cg_iterations"],
                                    "default_schedule_vs_this_mean_rad": float(ddx.mean()), "default_schedule_vs_this_max_rad": float(ddx.max())}}
 
@@ -506,13 +508,25 @@ def main():
                              traffic=pmc_bytes("k_matvec"), traffic_unit="bytes per launch (mat-vec + its finishing kernel, as kernel_ms)", traffic_source=(pmc[1] if pmc else pmc_note),
                              directed_entries_per_launch=int(nd), launches_per_solve=summ["num_cg_iterations"]),
         }
+        kept = summ["num_inexact_steps"] > 0 and summ["num_forcing_restarts"] == 0
         out["pcg_schedule"] = {"pcg_forcing": 1, "pcg_forcing_tolerance_rad": 1e-8, "inexact_steps_per_solve": summ["num_inexact_steps"], "continued_solves_per_solve": summ["num_forcing_refinements"],
-                               "what": "every LM step is solved loosely first (estimated deviation from the exact step <= 1e-8 rad rms); decisions are taken from it only when "
-                                       "a factor two away from their thresholds, otherwise PCG continues towards cg_relative_tolerance 1e-12 (include/gsfm_rot.h: pcg_forcing)"}
+                               "forcing_restarts_per_solve": summ["num_forcing_restarts"], "pcg_capped_steps_per_solve": summ["num_pcg_capped_steps"],
+                               "worst_accepted_cg_residual": summ["worst_accepted_cg_residual"],
+                               # which schedule `value` actually ran (round-4 review): the library's default options; the gate decides per run
+                               "value_ran": ("forcing schedule kept: every accepted step contracted below 0.3 x its predecessor, no restart" if kept else
+                                             "exact schedule (the forcing schedule was abandoned and the solve redone exactly: both attempts are inside `value`)"
+                                             if summ["num_forcing_restarts"] else "exact schedule (no inexact step was taken)"),
+                               "what": "every LM step is solved loosely first (estimated deviation from the exact step <= 1e-8 rad rms, no camera's block-Jacobi estimate above 1e-7); "
+                                       "decisions are taken from it only when a factor two away from their thresholds, otherwise PCG continues towards cg_relative_tolerance 1e-12; "
+                                       "the schedule is kept only while every accepted step is below 0.3 x its predecessor -- otherwise the run is redone with exact steps "
+                                       "(include/gsfm_rot.h: pcg_forcing; tests/manual/fuzz_forcing.py: 0 mismatches in 420 default-option trials, profiles/r05_fuzz_forcing.txt)"}
         if exact is not None:
             out["exact_schedule"] = exact
         if tree is not None:
             out["spanning_tree_init"] = tree
+            # SURVEY 8(d)'s own initialisation as a first-class number next to `value` (round-4 review): same graph, same library defaults
+            out["value_tree_init"] = tree["value"]
+            out["ms_per_step_tree_init"] = tree["ms_per_solve"]
         out["kernels_us"] = {k: 1e3 * v for k, v in kt.items()}
         if world == 1:
             def k1_entry(ms, out_bytes, what, pmc_key):

@@ -23,12 +23,10 @@
 
 namespace gsfm {
 
-#ifndef GSFM_COL_RB
-#define GSFM_COL_RB 512    // rows per block = positions per sub-chunk = lanes of a K3c workgroup (512 or 1024: -DGSFM_COL_RB=1024 -DGSFM_COLLIN_THREADS=512)
-#endif
+#define GSFM_COL_RB 512    // rows per block = positions per sub-chunk = lanes of a K3c workgroup (1024 measured slower: profiles/r04b_rb1024_ab.txt; the variant is gone)
 #define GSFM_COL_SUB GSFM_COL_RB
-#define GSFM_COL_SLOT_BITS (GSFM_COL_RB == 1024 ? 10 : 9)   // bits of a slot / a row inside its block; a row's count in a sub-chunk needs one more (0 .. SUB)
-static_assert(GSFM_COL_RB == (1 << GSFM_COL_SLOT_BITS), "row blocks of 512 or 1024 rows");
+#define GSFM_COL_SLOT_BITS 9   // bits of a slot / a row inside its block; a row's count in a sub-chunk needs one more (0 .. SUB)
+static_assert(GSFM_COL_RB == (1 << GSFM_COL_SLOT_BITS), "row blocks of 512 rows");
 #ifndef GSFM_COL_EPL
 #define GSFM_COL_EPL 1     // K3c: sub-chunks in flight per iteration (entries per lane); -DGSFM_COL_EPL=n: 1 measured best in the product (2: +4..9 %, 3: +8 %)
 #endif
@@ -139,78 +137,8 @@ __device__ __forceinline__ void mv_col_body(const ColMatvecArgs& a, Stop stop_af
   const size_t o = (size_t)w.part * RB + r, plane = (size_t)a.L.n_wg * RB;
   a.part[o] = y0; a.part[plane + o] = y1; a.part[2 * plane + o] = y2;
 }
-// The same product with FEWER lanes than positions: T lanes, K = RB / T positions per lane and sub-chunk, lane t owns rows t, t + T, ... (like K2c).
-// Smaller workgroups = more, smaller barrier groups per CU.  -DGSFM_K3C_THREADS=256; measured against the 512-lane form in profiles/r04b_k3c_threads_ab.txt.
-#ifndef GSFM_K3C_THREADS
+// (a 256-lane form of the same product -- more, smaller barrier groups per CU -- measured equal or slower, profiles/r04b_k3c_threads_ab.txt, and was removed in round 5)
 #define GSFM_K3C_THREADS GSFM_COL_RB
-#endif
-template <typename Stop>
-__device__ __forceinline__ void mv_col_body_k(const ColMatvecArgs& a, Stop stop_after_request) {
-  constexpr int RB = GSFM_COL_RB, T = GSFM_K3C_THREADS, K = RB / T;
-  static_assert(T >= GSFM_BLOCK && RB % T == 0, "k_mv_col_cg re-sums the gamma partials with the 256-lane kernels' tree");
-  __shared__ double slots[2][3][RB];
-  __shared__ uint32_t wtot[2][K][T / 64];
-  const ColWg w = a.L.wg[blockIdx.x];
-  const uint32_t r = threadIdx.x, wave = r >> 6;
-  double y[K][3];
-#pragma unroll
-  for (int j = 0; j < K; ++j) y[j][0] = y[j][1] = y[j][2] = 0.0;
-  uint32_t m[K], pos[K]; double2 A[K], B[K], C[K];
-  const uint32_t cmask = (1u << a.L.cbits) - 1u, cshift = a.L.cbits + GSFM_COL_SLOT_BITS, cmax = a.L.cmax;
-  auto request = [&](uint32_t s) {
-    const uint32_t sc = w.first_sub + min(s, w.n_sub - 1);
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-      const size_t e = (size_t)sc * RB + (size_t)k * T + r;
-      m[k] = __builtin_nontemporal_load(a.L.kcol + e); pos[k] = (uint32_t)e;
-      A[k] = nt_load2(a.b0 + e); B[k] = nt_load2(a.b1 + e); C[k] = nt_load2(a.b2 + e);
-    }
-  };
-  if (w.n_sub) request(0);
-  if (stop_after_request()) return;
-  int buf = 0;
-  for (uint32_t s = 0; s < w.n_sub; ++s, buf ^= 1) {
-    uint32_t cnt[K], inc[K];
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-      const uint32_t cam = (m[k] & cmask) == cmask ? 0u : (m[k] & cmask), pm = (m[k] >> a.L.cbits) & ((1u << GSFM_COL_SLOT_BITS) - 1u);
-      const double* um = a.u + 3 * (size_t)cam;
-      const double u0 = um[0], u1 = um[1], u2 = um[2];
-      slots[buf][0][pm] = A[k].x * u0 + A[k].y * u1 + B[k].x * u2;
-      slots[buf][1][pm] = A[k].y * u0 + B[k].y * u1 + C[k].x * u2;
-      slots[buf][2][pm] = B[k].x * u0 + C[k].x * u1 + C[k].y * u2;
-      uint32_t c = m[k] >> cshift;                      // the count of ROW k * T + r rides at position k * T + r
-      if (c == cmax) c = a.L.kcnt[pos[k]];
-      cnt[k] = c;
-      inc[k] = wave_incl_scan(c);
-      if ((r & 63u) == 63u) wtot[buf][k][wave] = inc[k];
-    }
-    if (s + 1 < w.n_sub) request(s + 1);
-    __syncthreads();
-    uint32_t carry = 0, s0[K], nmax = 0;
-#pragma unroll
-    for (int j = 0; j < K; ++j) {
-      uint32_t s1 = carry + inc[j];
-      for (uint32_t v = 0; v < T / 64; ++v) { const uint32_t wt = wtot[buf][j][v]; if (v < wave) s1 += wt; carry += wt; }
-      s0[j] = s1 - cnt[j];
-      nmax = max(nmax, cnt[j]);
-    }
-    for (uint32_t t = 0; t < nmax; ++t) {
-#pragma unroll
-      for (int j = 0; j < K; ++j)
-        if (t < cnt[j]) { y[j][0] += slots[buf][0][s0[j] + t]; y[j][1] += slots[buf][1][s0[j] + t]; y[j][2] += slots[buf][2][s0[j] + t]; }
-    }
-  }
-  const size_t plane = (size_t)a.L.n_wg * RB;
-#pragma unroll
-  for (int j = 0; j < K; ++j) {
-    const size_t o = (size_t)w.part * RB + (size_t)j * T + r;
-    a.part[o] = y[j][0]; a.part[plane + o] = y[j][1]; a.part[2 * plane + o] = y[j][2];
-  }
-}
-#if GSFM_K3C_THREADS != GSFM_COL_RB
-#define mv_col_body mv_col_body_k
-#endif
 __global__ void __launch_bounds__(GSFM_K3C_THREADS) k_mv_col(ColMatvecArgs a) {
   if (a.done && *a.done) return;
   mv_col_body(a, [] { return false; });
@@ -237,8 +165,9 @@ __global__ void __launch_bounds__(GSFM_K3C_THREADS) k_mv_col_cg(ColMatvecCgArgs 
     if (done) return true;
     bool conv;
     if (c.first) {
-      conv = !(gamma > 0.0);
-      if (blockIdx.x == 0 && threadIdx.x == 0) { c.sc->gamma0 = gamma; if (conv) c.sc->done = 1; }
+      const double rz_abs = c.sc->rz_abs;   // (as k_matvec_cg)
+      conv = !(gamma > rz_abs);
+      if (blockIdx.x == 0 && threadIdx.x == 0) { c.sc->gamma0 = gamma; c.sc->tol = cg_tol_with_floor(tol, rz_abs, gamma); if (conv) { c.sc->done = 1; c.sc->last_rel = 0.0; } }
     } else {
       const double rel = sqrt(gamma / gamma0);
       conv = !(rel > tol) || iters >= c.max_iters || estop;
@@ -347,9 +276,6 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_dense_assemble_col(DenseArgs a, 
 #ifndef GSFM_COLLIN_THREADS
 #define GSFM_COLLIN_THREADS 256
 #endif
-#ifndef GSFM_K2C_PIPE
-#define GSFM_K2C_PIPE 1
-#endif
 // which instantiations of K2c hand BODY-frame row sums to the finishing kernel (the host asks the same question: solver_launch.hpp)
 __host__ __device__ constexpr bool col_lin_body_frame(int functor, bool fast) { return fast && functor == F_AA; }
 struct ColLinArgs {
@@ -380,8 +306,8 @@ __device__ __forceinline__ void lin_col_body(const ColLinArgs& a) {
   // Software pipeline over the sub-chunks (round 4): the records and streams of sub-chunk s + 1 are requested BEFORE sub-chunk s is
   // evaluated and its neighbour quaternions before the row phase, so the HBM round trips run behind the ~1 100 VALU instructions of the
   // evaluation, the LDS row phase and the two barriers instead of in front of them.  The registers for it (2 x 24 per lane) are the ones
-  // the scalar-register transcendentals freed (devmath.hpp; 228 -> 169 without the pipeline).  -DGSFM_K2C_PIPE=0: the round-3 form, both
-  // trips of ONE sub-chunk requested together (two dependent round trips per sub-chunk, nothing in flight during the evaluation).
+  // the scalar-register transcendentals freed (devmath.hpp; 228 -> 169 without the pipeline).  (The round-3 form -- both trips of ONE sub-chunk
+  // requested together, nothing in flight during the evaluation -- measured 614 against 567 us, profiles/r04b_k2c_pipeline_ab.txt, and is gone.)
   constexpr int K = SUB / T;
   static_assert(K == RPL, "one record per owned row");
   uint2 mt[K];
@@ -404,7 +330,7 @@ __device__ __forceinline__ void lin_col_body(const ColLinArgs& a) {
     uint2 mtn[K];
     LinStreams Sn[K];
     Quat qmn[K];
-    if (GSFM_K2C_PIPE) request(s + 1, mtn, Sn);
+    request(s + 1, mtn, Sn);
 #pragma unroll
     for (int k = 0; k < K; ++k) {
       const uint32_t d = sc * SUB + k * T + t;
@@ -451,7 +377,7 @@ __device__ __forceinline__ void lin_col_body(const ColLinArgs& a) {
       inc[j] = wave_incl_scan(cnt[j]);
       if ((t & 63u) == 63u) wtot[j][t >> 6] = inc[j];
     }
-    if (GSFM_K2C_PIPE) gather(mtn, qmn);   // the next sub-chunk's neighbour quaternions travel during the row phase
+    gather(mtn, qmn);   // the next sub-chunk's neighbour quaternions travel during the row phase
     __syncthreads();
     uint32_t carry = 0, s0[RPL], nmax = 0;
 #pragma unroll
@@ -473,10 +399,8 @@ __device__ __forceinline__ void lin_col_body(const ColLinArgs& a) {
       }
     }
     __syncthreads();
-    if (GSFM_K2C_PIPE) {
 #pragma unroll
-      for (int k = 0; k < K; ++k) { mt[k] = mtn[k]; S[k] = Sn[k]; qm[k] = qmn[k]; }
-    } else if (s + 1 < w.n_sub) { request(s + 1, mt, S); gather(mt, qm); }
+    for (int k = 0; k < K; ++k) { mt[k] = mtn[k]; S[k] = Sn[k]; qm[k] = qmn[k]; }
   }
   const size_t plane = (size_t)a.L.n_wg * RB;
 #pragma unroll

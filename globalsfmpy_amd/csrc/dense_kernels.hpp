@@ -93,7 +93,7 @@ __host__ __device__ inline uint32_t chol_step_grid(uint32_t m /* trailing block 
 // profiles/r03_chol_steps.txt: the eliminations of a CU share more than its SIMDs -- two side by side run at full speed, four at ~0.7, six at ~0.6)
 inline uint32_t chol_step_tiles_per_wg(uint32_t m) { const uint32_t tiles = m * (m + 1) / 2; return tiles <= 256 ? 1u : tiles <= 512 ? 2u : 3u; }
 template <int GSFM_CHOL_NT>
-__global__ void __launch_bounds__(256) k_chol_step(CholArgs a) {
+__device__ __forceinline__ void chol_step_body(const CholArgs& a) {
   __shared__ double Pi[GSFM_CB][GSFM_CB + 1], Pj[GSFM_CHOL_NT][GSFM_CB][GSFM_CB + 1];
   const uint32_t k = a.k, T = a.T, tid = threadIdx.x;
   uint32_t i, j0 = k, nt = 1;   // nt tiles (i, j0 .. j0 + nt - 1)
@@ -170,6 +170,28 @@ __global__ void __launch_bounds__(256) k_chol_step(CholArgs a) {
       for (int q = 0; q < 4; ++q) d[4 * q * GSFM_CB] = own[u][q] - acc[q];
     }
   }
+}
+
+template <int GSFM_CHOL_NT>
+__global__ void __launch_bounds__(256) k_chol_step(CholArgs a) { chol_step_body<GSFM_CHOL_NT>(a); }
+
+// ---- the same factorisation for SEVERAL matrices at once (round 5): the connected components of a disconnected view graph -- the normal matrix
+// is block diagonal, the reference's Cholesky factorises block by block (estimator.cpp:299-305) -- each with its own tiles, size and status;
+// blockIdx.y is the matrix, block column k of every matrix that still has one runs in the same launch (the chain is as long as the LARGEST
+// component's, the launches are as wide as all of them together).
+struct CholBatchItem {
+  double* A; double* L; double* x;   // tiles (block rows 0..T), factor, solution (T * 32 doubles)
+  uint32_t T, n;                     // block rows, unknowns (3 x cameras of the component)
+  int* info;
+  const int* active;                 // 0: the component's right-hand side is below the absolute floor of the step (comp_kernels.hpp, k_comp_activity):
+                                     // its step is zero to 1e-14 rad, nothing of it is assembled or factorised in this LM step
+};
+template <int GSFM_CHOL_NT>
+__global__ void __launch_bounds__(256) k_chol_step_batch(const CholBatchItem* items, uint32_t k) {
+  const CholBatchItem it = items[blockIdx.y];
+  if (k >= it.T || blockIdx.x >= chol_step_grid(it.T - k, GSFM_CHOL_NT) || !*it.active) return;
+  const CholArgs a{it.A, it.L, it.T, k, it.info};
+  chol_step_body<GSFM_CHOL_NT>(a);
 }
 
 // Step k of the two-kernel schedule, first half: workgroup 0 (one wavefront) factors A_kk and writes L_kk; workgroup b >= 1 factors A_kk
@@ -265,10 +287,8 @@ __global__ void __launch_bounds__(256) k_chol_update_mfma(CholUpdArgs a) {
       for (int r = 0; r < 4; ++r) Aij[(16 * si + g + 4 * r) * GSFM_CB + 16 * sj + c] = acc[si][sj][r];
 }
 
-// x = L^-T y, one workgroup: block rows bottom-up; y stays in LDS.  Software-pipelined: while the other 15 wavefronts fold x_k into the
-// right-hand sides of the block rows j <= k - 2 (L_kj tiles are contiguous: block row k of L) and prefetch the next diagonal tile,
-// wavefront 0 folds x_k into block row k - 1 and runs that block's 32-step substitution (running right-hand side in lane registers,
-// solved components broadcast with v_readlane) -- one barrier per block row.
+// x_k = L_kk^-T y_k for one block: the 32-step substitution of one wavefront (running right-hand side in lane registers, solved components
+// broadcast with v_readlane).
 __device__ __forceinline__ void chol_back_block(const double (*Lk)[GSFM_CB + 1], double v, uint32_t lane, double* xk_out, double* x, uint32_t g0, uint32_t n) {
   const uint32_t l = lane & 31;
   const double rinv = 1.0 / Lk[l][l];   // all reciprocals at once, off the dependent chain
@@ -279,99 +299,6 @@ __device__ __forceinline__ void chol_back_block(const double (*Lk)[GSFM_CB + 1],
   }
   if (lane < GSFM_CB) { const double mine = v * rinv; xk_out[lane] = mine; if (g0 + lane < n) x[g0 + lane] = mine; }   // lane t was never modified after step t
 }
-template <int MAXT>
-__global__ void __launch_bounds__(1024) k_chol_back(const double* __restrict__ L, uint32_t n, uint32_t T, double* __restrict__ x) {
-  __shared__ double y[MAXT * GSFM_CB];
-  __shared__ double Lk[2][GSFM_CB][GSFM_CB + 1];
-  __shared__ double xk[2][GSFM_CB];
-  const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  for (uint32_t idx = tid; idx < T * GSFM_CB; idx += 1024) y[idx] = L[chol_tile_off(T, idx / GSFM_CB) + idx % GSFM_CB];
-  Lk[(T - 1) & 1][tid / GSFM_CB][tid % GSFM_CB] = L[chol_tile_off(T - 1, T - 1) + tid];
-  __syncthreads();
-  if (wave == 0) chol_back_block(Lk[(T - 1) & 1], y[(T - 1) * GSFM_CB + (lane & 31)], lane, xk[(T - 1) & 1], x, (T - 1) * GSFM_CB, n);
-  if (T >= 2) { const uint32_t e = tid; Lk[T & 1][e / GSFM_CB][e % GSFM_CB] = L[chol_tile_off(T - 2, T - 2) + e]; }   // (T-2) & 1 == T & 1; all lanes incl. wave 0 after its solve
-  __syncthreads();
-  for (uint32_t k = T - 1; k >= 1; --k) {
-    const double* xs = xk[k & 1];                     // x_k
-    if (wave == 0) {
-      // y_{k-1} -= L_{k,k-1}^T x_k (lanes 0..31 by column, lanes 32..63 mirror), then the substitution of block k - 1
-      const double* t = L + chol_tile_off(k, k - 1) + (lane & 31);
-      double s2 = 0.0;
-#pragma unroll
-      for (int r = 0; r < GSFM_CB; ++r) s2 += t[r * GSFM_CB] * xs[r];
-      const double v = y[(k - 1) * GSFM_CB + (lane & 31)] - s2;
-      chol_back_block(Lk[(k - 1) & 1], v, lane, xk[(k - 1) & 1], x, (k - 1) * GSFM_CB, n);
-    } else {
-      for (uint32_t idx = tid - 64; idx + GSFM_CB < k * GSFM_CB; idx += 960) {   // block rows j <= k - 2
-        const uint32_t j = idx / GSFM_CB, c = idx % GSFM_CB;
-        const double* t = L + chol_tile_off(k, j) + c;
-        double s2 = 0.0;
-#pragma unroll
-        for (int r = 0; r < GSFM_CB; ++r) s2 += t[r * GSFM_CB] * xs[r];
-        y[idx] -= s2;
-      }
-      if (k >= 2) for (uint32_t e = tid - 64; e < GSFM_TILE_ELEMS; e += 960) Lk[k & 1][e / GSFM_CB][e % GSFM_CB] = L[chol_tile_off(k - 2, k - 2) + e];   // diag tile k-2 replaces tile k
-    }
-    __syncthreads();
-  }
-}
-
-// Backward substitution for the larger matrices (two-kernel schedule), one launch per block row k = T-1 .. 0 instead of one workgroup
-// streaming all of L: workgroup j < k folds x_k into the running right-hand side, y_j -= L_kj^T x_k (one 8 KiB tile each, all tiles of
-// block row k in parallel), and the workgroup of j = k - 1 -- whose right-hand side is complete with that -- solves L_{k-1,k-1}^T x_{k-1} =
-// y_{k-1} and publishes x_{k-1} for the next launch.  y lives in global memory (block row T of L: the forward-substituted right-hand side).
-// Launch k = T (no x yet): only the solve of the last block.  ~5 us per block row instead of 26 (3.4 ms at 3N = 4500 for the single
-// workgroup, bound by one CU streaming 81 MB).
-struct CholBackArgs { double* L; double* x; uint32_t n, T, k; };   // the running right-hand side y_j = first row of tile (T, j) of L
-__global__ void __launch_bounds__(64) k_chol_back_step(CholBackArgs a) {
-  __shared__ double Lk[GSFM_CB][GSFM_CB + 1];
-  __shared__ double xs[GSFM_CB];
-  const uint32_t lane = threadIdx.x, l = lane & 31, k = a.k, j = blockIdx.x;   // grid: max(k, 1) workgroups; k == T: one
-  const bool solver = k < a.T ? j + 1 == k : j == 0;     // the workgroup whose block (index k - 1) becomes ready in this launch
-  if (k == a.T && !solver) return;
-  // everything this workgroup reads that does not depend on anything else is requested first: its tile of block row k, and (solver) the
-  // diagonal tile of its own block -- one memory round trip on the chain instead of three (7.2 -> ... us per block row at 3N = 4500)
-  const uint32_t r0 = lane < 32 ? 0 : 16;
-  double tv[16], dv[16];
-  if (k < a.T) {
-    const double* t = a.L + chol_tile_off(k, j) + l;      // column l of tile (k, j), rows r = 0..31 (lanes 32..63 take the upper half)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) tv[r] = t[(r0 + r) * GSFM_CB];
-  }
-  const uint32_t kb = k - 1;
-  if (solver) {
-    const double* d = a.L + chol_tile_off(kb, kb);
-#pragma unroll
-    for (int i = 0; i < 16; ++i) dv[i] = d[lane + 64 * i];
-  }
-  double v = 0.0;
-  if (k < a.T) {
-    if (lane < GSFM_CB) xs[lane] = a.x[k * GSFM_CB + lane];
-    __syncthreads();
-    double s2 = 0.0;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) s2 += tv[r] * xs[r0 + r];
-    s2 += __shfl_xor(s2, 32, 64);
-    double* yj = a.L + chol_tile_off(a.T, j);
-    v = yj[l] - s2;
-    if (lane < GSFM_CB) yj[l] = v;
-    if (!solver) return;
-  } else {
-    v = a.L[chol_tile_off(a.T, a.T - 1) + l];
-  }
-  // this workgroup's block is ready: triangular solve, as in chol_back_block
-#pragma unroll
-  for (int i = 0; i < 16; ++i) { const uint32_t e = lane + 64 * i; Lk[e / GSFM_CB][e % GSFM_CB] = dv[i]; }
-  __syncthreads();
-  const double rinv = 1.0 / Lk[l][l];
-#pragma unroll
-  for (int t = GSFM_CB - 1; t >= 0; --t) {
-    const double xt = readlane_f64(v * rinv, t);
-    if (l < (uint32_t)t) v -= Lk[t][l] * xt;
-  }
-  if (lane < GSFM_CB) a.x[kb * GSFM_CB + lane] = v * rinv;   // (entries beyond n belong to the identity padding: harmless)
-}
-
 // Backward substitution in GROUPS of block rows (both schedules): `k_chol_back_group` -- one workgroup -- solves the block rows k1 - 1 .. k0
 // bottom-up (wavefront 0: the 32-step substitution of block k, as chol_back_block; wavefronts 1..7: one tile (k, j) of the group each, loaded
 // while wavefront 0 solves, folded into the group's right-hand sides once x_k is there), then `k_chol_back_update` -- one workgroup per block
@@ -381,7 +308,7 @@ __global__ void __launch_bounds__(64) k_chol_back_step(CholBackArgs a) {
 // costs its 8 or 16 dependent block rows inside one launch and the bulk of L is read by many CUs at once (2 launches per group).
 struct CholBackGroupArgs { double* L; double* x; uint32_t n, T, k0, k1; };   // x: T * 32 doubles (padded); y_j = first row of tile (T, j) of L
 template <int GR>   // block rows per group = wavefronts of the workgroup (8 or 16)
-__global__ void __launch_bounds__(64 * GR) k_chol_back_group(CholBackGroupArgs a) {
+__device__ __forceinline__ void chol_back_group_body(const CholBackGroupArgs& a) {
   constexpr uint32_t NT = 64 * GR, LOADERS = 32 * (GR - 1), PER = (GSFM_TILE_ELEMS + LOADERS - 1) / LOADERS;
   __shared__ double yg[GR][GSFM_CB];
   __shared__ double Lk[2][GSFM_CB][GSFM_CB + 1];
@@ -423,7 +350,9 @@ __global__ void __launch_bounds__(64 * GR) k_chol_back_group(CholBackGroupArgs a
   }
 }
 template <int GR>
-__global__ void __launch_bounds__(32 * GR) k_chol_back_update(CholBackGroupArgs a) {
+__global__ void __launch_bounds__(64 * GR) k_chol_back_group(CholBackGroupArgs a) { chol_back_group_body<GR>(a); }
+template <int GR>
+__device__ __forceinline__ void chol_back_update_body(const CholBackGroupArgs& a) {
   __shared__ double xs[GR][GSFM_CB], s2s[GR][GSFM_CB];
   const uint32_t tid = threadIdx.x, c = tid & 31, kk = tid >> 5, j = blockIdx.x, G = a.k1 - a.k0;   // kk: block row k0 + kk of the group
   double tv[GSFM_CB];
@@ -447,6 +376,26 @@ __global__ void __launch_bounds__(32 * GR) k_chol_back_update(CholBackGroupArgs 
     for (uint32_t q = G; q-- > 0;) v -= s2s[q][c];
     yj[c] = v;
   }
+}
+template <int GR>
+__global__ void __launch_bounds__(32 * GR) k_chol_back_update(CholBackGroupArgs a) { chol_back_update_body<GR>(a); }
+// batched: group g (counted from the bottom) of every matrix that has one; the update's workgroups beyond a matrix's k0 leave at once
+template <int GR>
+__global__ void __launch_bounds__(64 * GR) k_chol_back_group_batch(const CholBatchItem* items, uint32_t g) {
+  const CholBatchItem it = items[blockIdx.y];
+  if (g * GR >= it.T || !*it.active) return;
+  const uint32_t k1 = it.T - g * GR, k0 = k1 > GR ? k1 - GR : 0;
+  const CholBackGroupArgs a{it.L, it.x, it.n, it.T, k0, k1};
+  chol_back_group_body<GR>(a);
+}
+template <int GR>
+__global__ void __launch_bounds__(32 * GR) k_chol_back_update_batch(const CholBatchItem* items, uint32_t g) {
+  const CholBatchItem it = items[blockIdx.y];
+  if (g * GR >= it.T || !*it.active) return;
+  const uint32_t k1 = it.T - g * GR, k0 = k1 > GR ? k1 - GR : 0;
+  if (blockIdx.x >= k0) return;
+  const CholBackGroupArgs a{it.L, it.x, it.n, it.T, k0, k1};
+  chol_back_update_body<GR>(a);
 }
 
 

@@ -24,6 +24,7 @@
 #include "kernels.hpp"
 #include "cov_kernels.hpp"
 #include "dense_kernels.hpp"
+#include "comp_kernels.hpp"
 #include "colsort_kernels.hpp"
 
 using namespace gsfm;
@@ -270,6 +271,7 @@ struct gsfm_rot_problem {
   DevBuf<double> x, x_trial, aa_io, active, scale, gD, Mblk, Minv, Lam, Tinv, b, D6;
   DevBuf<double2> q, q_trial;
   DevBuf<double> xcg, r, z, p, Ap, s_dir, part_g2, part_d2;
+  const double* b_rhs = nullptr;   // non-null: the right-hand side PCG starts from instead of b (solver_components.hpp: b with the factorised components zeroed)
   DevBuf<double> w_gather;   // sharded single-reduction PCG: per rank [slice of A u | delta partials of its rows] (run_pcg2)
   uint32_t w_tail = 0;
   DevBuf<Cg2Scalars> cg2sc;
@@ -280,17 +282,24 @@ struct gsfm_rot_problem {
   std::vector<double> h_coarse, h_coarse_inv;
   void* pin = nullptr;              // 512 B of pinned host memory: [0, 256) staging for the small read-backs of the solve loop (read_back), [256, 264) the deferred gradient norm (lm_solve)
   DevBuf<double> denseA, denseL, dense_x;
-  // One exact LM iteration under device control as ONE graph (solver_lm.hpp, enqueue_exact): factorisation, step, trial cost, decision,
-  // predicated accept path, damping, record.  Valid for the loss, options and block form it was captured with.
-  struct IterGraph {
-    hipGraphExec_t exec = nullptr;
-    bool unusable = false, lap = false;
-    int plain_runs = 0;           // iterations enqueued plainly so far (the first one allocates: it cannot be captured)
-    uint64_t loss_epoch = 0;
-    const void* x_ptr = nullptr;   // the state buffer its kernels address (host-controlled steps swap x and x_trial)
-    double key[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // the by-value options its kernels froze (tolerances, radius bounds, damping clamps, Jacobi scaling)
-    void reset() { if (exec) (void)hipGraphExecDestroy(exec); exec = nullptr; plain_runs = 0; }
-  } iter_graph;
+  // Disconnected view graph (unsharded): the small components are factorised exactly, side by side (solver_components.hpp)
+  struct Components {
+    std::vector<uint32_t> comp_of;     // per camera (internal numbering): component index, 0xffffffff for a camera without edges
+    std::vector<uint32_t> size;        // cameras per component
+    int built_cap = -1;                // the size limit the batch below was built for (-1: not built)
+    uint32_t n_items = 0, Tmax = 0, n_dense_cams = 0, n_pcg_comps = 0;
+    size_t a_words = 0;                // doubles of the A tiles (the head of the slab: one memset clears them)
+    bool all_dense = false;            // every camera with an edge lies in a factorised component: no PCG at all
+    DevBuf<int32_t> cam_item;
+    DevBuf<uint32_t> cam_loc;
+    DevBuf<CholBatchItem> items;
+    DevBuf<double> slab, b_pcg;
+    DevBuf<int> info, active;          // per item: factorisation status; has anything to solve in this LM step (k_comp_activity)
+    DevBuf<uint32_t> item_ptr, item_cams;   // the cameras of every item, item by item
+    hipGraphExec_t graph = nullptr;
+    bool graph_lap = false;
+    void drop_graph() { if (graph) (void)hipGraphExecDestroy(graph); graph = nullptr; }
+  } comps;
   uint64_t loss_epoch = 0;                // bumped whenever the loss (and with it the choice of kernels) changes
   hipGraphExec_t dense_graph = nullptr;   // zero + assemble + blocked Cholesky + solve, captured once
   bool dense_graph_lap = false;           // form of the blocks the captured assemble kernel expects
@@ -337,6 +346,8 @@ struct gsfm_rot_problem {
   DevBuf<double> mail_count;
   double mail_expected = 0.0;
   int mail_state = 0;
+  bool loss_staircase = false;  // the loss program contains a MAGSAC leaf: the cost is a staircase in every edge's s
+  bool loss_cuts_off = false;   // the loss program contains a leaf whose rho' is identically zero beyond a cut-off (Tukey)
   bool fast_lin_ok = true;   // the loss's rho'' is <= 0 for every s (decided from leaf kind AND parameter signs in prepare_loss): K2's alpha = 0 fast path applies
   int graph_launches = 0;
   int n_collectives = 0, n_pcg_collectives = 0, n_pcg_launched = 0;   // issued (or replayed from a graph) since the solve started

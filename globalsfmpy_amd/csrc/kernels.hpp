@@ -1204,6 +1204,32 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_max_partials(const double* __res
   if (threadIdx.x == 0) out[0] = t;
 }
 
+// Absolute floor of the PCG tolerance (round 5).  A relative residual of 1e-12 stands in for the reference's exact Cholesky solve; on a step of
+// 0.1 rad that is an error of 1e-13 rad, and that -- not twelve digits of a step that is itself 1e-9 rad long -- is what the answer can feel.  A
+// solve therefore also stops once block-Jacobi's estimate of what ANY camera's step still lacks is below `floor` radians:
+//   |delta_k|^2 = |Tinv_k Minv_k r_k|^2 <= |Tinv_k|^2 |Minv_k| (r_k . Minv_k r_k) <= B (r . Minv r),   B = max_k |Tinv_k|_F^2 |Minv_k|_F,
+// i.e. once r.z <= floor^2 / B.  B is taken here, once per LM step (cameras without an edge excluded: their residual is zero); the init
+// kernels of the solves turn it into a floor under the relative tolerance.  Decisive for disconnected problems (C4: thirteen scenes have
+// converged to 1e-12 rad steps while the fourteenth iterates on -- each of their solves used to run 40 iterations on a right-hand side of nothing).
+__global__ void __launch_bounds__(GSFM_BLOCK) k_cam_bound(const double* __restrict__ Minv, const double* __restrict__ Tinv, const double* __restrict__ active, uint32_t n, double* partials) {
+  __shared__ double lds[8];
+  const uint32_t k = blockIdx.x * GSFM_BLOCK + threadIdx.x;
+  double v = 0.0;
+  if (k < n && active[k] != 0.0) {
+    const double* M = Minv + 6 * (size_t)k;
+    const double* T = Tinv + 9 * (size_t)k;
+    const double m2 = M[0] * M[0] + M[3] * M[3] + M[5] * M[5] + 2.0 * (M[1] * M[1] + M[2] * M[2] + M[4] * M[4]);
+    double t2 = 0.0;
+#pragma unroll
+    for (int c = 0; c < 9; ++c) t2 += T[c] * T[c];
+    v = t2 * sqrt(m2);
+  }
+  const double t = block_max_bcast(v, lds);
+  if (threadIdx.x == 0) partials[blockIdx.x] = t;
+}
+// relative tolerance of a solve whose initial r.z is rz0: the requested one, or the one the absolute floor allows
+__device__ __forceinline__ double cg_tol_with_floor(double tol, double rz_abs, double rz0) { return rz0 > 0.0 ? fmax(tol, sqrt(rz_abs / rz0)) : tol; }
+
 // Forcing schedule: a LOOSE PCG iterate carries a component along the gauge direction eta_k = R_k v (all cameras rotated by the same v in their body
 // frames: the exact null space of J^T J, held only by the LM damping, hence the last thing PCG resolves and invisible to its energy norm).  The
 // exact step has none: v^T sum_k R_k^T Lam_k eta_k = 0 for every v, because the gradient is orthogonal to the gauge.  These two kernels remove it
@@ -1277,7 +1303,13 @@ struct StepArgs {
   const double* Tinv;     // 9
   double* x_trial;
   double2* q_trial;
-  double* partials;       // 5 * gridDim.x : eta.g, eta.rcg, eta^T Lam eta, |x - x_trial|^2, |x_trial|^2
+  double* partials;       // 6 * gridDim.x : eta.g, eta.rcg, eta^T Lam eta, |x - x_trial|^2, |x_trial|^2, sum_k |Tinv Minv rcg|_k^8 (0 unless Minv is given)
+  const double* Minv;     // non-null (a loose PCG iterate, round 5): the sixth sum -- what block-Jacobi says each camera's step still lacks, in the
+                          // units of the update (radians; half-angles for the quaternion state).  The energy norm the loose solve stops on weights a
+                          // camera by its own weight sum: a camera whose edges are nearly all cut off by a redescending loss is invisible to it
+                          // and can be left 1e-4 rad from its exact step under an energy error of 1e-8 (tests/manual/fuzz_forcing.py dense 5:14,
+                          // 6:52: Tukey on ROTATION_MAT_FNORM).  The eighth-power sum is a smooth maximum: its 8th root lies between the largest
+                          // camera's value and N^(1/8) times it (4.2 x at 100k cameras); lm_solve holds it against 10 x the rms tolerance.
   // a loose PCG iterate (forcing schedule): the nine sums of k_gauge_part; the gauge component is taken out of eta and the residual corrected
   // on the fly (round 4: the kernel that wrote the corrected copies is gone -- one launch fewer per loose step; the PCG state stays untouched)
   const double* gauge_part; int gauge_nb; const double2* gauge_q;
@@ -1286,7 +1318,7 @@ struct StepArgs {
 // parameter-tolerance test (TrustRegionMinimizer::ComputeCandidatePointAndEvaluateCost).
 __global__ void __launch_bounds__(GSFM_BLOCK) k_cam_step(StepArgs a) {
   __shared__ double lds[8];
-  double v[5] = {0, 0, 0, 0, 0};
+  double v[6] = {0, 0, 0, 0, 0, 0};
   const uint32_t k = blockIdx.x * GSFM_BLOCK + threadIdx.x;
   double gw[3] = {0.0, 0.0, 0.0};
   if (a.gauge_part) gauge_solve(a.gauge_part, a.gauge_nb, lds, gw);
@@ -1303,6 +1335,13 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_cam_step(StepArgs a) {
     v[1] = e[0] * rc[0] + e[1] * rc[1] + e[2] * rc[2];
     v[2] = e[0] * le[0] + e[1] * le[1] + e[2] * le[2];
     const double act = a.active[k];
+    if (a.Minv) {
+      double z[3];
+      sym3_mulvec(a.Minv + 6 * (size_t)k, rc, z);
+      const double dz0 = Ti[0] * z[0] + Ti[1] * z[1] + Ti[2] * z[2], dz1 = Ti[3] * z[0] + Ti[4] * z[1] + Ti[5] * z[2], dz2 = Ti[6] * z[0] + Ti[7] * z[1] + Ti[8] * z[2];
+      const double m2 = act * (dz0 * dz0 + dz1 * dz1 + dz2 * dz2), m4 = m2 * m2;
+      v[5] = m4 * m4;
+    }
     Quat qt;
     if (a.param_dim == 3) {
       const double x0 = a.x[k3] + d[0], x1 = a.x[k3 + 1] + d[1], x2 = a.x[k3 + 2] + d[2];
@@ -1330,7 +1369,7 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_cam_step(StepArgs a) {
     a.q_trial[2 * (size_t)k + 1] = make_double2(qt.z, qt.w);
   }
 #pragma unroll
-  for (int c = 0; c < 5; ++c) {
+  for (int c = 0; c < 6; ++c) {
     const double t = block_sum_bcast(v[c], lds);
     if (threadIdx.x == 0) a.partials[(size_t)c * gridDim.x + blockIdx.x] = t;
   }
@@ -1404,6 +1443,7 @@ struct CgScalars {
   double etol2;     // loose solves: stop once the ESTIMATED relative energy-norm error of the iterate, squared, is below this (0 = off); see cg_energy_stop
   double esum;      // sum of the iterations' decreases of the quadratic model, alpha_j (r_j . z_j) = |x_{j+1}|_A^2 - |x_j|_A^2 growth (Hestenes-Stiefel)
   double einc[4];   // the last four of them (ring, indexed by iteration & 3)
+  double rz_abs;    // absolute floor on r.z (k_cam_bound): `tol` never drops below sqrt(rz_abs / rz0)
 };
 // Energy-norm stopping rule of the forcing schedule.  PCG from x_0 = 0 gains inc_j = alpha_j (r_j . z_j) of |x|_A^2 per iteration, and the squared
 // energy error after k iterations is the sum of all LATER gains (Hestenes & Stiefel 1952; Strakos & Tichy 2002).  The later gains are extrapolated
@@ -1418,11 +1458,12 @@ __device__ __forceinline__ bool cg_energy_stop(const double* ring, double esum, 
   // (round 5) the tolerance is asked of the step in RADIANS (rms), the energy norm weights a mode by its eigenvalue: the error that is left sits in the
   // weakest modes the solve has met, where a unit of energy buys sqrt(kappa) times the rotation it buys on average.  kappa is not known; what
   // is, is the rate the solve converges at right now -- q is the decay of the squared energy error over two iterations, so r = q^(1/4) per
-  // iteration -- and a rate r is what kappa = ((1 + r) / (1 - r))^2 gives.  The estimate is held against etol2 / kappa: nothing for the
-  // well-conditioned systems the schedule was made for (r = 0.33: 4 x, one iteration), and a solve crawling at r = 0.95 goes on 1500 x further
-  // down -- close to its tight tolerance, as it should: its energy estimate says least about its rotations.
+  // iteration -- and a rate r is what kappa = ((1 + r) / (1 - r))^2 gives.  The estimate is held against 16 etol2 / kappa: nothing for the
+  // well-conditioned systems the schedule was made for (r <= 0.6), and a solve crawling at r = 0.95 goes on 95 x further down -- towards its
+  // tight tolerance, as it should: its energy estimate says least about its rotations.
+  // (a factor sqrt(kappa) <= 4 is inside the margin between the per-step tolerance and the parity bar: the correction starts at kappa = 16, r = 0.6)
   const double r = sqrt(sqrt(q)), kap = (1.0 + r) / (1.0 - r);
-  return a * q * kap * kap <= etol2 * esum * (1.0 - q);
+  return a * q * fmax(1.0, kap * kap * 0.0625) <= etol2 * esum * (1.0 - q);
 }
 struct CgArgs {
   uint32_t n;        // cameras
@@ -1436,6 +1477,7 @@ struct CgArgs {
   double *xcg, *r, *z, *p, *Ap;
   double* part_a;    // [nb]
   double* part_b;    // [nb]
+  const double* zbound; double abs_floor2;   // k_cam_bound's B (device scalar; null or 0: no floor) and floor^2
   CgScalars* sc;
   const double2* q;  // Laplacian form: camera quaternions and
   double* u;         //   u_k = R_k^T p_k, written wherever p is (null otherwise)
@@ -1483,14 +1525,18 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_cg_init_fin(CgArgs a) {
   __shared__ double lds[8];
   const double rz = sum_partials_bcast(a.part_b, a.nb, lds);
   if (threadIdx.x == 0) {
-    a.sc->rz[0] = rz; a.sc->rz[1] = rz; a.sc->rz0 = rz; a.sc->last_rel = 1.0; a.sc->best_rel = 1.0;
-    a.sc->done = !(rz > 0.0); a.sc->iters = 0; a.sc->stall = 0; a.sc->stalled = 0; a.sc->done_seen = a.sc->done; a.sc->tol = a.tol;
+    const double bound = a.zbound ? *a.zbound : 0.0, rz_abs = bound > 0.0 ? a.abs_floor2 / bound : 0.0;
+    a.sc->rz_abs = rz_abs;
+    a.sc->rz[0] = rz; a.sc->rz[1] = rz; a.sc->rz0 = rz; a.sc->best_rel = 1.0;
+    a.sc->done = !(rz > rz_abs); a.sc->last_rel = a.sc->done ? 0.0 : 1.0;   // (nothing to solve: converged, not "stopped above the tolerance")
+    a.sc->iters = 0; a.sc->stall = 0; a.sc->stalled = 0; a.sc->done_seen = a.sc->done; a.sc->tol = cg_tol_with_floor(a.tol, rz_abs, rz);
     a.sc->etol2 = a.etol2; a.sc->esum = 0.0; a.sc->einc[0] = a.sc->einc[1] = a.sc->einc[2] = a.sc->einc[3] = 0.0;
   }
 }
 // Continue a stopped solve to a tighter tolerance: the vectors, rz and the iteration count are exactly what the stopping iteration left
 // (see done_seen), so the iterates that follow are those of a solve that ran at `tol` from the start.
 __global__ void k_cg_resume(CgScalars* sc, double tol, double etol2, int max_iters) {
+  tol = cg_tol_with_floor(tol, sc->rz_abs, sc->rz0);
   sc->tol = tol; sc->etol2 = etol2;
   sc->done = !(sc->rz0 > 0.0) || !(sc->last_rel > tol) || sc->iters >= max_iters || sc->stalled;
   sc->done_seen = sc->done;
@@ -1689,7 +1735,8 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_cg_init_coarse(CgArgs a) {
 }
 __global__ void k_cg_init_coarse_fin(CgArgs a) {
   const double rz = a.sc->rz[0] + a.xc[3 * a.coarse_n];
-  a.sc->rz[0] = rz; a.sc->rz[1] = rz; a.sc->rz0 = rz; a.sc->done = !(rz > 0.0);
+  a.sc->rz[0] = rz; a.sc->rz[1] = rz; a.sc->rz0 = rz; a.sc->done = !(rz > a.sc->rz_abs); a.sc->done_seen = a.sc->done; a.sc->last_rel = a.sc->done ? 0.0 : 1.0;
+  a.sc->tol = cg_tol_with_floor(a.tol, a.sc->rz_abs, rz);
 }
 // Ac = P^T A P from the stored blocks of the Laplacian form: off-diagonal entry (k -> m) contributes -R_k^T G_k R_k to block (agg k, agg m),
 // the diagonal block R_k^T M_k R_k to (agg k, agg k).  G lanes per row; a lane sums its consecutive entries that fall into the same
@@ -1846,11 +1893,15 @@ __global__ void k_pcg_mail(const double* __restrict__ sc, int nwords, double* ma
 // The LM loop's look at a trial point in ONE launch: the step's five sums and the trial cost's (the reductions k_sum_partials_multi /
 // k_sum_partials would have launched: same routine, same order, same bits, written to the same scalars), then the scalar block's post.
 __global__ void __launch_bounds__(GSFM_BLOCK) k_trial_post(double* scal, int sc_step, int sc_trial, const double* __restrict__ step_part, int nb_cam,
-                                                           const double* __restrict__ cost_part, int nb_cost, int nwords, double* mail, double* counter) {
+                                                           const double* __restrict__ cost_part, int nb_cost, int nwords, double* mail, double* counter, int sc_z) {
   __shared__ double lds[8];
   for (int c = 0; c < 5; ++c) {
     const double t = sum_partials_bcast(step_part + (size_t)c * nb_cam, nb_cam, lds);
     if (threadIdx.x == 0) scal[sc_step + c] = t;
+  }
+  if (sc_z >= 0) {   // (k_cam_step's sixth sum: the per-camera Jacobi estimate of a loose step's error)
+    const double t = sum_partials_bcast(step_part + (size_t)5 * nb_cam, nb_cam, lds);
+    if (threadIdx.x == 0) scal[sc_z] = t;
   }
   const double t = sum_partials_bcast(cost_part, nb_cost, lds);
   if (threadIdx.x != 0) return;
@@ -1871,6 +1922,7 @@ struct Cg2Scalars {
   int iters;
   double tol;        // relative tolerance of the current run (device-resident: see CgScalars::tol)
   double etol2, esum, einc[4];   // energy-norm stopping rule of the loose solves (cg_energy_stop): inc_j = alpha_j gamma_j
+  double rz_abs;     // absolute floor on gamma = r.z (k_cam_bound): `tol` never drops below sqrt(rz_abs / gamma0)
 };
 struct Cg2Args {
   uint32_t n;            // cameras
@@ -1880,6 +1932,7 @@ struct Cg2Args {
   int first;             // 1 on iteration 0
   int max_iters;
   double tol, etol2;     // (read by k_cg2_init only: the run's tolerances live in Cg2Scalars)
+  const double* zbound; double abs_floor2;   // k_cam_bound's B (device scalar; null or 0: no floor) and floor^2
   const double* Minv;
   const double* b;
   double *x, *r, *u, *w, *p, *s;
@@ -1919,13 +1972,14 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_cg2_init(Cg2Args a) {
   const double t = block_sum_bcast(v, lds);
   if (threadIdx.x == 0) a.part_g[blockIdx.x] = t;
   if (blockIdx.x == 0 && threadIdx.x == 0) { a.sc->done = 0; a.sc->iters = 0; a.sc->last_rel = 1.0; a.sc->gamma0 = 0.0; a.sc->tol = a.tol;
+    { const double bound = a.zbound ? *a.zbound : 0.0; a.sc->rz_abs = bound > 0.0 ? a.abs_floor2 / bound : 0.0; }
     a.sc->etol2 = a.etol2; a.sc->esum = 0.0; a.sc->einc[0] = a.sc->einc[1] = a.sc->einc[2] = a.sc->einc[3] = 0.0; }
 }
 // Continue a stopped solve to a tighter tolerance.  The recurrence stops at a mat-vec ENTRY (every workgroup takes the same decision from
 // the same gamma partials, nothing of the iteration has been written), so clearing the flag lets the next mat-vec -- launched with the
 // parity and `first` flag of the iteration that stopped -- take the decision again, against the new tolerance.
 __global__ void k_cg2_resume(Cg2Scalars* sc, double tol, double etol2) {
-  sc->tol = tol; sc->etol2 = etol2;
+  sc->tol = cg_tol_with_floor(tol, sc->rz_abs, sc->gamma0); sc->etol2 = etol2;
   sc->done = 0;
 }
 
@@ -1992,8 +2046,9 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_matvec_cg(MatvecCgArgs aa) {
   if (done) return;
   bool conv;
   if (c.first) {
-    conv = !(gamma > 0.0);
-    if (blockIdx.x == 0 && threadIdx.x == 0) { c.sc->gamma0 = gamma; if (conv) c.sc->done = 1; }
+    const double rz_abs = c.sc->rz_abs;   // (written by k_cg2_init, the launch before)
+    conv = !(gamma > rz_abs);
+    if (blockIdx.x == 0 && threadIdx.x == 0) { c.sc->gamma0 = gamma; c.sc->tol = cg_tol_with_floor(tol, rz_abs, gamma); if (conv) { c.sc->done = 1; c.sc->last_rel = 0.0; } }
   } else {
     const double rel = sqrt(gamma / gamma0);
     // the iteration cap is applied here, at a kernel entry, from a counter written by the PREVIOUS launch: every workgroup takes
@@ -2182,7 +2237,6 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_dense_assemble(DenseArgs a) {
   }
 }
 
-
 // ------------------------------------------------------------------------------------------
 // Device-side Levenberg-Marquardt control for EXACT steps (latency regime: Madrid-sized graphs, one Cholesky step per iteration).  The
 // decisions of TrustRegionMinimizer the host loop takes between two synchronisations -- step validity, the two tolerance tests, acceptance,
@@ -2198,6 +2252,8 @@ struct LmOpts { double function_tolerance, gradient_tolerance, parameter_toleran
 // t^2 = h + l and h t = p + e exactly (FMA residues), the cube is p + (e + l t): one rounding of a value good to 2^-100, i.e. the correctly rounded
 // result but for ties nobody will meet -- the device's radius trace equals the oracle's bit for bit (tests/test_gpu_round5.py).
 __device__ __forceinline__ double lm_cube(double t) {
+#pragma clang fp contract(off)   // (under the device default, -ffp-contract=fast, `p + fma(l, t, e)` becomes fma(h, t, fma(l, t, e)), which counts the residue e twice;
+                                 // HIP's __dmul_rn / __dadd_rn are plain operators and do not stop it)
   const double h = t * t, l = fma(t, t, -h);
   const double p = h * t, e = fma(h, t, -p);
   return p + fma(l, t, e);

@@ -143,7 +143,7 @@ int build_colsort(gsfm_rot_problem* P, const std::vector<uint32_t>& rp, hvec<uin
   std::vector<ColWg> h_wg((size_t)nblk * C.nch);
   // (graded only where the tasks outnumber the chip's resident workgroups several times over -- K2c holds 512, K3c 1024: with a single round,
   // as on one rank's share of a sharded problem (400 tasks), the kernel takes as long as its LARGEST task, and grading made K3c 33 -> 40 us there)
-  const bool graded = C.nch > 1 && (size_t)nblk * C.nch >= (size_t)(GSFM_COL_RB == 512 ? 1280 : 640) && !(getenv("GSFM_COL_EVEN") && atoi(getenv("GSFM_COL_EVEN")) > 0);
+  const bool graded = C.nch > 1 && (size_t)nblk * C.nch >= (size_t)1280;
   parallel_run(std::max(1, std::min<int>(n_threads, (int)nblk)), [&](int t, int T) {
     std::vector<std::pair<uint64_t, uint32_t>> ent;   // (camera << 16 | local row, d): a repeated camera pair is ordered by d
     std::vector<uint32_t> cnt(RB + 1), fill(RB), chist;
@@ -170,7 +170,6 @@ int build_colsort(gsfm_rot_problem* P, const std::vector<uint32_t>& rp, hvec<uin
       // the large tasks of all blocks first, the small ones last.  Equal tasks fill the chip in whole rounds (K2c: 2 x 256 resident
       // workgroups, 1764 equal tasks = 3.45 rounds, the last one half empty; measured as a saw-tooth in the task count: 616 us at 1960
       // tasks, 645 at 2156, 612 at 2548: profiles/r04b_wgs_sweep.txt); with graded sizes the tail is as long as the SMALLEST task.
-      // GSFM_COL_EVEN=1: equal sizes (the round-3 dealing).
       for (uint32_t c = 0; c < C.nch; ++c) {
         size_t lo, hi;
         if (graded && ns >= 4 * (size_t)C.nch) {
@@ -408,7 +407,10 @@ static gsfm_status problem_create_impl(uint32_t n_cams, uint64_t n_edges, const 
   }
   // connected components of the view graph: counted here on one GPU; a rank of a sharded problem sees only its own edges, so the
   // partitioner passes the verdict in the shard descriptor (GSFM_SHARD_DISCONNECTED)
-  if (!P->sharded) P->n_components = std::max<uint32_t>(1, count_components(n_cams, n_edges, edge_i, edge_j));
+  if (!P->sharded) {
+    P->n_components = std::max<uint32_t>(1, count_components(n_cams, n_edges, edge_i, edge_j));
+    if (P->n_components > 1) component_labels(n_cams, n_edges, edge_i, edge_j, &P->comps.comp_of, &P->comps.size);   // (internal numbering: solver_components.hpp)
+  }
   else P->n_components = (P->shard.flags & GSFM_SHARD_DISCONNECTED) ? 2 : 1;
   lap("connected components");
   const size_t nd = rp[P->n_rows];
@@ -569,7 +571,7 @@ static gsfm_status problem_create_impl(uint32_t n_cams, uint64_t n_edges, const 
     P->lap = P->lap_capable;
   }
   ok &= P->part_a.alloc(P->nb_cam) == hipSuccess; ok &= P->part_b.alloc(P->nb_cam) == hipSuccess;
-  ok &= P->part_cam.alloc((size_t)5 * P->nb_cam) == hipSuccess; ok &= P->part_gauge.alloc((size_t)9 * P->nb_cam) == hipSuccess; ok &= P->part_cost.alloc((size_t)2 * P->nb_cost) == hipSuccess;
+  ok &= P->part_cam.alloc((size_t)6 * P->nb_cam) == hipSuccess; ok &= P->part_gauge.alloc((size_t)9 * P->nb_cam) == hipSuccess; ok &= P->part_cost.alloc((size_t)2 * P->nb_cost) == hipSuccess;
   ok &= P->scal.alloc(SC_ALL, true) == hipSuccess; ok &= P->cgsc.alloc(1, true) == hipSuccess;
   {  // fused mat-vec of the single-reduction PCG: one row group (256 / G rows) per workgroup unless that leaves too many partials
     const size_t rows_per_group = GSFM_BLOCK / P->G, groups = (P->n_rows + rows_per_group - 1) / rows_per_group;

@@ -33,7 +33,7 @@ int run_dense(gsfm_rot_problem* P, bool* used, bool plain = false) {
       for (uint32_t k = 0; k < T; ++k) {
         CholArgs c{P->denseA.p, P->denseL.p, T, k, info};
         const uint64_t m = T - k;
-        { const uint32_t nt = getenv("GSFM_CHOL_NT") ? (uint32_t)std::max(1, std::min(3, atoi(getenv("GSFM_CHOL_NT")))) : chol_step_tiles_per_wg((uint32_t)m); const dim3 grid(chol_step_grid((uint32_t)m, nt));
+        { const uint32_t nt = chol_step_tiles_per_wg((uint32_t)m); const dim3 grid(chol_step_grid((uint32_t)m, nt));
           if (nt == 3) hipLaunchKernelGGL(k_chol_step<3>, grid, dim3(256), 0, P->stream, c); else if (nt == 2) hipLaunchKernelGGL(k_chol_step<2>, grid, dim3(256), 0, P->stream, c); else hipLaunchKernelGGL(k_chol_step<1>, grid, dim3(256), 0, P->stream, c); }
       }
     } else {
@@ -63,32 +63,17 @@ int run_dense(gsfm_rot_problem* P, bool* used, bool plain = false) {
       }
     }
     // backward substitution, L^T x = y (y = block row T of L), in groups of 8 block rows: one workgroup solves a group, one launch
-    // folds its x into all block rows above it (dense_kernels.hpp).  GSFM_CHOL_BACK_GROUPS=0: the forms it replaced (one workgroup for
-    // everything up to 48 block rows, one launch per block row beyond), kept for A/B measurements.
-    static const bool grouped = [] { const char* e = getenv("GSFM_CHOL_BACK_GROUPS"); return !(e && atoi(e) == 0); }();
-    if (grouped) {
-      static const uint32_t GR = [] { const char* e = getenv("GSFM_CHOL_BACK_GROUP"); return e && atoi(e) == 16 ? 16u : 8u; }();   // (Madrid, linear solves per solve: 8 rows per group 35.1 ms, 16: 36.0, the single workgroup it replaces 37.6)
-      for (uint32_t k1 = T; k1 > 0;) {
-        const uint32_t k0 = k1 > GR ? k1 - GR : 0;
-        CholBackGroupArgs b{P->denseL.p, P->dense_x.p, n, T, k0, k1};
-        if (GR == 16) {
-          hipLaunchKernelGGL(k_chol_back_group<16>, dim3(1), dim3(1024), 0, P->stream, b);
-          if (k0) hipLaunchKernelGGL(k_chol_back_update<16>, dim3(k0), dim3(512), 0, P->stream, b);
-        } else {
-          hipLaunchKernelGGL(k_chol_back_group<8>, dim3(1), dim3(512), 0, P->stream, b);
-          if (k0) hipLaunchKernelGGL(k_chol_back_update<8>, dim3(k0), dim3(256), 0, P->stream, b);
-        }
-        k1 = k0;
-      }
-      (void)hipMemcpyAsync(P->xcg.p, P->dense_x.p, 8 * (size_t)n, hipMemcpyDeviceToDevice, P->stream);
-    } else if (T <= split_T) hipLaunchKernelGGL(k_chol_back<GSFM_CHOL_SPLIT_T>, dim3(1), dim3(1024), 0, P->stream, (const double*)P->denseL.p, n, T, P->xcg.p);
-    else {   // one launch per block row, all tiles of the row in parallel; the running right-hand side is block row T of L, x goes to dense_x (padded to T * 32)
-      for (uint32_t k = T; k >= 1; --k) {
-        CholBackArgs b{P->denseL.p, P->dense_x.p, n, T, k};
-        hipLaunchKernelGGL(k_chol_back_step, dim3(k == T ? 1 : k), dim3(64), 0, P->stream, b);
-      }
-      (void)hipMemcpyAsync(P->xcg.p, P->dense_x.p, 8 * (size_t)n, hipMemcpyDeviceToDevice, P->stream);
+    // folds its x into all block rows above it (dense_kernels.hpp).  (The forms it replaced -- one workgroup for everything, one launch per
+    // block row -- and groups of 16 lost their A/B runs, Madrid 37.6 / 36.0 against 35.1 ms of linear solves, and were removed in round 5.)
+    constexpr uint32_t GR = 8;
+    for (uint32_t k1 = T; k1 > 0;) {
+      const uint32_t k0 = k1 > GR ? k1 - GR : 0;
+      CholBackGroupArgs b{P->denseL.p, P->dense_x.p, n, T, k0, k1};
+      hipLaunchKernelGGL(k_chol_back_group<GR>, dim3(1), dim3(64 * GR), 0, P->stream, b);
+      if (k0) hipLaunchKernelGGL(k_chol_back_update<GR>, dim3(k0), dim3(32 * GR), 0, P->stream, b);
+      k1 = k0;
     }
+    (void)hipMemcpyAsync(P->xcg.p, P->dense_x.p, 8 * (size_t)n, hipMemcpyDeviceToDevice, P->stream);
     // (exact solve: the PCG residual term of the model decrease is zero -- k_dense_assemble cleared it)
   };
   if (plain) {

@@ -170,6 +170,12 @@ int prepare_loss(gsfm_rot_problem* P, const gsfm_loss_node* prog, int n) {
     if (s0.kind == GSFM_LOSS_MAGSAC && !(s0.p[0] > 0.0)) P->fast_lin_ok = false;
     if ((s0.kind == GSFM_LOSS_TUKEY || s0.kind == GSFM_LOSS_SOFT_L1 || s0.kind == GSFM_LOSS_HUBER) && !(s0.p[0] != 0.0)) P->fast_lin_ok = false;
   }
+  // a loss that switches edges off altogether (rho' identically 0 beyond a cut-off: Tukey): see lm_solve, the forcing schedule
+  P->loss_cuts_off = P->loss_staircase = false;
+  for (int i = 0; i < n; ++i) {
+    if (prog[i].kind == GSFM_LOSS_TUKEY) P->loss_cuts_off = true;
+    if (prog[i].kind == GSFM_LOSS_MAGSAC) P->loss_staircase = true;   // rho and rho' piecewise constant in s: the table index is rounded (loss_functions.py:303)
+  }
   P->h_loss = L;
   if (!P->d_loss.p && P->d_loss.alloc(1) != hipSuccess) return fail(GSFM_ERR_HIP, "alloc loss");
   HIPCHK(hipMemcpy(P->d_loss.p, &P->h_loss, sizeof(DevLoss), hipMemcpyHostToDevice));
@@ -198,7 +204,7 @@ int all_reduce(gsfm_rot_problem* P, double* buf, size_t count) {
 }
 
 // ---- launches -----------------------------------------------------------------------------
-enum { SC_COST = 0, SC_GMAX = 1, SC_STEP = 2 /* ..6 */, SC_XNORM2 = 7, SC_TRIAL = 8, SC_DENSE_INFO = 15 /* an int: status of the Cholesky factorisation */, SC_N = 16,
+enum { SC_COST = 0, SC_GMAX = 1, SC_STEP = 2 /* ..6 */, SC_XNORM2 = 7, SC_TRIAL = 8, SC_ZL8 = 9 /* k_cam_step's sixth sum (loose steps) */, SC_ZBOUND = 10 /* k_cam_bound's B: the absolute floor of the PCG tolerance */, SC_DENSE_INFO = 15 /* an int: status of the Cholesky factorisation */, SC_N = 16,
        SC_CTL = 16 /* .. 31: the device-side LM control block (kernels.hpp, CT_*) */, SC_REC = 32 /* .. 95: ring of four per-iteration records of it */, SC_ALL = 96 };
 enum { T_LIN = 0, T_SWEEP = 1, T_CG = 2 };
 
@@ -338,7 +344,14 @@ void launch_prep(gsfm_rot_problem* P, const gsfm_rot_options& o, double radius, 
   a.init_scale = init_scale; a.jacobi_scaling = o.jacobi_scaling; a.radius = radius; a.min_diag = o.min_lm_diagonal; a.max_diag = o.max_lm_diagonal;
   a.Mblk = P->Mblk.p; a.Minv = P->Minv.p; a.Lam = P->Lam.p; a.Tinv = P->Tinv.p; a.b = P->b.p; a.gmax_partials = P->part_cam.p;
   hipLaunchKernelGGL(k_cam_prep, dim3(P->nb_cam), dim3(GSFM_BLOCK), 0, P->stream, a);
-  if (reduce) hipLaunchKernelGGL(k_max_partials, dim3(1), dim3(GSFM_BLOCK), 0, P->stream, P->part_cam.p, P->nb_cam, P->scal.p + SC_GMAX);
+  if (reduce) {
+    hipLaunchKernelGGL(k_max_partials, dim3(1), dim3(GSFM_BLOCK), 0, P->stream, P->part_cam.p, P->nb_cam, P->scal.p + SC_GMAX);
+    // B of the PCG tolerance's absolute floor (kernels.hpp, k_cam_bound) for the damping just built -- host-controlled steps only: the
+    // device-controlled exact pipeline runs no PCG (a PCG step behind it finds the bound of the last host-controlled prep, or none)
+    double* part = P->part_cam.p + (size_t)5 * P->nb_cam;
+    hipLaunchKernelGGL(k_cam_bound, dim3(P->nb_cam), dim3(GSFM_BLOCK), 0, P->stream, (const double*)P->Minv.p, (const double*)P->Tinv.p, (const double*)P->active.p, P->n_cams, part);
+    hipLaunchKernelGGL(k_max_partials, dim3(1), dim3(GSFM_BLOCK), 0, P->stream, (const double*)part, P->nb_cam, P->scal.p + SC_ZBOUND);
+  }
 }
 
 int launch_matvec(gsfm_rot_problem* P, const double* Mblk, const double* p, double* y, const int* done, double* dot_part = nullptr, bool* dot_done = nullptr) {

@@ -18,10 +18,14 @@ int launch_step(gsfm_rot_problem* P, bool inexact = false, bool reduce = true) {
     hipLaunchKernelGGL(k_gauge_part, dim3(P->nb_cam), dim3(GSFM_BLOCK), 0, P->stream, ga);
     a.gauge_part = P->part_gauge.p; a.gauge_nb = P->nb_cam; a.gauge_q = gq;
   }
+  a.Minv = inexact ? P->Minv.p : nullptr;
   a.n = P->n_cams; a.param_dim = P->param_dim; a.x = P->x.p; a.active = P->active.p; a.eta = P->xcg.p; a.b = P->b.p; a.rcg = P->r.p;
   a.Lam = P->Lam.p; a.Tinv = P->Tinv.p; a.x_trial = P->x_trial.p; a.q_trial = P->q_trial.p; a.partials = P->part_cam.p;
   hipLaunchKernelGGL(k_cam_step, dim3(P->nb_cam), dim3(GSFM_BLOCK), 0, P->stream, a);
-  if (reduce) hipLaunchKernelGGL(k_sum_partials_multi, dim3(1), dim3(GSFM_BLOCK), 0, P->stream, P->part_cam.p, P->nb_cam, 5, P->scal.p + SC_STEP);
+  if (reduce) {
+    hipLaunchKernelGGL(k_sum_partials_multi, dim3(1), dim3(GSFM_BLOCK), 0, P->stream, P->part_cam.p, P->nb_cam, 5, P->scal.p + SC_STEP);
+    if (inexact) hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(GSFM_BLOCK), 0, P->stream, P->part_cam.p + (size_t)5 * P->nb_cam, P->nb_cam, P->scal.p + SC_ZL8);
+  }
   return 0;
 }
 
@@ -46,7 +50,7 @@ int evaluate_trial(gsfm_rot_problem* P, bool inexact, double* h) {
     launch_step(P, inexact, false);
     if (int st = launch_cost(P, P->q_trial.p, SC_TRIAL, CostOutputs(), false)) return st;
     hipLaunchKernelGGL(k_trial_post, dim3(1), dim3(GSFM_BLOCK), 0, P->stream, P->scal.p, (int)SC_STEP, (int)SC_TRIAL, (const double*)P->part_cam.p, P->nb_cam,
-                       (const double*)P->part_cost.p, P->nb_cost, (int)SC_N, P->mail_dev, P->mail_count.p);
+                       (const double*)P->part_cost.p, P->nb_cost, (int)SC_N, P->mail_dev, P->mail_count.p, inexact ? (int)SC_ZL8 : -1);
     P->mail_expected += 1.0;
     return mail_wait(P, h, SC_N * sizeof(double));
   }
@@ -126,9 +130,8 @@ int lm_solve(gsfm_rot_problem* P, const gsfm_rot_options& o_in, gsfm_rot_summary
   // the top of the NEXT iteration, so it is copied to pinned memory behind the damping rebuild and read at that iteration's first host
   // synchronisation (the PCG's first look, or the trial cost's) -- one read-back + idle GPU (25-35 us) fewer per accepted step; if the test then
   // fires, the linear solve that was started is discarded (nothing of it had been applied) and the run ends where it would have.  The trace row of
-  // the accepting iteration gets its |g| when it arrives.  GSFM_DEFER_GMAX=0, verbose runs: the round-3 read-back.
-  static const bool defer_env = [] { const char* e = getenv("GSFM_DEFER_GMAX"); return !(e && *e && atoi(e) == 0); }();
-  const bool defer_gmax = defer_env && P->pin && !o.verbose;
+  // the accepting iteration gets its |g| when it arrives.  (Verbose runs: the round-3 read-back, so that every line is complete when printed.)
+  const bool defer_gmax = P->pin && !o.verbose;
   bool gmax_deferred = false;
   size_t gmax_trace_slot = 0;
   volatile double* const gmax_pin = P->pin ? (volatile double*)((char*)P->pin + 256) : nullptr;
@@ -196,7 +199,12 @@ int lm_solve(gsfm_rot_problem* P, const gsfm_rot_options& o_in, gsfm_rot_summary
   // (and not for disconnected graphs: tried on C4 -- the 14-scene batch ended after 30 LM iterations instead of the oracle's 46, 36.8 instead of 86.4 ms: a
   // component that has nearly converged while the batch iterates on gets the share of a loose solve its share of the energy asks for, i.e. none, its
   // cost change vanishes and the global function-tolerance test fires early; the energy norm of the whole step says nothing about one component)
-  const bool forcing = o.pcg_forcing > 0 && P->n_components <= 1 && eps_rad > 0.0 && P->functor != F_QNORM;
+  // (and not under a loss that switches edges OFF -- Tukey: rho' is identically zero beyond a^2 -- or one the library cannot see into, a host callback:
+  // a camera whose edges are all but cut off has next to no weight of its own, so no norm a loose solve can be stopped on -- energy, residual,
+  // block-Jacobi's per-camera estimate -- bounds how far it is left from its exact step, and it is exactly those cameras whose next
+  // linearisation decides which of their edges come back.  tests/manual/fuzz_forcing.py, dense graphs 5:14 / 6:52: 3 to 5 LM iterations, every
+  // step contracting, 8e-7 / 3.6e-6 rad mean and 1e-4 max on a handful of cameras at every per-step tolerance down to 1e-9 rad.  pcg_forcing = 3 forces it on.)
+  const bool forcing = o.pcg_forcing > 0 && P->n_components <= 1 && eps_rad > 0.0 && P->functor != F_QNORM && ((!P->loss_cuts_off && !P->cb) || o.pcg_forcing == 3);
   double pred_rms = -1.0;          // rms size of the last accepted step: the (conservative: steps shrink) prediction of the next one's
   // Contraction gate of the forcing schedule (round 5).  An inexact step leaves the iterate ~eps_rad away from the reference's trajectory; whether
   // that matters at the END is a property of the trajectory: where consecutive steps shrink fast (every benchmark configuration from a sensible
@@ -276,37 +284,11 @@ int lm_solve(gsfm_rot_problem* P, const gsfm_rot_options& o_in, gsfm_rot_summary
         hipLaunchKernelGGL(k_lm_after, dim3(1), dim3(GSFM_BLOCK), 0, P->stream, lo, P->scal.p, (int)SC_GMAX, ctl, P->rec_dev, (int)REC, it_dev, (const double*)P->part_cam.p, P->nb_cam);
         return 0;
       };
-      // The iteration as ONE hipGraph (GSFM_LM_ITER_GRAPH=1; asked for by three reviews): no kernel of it takes a per-iteration argument (radius,
-      // verdicts and the iteration's number live on the device), so the ~60 dependent launches of an exact step and the six behind it replay
-      // without a launch in between -- captured on the second iteration enqueued for a (loss, options, block form, state buffer) (the first one
-      // allocates the factorisation's buffers and builds the Cholesky graph, which cannot happen under a capture).  Measured NEUTRAL on Madrid
-      // (MAGSAC 32.48 against 32.45 ms, SoftL1 23.25 / 23.27, quaternion-Huber 12.66 / 12.64: profiles/r04b_iter_graph_ab.txt) -- the
-      // factorisation already replays as a graph and the six launches behind it are queued while it runs -- so it stays an option, off by
-      // default; bit-identical to the plain pipeline (tests/test_gpu_control_flow.py).
-      static const bool iter_graph_env = [] { const char* e = getenv("GSFM_LM_ITER_GRAPH"); return e && *e && atoi(e) != 0; }();
+      // (The whole iteration as ONE hipGraph -- asked for by three reviews, built in round 4 -- measured neutral on Madrid, 32.48 against 32.45 ms:
+      // the factorisation already replays as a graph and the six launches behind it are queued while it runs.  profiles/r04b_iter_graph_ab.txt; removed in round 5.)
       auto enqueue_exact = [&](int it) -> int {
         const Mute muted(P->timer);
         P->rec_host[REC * (it & 3) + CT_N] = -1.0;   // (the slot's previous user, iteration it - 4, was read long ago)
-        auto& G = P->iter_graph;
-        const bool generic = iter_graph_env && o.pcg_hip_graph && !P->sigma_pending_cost && !P->sigma_pending_lin && !P->pcg_graph.unusable;
-        const double key[9] = {lo.function_tolerance, lo.gradient_tolerance, lo.parameter_tolerance, lo.min_relative_decrease, lo.max_radius, lo.min_radius,
-                               o.min_lm_diagonal, o.max_lm_diagonal, (double)o.jacobi_scaling};
-        // (x_ptr: an accepted HOST-controlled step -- a PCG step between exact ones -- swaps the state buffers; the captured kernels hold addresses)
-        if (G.exec && (G.loss_epoch != P->loss_epoch || G.lap != P->lap || G.x_ptr != (const void*)P->x.p || std::memcmp(G.key, key, sizeof(key)) != 0)) G.reset();
-        if (generic && !G.exec && !G.unusable && G.plain_runs >= 1 && P->have_lin && P->lin_is_lap == P->lap) {
-          hipGraph_t captured = nullptr;
-          if (hipStreamBeginCapture(P->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-            const int st = enqueue_kernels(true);
-            const hipError_t e = hipStreamEndCapture(P->stream, &captured);
-            if (st == 0 && e == hipSuccess && captured && hipGraphInstantiate(&G.exec, captured, nullptr, nullptr, 0) == hipSuccess) {
-              G.loss_epoch = P->loss_epoch; G.lap = P->lap; G.x_ptr = P->x.p; std::memcpy(G.key, key, sizeof(key));
-            } else G.exec = nullptr;
-            if (captured) (void)hipGraphDestroy(captured);
-          }
-          if (!G.exec) { (void)hipGetLastError(); G.unusable = true; }
-        }
-        if (generic && G.exec) { HIPCHK(hipGraphLaunch(G.exec, P->stream)); P->graph_launches++; return 0; }
-        G.plain_runs++;
         return enqueue_kernels(false);
       };
       int eq = 0;
@@ -391,7 +373,25 @@ int lm_solve(gsfm_rot_problem* P, const gsfm_rot_options& o_in, gsfm_rot_summary
     // and COUNTED (gsfm_rot_summary::num_pcg_capped_steps, worst_accepted_cg_residual) -- never silently.
     const bool dense_rescue = !P->sharded && o.dense_cholesky_max_cams > 0 && (int64_t)P->n_cams <= (int64_t)o.dense_cholesky_auto_cams;
     bool dense_failed = false;
-    for (int attempt = 0; attempt < 2; ++attempt) {
+    // Disconnected view graph: the small components factorised exactly, side by side, PCG on the large ones (solver_components.hpp)
+    bool comp_used = false;
+    if (!dense_used && P->n_components > 1 && !P->sharded) {
+      if (int st = run_component_step(P, o, o_in.cg_relative_tolerance, pcg_struggles, &comp_used, &cg, &cg_rel)) return st;
+      if (comp_used) {
+        loose = false;
+        if (gmax_deferred) {
+          if (P->comps.all_dense) { if (int st = sync_check(P, "gradient norm")) return st; }
+          take_gmax();
+          if (gmax <= o.gradient_tolerance) { --iteration; return finish(GSFM_TERM_GRADIENT_TOLERANCE); }
+        }
+        if (int st = evaluate_trial(P, false, h)) return st;
+        int info = 0;
+        std::memcpy(&info, &h[SC_DENSE_INFO], sizeof(int));
+        if (info != 0) { comp_used = false; cg_spent += cg; cg = 0; }   // a component's factor broke down: plain PCG solves the whole step
+        else { sum->num_dense_solves++; dense_used = P->comps.all_dense; }
+      }
+    }
+    for (int attempt = 0; attempt < 2 && !comp_used; ++attempt) {
       if (!dense_used) {
         if (int st = coarse_build(P, pcg_struggles)) return st;
         use_pcg2 = P->coarse_n == 0 && use_single_reduction(P, o);
@@ -406,7 +406,7 @@ int lm_solve(gsfm_rot_problem* P, const gsfm_rot_options& o_in, gsfm_rot_summary
         }
       }
       if (int st = evaluate_trial(P, !dense_used && loose, h)) return st;
-      for (int pass = 0; pass < 3 && !dense_used && loose && cg_rel > o.cg_relative_tolerance; ++pass) {
+      for (int pass = 0; pass < 4 && !dense_used && loose && cg_rel > o.cg_relative_tolerance; ++pass) {
         // The loose step has been evaluated.  Every decision the trust-region loop takes from it must be the one the exact step would give:
         //  * termination (function / parameter tolerance): the decisive quantities -- cost change, step norm -- of the loose step are within
         //    O(tau) of the exact step's (the model decrease even within O(tau^2)), so a value more than a factor two away from its threshold
@@ -427,8 +427,14 @@ int lm_solve(gsfm_rot_problem* P, const gsfm_rot_options& o_in, gsfm_rot_summary
           if (sn <= 2.0 * pt || std::fabs(cc) <= 2.0 * ft || cc / mcc <= std::fmax(o.min_relative_decrease, 0.25)) tight = true;
           else {
             tau_need = std::fmax(kappa * sn / sqrt_n, eps_rad / std::fmax(sn / sqrt_n, 1e-300));
-            if (tau <= 1.5 * tau_need) { sum->num_inexact_steps++; break; }
-            if (tau_need <= 4.0 * o.cg_relative_tolerance || pass == 2) tight = true;
+            // ... and no single camera may be left far from its exact step: block-Jacobi's estimate of what each camera's step still lacks
+            // (k_cam_step's sixth sum, a smooth maximum in radians) is held against 10 x the rms tolerance -- the energy norm does not see a
+            // camera whose weights have all but vanished (kernels.hpp, StepArgs::Minv)
+            const double zmax = std::pow(std::fmax(h[SC_ZL8], 0.0), 0.125) * (P->param_dim == 4 ? 2.0 : 1.0);
+            const bool cams_ok = zmax <= 10.0 * eps_rad;
+            if (!cams_ok) tau_need = std::fmin(tau_need, 0.5 * tau * (10.0 * eps_rad / zmax));
+            if (cams_ok && tau <= 1.5 * tau_need) { sum->num_inexact_steps++; break; }
+            if (tau_need <= 4.0 * o.cg_relative_tolerance || pass == 3) tight = true;
           }
         }
         if (tight) { loose = false; tau = 0.0; } else tau = std::fmin(tau, tau_need);
@@ -483,6 +489,23 @@ int lm_solve(gsfm_rot_problem* P, const gsfm_rot_options& o_in, gsfm_rot_summary
     const double step_norm = std::sqrt(h[SC_STEP + 3]);
     const double cost_change = x_cost - cand_cost;
     const double rel_dec = cost_change / model_cost_change;
+    if (forcing && loose_applied) {
+      // A decision that hangs by less than a factor two -- stop here or go on, take the step or not -- is only the reference's if the POINT it is
+      // taken at is the reference's: under the MAGSAC losses a cost change is a sum of table-cell jumps, and a state 1e-9 rad off moves it by
+      // ten per cent (fuzz_forcing seed 9 trial 87: 0.9e-6 against 1.1e-6 of the cost at the function tolerance of 1e-6 -- 7 LM iterations
+      // against 14, the same rotations).  The run has taken inexact steps, so it is redone with exact ones.
+      // (Only where the decision moves the ANSWER: a candidate that lowers the cost -- stopping leaves it unapplied, going on applies it.  A
+      // rejected candidate changes nothing whichever iteration the run ends at.  And a factor two only where the cost is a staircase; under a
+      // smooth loss the decisive quantities of the two trajectories agree to ~1e-5 relative, the band is one per mille.)
+      const double pt = o.parameter_tolerance * (x_norm + o.parameter_tolerance), ft = o.function_tolerance * x_cost, acc = std::fabs(cost_change);
+      // (the staircase's noise in a cost change falls with the number of edges that make it up: 0.9 against 1.1 at 44k edges, 1.797 against
+      // 1.815 at 300k -- the band is +- 100 / sqrt(E) relative, at most the factor two)
+      const double n_e = (double)std::max<size_t>(1, P->cost.n) * (P->sharded ? (double)P->shard.world_size : 1.0);
+      const double w = P->loss_staircase ? std::fmin(1.0, 100.0 / std::sqrt(n_e)) : 1e-3, lo = 1.0 / (1.0 + w), hi = 1.0 + w;
+      if (cost_change > 0.0 && ((step_norm > lo * pt && step_norm <= hi * pt) || (acc > lo * ft && acc <= hi * ft) || (rel_dec > lo * o.min_relative_decrease && rel_dec <= hi * o.min_relative_decrease))) {
+        record(x_cost, cost_change, step_norm, rel_dec, cg); finish(GSFM_TERM_NO_CONVERGENCE); return GSFM_INTERNAL_RESTART;
+      }
+    }
     if (sum->iters_to_1e6 < 0 && std::fabs(cost_change) <= 1e-6 * x_cost) sum->iters_to_1e6 = iteration;
     if (step_norm <= o.parameter_tolerance * (x_norm + o.parameter_tolerance)) { record(x_cost, cost_change, step_norm, rel_dec, cg); return finish(GSFM_TERM_PARAMETER_TOLERANCE); }
     if (std::fabs(cost_change) <= o.function_tolerance * x_cost) { record(x_cost, cost_change, step_norm, rel_dec, cg); return finish(GSFM_TERM_FUNCTION_TOLERANCE); }

@@ -93,12 +93,11 @@ bool graph_collectives_ok(const gsfm_rot_problem* P, const gsfm_rot_options& o) 
 }
 
 // ---- the PCG's status without a stream synchronisation (kernels.hpp, k_pcg_mail) -----------------------------------------------------------
-// mail_usable: allocates on first use (mapped, coherent host memory + the device counter); GSFM_PCG_MAILBOX=0 keeps the read-backs.
+// mail_usable: allocates on first use (mapped, coherent host memory + the device counter); the read-backs remain the fallback when that fails.
 bool mail_usable(gsfm_rot_problem* P) {
   if (P->mail_state == 0) {
-    static const bool off = [] { const char* e = getenv("GSFM_PCG_MAILBOX"); return e && *e && atoi(e) == 0; }();
     P->mail_state = -1;
-    if (!off && hipHostMalloc((void**)&P->mail_host, (GSFM_MAIL_WORDS + 1) * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) {
+    if (hipHostMalloc((void**)&P->mail_host, (GSFM_MAIL_WORDS + 1) * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) {
       std::memset(P->mail_host, 0, (GSFM_MAIL_WORDS + 1) * sizeof(double));
       if (hipHostGetDevicePointer((void**)&P->mail_dev, P->mail_host, 0) == hipSuccess && P->mail_count.alloc(1, true) == hipSuccess) { P->mail_expected = 0.0; P->mail_state = 1; }
     }
@@ -141,6 +140,13 @@ struct PcgStagnation {
   }
 };
 
+// floor^2 of the absolute tolerance (kernels.hpp, k_cam_bound): 2e-14 rad -- below what a relative residual of 1e-12 leaves on a step of a degree;
+// GSFM_PCG_ABS_FLOOR overrides (0 = off)
+double pcg_abs_floor2() {
+  static const double f = [] { const char* e = getenv("GSFM_PCG_ABS_FLOOR"); return e && *e ? atof(e) : 2e-14; }();
+  return f * f;
+}
+
 // block-Jacobi PCG on (J^T J + Lambda) eta = -g to the relative residual `tol` -- or, etol2 > 0 (a loose solve of the forcing schedule), until the
 // estimated relative energy-norm error squared falls below etol2 (kernels.hpp, cg_energy_stop); returns iterations.  resume_iters >= 0: continue the solve
 // that stopped after that many iterations (at a looser tolerance) instead of starting one -- the device state is exactly what the stopping
@@ -149,8 +155,9 @@ int run_pcg(gsfm_rot_problem* P, const gsfm_rot_options& o, double tol, double e
   const bool resume = resume_iters >= 0;
   CgArgs a{};
   a.n = P->n_cams; a.nb = P->nb_cam; a.par = 0; a.tol = tol; a.etol2 = etol2; a.max_iters = o.max_cg_iterations; a.stall_limit = o.cg_stall_iterations;
-  a.Minv = P->Minv.p; a.b = P->b.p; a.xcg = P->xcg.p; a.r = P->r.p; a.z = P->z.p; a.p = P->p.p; a.Ap = P->Ap.p;
+  a.Minv = P->Minv.p; a.b = P->b_rhs ? P->b_rhs : P->b.p; a.xcg = P->xcg.p; a.r = P->r.p; a.z = P->z.p; a.p = P->p.p; a.Ap = P->Ap.p;
   a.part_a = P->part_a.p; a.part_b = P->part_b.p; a.sc = P->cgsc.p;
+  a.zbound = P->scal.p + SC_ZBOUND; a.abs_floor2 = pcg_abs_floor2();
   a.q = P->q_lin; a.u = P->lin_is_lap ? P->u_rot.p : nullptr;
   a.coarse_n = P->coarse_n; a.coarse_chunk = P->coarse_chunk; a.xc = P->coarse_xc.p; a.active = P->active.p;
   // aggregates at least as wide as a block of the camera kernels (always, unless forced narrower): the restriction rides along in k_cg_update
@@ -249,7 +256,7 @@ int run_pcg(gsfm_rot_problem* P, const gsfm_rot_options& o, double tol, double e
     }
     chunks = std::min(chunks, std::max(1, (o.max_cg_iterations + chunk - launched + chunk - 1) / chunk));
   }
-  *iters_out = h.iters; *rel_out = h.last_rel;
+  *iters_out = h.iters; *rel_out = h.last_rel <= h.tol ? std::fmin(h.last_rel, tol) : h.last_rel;   // (converged against the floor-adjusted tolerance: converged)
   return 0;
 }
 
@@ -260,8 +267,9 @@ int run_pcg2(gsfm_rot_problem* P, const gsfm_rot_options& o, double tol, double 
   Cg2Args c{};
   const int nb_mv = P->nb_mv, reps = P->mv_reps;
   c.n = P->n_cams; c.nb_cam = P->nb_cam; c.n_part_d = (P->sharded || P->cs.active) ? P->nb_cam : nb_mv; c.par = 0; c.first = 1; c.tol = tol; c.etol2 = etol2; c.max_iters = o.max_cg_iterations;
-  c.Minv = P->Minv.p; c.b = P->b.p; c.x = P->xcg.p; c.r = P->r.p; c.u = P->z.p; c.w = P->Ap.p; c.p = P->p.p; c.s = P->s_dir.p;
+  c.Minv = P->Minv.p; c.b = P->b_rhs ? P->b_rhs : P->b.p; c.x = P->xcg.p; c.r = P->r.p; c.u = P->z.p; c.w = P->Ap.p; c.p = P->p.p; c.s = P->s_dir.p;
   c.part_g = P->part_g2.p; c.part_d = P->part_d2.p; c.sc = P->cg2sc.p;
+  c.zbound = P->scal.p + SC_ZBOUND; c.abs_floor2 = pcg_abs_floor2();
   c.q = P->q_lin; c.urot = P->lin_is_lap ? P->u_rot.p : nullptr;
   // Sharded: A u and the delta partials of a rank's rows leave in ONE all-gather (slot = slice of w, then the partials); the mat-vec kernels
   // address y by global camera index, so they get the slot's base shifted back by the rank's first camera.
@@ -361,7 +369,7 @@ int run_pcg2(gsfm_rot_problem* P, const gsfm_rot_options& o, double tol, double 
       chunks = (int)std::min(8.0, std::max(1.0, std::ceil(remaining / chunk)));
     }
   }
-  *iters_out = h.iters; *rel_out = h.last_rel;
+  *iters_out = h.iters; *rel_out = h.last_rel <= h.tol ? std::fmin(h.last_rel, tol) : h.last_rel;   // (converged against the floor-adjusted tolerance: converged)
   return 0;
 }
 

@@ -1,5 +1,5 @@
 """Helper of tests/test_gpu_control_flow.py: a fixed set of solves (PCG steps, every termination kind that is cheap to provoke), results to an .npz.
-The environment of the process selects the host-side control variant (GSFM_PCG_MAILBOX, GSFM_DEFER_GMAX, GSFM_PHASE_TIMERS, GSFM_COL_EVEN)."""
+The environment of the process selects the host-side control variant (GSFM_PHASE_TIMERS)."""
 import os
 import sys
 

@@ -28,23 +28,12 @@ def test_host_control_variants_are_bit_identical(tmp_path):
     # the run on exact data must really end on the gradient tolerance (termination 1), with rejected steps in the far-start run
     assert int(base["exact_data_sum"][1]) == 1, base["exact_data_sum"]
     assert base["far_sum"][6] >= 1
-    variants = {"no_mailbox": dict(GSFM_PCG_MAILBOX=0), "gmax_read_back": dict(GSFM_DEFER_GMAX=0), "timers_on": dict(GSFM_PHASE_TIMERS=1),
-                "round3_control": dict(GSFM_PCG_MAILBOX=0, GSFM_DEFER_GMAX=0, GSFM_PHASE_TIMERS=1),
-                "iteration_graph": dict(GSFM_LM_ITER_GRAPH=1)}   # (exact steps: the whole LM iteration replayed as one hipGraph)
+    # (round 5: the switches for the controls that lost their A/B runs -- read-backs instead of the mailbox, the gradient norm read at once,
+    # the LM iteration as one hipGraph -- are gone with those variants; what remains selectable is the per-phase event timers)
+    variants = {"timers_on": dict(GSFM_PHASE_TIMERS=1), "timers_off": dict(GSFM_PHASE_TIMERS=0)}
     for tag, env in variants.items():
         v = _run(tmp_path, tag, **env)
         for c in CASES:
             for part in ("_rot", "_trace", "_sum"):
                 a, b = base[c + part], v[c + part]
                 assert a.shape == b.shape and np.array_equal(a, b), "%s: %s%s differs from the default control" % (tag, c, part)
-
-
-@pytest.mark.gpu
-def test_graded_task_sizes_change_the_answer_only_by_rounding(tmp_path):
-    base = _run(tmp_path, "graded")
-    even = _run(tmp_path, "even", GSFM_COL_EVEN=1)
-    a, b = base["colsort_sum"], even["colsort_sum"]
-    assert a[0] == b[0] and a[1] == b[1] and abs(a[2] - b[2]) <= 1e-11 * abs(b[2])
-    assert np.abs(base["colsort_rot"] - even["colsort_rot"]).max() <= 1e-9
-    for c in ("magsac", "exact_data", "far", "exact_steps", "broken_factor"):   # (row-major layout: nothing to deal)
-        assert np.array_equal(base[c + "_rot"], even[c + "_rot"])

@@ -60,8 +60,10 @@ def test_device_lm_step_equals_a_direct_solve(oracle, case):
         err, err_t, dmax = np.abs(rd - (x + delta)).max(), np.abs(rt - (x + delta)).max(), np.abs(delta).max()
         print("%s, step %d from the device's own iterate: |delta|_inf = %.2e; |x_dev - (x + delta_direct)|_inf = %.2e with PCG to 1e-12 (%d iterations), %.2e with PCG to 1e-14 (%d)" % (
             name, k + 1, dmax, err, sd["num_cg_iterations"], err_t, st["num_cg_iterations"]))
-        assert err_t <= 1e-10 * dmax, (name, k, err_t)
-        assert err <= 1e-8 * dmax, (name, k, err)
+        # (round 5: no solve runs below the absolute floor of the step -- block-Jacobi's estimate of what any camera still lacks under 2e-14 rad,
+        # kernels.hpp k_cam_bound; the true error is that times the conditioning the docstring speaks of: a few 1e-12 rad at most)
+        assert err_t <= max(1e-10 * dmax, 5e-12), (name, k, err_t)
+        assert err <= max(1e-8 * dmax, 5e-12), (name, k, err)
         if n <= 5333 and not env:
             # the device's own exact step at this size (tiled Cholesky, trailing update on the fp64 matrix cores) against the same direct solve
             rx, sx = dev.solve(x, max_num_iterations=1, dense_cholesky_max_cams=n)

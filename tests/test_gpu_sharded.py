@@ -112,8 +112,10 @@ def test_disconnected_graph_keeps_its_tighter_pcg_tolerance_when_sharded(tmp_pat
     g = two_component_graph()
     p = RotationProblem(g["n_cams"], g["edge_i"], g["edge_j"], g["rel_aa"], _abi.ANGLE_AXIS_COVARIANCE, cov6=g["cov6"])
     p.set_loss(MAGSACWeightBasedLoss(0.02))
-    rot, s = p.solve(g["init_aa"], pcg_single_reduction=0)
-    _, s12 = p.solve(g["init_aa"], pcg_single_reduction=0, cg_relative_tolerance=1e-12)   # (still solved at 1e-14: the floor applies)
+    # (dense_cholesky_max_cams=0: round 5 factorises the small component of an UNSHARDED disconnected problem exactly, solver_components.hpp;
+    # here the one-PCG-over-everything path is what the sharded solve is held against)
+    rot, s = p.solve(g["init_aa"], pcg_single_reduction=0, dense_cholesky_max_cams=0)
+    _, s12 = p.solve(g["init_aa"], pcg_single_reduction=0, cg_relative_tolerance=1e-12, dense_cholesky_max_cams=0)   # (still solved at 1e-14: the floor applies)
     assert s12["num_cg_iterations"] == s["num_cg_iterations"]
     res = _launch(2, "gloo", str(tmp_path / "disc.npz"), case="disconnected")
     assert int(res["iters"]) == s["num_iterations"] and int(res["cg"]) == s["num_cg_iterations"]
