@@ -76,7 +76,9 @@ __global__ void __launch_bounds__(PEER_BLOCK) k_peer_pull(PeerDev d, double* dst
   if (threadIdx.x < (unsigned)d.world) {
     const unsigned long long t0 = wall_clock64();
     while (__hip_atomic_load(d.flags[d.rank] + threadIdx.x, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < call) {
-      if (wall_clock64() - t0 > 500000000ull) { ok = 0; break; }   // ~5 s of the 100 MHz wall clock: a peer that never arrives must not hang the GPU
+      // (a communicator that has timed out once does not wait again: the calls still in flight -- a replayed PCG chunk holds eight of them --
+      // leave at once instead of spending 5 s each; the host fails the solve at its next look)
+      if (*(volatile int*)d.error != 0 || wall_clock64() - t0 > 500000000ull) { ok = 0; break; }   // ~5 s of the 100 MHz wall clock: a peer that never arrives must not hang the GPU
       __builtin_amdgcn_s_sleep(8);
     }
   }

@@ -354,13 +354,27 @@ struct SigmaDev {
   int table_len;
   int on;                 // 1: this launch computes and stores the weights
   double ssm2, one_over_sigma, gk, weight_zero;
+  double inv_ssm2;        // 1 / ssm2 (the fast path of sigma_weight)
 };
+// The reference's arithmetic -- residual = sqrt(s), squared_residual = residual * residual, x = round(1000 * squared_residual / ssm2) -- costs a
+// correctly rounded fp64 square root and division per edge (~45 VALU instructions: the sweep is issue-bound, round-4 SQ counters) for the sake
+// of an INTEGER: the table cell.  Round 5: the cell is taken from t = 1000 s / ssm2 evaluated with one multiplication by the reciprocal,
+// which is within a few ulp of the reference's argument of round() (sqrt-then-square moves s by at most 2 ulp, the reciprocal by 1.5), so it
+// names the same cell unless t lies within ~1e-15 t of a half-integer; lanes closer than 1e-12 t to one (and the ones at the zero-residual
+// test) redo it the reference's way.  Same cell -> the same table entry -> the same weight, bit for bit (tests/test_gpu_round3.py).
 __device__ __forceinline__ double sigma_weight(const SigmaDev& g, double s_unit) {
-  const double residual = sqrt(s_unit);
-  if (residual < 2.220446049250313e-16) return g.weight_zero;
-  const double squared_residual = residual * residual;                 // as written in the reference, not s itself
-  double xf = round(1000.0 * squared_residual / g.ssm2);               // std::round: halves away from zero
-  if (!(xf < (double)(g.table_len - 1))) xf = (double)(g.table_len - 1);  // last stored entry (the reference reads one past it)
+  const double last = (double)(g.table_len - 1);
+  const double t = 1000.0 * s_unit * g.inv_ssm2;
+  double xf = round(t);                                                  // std::round: halves away from zero
+  const double frac = fabs(t - xf);                                      // distance to the nearest integer: 0.5 at a cell boundary
+  const bool sure = s_unit > 1e-30 && (t > last + 1.0 || fabs(frac - 0.5) > 1e-12 * fmax(t, 1.0));
+  if (!sure) {
+    const double residual = sqrt(s_unit);
+    if (residual < 2.220446049250313e-16) return g.weight_zero;
+    const double squared_residual = residual * residual;                 // as written in the reference, not s itself
+    xf = round(1000.0 * squared_residual / g.ssm2);
+  }
+  if (!(xf < last)) xf = last;                                           // last stored entry (the reference reads one past it)
   return g.one_over_sigma * (g.table[(int)xf] - g.gk);
 }
 
@@ -1455,15 +1469,10 @@ __device__ __forceinline__ bool cg_energy_stop(const double* ring, double esum, 
   const double a = ring[(k - 1) & 3] + ring[(k - 2) & 3], b = ring[(k - 3) & 3] + ring[(k - 4) & 3];
   if (!(a < b) || !(a >= 0.0)) return false;   // no decay (or a breakdown): carry on
   const double q = a / b;
-  // (round 5) the tolerance is asked of the step in RADIANS (rms), the energy norm weights a mode by its eigenvalue: the error that is left sits in the
-  // weakest modes the solve has met, where a unit of energy buys sqrt(kappa) times the rotation it buys on average.  kappa is not known; what
-  // is, is the rate the solve converges at right now -- q is the decay of the squared energy error over two iterations, so r = q^(1/4) per
-  // iteration -- and a rate r is what kappa = ((1 + r) / (1 - r))^2 gives.  The estimate is held against 16 etol2 / kappa: nothing for the
-  // well-conditioned systems the schedule was made for (r <= 0.6), and a solve crawling at r = 0.95 goes on 95 x further down -- towards its
-  // tight tolerance, as it should: its energy estimate says least about its rotations.
-  // (a factor sqrt(kappa) <= 4 is inside the margin between the per-step tolerance and the parity bar: the correction starts at kappa = 16, r = 0.6)
-  const double r = sqrt(sqrt(q)), kap = (1.0 + r) / (1.0 - r);
-  return a * q * fmax(1.0, kap * kap * 0.0625) <= etol2 * esum * (1.0 - q);
+  // (Round 5 tried a conditioning correction here -- the estimate held against etol2 / kappa, kappa from the current rate q^(1/4) -- for the
+  // ill-conditioned far-start problems the round-4 fuzz lost.  Those are caught by the contraction gate of lm_solve instead; with it in place
+  // the correction changed no outcome in 420 fuzz trials and cost the spanning-tree start 35 % more iterations: removed.)
+  return a * q <= etol2 * esum * (1.0 - q);
 }
 struct CgArgs {
   uint32_t n;        // cameras

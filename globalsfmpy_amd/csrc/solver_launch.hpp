@@ -188,6 +188,7 @@ int prepare_loss(gsfm_rot_problem* P, const gsfm_loss_node* prog, int n) {
 // the next solve captures afresh, through the callbacks.
 int comm_failed(gsfm_rot_problem* P, const char* what) {
   P->pcg_graph.reset(); P->pcg2_graph.reset();
+  P->shard.flags &= ~GSFM_SHARD_CAPTURABLE;   // ... and whatever it falls back to (host-staged collectives, say) is not assumed to be capturable: plain launches from now on
   return fail(GSFM_ERR_COMM, what);
 }
 int all_gather(gsfm_rot_problem* P, double* buf, size_t count_per_rank) {

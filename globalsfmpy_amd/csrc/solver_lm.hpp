@@ -431,8 +431,9 @@ int lm_solve(gsfm_rot_problem* P, const gsfm_rot_options& o_in, gsfm_rot_summary
             // (k_cam_step's sixth sum, a smooth maximum in radians) is held against 10 x the rms tolerance -- the energy norm does not see a
             // camera whose weights have all but vanished (kernels.hpp, StepArgs::Minv)
             const double zmax = std::pow(std::fmax(h[SC_ZL8], 0.0), 0.125) * (P->param_dim == 4 ? 2.0 : 1.0);
-            const bool cams_ok = zmax <= 10.0 * eps_rad;
-            if (!cams_ok) tau_need = std::fmin(tau_need, 0.5 * tau * (10.0 * eps_rad / zmax));
+            static const double zcap = [] { const char* e = getenv("GSFM_FORCING_ZCAP"); return e && *e ? atof(e) : 100.0; }();
+            const bool cams_ok = zmax <= zcap * eps_rad;
+            if (!cams_ok) tau_need = std::fmin(tau_need, 0.5 * tau * (zcap * eps_rad / zmax));
             if (cams_ok && tau <= 1.5 * tau_need) { sum->num_inexact_steps++; break; }
             if (tau_need <= 4.0 * o.cg_relative_tolerance || pass == 3) tight = true;
           }

@@ -233,3 +233,25 @@ def test_peer_store_exchange_inside_the_captured_pcg_chunks(tmp_path):
     b = _launch(2, "gloo", str(tmp_path / "peer_plain.npz"), mode="peer", extra_env={"GSFM_TEST_PCG_GRAPH": "0"})
     assert int(a["graph_launches"]) > 0 and int(b["graph_launches"]) == 0 and not bool(a["peer_error"])
     assert np.array_equal(a["rot"], b["rot"]) and int(a["cg"]) == int(b["cg"])
+
+
+def test_sharded_equals_unsharded_at_the_default_tolerance_on_a_large_ill_conditioned_graph(tmp_path):
+    """Round-3 advisor's open item: 40 000 cameras / 1.05 M edges (2.1 M directed entries: the unsharded solve takes the textbook recurrence, the
+    sharded one the single-reduction one), spatially coherent and MAGSAC-weighted, DEFAULT options on both sides, to convergence."""
+    res = _launch(2, "gloo", str(tmp_path / "bigcoh.npz"), case="bigcoherent")
+    assert int(res["directed"]) > 2000000
+    print("sharded %d LM / %d PCG (restarts %d, capped %d); unsharded %d LM / %d PCG (restarts %d, capped %d)" % (
+        res["iters"], res["cg"], res["restarts"], res["capped"], res["ref_iters"], res["ref_cg"], res["ref_restarts"], res["ref_capped"]))
+    assert int(res["iters"]) == int(res["ref_iters"]) and int(res["capped"]) == 0 and int(res["ref_capped"]) == 0
+    assert abs(float(res["cost"]) - float(res["ref_cost"])) <= 1e-9 * float(res["ref_cost"])
+    d = synth.angular_distance(synth.align_rotations(res["rot"], res["ref_rot"]), res["ref_rot"])
+    print("rotations: mean %.2e max %.2e rad" % (d.mean(), d.max()))
+    assert d.mean() <= 1e-6
+
+
+def test_peer_store_time_out_fails_the_solve_and_the_next_one_runs_on_the_fallback(tmp_path):
+    res = _launch(2, "gloo", str(tmp_path / "peererr.npz"), mode="peer", case="peererror")
+    failed, flagged, same, few_peer_calls, fallback_used = [int(v) for v in res["flags"]]
+    assert failed == 1, "the solve in which a wait timed out must fail on every rank"
+    assert flagged == 1 and fallback_used == 1 and few_peer_calls == 1
+    assert same == 1 and int(res["iters"]) == int(res["ref_iters"])
