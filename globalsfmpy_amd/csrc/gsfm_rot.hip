@@ -156,7 +156,7 @@ gsfm_status gsfm_rot_solve_sigma_consensus(gsfm_rot_problem* P, double* rot, int
   if (P->cost.n) HIPCHK_S(hipMemsetAsync(P->cost.ws.p, 0, 8 * P->cost.n, P->stream));
   if (!P->sigma_table.p && P->sigma_table.upload(magsac_table(3)) != hipSuccess) return (gsfm_status)fail(GSFM_ERR_HIP, "alloc sigma consensus buffers");
   if (!P->sigma_sum.p && P->sigma_sum.alloc(2, true) != hipSuccess) return (gsfm_status)fail(GSFM_ERR_HIP, "alloc sigma consensus buffers");
-  P->sigma.table = P->sigma_table.p; P->sigma.table_len = c.n; P->sigma.on = 0; P->sigma.ssm2 = squared_sigma_max_2;
+  P->sigma.table = P->sigma_table.p; P->sigma.table_len = c.n; P->sigma.on = 0; P->sigma.ssm2 = squared_sigma_max_2; P->sigma.inv_ssm2 = 1.0 / squared_sigma_max_2;
   P->sigma.one_over_sigma = one_over_sigma; P->sigma.gk = c.gk; P->sigma.weight_zero = weight_zero;
   double global_edges = (double)P->n_edges_in;
   if (P->sharded) {
@@ -449,7 +449,7 @@ gsfm_status gsfm_rot_time_sweep_variants(gsfm_rot_problem* P, const double* rot,
     if (!st) {
       const double sigma_max = 0.02, one_over_sigma = c.C * std::pow(2.0, (c.nu - 1.0) / 2.0) / sigma_max;
       SigmaDev sg{};
-      sg.table = P->sigma_table.p; sg.table_len = c.n; sg.on = 1; sg.ssm2 = 2.0 * sigma_max * sigma_max; sg.one_over_sigma = one_over_sigma;
+      sg.table = P->sigma_table.p; sg.table_len = c.n; sg.on = 1; sg.ssm2 = 2.0 * sigma_max * sigma_max; sg.inv_ssm2 = 1.0 / sg.ssm2; sg.one_over_sigma = one_over_sigma;
       sg.gk = c.gk; sg.weight_zero = one_over_sigma * (std::tgamma((c.nu - 1.0) / 2.0) - c.gk);
       (void)hipMemcpyAsync(keep_c.p, P->cost.ws.p, 8 * P->cost.n, hipMemcpyDeviceToDevice, P->stream);
       (void)hipMemcpyAsync(keep_d.p, P->dir.ws.p, 8 * P->dir.n, hipMemcpyDeviceToDevice, P->stream);

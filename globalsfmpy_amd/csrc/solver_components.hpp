@@ -122,8 +122,7 @@ void comps_enqueue_dense(gsfm_rot_problem* P) {
 int run_component_step(gsfm_rot_problem* P, const gsfm_rot_options& o, double tol_requested, bool pcg_struggles, bool* used, int* cg, double* cg_rel) {
   *used = false; *cg = 0; *cg_rel = 0.0;
   if (P->sharded || P->n_components <= 1 || o.dense_cholesky_max_cams <= 0 || P->cs.active) return 0;
-  static const bool off = [] { const char* e = getenv("GSFM_COMPONENT_SOLVE"); return e && *e && atoi(e) == 0; }();
-  if (off || !comps_build(P, o.dense_cholesky_max_cams)) return 0;
+  if (!comps_build(P, o.dense_cholesky_max_cams)) return 0;
   auto& C = P->comps;
   const int tk = P->timer.begin(T_CG);
   if (C.graph && C.graph_lap != P->lin_is_lap) C.drop_graph();

@@ -19,8 +19,8 @@ int run_dense(gsfm_rot_problem* P, bool* used, bool plain = false) {
   // schedule: one fused kernel per block column (shortest chain for tiny matrices), or panel + MFMA update + one backward launch per block
   // row.  Measured (tools/bench_chol.hip, profiles/r03_bench_chol.txt): 1.42 vs 2.7 ms at 3N = 2400, 3.45 vs 10.2 ms at 4500; at Madrid's
   // 1182 the fused schedule is the faster one inside the solver (37.7 vs 39.3 ms of linear solves per 63 LM iterations), and up to
-  // ~68 block columns in the benchmark (2048: 1.06 vs 1.10 ms), so the switch is at 64 block columns (682 cameras).  GSFM_CHOL_SPLIT_T overrides the switch point (block columns; A/B measurements).
-  static const uint32_t split_T = [] { const char* e = getenv("GSFM_CHOL_SPLIT_T"); const int v = e && *e ? atoi(e) : GSFM_CHOL_SPLIT_DEFAULT; return (uint32_t)std::max(0, std::min(v, GSFM_CHOL_SPLIT_T)); }();
+  // ~68 block columns in the benchmark (2048: 1.06 vs 1.10 ms), so the switch is at 64 block columns (682 cameras).
+  constexpr uint32_t split_T = GSFM_CHOL_SPLIT_DEFAULT;
   auto enqueue = [&]() {
     (void)hipMemsetAsync(P->denseA.p, 0, 8 * elems, P->stream);
     int* const info = (int*)(P->scal.p + SC_DENSE_INFO);

@@ -177,9 +177,9 @@ int lm_solve(gsfm_rot_problem* P, const gsfm_rot_options& o_in, gsfm_rot_summary
   };
   // LM control on the device for exact steps (GSFM_LM_DEVICE_CONTROL=0: the host loop, for A/B and for the bit-identity test): unsharded
   // problems with a native loss on the row-major layout -- the linearisation of the accept path must be enqueueable without the host
-  static const bool device_control_env = [] { const char* e = getenv("GSFM_LM_DEVICE_CONTROL"); return !(e && *e && atoi(e) == 0); }();
+
   bool exact_pipeline_broken = false;   // exact steps turned out impossible (size, memory)
-  const bool device_control = device_control_env && o.lm_device_control != 0 && !P->sharded && !P->cb && !P->cs.active;
+  const bool device_control = o.lm_device_control != 0 && !P->sharded && !P->cb && !P->cs.active;
   // Forcing schedule (gsfm_rot_options::pcg_forcing): steps far from convergence may deviate from the exact step by at most `eps_rad` (rms over the
   // cameras); off for disconnected graphs (their 1e-14 rule stands).
   const double eps_rad = o.pcg_forcing_tolerance, tau_max = 1e-2, sqrt_n = std::sqrt((double)std::max<uint32_t>(1, P->n_cams));
@@ -192,8 +192,7 @@ int lm_solve(gsfm_rot_problem* P, const gsfm_rot_options& o_in, gsfm_rot_summary
   // 97 / 85 / 80 ms, C5 36 / 35 / 34 iterations, the same two misses among 40 random graphs up to 1e-4) and NOT adopted: at 1e-4 the suite's own
   // forcing pass loses a 172-iteration trajectory (trust region creeping up, steps above 0.6 degrees for dozens of iterations: the deviations of
   // consecutive steps add up faster than the slow convergence contracts them -- 5e-4 rad from the oracle, where 5e-6 follows it).
-  // GSFM_FORCING_KAPPA overrides (0 = absolute bound only).
-  static const double kappa = [] { const char* e = getenv("GSFM_FORCING_KAPPA"); return e && *e ? atof(e) : 5e-6; }();
+  constexpr double kappa = 5e-6;   // (swept again under the contraction gate in round 5: 1e-4 / 3e-4 buy the tree start 7 % and lose a 13-iteration MAGSAC trajectory, profiles/r05_kappa_sweep.txt)
   // (not for QUATERNION_NORM: that functor canonicalises the sign of two quaternions separately, quat.hpp:135-142 -- a DISCONTINUOUS residual, where a
   // 1e-8 rad difference in an iterate flips signs the exact schedule does not flip; tests/manual/fuzz_forcing.py found it)
   // (and not for disconnected graphs: tried on C4 -- the 14-scene batch ended after 30 LM iterations instead of the oracle's 46, 36.8 instead of 86.4 ms: a
@@ -217,7 +216,7 @@ int lm_solve(gsfm_rot_problem* P, const gsfm_rot_options& o_in, gsfm_rot_summary
   // violation switches the schedule off for the rest of the run, and if an inexact step has already been applied the run is REDONE from the
   // initial rotations with exact steps (GSFM_INTERNAL_RESTART; typically after two cheap loose steps of a run that needs dozens).  A run that
   // completes under the schedule therefore carries the deviation of its last inexact step plus a geometric tail of the earlier ones.
-  static const double contraction_max = [] { const char* e = getenv("GSFM_FORCING_CONTRACTION"); return e && *e ? atof(e) : 0.3; }();
+  constexpr double contraction_max = 0.3;
   bool forcing_live = forcing, loose_applied = false;
   double prev_accepted_norm = -1.0;
   while (true) {
@@ -301,8 +300,7 @@ int lm_solve(gsfm_rot_problem* P, const gsfm_rot_options& o_in, gsfm_rot_summary
       if (eq == 1) exact_pipeline_broken = true;   // (falls through to the generic path below: PCG)
       else {
         spec_enqueued = false;
-        static const bool ahead = [] { const char* e = getenv("GSFM_LM_ENQUEUE_AHEAD"); return !(e && *e && atoi(e) == 0); }();
-        if (ahead && iteration + 1 <= o.max_num_iterations) {
+        if (iteration + 1 <= o.max_num_iterations) {
           const int e2 = enqueue_exact(iteration + 1);
           if (e2 < 0) return -e2;
           spec_enqueued = e2 == 0;
@@ -431,7 +429,7 @@ int lm_solve(gsfm_rot_problem* P, const gsfm_rot_options& o_in, gsfm_rot_summary
             // (k_cam_step's sixth sum, a smooth maximum in radians) is held against 10 x the rms tolerance -- the energy norm does not see a
             // camera whose weights have all but vanished (kernels.hpp, StepArgs::Minv)
             const double zmax = std::pow(std::fmax(h[SC_ZL8], 0.0), 0.125) * (P->param_dim == 4 ? 2.0 : 1.0);
-            static const double zcap = [] { const char* e = getenv("GSFM_FORCING_ZCAP"); return e && *e ? atof(e) : 100.0; }();
+            constexpr double zcap = 100.0;   // (10 and "off" gave the same 420 fuzz outcomes; 10 cost C5 13 iterations: profiles/r05_fuzz_forcing.txt)
             const bool cams_ok = zmax <= zcap * eps_rad;
             if (!cams_ok) tau_need = std::fmin(tau_need, 0.5 * tau * (zcap * eps_rad / zmax));
             if (cams_ok && tau <= 1.5 * tau_need) { sum->num_inexact_steps++; break; }

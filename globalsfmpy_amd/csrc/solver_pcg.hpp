@@ -140,12 +140,8 @@ struct PcgStagnation {
   }
 };
 
-// floor^2 of the absolute tolerance (kernels.hpp, k_cam_bound): 2e-14 rad -- below what a relative residual of 1e-12 leaves on a step of a degree;
-// GSFM_PCG_ABS_FLOOR overrides (0 = off)
-double pcg_abs_floor2() {
-  static const double f = [] { const char* e = getenv("GSFM_PCG_ABS_FLOOR"); return e && *e ? atof(e) : 2e-14; }();
-  return f * f;
-}
+// floor^2 of the absolute tolerance (kernels.hpp, k_cam_bound): 2e-14 rad -- below what a relative residual of 1e-12 leaves on a step of a degree
+constexpr double pcg_abs_floor2() { return 2e-14 * 2e-14; }
 
 // block-Jacobi PCG on (J^T J + Lambda) eta = -g to the relative residual `tol` -- or, etol2 > 0 (a loose solve of the forcing schedule), until the
 // estimated relative energy-norm error squared falls below etol2 (kernels.hpp, cg_energy_stop); returns iterations.  resume_iters >= 0: continue the solve

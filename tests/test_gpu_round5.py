@@ -143,3 +143,52 @@ def test_forcing_fuzz_known_misses_by_number(oracle, seed, trials):
 def test_forcing_fuzz_short_pass_on_dense_graphs(oracle):
     import fuzz_forcing
     assert fuzz_forcing.run(trials=6, seed=5, dense=True, oracle_every=3) == 0
+
+
+def _batch_of_scenes(sizes, seed0, shuffle_seed=None, deg=10):
+    """Several synthetic scenes as ONE disconnected problem; shuffle_seed: the cameras of all scenes interleaved in one random numbering
+    (components that are not contiguous index ranges)."""
+    scenes = [synth.make_graph(n, deg * n, seed=seed0 + k, outlier_frac=0.1) for k, n in enumerate(sizes)]
+    offs = np.cumsum([0] + [g["n_cams"] for g in scenes])
+    N = int(offs[-1])
+    ei = np.concatenate([g["edge_i"] + o for o, g in zip(offs, scenes)]).astype(np.int64)
+    ej = np.concatenate([g["edge_j"] + o for o, g in zip(offs, scenes)]).astype(np.int64)
+    rel = np.concatenate([g["rel_aa"] for g in scenes]); cov = np.concatenate([g["cov6"] for g in scenes]); init = np.concatenate([g["init_aa"] for g in scenes])
+    comp = np.concatenate([np.full(g["n_cams"], c) for c, g in enumerate(scenes)])
+    if shuffle_seed is not None:
+        perm = np.random.default_rng(shuffle_seed).permutation(N)    # new id of camera k
+        ei, ej = perm[ei], perm[ej]
+        inv = np.empty(N, dtype=np.int64); inv[perm] = np.arange(N)
+        init, comp = init[inv], comp[inv]
+    return N, ei.astype(np.uint32), ej.astype(np.uint32), rel, cov, init, comp
+
+
+@pytest.mark.parametrize("sizes,shuffle", [((300, 700, 120, 450, 64), None), ((300, 700, 120, 450, 64), 3), ((200, 260, 150, 90), 5)])
+def test_disconnected_problem_small_components_factorised_exactly(oracle, sizes, shuffle):
+    """solver_components.hpp: the components of at most 512 cameras are factorised side by side (batched tiled Cholesky), the larger ones solved
+    by PCG on the right-hand side with the others zeroed -- contiguous scenes, scenes interleaved in one random numbering, and a batch in which
+    EVERY component is small (no PCG at all).  Against the oracle per component (each has its own gauge) and against the one-PCG-over-everything
+    path of rounds 1-4 (dense_cholesky_max_cams = 0)."""
+    N, ei, ej, rel, cov, init, comp = _batch_of_scenes(sizes, 700, shuffle)
+    if shuffle is not None:   # a pair whose order the renumbering reversed: first < second again, with the inverse measurement
+        sw = ei > ej
+        rel = rel.copy(); rel[sw] = -rel[sw]
+        ei, ej = np.where(sw, ej, ei).astype(np.uint32), np.where(sw, ei, ej).astype(np.uint32)
+    loss = LF.HuberLoss(0.1)
+    dev = RotationProblem(N, ei, ej, rel, _abi.ANGLE_AXIS_COVTRACE, cov6=cov)
+    dev.set_loss(loss)
+    rd, sd = dev.solve(init)
+    r1, s1 = dev.solve(init, dense_cholesky_max_cams=0)
+    ora = oracle.OracleProblem(N, ei, ej, rel, _abi.ANGLE_AXIS_COVTRACE, cov6=cov)
+    ora.set_loss(loss)
+    ro, so = ora.solve(init)
+    all_small = max(sizes) <= 512
+    print("sizes %s shuffle %s: %d LM it (oracle %d), %d component steps, %d PCG iterations (one PCG over everything: %d)" % (
+        sizes, shuffle, sd["num_iterations"], so["num_iterations"], sd["num_dense_solves"], sd["num_cg_iterations"], s1["num_cg_iterations"]))
+    assert sd["num_iterations"] == so["num_iterations"] == s1["num_iterations"] and sd["num_dense_solves"] == sd["num_iterations"]
+    assert sd["num_pcg_capped_steps"] == 0 and (sd["num_cg_iterations"] == 0) == all_small
+    assert abs(sd["final_cost"] - so["final_cost"]) <= 1e-9 * so["final_cost"]
+    for c in range(len(sizes)):
+        m = comp == c
+        for other in (ro, r1):
+            assert synth.angular_distance(synth.align_rotations(rd[m], other[m]), other[m]).mean() <= 1e-6, c
