@@ -18,8 +18,14 @@ struct CompMap {
 // i.e. when block-Jacobi's estimate of every one of its cameras' steps is below the absolute floor of the step (kernels.hpp, k_cam_bound) -- a
 // scene that converged dozens of LM iterations ago while the batch iterates on.  One workgroup per component over its cameras in a fixed
 // order: the same decision on every run.  (Its A tiles are then neither assembled nor factorised, its step is zero.)
+// Under a SMOOTH loss a component is moreover put to rest for the remainder of the solve once its EXACT step -- the factorisation's, measured
+// by k_comp_scatter: the largest camera update of the component in radians -- has been below `freeze_below` (1e-10 rad): the scenes of a batch
+// are independent problems, a scene whose Newton step is 1e-10 rad has 1e-9 rad left to go at most (steps near convergence contract), three
+// orders inside the parity bar, and factorising it 30 more times while another scene iterates on is what made C4 cost twice the slow scene
+// alone.  Never under the MAGSAC losses (freeze_below = 0): there an iterate 1e-10 rad off can sit in another table cell.
 __global__ void __launch_bounds__(GSFM_BLOCK) k_comp_activity(const uint32_t* __restrict__ cam_ptr, const uint32_t* __restrict__ cams, const double* __restrict__ b,
-                                                              const double* __restrict__ Minv, const double* zbound, double floor2, int* active) {
+                                                              const double* __restrict__ Minv, const double* zbound, double floor2, int* active,
+                                                              unsigned long long* stepmax, int* frozen, double freeze_below) {
   __shared__ double lds[8];
   const uint32_t c = blockIdx.x;
   double v = 0.0;
@@ -31,7 +37,13 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_comp_activity(const uint32_t* __
     v += r[0] * z[0] + r[1] * z[1] + r[2] * z[2];
   }
   const double t = block_sum_bcast(v, lds);
-  if (threadIdx.x == 0) { const double B = *zbound; active[c] = !(B > 0.0) || t * B > floor2; }
+  if (threadIdx.x == 0) {
+    const double B = *zbound;
+    int fr = frozen[c];
+    if (!fr && freeze_below > 0.0 && __longlong_as_double((long long)stepmax[c]) <= freeze_below) fr = 1;   // (last iteration's exact step; +inf before the first)
+    frozen[c] = fr; stepmax[c] = 0ull;
+    active[c] = !fr && (!(B > 0.0) || t * B > floor2);
+  }
 }
 __global__ void __launch_bounds__(GSFM_BLOCK) k_comp_assemble(DenseArgs a, CompMap cm, const CholBatchItem* items) {
   const uint32_t row = blockIdx.x;
@@ -82,7 +94,8 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_comp_mask_rhs(const double* b, C
 // the factorised components' solutions into the step vector (their PCG residual is exactly zero: PCG ran on a zero right-hand side there --
 // or did not run at all: all_dense, then the large components' entries are cleared too), and the first failing factorisation, if any, into
 // the scalar block's status word (the caller then solves the whole step by PCG)
-__global__ void __launch_bounds__(GSFM_BLOCK) k_comp_scatter(CompMap cm, const CholBatchItem* items, uint32_t n_items, uint32_t n, int all_dense, double* eta, double* rcg, double* info_slot) {
+__global__ void __launch_bounds__(GSFM_BLOCK) k_comp_scatter(CompMap cm, const CholBatchItem* items, uint32_t n_items, uint32_t n, int all_dense, double* eta, double* rcg, double* info_slot,
+                                                             const double* __restrict__ Tinv, unsigned long long* stepmax) {
   const uint32_t k = blockIdx.x * GSFM_BLOCK + threadIdx.x;
   if (k == 0) {
     int bad = 0;
@@ -96,6 +109,11 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_comp_scatter(CompMap cm, const C
     const double* x = items[ci].x + 3 * (size_t)cm.loc[k];
 #pragma unroll
     for (int c = 0; c < 3; ++c) { eta[3 * (size_t)k + c] = live ? x[c] : 0.0; rcg[3 * (size_t)k + c] = 0.0; }
+    if (live) {   // the component's largest camera update (delta = Tinv eta, radians; half-angles for the quaternion state): positive doubles order like their bits
+      const double* Ti = Tinv + 9 * (size_t)k;
+      const double d0 = Ti[0] * x[0] + Ti[1] * x[1] + Ti[2] * x[2], d1 = Ti[3] * x[0] + Ti[4] * x[1] + Ti[5] * x[2], d2 = Ti[6] * x[0] + Ti[7] * x[1] + Ti[8] * x[2];
+      atomicMax(stepmax + ci, (unsigned long long)__double_as_longlong(2.0 * sqrt(d0 * d0 + d1 * d1 + d2 * d2)));
+    }
   } else if (all_dense) {
 #pragma unroll
     for (int c = 0; c < 3; ++c) { eta[3 * (size_t)k + c] = 0.0; rcg[3 * (size_t)k + c] = 0.0; }

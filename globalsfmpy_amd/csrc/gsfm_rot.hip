@@ -48,7 +48,7 @@ void gsfm_rot_problem_destroy(gsfm_rot_problem* P) {
   P->timer.destroy();
   P->pcg_graph.reset(); P->pcg2_graph.reset();
   if (P->dense_graph) (void)hipGraphExecDestroy(P->dense_graph);
-  P->comps.drop_graph();
+  P->comps.drop_graph(); P->comps.drop_side();
   if (P->own_stream && P->stream) (void)hipStreamDestroy(P->stream);
   if (P->pin) (void)hipHostFree(P->pin);
   if (P->rec_host) (void)hipHostFree(P->rec_host);
@@ -62,7 +62,7 @@ gsfm_status gsfm_rot_set_stream(gsfm_rot_problem* P, void* s) {
   if (P->own_stream && P->stream) { (void)hipStreamSynchronize(P->stream); (void)hipStreamDestroy(P->stream); }
   P->pcg_graph.reset(); P->pcg_graph.unusable = false; P->pcg2_graph.reset(); P->pcg2_graph.unusable = false;
   if (P->dense_graph) { (void)hipGraphExecDestroy(P->dense_graph); P->dense_graph = nullptr; }
-  P->comps.drop_graph();
+  P->comps.drop_graph(); P->comps.drop_side();
   if (s) { P->stream = (hipStream_t)s; P->own_stream = false; }
   else { if (hipStreamCreateWithFlags(&P->stream, hipStreamNonBlocking) != hipSuccess) return (gsfm_status)fail(GSFM_ERR_HIP, "hipStreamCreate failed"); P->own_stream = true; }
   P->timer.stream = P->stream;

@@ -296,9 +296,22 @@ struct gsfm_rot_problem {
     DevBuf<double> slab, b_pcg;
     DevBuf<int> info, active;          // per item: factorisation status; has anything to solve in this LM step (k_comp_activity)
     DevBuf<uint32_t> item_ptr, item_cams;   // the cameras of every item, item by item
+    DevBuf<unsigned long long> stepmax;     // per item: bits of the largest camera update (rad) of its last exact step
+    DevBuf<int> frozen;                      // per item: put to rest for the remainder of the solve (k_comp_activity)
+    double graph_freeze = -1.0;
     hipGraphExec_t graph = nullptr;
     bool graph_lap = false;
     void drop_graph() { if (graph) (void)hipGraphExecDestroy(graph); graph = nullptr; }
+    // the factorisations run on a stream of their own, beside the PCG solve of the large components (fork / join by events)
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int side_state = 0;   // 0 not tried, 1 usable, -1 unavailable
+    void drop_side() {
+      if (ev_fork) (void)hipEventDestroy(ev_fork);
+      if (ev_join) (void)hipEventDestroy(ev_join);
+      if (side) (void)hipStreamDestroy(side);
+      side = nullptr; ev_fork = ev_join = nullptr; side_state = 0;
+    }
   } comps;
   uint64_t loss_epoch = 0;                // bumped whenever the loss (and with it the choice of kernels) changes
   hipGraphExec_t dense_graph = nullptr;   // zero + assemble + blocked Cholesky + solve, captured once

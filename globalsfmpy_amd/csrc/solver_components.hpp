@@ -81,6 +81,7 @@ bool comps_build(gsfm_rot_problem* P, int cap) {
   item_cams.resize(item_ptr.back());
   { std::vector<uint32_t> fill(item_ptr.begin(), item_ptr.end() - 1); for (uint32_t k = 0; k < P->n_cams; ++k) if (cam_item[k] >= 0) item_cams[fill[cam_item[k]]++] = k; }
   if (C.slab.alloc(words, true) != hipSuccess || C.info.alloc(items.size(), true) != hipSuccess || C.active.alloc(items.size(), true) != hipSuccess ||
+      C.stepmax.alloc(items.size(), true) != hipSuccess || C.frozen.alloc(items.size(), true) != hipSuccess ||
       C.item_ptr.upload(item_ptr) != hipSuccess || C.item_cams.upload(item_cams) != hipSuccess || C.b_pcg.alloc(3 * (size_t)P->n_cams, true) != hipSuccess) {
     (void)hipGetLastError(); C.slab.release(); return false;
   }
@@ -92,52 +93,70 @@ bool comps_build(gsfm_rot_problem* P, int cap) {
 }
 
 // enqueue: clear + assemble + factorise + substitute, all factorised components side by side
-void comps_enqueue_dense(gsfm_rot_problem* P) {
+void comps_enqueue_dense(gsfm_rot_problem* P, hipStream_t st) {
   auto& C = P->comps;
-  (void)hipMemsetAsync(C.slab.p, 0, 8 * C.a_words, P->stream);
-  hipLaunchKernelGGL(k_comp_activity, dim3(C.n_items), dim3(GSFM_BLOCK), 0, P->stream, (const uint32_t*)C.item_ptr.p, (const uint32_t*)C.item_cams.p, (const double*)P->b.p,
-                     (const double*)P->Minv.p, (const double*)(P->scal.p + SC_ZBOUND), pcg_abs_floor2(), C.active.p);
+  (void)hipMemsetAsync(C.slab.p, 0, 8 * C.a_words, st);
+  hipLaunchKernelGGL(k_comp_activity, dim3(C.n_items), dim3(GSFM_BLOCK), 0, st, (const uint32_t*)C.item_ptr.p, (const uint32_t*)C.item_cams.p, (const double*)P->b.p,
+                     (const double*)P->Minv.p, (const double*)(P->scal.p + SC_ZBOUND), pcg_abs_floor2(P), C.active.p, C.stepmax.p, C.frozen.p, comp_freeze_below(P));
   DenseArgs a{};
   a.n_rows = P->n_rows; a.row_ptr = P->row_ptr.p; a.col = P->col.p; a.h0 = P->h0.p; a.h1 = P->h1.p; a.h2 = P->h2.p; a.h3 = P->h3.p; a.h4 = P->h4.p;
   a.Mblk = P->Mblk.p; a.b = P->b.p; a.A = nullptr; a.n = 0; a.T = 0; a.q = P->q_lin; a.lap = P->lin_is_lap; a.info_slot = P->scal.p + SC_DENSE_INFO; a.rcg = P->r.p;
   const CompMap cm{C.cam_item.p, C.cam_loc.p};
-  hipLaunchKernelGGL(k_comp_assemble, dim3(P->n_rows), dim3(GSFM_BLOCK), 0, P->stream, a, cm, (const CholBatchItem*)C.items.p);
+  hipLaunchKernelGGL(k_comp_assemble, dim3(P->n_rows), dim3(GSFM_BLOCK), 0, st, a, cm, (const CholBatchItem*)C.items.p);
   for (uint32_t k = 0; k < C.Tmax; ++k) {
     const uint32_t m = C.Tmax - k, nt = chol_step_tiles_per_wg(m);
     const dim3 grid(chol_step_grid(m, nt), C.n_items);
-    if (nt == 3) hipLaunchKernelGGL(k_chol_step_batch<3>, grid, dim3(256), 0, P->stream, (const CholBatchItem*)C.items.p, k);
-    else if (nt == 2) hipLaunchKernelGGL(k_chol_step_batch<2>, grid, dim3(256), 0, P->stream, (const CholBatchItem*)C.items.p, k);
-    else hipLaunchKernelGGL(k_chol_step_batch<1>, grid, dim3(256), 0, P->stream, (const CholBatchItem*)C.items.p, k);
+    if (nt == 3) hipLaunchKernelGGL(k_chol_step_batch<3>, grid, dim3(256), 0, st, (const CholBatchItem*)C.items.p, k);
+    else if (nt == 2) hipLaunchKernelGGL(k_chol_step_batch<2>, grid, dim3(256), 0, st, (const CholBatchItem*)C.items.p, k);
+    else hipLaunchKernelGGL(k_chol_step_batch<1>, grid, dim3(256), 0, st, (const CholBatchItem*)C.items.p, k);
   }
   constexpr uint32_t GR = 8;
   for (uint32_t g = 0; g * GR < C.Tmax; ++g) {
-    hipLaunchKernelGGL(k_chol_back_group_batch<GR>, dim3(1, C.n_items), dim3(64 * GR), 0, P->stream, (const CholBatchItem*)C.items.p, g);
+    hipLaunchKernelGGL(k_chol_back_group_batch<GR>, dim3(1, C.n_items), dim3(64 * GR), 0, st, (const CholBatchItem*)C.items.p, g);
     const uint32_t k1 = C.Tmax - g * GR, k0 = k1 > GR ? k1 - GR : 0;
-    if (k0) hipLaunchKernelGGL(k_chol_back_update_batch<GR>, dim3(k0, C.n_items), dim3(32 * GR), 0, P->stream, (const CholBatchItem*)C.items.p, g);
+    if (k0) hipLaunchKernelGGL(k_chol_back_update_batch<GR>, dim3(k0, C.n_items), dim3(32 * GR), 0, st, (const CholBatchItem*)C.items.p, g);
   }
 }
 
 // The step of a disconnected problem: *used = false if the path does not apply (the caller then runs its generic one).  On return the step
 // vector and the PCG residual are complete and the status word of the scalar block says whether every factorisation went through.
-int run_component_step(gsfm_rot_problem* P, const gsfm_rot_options& o, double tol_requested, bool pcg_struggles, bool* used, int* cg, double* cg_rel) {
+int run_component_step(gsfm_rot_problem* P, const gsfm_rot_options& o, double tol_requested, bool pcg_struggles, bool first_step, bool* used, int* cg, double* cg_rel) {
   *used = false; *cg = 0; *cg_rel = 0.0;
   if (P->sharded || P->n_components <= 1 || o.dense_cholesky_max_cams <= 0 || P->cs.active) return 0;
   if (!comps_build(P, o.dense_cholesky_max_cams)) return 0;
   auto& C = P->comps;
+  if (first_step) {   // a new solve: nobody is at rest, no step has been measured (+inf)
+    std::vector<unsigned long long> inf(C.n_items, 0x7ff0000000000000ull);
+    HIPCHK(hipMemsetAsync(C.frozen.p, 0, sizeof(int) * C.n_items, P->stream));
+    HIPCHK(hipMemcpyAsync(C.stepmax.p, inf.data(), 8 * C.n_items, hipMemcpyHostToDevice, P->stream));
+    HIPCHK(hipStreamSynchronize(P->stream));   // (the staging vector dies with this scope)
+  }
+  // The factorisations and the PCG solve of the large components touch disjoint outputs and read the same inputs: with something left for PCG
+  // the chain of the factorisations runs on a stream of its own beside it (fork behind the damping's kernels, join in front of the scatter).
+  if (C.side_state == 0) {
+    C.side_state = -1;
+    if (hipStreamCreateWithFlags(&C.side, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&C.ev_fork, hipEventDisableTiming) == hipSuccess &&
+        hipEventCreateWithFlags(&C.ev_join, hipEventDisableTiming) == hipSuccess) C.side_state = 1;
+    else { (void)hipGetLastError(); C.drop_side(); C.side_state = -1; }
+  }
+  const bool beside = !C.all_dense && C.side_state == 1;
+  const hipStream_t ds = beside ? C.side : P->stream;
   const int tk = P->timer.begin(T_CG);
-  if (C.graph && C.graph_lap != P->lin_is_lap) C.drop_graph();
+  if (C.graph && (C.graph_lap != P->lin_is_lap || C.graph_freeze != comp_freeze_below(P))) C.drop_graph();
+  if (beside) { HIPCHK(hipEventRecord(C.ev_fork, P->stream)); HIPCHK(hipStreamWaitEvent(ds, C.ev_fork, 0)); }
   if (!C.graph && o.pcg_hip_graph && !P->pcg_graph.unusable) {
-    C.graph_lap = P->lin_is_lap;
+    C.graph_lap = P->lin_is_lap; C.graph_freeze = comp_freeze_below(P);
     hipGraph_t captured = nullptr;
-    if (hipStreamBeginCapture(P->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-      comps_enqueue_dense(P);
-      if (hipStreamEndCapture(P->stream, &captured) != hipSuccess || !captured || hipGraphInstantiate(&C.graph, captured, nullptr, nullptr, 0) != hipSuccess) C.graph = nullptr;
+    if (hipStreamBeginCapture(ds, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+      comps_enqueue_dense(P, ds);
+      if (hipStreamEndCapture(ds, &captured) != hipSuccess || !captured || hipGraphInstantiate(&C.graph, captured, nullptr, nullptr, 0) != hipSuccess) C.graph = nullptr;
       if (captured) (void)hipGraphDestroy(captured);
     }
     if (!C.graph) (void)hipGetLastError();
   }
-  if (C.graph) { HIPCHK(hipGraphLaunch(C.graph, P->stream)); P->graph_launches++; }
-  else comps_enqueue_dense(P);
+  if (C.graph) { HIPCHK(hipGraphLaunch(C.graph, ds)); P->graph_launches++; }
+  else comps_enqueue_dense(P, ds);
+  if (beside) HIPCHK(hipEventRecord(C.ev_join, ds));
   P->timer.end(tk);
   const CompMap cm{C.cam_item.p, C.cam_loc.p};
   if (!C.all_dense) {
@@ -152,8 +171,9 @@ int run_component_step(gsfm_rot_problem* P, const gsfm_rot_options& o, double to
     if (st) return st;
     if (*cg_rel <= tol) *cg_rel = std::min(*cg_rel, o.cg_relative_tolerance);   // (held against the caller's tolerance afterwards)
   }
+  if (beside) HIPCHK(hipStreamWaitEvent(P->stream, C.ev_join, 0));
   hipLaunchKernelGGL(k_comp_scatter, dim3(grid_for(P->n_cams)), dim3(GSFM_BLOCK), 0, P->stream, cm, (const CholBatchItem*)C.items.p, C.n_items, P->n_cams, C.all_dense ? 1 : 0,
-                     P->xcg.p, P->r.p, P->scal.p + SC_DENSE_INFO);
+                     P->xcg.p, P->r.p, P->scal.p + SC_DENSE_INFO, (const double*)P->Tinv.p, C.stepmax.p);
   *used = true;
   return 0;
 }

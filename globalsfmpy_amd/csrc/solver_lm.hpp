@@ -374,7 +374,7 @@ int lm_solve(gsfm_rot_problem* P, const gsfm_rot_options& o_in, gsfm_rot_summary
     // Disconnected view graph: the small components factorised exactly, side by side, PCG on the large ones (solver_components.hpp)
     bool comp_used = false;
     if (!dense_used && P->n_components > 1 && !P->sharded) {
-      if (int st = run_component_step(P, o, o_in.cg_relative_tolerance, pcg_struggles, &comp_used, &cg, &cg_rel)) return st;
+      if (int st = run_component_step(P, o, o_in.cg_relative_tolerance, pcg_struggles, iteration == 1, &comp_used, &cg, &cg_rel)) return st;
       if (comp_used) {
         loose = false;
         if (gmax_deferred) {

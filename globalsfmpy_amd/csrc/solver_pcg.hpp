@@ -141,7 +141,12 @@ struct PcgStagnation {
 };
 
 // floor^2 of the absolute tolerance (kernels.hpp, k_cam_bound): 2e-14 rad -- below what a relative residual of 1e-12 leaves on a step of a degree
-constexpr double pcg_abs_floor2() { return 2e-14 * 2e-14; }
+// For a DISCONNECTED problem under a smooth loss the floor is 1e-11 rad: its scenes are independent problems that converge at their own pace,
+// and the ones that have converged must stop costing iterations while the slowest iterates on (C4: 13 of 14); what they are left short of is
+// their conditioning times 1e-11 rad, five orders inside the bar.  (Not under MAGSAC: an iterate 1e-11 rad off can sit in another table cell.)
+double pcg_abs_floor2(const gsfm_rot_problem* P) { const double f = (P->n_components > 1 && !P->loss_staircase && !P->cb) ? 1e-11 : 2e-14; return f * f; }
+// ... and a factorised component whose exact step has fallen below this is put to rest for the remainder of the solve (comp_kernels.hpp, k_comp_activity)
+double comp_freeze_below(const gsfm_rot_problem* P) { return (!P->loss_staircase && !P->cb) ? 1e-10 : 0.0; }
 
 // block-Jacobi PCG on (J^T J + Lambda) eta = -g to the relative residual `tol` -- or, etol2 > 0 (a loose solve of the forcing schedule), until the
 // estimated relative energy-norm error squared falls below etol2 (kernels.hpp, cg_energy_stop); returns iterations.  resume_iters >= 0: continue the solve
@@ -153,7 +158,7 @@ int run_pcg(gsfm_rot_problem* P, const gsfm_rot_options& o, double tol, double e
   a.n = P->n_cams; a.nb = P->nb_cam; a.par = 0; a.tol = tol; a.etol2 = etol2; a.max_iters = o.max_cg_iterations; a.stall_limit = o.cg_stall_iterations;
   a.Minv = P->Minv.p; a.b = P->b_rhs ? P->b_rhs : P->b.p; a.xcg = P->xcg.p; a.r = P->r.p; a.z = P->z.p; a.p = P->p.p; a.Ap = P->Ap.p;
   a.part_a = P->part_a.p; a.part_b = P->part_b.p; a.sc = P->cgsc.p;
-  a.zbound = P->scal.p + SC_ZBOUND; a.abs_floor2 = pcg_abs_floor2();
+  a.zbound = P->scal.p + SC_ZBOUND; a.abs_floor2 = pcg_abs_floor2(P);
   a.q = P->q_lin; a.u = P->lin_is_lap ? P->u_rot.p : nullptr;
   a.coarse_n = P->coarse_n; a.coarse_chunk = P->coarse_chunk; a.xc = P->coarse_xc.p; a.active = P->active.p;
   // aggregates at least as wide as a block of the camera kernels (always, unless forced narrower): the restriction rides along in k_cg_update
@@ -265,7 +270,7 @@ int run_pcg2(gsfm_rot_problem* P, const gsfm_rot_options& o, double tol, double 
   c.n = P->n_cams; c.nb_cam = P->nb_cam; c.n_part_d = (P->sharded || P->cs.active) ? P->nb_cam : nb_mv; c.par = 0; c.first = 1; c.tol = tol; c.etol2 = etol2; c.max_iters = o.max_cg_iterations;
   c.Minv = P->Minv.p; c.b = P->b_rhs ? P->b_rhs : P->b.p; c.x = P->xcg.p; c.r = P->r.p; c.u = P->z.p; c.w = P->Ap.p; c.p = P->p.p; c.s = P->s_dir.p;
   c.part_g = P->part_g2.p; c.part_d = P->part_d2.p; c.sc = P->cg2sc.p;
-  c.zbound = P->scal.p + SC_ZBOUND; c.abs_floor2 = pcg_abs_floor2();
+  c.zbound = P->scal.p + SC_ZBOUND; c.abs_floor2 = pcg_abs_floor2(P);
   c.q = P->q_lin; c.urot = P->lin_is_lap ? P->u_rot.p : nullptr;
   // Sharded: A u and the delta partials of a rank's rows leave in ONE all-gather (slot = slice of w, then the partials); the mat-vec kernels
   // address y by global camera index, so they get the slot's base shifted back by the rank's first camera.
