@@ -440,13 +440,13 @@ def main():
 
     pmc, pmc_note = None, None
     try:  # committed PMC measurement (bench.py cannot run rocprofv3 on itself): used only if it was taken on THESE kernel sources and this workload
-        path = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")
+        path = os.path.join(ROOT, "profiles", "r05_pmc_traffic.json")
         if os.path.exists(path):
             pm = json.load(open(path))
             if world == 1 and pm["workload"] == {"cams": n_cams, "edges": n_edges} and pm.get("kernel_source_sha16") == kernel_source_sha16():
-                pmc = (pm, "profiles/r04_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH x2 gfx950 correction; kernel sources %s)" % pm["kernel_source_sha16"])
+                pmc = (pm, "profiles/r05_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH x2 gfx950 correction; kernel sources %s)" % pm["kernel_source_sha16"])
             else:
-                pmc_note = "profiles/r04_pmc_traffic.json is for other kernel sources or another workload: not reported"
+                pmc_note = "profiles/r05_pmc_traffic.json is for other kernel sources or another workload: not reported"
     except Exception:
         pass
 
