@@ -127,7 +127,12 @@ typedef struct {
                                           Looser values are a documented trade: on the C5 graph
                                           1e-8 halves the PCG work and moves the solution by 3e-10 rad (mean), but on the
                                           ill-conditioned real Madrid graph 1e-10 already costs 1e-6 rad mid-trajectory.
-                                          A DISCONNECTED view graph (several scenes batched as one problem) is never solved looser than
+                                          Absolute floor (round 5): no solve runs below the point where block-Jacobi's estimate of what ANY camera's
+                                          update still lacks is under 2e-14 rad (a relative 1e-12 of a one-degree step leaves more) -- 1e-11 rad for a
+                                          disconnected problem under a smooth loss, whose converged scenes must not cost iterations while another iterates.
+                                          A DISCONNECTED view graph (several scenes batched as one problem) is solved per connected component when
+                                          unsharded: components of at most dense_cholesky_max_cams cameras by exact factorisations side by side, the
+                                          others by PCG (csrc/solver_components.hpp); where one PCG still covers several components it is never solved looser than
                                           1e-14: the residual norm is global, and a component that has already converged would otherwise be
                                           left with an error that is large against its own right-hand side (measured: 3e-5 rad on the real
                                           Madrid component of the 14-scene batch at 1e-12, 4e-9 rad at 1e-14, for 9 % more iterations).
@@ -190,7 +195,20 @@ typedef struct {
                                           an iteration cap allows is always solved tightly.  Not applied to disconnected graphs (their 1e-14 rule
                                           above stands), to exact Cholesky steps, or to QUATERNION_NORM (a discontinuous residual: its sign
                                           canonicalisation flips under differences the schedule allows).
-                                          0: every step at cg_relative_tolerance (rounds 1-3).  2 (a testing aid): every loose solve is continued
+                                          ROUND 5 -- the schedule is kept only where it cannot move the answer: loose solves are taken only while
+                                          every accepted step so far was at most 0.3 x its predecessor (the benchmark configurations: 0.06-0.21;
+                                          far starts under redescending or cut-off losses: 0.3-0.95 for dozens of iterations, where nothing injected
+                                          early is forgotten and -- MAGSAC: rho and rho' are piecewise constant in s -- one edge moved across a
+                                          table cell puts the run on another self-consistent weighting).  The first violation switches the schedule
+                                          off for the rest of the run, and a run that has already applied an inexact step is REDONE from the initial
+                                          rotations with exact steps (gsfm_rot_summary::num_forcing_restarts; bit-identical to pcg_forcing = 0).  Also
+                                          redone: a run whose termination / acceptance decision on a cost-lowering candidate hangs by less than the
+                                          noise of the loss (MAGSAC: +- 100 / sqrt(edges), at most a factor two; smooth losses: one per mille).  Every
+                                          loose step is moreover checked camera by camera (block-Jacobi's estimate of what each camera's update still
+                                          lacks: below 1e-6 rad).  Not applied under a loss that switches edges off (Tukey) or one the library cannot
+                                          see into (a host callback).  tests/manual/fuzz_forcing.py, 420 default-option trials: none beyond 1e-6 rad.
+                                          0: every step at cg_relative_tolerance (rounds 1-3).  3: as 1, also under Tukey / callback losses (testing).
+                                          2 (a testing aid): every loose solve is continued
                                           to cg_relative_tolerance whatever its evaluation says -- the solve must then reproduce pcg_forcing = 0
                                           bit for bit, PCG iteration counts included (tests/test_gpu_round4.py). */
   int32_t dense_cholesky_auto_cams;    /* default 5333 (the largest matrix the exact step supports; 0 = off): graphs with more than
