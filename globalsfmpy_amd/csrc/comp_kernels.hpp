@@ -91,6 +91,15 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_comp_mask_rhs(const double* b, C
 #pragma unroll
   for (int c = 0; c < 3; ++c) b_pcg[3 * (size_t)k + c] = dense ? 0.0 : b[3 * (size_t)k + c];
 }
+// out = b on the cameras [lo, hi), zero elsewhere: the right-hand side of a rank's own PCG on a PACKED sharded problem (problem_create.hpp) -- x, r, z
+// and p then stay exactly zero on the other ranks' cameras and every dot product is the rank's own
+__global__ void __launch_bounds__(GSFM_BLOCK) k_mask_range(const double* b, uint32_t lo, uint32_t hi, uint32_t n, double* out) {
+  const uint32_t k = blockIdx.x * GSFM_BLOCK + threadIdx.x;
+  if (k >= n) return;
+  const bool own = k >= lo && k < hi;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) out[3 * (size_t)k + c] = own ? b[3 * (size_t)k + c] : 0.0;
+}
 // the factorised components' solutions into the step vector (their PCG residual is exactly zero: PCG ran on a zero right-hand side there --
 // or did not run at all: all_dense, then the large components' entries are cleared too), and the first failing factorisation, if any, into
 // the scalar block's status word (the caller then solves the whole step by PCG)

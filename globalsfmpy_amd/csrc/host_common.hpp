@@ -317,6 +317,9 @@ struct gsfm_rot_problem {
   hipGraphExec_t dense_graph = nullptr;   // zero + assemble + blocked Cholesky + solve, captured once
   bool dense_graph_lap = false;           // form of the blocks the captured assemble kernel expects
   int nb_mv = 1, mv_reps = 1;
+  bool packed = false;        // sharded: no rank holds an edge that leaves its slice (whole components per rank): every rank runs its own PCG, no collective in the loop
+  bool pcg_local = false;     //   ... set while such a PCG runs: the mat-vec does not gather
+  DevBuf<double> b_own;       //   ... its right-hand side: b with the other ranks' cameras zeroed
   uint32_t n_components = 1;  // connected components of the view graph (1 when sharded: a rank sees only its own edges)
   DevBuf<double> part_a, part_b, part_cost, part_cam, part_gauge, scal;
   DevBuf<CgScalars> cgsc;

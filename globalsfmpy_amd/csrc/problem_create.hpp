@@ -563,7 +563,7 @@ static gsfm_status problem_create_impl(uint32_t n_cams, uint64_t n_edges, const 
   ok &= P->Mblk.alloc(6 * N) == hipSuccess; ok &= P->Minv.alloc(6 * N) == hipSuccess; ok &= P->Lam.alloc(6 * N) == hipSuccess;
   ok &= P->Tinv.alloc(9 * N) == hipSuccess; ok &= P->b.alloc(3 * N) == hipSuccess; ok &= P->D6.alloc(6 * N) == hipSuccess;
   ok &= P->q.alloc(2 * N) == hipSuccess; ok &= P->q_trial.alloc(2 * N) == hipSuccess;
-  ok &= P->xcg.alloc(3 * N) == hipSuccess; ok &= P->r.alloc(3 * N) == hipSuccess; ok &= P->z.alloc(3 * N) == hipSuccess;
+  ok &= P->xcg.alloc(3 * NP, true) == hipSuccess; ok &= P->r.alloc(3 * NP, true) == hipSuccess; ok &= P->z.alloc(3 * N) == hipSuccess;   // (xcg, r: padded like p / Ap -- a packed sharded problem all-gathers them)
   ok &= P->p.alloc(3 * NP, true) == hipSuccess; ok &= P->Ap.alloc(3 * NP, true) == hipSuccess; ok &= P->u_rot.alloc(3 * NP, true) == hipSuccess;
   {
     const char* env = getenv("GSFM_LAPLACIAN");   // =0: keep the general 9-value blocks (A/B measurements)
@@ -638,6 +638,20 @@ static gsfm_status problem_create_impl(uint32_t n_cams, uint64_t n_edges, const 
     uint32_t comps = 0;
     for (uint32_t c = 0; c < NP; ++c) if (act[c] != 0.0 && find(c) == c) ++comps;
     P->n_components = std::max<uint32_t>(std::max<uint32_t>(1, comps), (P->shard.flags & GSFM_SHARD_DISCONNECTED) ? 2u : 1u);
+    // PACKED (round 5; SURVEY 8(e): "whole components can be packed per GPU => zero cross-GPU coupling except the scalar cost"): no rank holds an
+    // edge that leaves its own slice -- every camera a rank's edges touch, and the label they gave it, lies in that rank's slice.  Read off the
+    // gathered labels, so every rank arrives at the same verdict without another collective.  The normal matrix is then block diagonal ACROSS
+    // the ranks and each rank solves its own block with its own PCG (solver_pcg.hpp): no collective inside the PCG loop at all.
+    bool packed = P->n_components > 1;
+    for (int r = 0; r < P->shard.world_size && packed; ++r) {
+      const uint64_t lo = std::min<uint64_t>((uint64_t)r * P->shard.slice_width, NP), hi = std::min<uint64_t>((uint64_t)(r + 1) * P->shard.slice_width, NP);
+      for (uint32_t c = 0; c < NP; ++c) {
+        const uint32_t l = (uint32_t)all[(size_t)r * NP + c];
+        if (l != c && !(c >= lo && c < hi && l >= lo && l < hi)) { packed = false; break; }
+      }
+    }
+    P->packed = packed;
+    if (packed) P->coarse_want = 0;   // (its coarse matrix is an all-reduce per LM step and its use a decision taken from the iteration counts, which now differ from rank to rank)
   }
   *live = nullptr;
   *out = P;

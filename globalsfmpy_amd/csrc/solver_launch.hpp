@@ -371,11 +371,11 @@ int launch_matvec(gsfm_rot_problem* P, const double* Mblk, const double* p, doub
     f.n_rows = P->n_rows; f.row_base = P->own_begin; f.nch = c.nch; f.n_wg = c.n_wg; f.part = c.part.p; f.Mblk = Mblk; f.p = p; f.q = P->q_lin; f.y = y; f.done = done;
     if (dot_part && !P->sharded) { f.dot_part = dot_part; *dot_done = true; }   // (one GPU: rows = cameras, the finish grid is the camera kernels' grid)
     hipLaunchKernelGGL(k_mv_col_finish, dim3(grid_for(P->n_rows)), dim3(GSFM_BLOCK), 0, P->stream, f);
-    return all_gather(P, y, (size_t)P->shard.slice_width * 3);
+    return P->pcg_local ? 0 : all_gather(P, y, (size_t)P->shard.slice_width * 3);
   }
   if (P->lin_is_lap) hipLaunchKernelGGL(k_matvec<true>, dim3(grid_for((size_t)P->n_rows * P->G)), dim3(GSFM_BLOCK), 0, P->stream, a);
   else hipLaunchKernelGGL(k_matvec<false>, dim3(grid_for((size_t)P->n_rows * P->G)), dim3(GSFM_BLOCK), 0, P->stream, a);
-  return all_gather(P, y, (size_t)P->shard.slice_width * 3);
+  return P->pcg_local ? 0 : all_gather(P, y, (size_t)P->shard.slice_width * 3);
 }
 
 }  // namespace

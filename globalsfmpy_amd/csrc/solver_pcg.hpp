@@ -154,6 +154,15 @@ double comp_freeze_below(const gsfm_rot_problem* P) { return (!P->loss_staircase
 // iteration left (kernels.hpp, CgScalars::done_seen), so the iterates are those of an uninterrupted solve at `tol`.
 int run_pcg(gsfm_rot_problem* P, const gsfm_rot_options& o, double tol, double etol2, int resume_iters, int* iters_out, double* rel_out) {
   const bool resume = resume_iters >= 0;
+  // PACKED sharded problem: this rank's own block of a block-diagonal system, solved without a collective -- right-hand side zero outside the
+  // rank's cameras (everything the recurrence touches stays zero there), mat-vec without the gather; the step and the residual are gathered
+  // once, behind the solve.  The ranks' solves end after different iteration counts: nothing in the LM loop is decided from them.
+  struct LocalScope { gsfm_rot_problem* P; bool on; ~LocalScope() { if (on) { P->pcg_local = false; P->b_rhs = nullptr; } } } local{P, P->sharded && P->packed};
+  if (local.on) {
+    if (!P->b_own.p && P->b_own.alloc(3 * (size_t)P->n_cams, true) != hipSuccess) return fail(GSFM_ERR_HIP, "allocating the rank-local right-hand side failed");
+    if (!resume) hipLaunchKernelGGL(k_mask_range, dim3(grid_for(P->n_cams)), dim3(GSFM_BLOCK), 0, P->stream, (const double*)P->b.p, P->own_begin, P->own_end, P->n_cams, P->b_own.p);
+    P->b_rhs = P->b_own.p; P->pcg_local = true;
+  }
   CgArgs a{};
   a.n = P->n_cams; a.nb = P->nb_cam; a.par = 0; a.tol = tol; a.etol2 = etol2; a.max_iters = o.max_cg_iterations; a.stall_limit = o.cg_stall_iterations;
   a.Minv = P->Minv.p; a.b = P->b_rhs ? P->b_rhs : P->b.p; a.xcg = P->xcg.p; a.r = P->r.p; a.z = P->z.p; a.p = P->p.p; a.Ap = P->Ap.p;
@@ -187,7 +196,7 @@ int run_pcg(gsfm_rot_problem* P, const gsfm_rot_options& o, double tol, double e
   auto enqueue_iter = [&]() -> int {
     bool dotted = false;
     if (int st = launch_matvec(P, P->Mblk.p, P->p.p, P->Ap.p, &P->cgsc.p->done, a.part_a, &dotted)) return st;
-    if (P->sharded) P->n_pcg_collectives++;
+    if (P->sharded && !P->pcg_local) P->n_pcg_collectives++;
     if (!dotted) hipLaunchKernelGGL(k_cg_dot, g, blk, 0, P->stream, a);
     hipLaunchKernelGGL(k_cg_update, g, blk, 0, P->stream, a);
     if (a.coarse_n) {
@@ -206,7 +215,7 @@ int run_pcg(gsfm_rot_problem* P, const gsfm_rot_options& o, double tol, double e
   };
   // The chunk between two host checks as one hipGraph launch: 4 * chunk dependent kernels whose arguments never change.
   auto& G = P->pcg_graph;
-  bool graph = o.pcg_hip_graph && (!P->sharded || graph_collectives_ok(P, o)) && chunk % 2 == 0 && !G.unusable;
+  bool graph = o.pcg_hip_graph && (!P->sharded || P->pcg_local || graph_collectives_ok(P, o)) && chunk % 2 == 0 && !G.unusable;
   // (the tolerance is device-resident, CgScalars::tol: a captured chunk serves every tolerance)
   if (graph && (!G.exec || G.max_iters != a.max_iters || G.stall != a.stall_limit || G.chunk != chunk || G.lap != P->lin_is_lap || G.coarse != a.coarse_n)) {
     G.reset();
@@ -258,6 +267,10 @@ int run_pcg(gsfm_rot_problem* P, const gsfm_rot_options& o, double tol, double e
     chunks = std::min(chunks, std::max(1, (o.max_cg_iterations + chunk - launched + chunk - 1) / chunk));
   }
   *iters_out = h.iters; *rel_out = h.last_rel <= h.tol ? std::fmin(h.last_rel, tol) : h.last_rel;   // (converged against the floor-adjusted tolerance: converged)
+  if (local.on) {   // every rank's block of the step and of the residual, to everybody (the LM scalars are computed replicated)
+    if (int st = all_gather(P, P->xcg.p, (size_t)P->shard.slice_width * 3)) return st;
+    if (int st = all_gather(P, P->r.p, (size_t)P->shard.slice_width * 3)) return st;
+  }
   return 0;
 }
 

@@ -114,6 +114,35 @@ def big_coherent_case(out, prefer_native):
     dist.destroy_process_group()
 
 
+def packed_case(out, prefer_native):
+    """Six scenes as one disconnected problem, whole components per rank (sharding.pack_components): the library finds that no rank holds an
+    edge leaving its slice (PACKED) and every rank solves its own block with its own PCG -- no collective inside the PCG loop."""
+    import torch.distributed as dist
+    from globalsfmpy_amd import loss_functions as LF
+    from globalsfmpy_amd.solver import RotationProblem
+    sizes = [700, 300, 900, 250, 620, 410]
+    scenes = [synth.make_graph(n, 12 * n, seed=900 + k, outlier_frac=0.1) for k, n in enumerate(sizes)]
+    offs = np.cumsum([0] + sizes)
+    g = {"n_cams": int(offs[-1])}
+    for k in ("rel_aa", "cov6", "inlier_weight", "init_aa", "gt_aa"):
+        g[k] = np.concatenate([s_[k] for s_ in scenes])
+    g["edge_i"] = np.concatenate([s_["edge_i"] + o for o, s_ in zip(offs, scenes)]).astype(np.uint32)
+    g["edge_j"] = np.concatenate([s_["edge_j"] + o for o, s_ in zip(offs, scenes)]).astype(np.uint32)
+    loss = LF.HuberLoss(0.1)
+    prob, part = sharding.make_sharded_problem(g, _abi.ANGLE_AXIS_COVTRACE, loss=loss, prefer_native=prefer_native)
+    rot, summ = prob.solve(part.scatter(g["init_aa"]))
+    import torch
+    cg = torch.tensor([summ["num_pcg_collectives"], summ["num_cg_iterations"]], dtype=torch.int64)
+    lo = cg.clone(); dist.all_reduce(cg, op=dist.ReduceOp.MAX); dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    if dist.get_rank() == 0:
+        ref = RotationProblem(g["n_cams"], g["edge_i"], g["edge_j"], g["rel_aa"], _abi.ANGLE_AXIS_COVTRACE, cov6=g["cov6"]); ref.set_loss(loss)
+        r1, s1 = ref.solve(g["init_aa"])
+        np.savez(out, rot=part.gather(rot), ref_rot=r1, cost=summ["final_cost"], ref_cost=s1["final_cost"], iters=summ["num_iterations"], ref_iters=s1["num_iterations"],
+                 pcg_collectives_max=int(cg[0]), cg_max=int(cg[1]), cg_min=int(lo[1]), collectives=summ["num_collectives"], offs=offs, capped=summ["num_pcg_capped_steps"])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def peer_error_case(out):
     """A peer-store wait that times out (injected on rank 0) fails THAT solve on every rank -- rank 0 at its next collective call, the others after
     their own 5 s bound, because rank 0 has stopped storing -- and every later call of the communicator goes to its fallback collectives:
@@ -166,6 +195,8 @@ def main():
         return coarse_case(out, len(sys.argv) > 3 and sys.argv[3] == "native")
     if case == "bigcoherent":
         return big_coherent_case(out, len(sys.argv) > 3 and sys.argv[3] == "native")
+    if case == "packed":
+        return packed_case(out, len(sys.argv) > 3 and sys.argv[3] == "native")
     if case == "peererror":
         return peer_error_case(out)
     if case.startswith("random"):

@@ -255,3 +255,19 @@ def test_peer_store_time_out_fails_the_solve_and_the_next_one_runs_on_the_fallba
     assert failed == 1, "the solve in which a wait timed out must fail on every rank"
     assert flagged == 1 and fallback_used == 1 and few_peer_calls == 1
     assert same == 1 and int(res["iters"]) == int(res["ref_iters"])
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_packed_components_solve_without_a_collective_in_the_pcg_loop(tmp_path, world):
+    """SURVEY 8(e) / round-4 review item 3: six scenes, whole components per rank -- num_pcg_collectives == 0 on every rank, the ranks' own PCG
+    solves end after different iteration counts, the answer equals the single-GPU solve per component."""
+    res = _launch(world, "gloo", str(tmp_path / ("packed%d.npz" % world)), case="packed")
+    print("packed, %d ranks: %d LM iterations (one GPU: %d), PCG iterations per rank %d..%d, %d collectives per solve, none in the PCG loop" % (
+        world, res["iters"], res["ref_iters"], res["cg_min"], res["cg_max"], res["collectives"]))
+    assert int(res["pcg_collectives_max"]) == 0 and int(res["capped"]) == 0
+    assert int(res["iters"]) == int(res["ref_iters"])
+    assert abs(float(res["cost"]) - float(res["ref_cost"])) <= 1e-9 * float(res["ref_cost"])
+    offs = res["offs"]
+    for c in range(len(offs) - 1):
+        sl = slice(int(offs[c]), int(offs[c + 1]))
+        assert synth.angular_distance(synth.align_rotations(res["rot"][sl], res["ref_rot"][sl]), res["ref_rot"][sl]).mean() <= 1e-6, c
