@@ -13,6 +13,7 @@ namespace gsfm {
 struct CompMap {
   const int32_t* item;    // per camera: index of its component in the batch, -1: not factorised (a large component, a camera without edges)
   const uint32_t* loc;    // per camera: its index inside its component
+  uint32_t row_base;      // camera of row 0 (a rank of a packed sharded problem holds the rows of its own cameras only)
 };
 // Which factorised components have anything to solve in this LM step: component c is skipped when sum_{k in c} b_k . Minv_k b_k <= floor^2 / B,
 // i.e. when block-Jacobi's estimate of every one of its cameras' steps is below the absolute floor of the step (kernels.hpp, k_cam_bound) -- a
@@ -46,9 +47,10 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_comp_activity(const uint32_t* __
   }
 }
 __global__ void __launch_bounds__(GSFM_BLOCK) k_comp_assemble(DenseArgs a, CompMap cm, const CholBatchItem* items) {
-  const uint32_t row = blockIdx.x;
-  if (row >= a.n_rows) return;
-  if (row == 0 && threadIdx.x == 3) *a.info_slot = 0.0;
+  const uint32_t lrow = blockIdx.x;                 // row of the stored blocks
+  if (lrow >= a.n_rows) return;
+  const uint32_t row = cm.row_base + lrow;          // its camera
+  if (lrow == 0 && threadIdx.x == 3) *a.info_slot = 0.0;
   const int32_t ci = cm.item[row];
   if (ci < 0) return;
   const CholBatchItem it = items[ci];
@@ -61,7 +63,7 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_comp_assemble(DenseArgs a, CompM
     for (int c = 0; c < 3; ++c) it.A[(((size_t)it.T * (it.T + 1) / 2) + (3 * lr + c) / 32) * 1024 + (3 * lr + c) % 32] = a.b[3 * (size_t)row + c];
     if (lr == 0) { for (uint32_t g = it.n; g < it.T * 32; ++g) *dense_elem(it.A, g, g) = 1.0; *it.info = 0; }   // padding of the last tile: identity
   }
-  for (uint32_t d = a.row_ptr[row] + threadIdx.x; d < a.row_ptr[row + 1]; d += GSFM_BLOCK) {
+  for (uint32_t d = a.row_ptr[lrow] + threadIdx.x; d < a.row_ptr[lrow + 1]; d += GSFM_BLOCK) {
     const uint32_t m = a.col[d] & 0x7fffffffu;
     if (m >= row) continue;   // upper triangle; (m and row are in the same component: cm.item[m] == ci)
     const uint32_t lm = cm.loc[m];
@@ -104,12 +106,13 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_mask_range(const double* b, uint
 // or did not run at all: all_dense, then the large components' entries are cleared too), and the first failing factorisation, if any, into
 // the scalar block's status word (the caller then solves the whole step by PCG)
 __global__ void __launch_bounds__(GSFM_BLOCK) k_comp_scatter(CompMap cm, const CholBatchItem* items, uint32_t n_items, uint32_t n, int all_dense, double* eta, double* rcg, double* info_slot,
-                                                             const double* __restrict__ Tinv, unsigned long long* stepmax) {
+                                                             const double* __restrict__ Tinv, unsigned long long* stepmax, double* bad_flag) {
   const uint32_t k = blockIdx.x * GSFM_BLOCK + threadIdx.x;
   if (k == 0) {
     int bad = 0;
     for (uint32_t c = 0; c < n_items && !bad; ++c) bad = *items[c].info;
     __builtin_memcpy(info_slot, &bad, sizeof(int));
+    if (bad_flag) *bad_flag = bad ? 1.0 : 0.0;   // (packed sharded problems: summed over the ranks, so that all of them fall back together)
   }
   if (k >= n) return;
   const int32_t ci = cm.item[k];

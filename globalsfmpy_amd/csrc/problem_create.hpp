@@ -651,6 +651,18 @@ static gsfm_status problem_create_impl(uint32_t n_cams, uint64_t n_edges, const 
       }
     }
     P->packed = packed;
+    if (packed) {   // this rank's own components, for the per-component step (solver_components.hpp): labels of its own cameras that carry an edge
+      auto& C = P->comps;
+      C.comp_of.assign(n_cams, 0xffffffffu); C.size.clear();
+      std::vector<uint32_t> id_of_root(NP, 0xffffffffu);
+      for (uint32_t c = P->own_begin; c < P->own_end; ++c) {
+        if (act[c] == 0.0) continue;
+        const uint32_t r = comp_label[c];
+        if (id_of_root[r] == 0xffffffffu) { id_of_root[r] = (uint32_t)C.size.size(); C.size.push_back(0); }
+        C.comp_of[c] = id_of_root[r];
+        C.size[id_of_root[r]]++;
+      }
+    }
     if (packed) P->coarse_want = 0;   // (its coarse matrix is an all-reduce per LM step and its use a decision taken from the iteration counts, which now differ from rank to rank)
   }
   *live = nullptr;

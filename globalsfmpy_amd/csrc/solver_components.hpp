@@ -11,7 +11,8 @@
 //     iterates stay exactly zero, they contribute nothing to any of its scalars, and the solve converges at the rate of the components it is
 //     actually solving;
 //   * a factorisation that meets a non-positive pivot hands the whole step back to the plain PCG (lm_solve).
-// Unsharded problems only (a rank of a sharded problem sees its own rows of every component it holds).
+// Unsharded problems, and PACKED sharded ones (whole components per rank, problem_create.hpp): there every rank runs this on its own components and the
+// step is gathered once per LM iteration (packed_exchange); a sharded problem with cut components keeps one PCG over its replicated vectors.
 #pragma once
 #include "host_common.hpp"
 
@@ -45,7 +46,7 @@ bool comps_build(gsfm_rot_problem* P, int cap) {
   auto& C = P->comps;
   if (C.built_cap == cap) return C.n_items > 0;
   C.built_cap = cap; C.n_items = 0; C.drop_graph();
-  if (C.comp_of.size() != P->n_cams || C.size.size() < 2) return false;
+  if (C.comp_of.size() != P->n_cams || C.size.empty() || (!P->sharded && C.size.size() < 2)) return false;   // (a packed rank may hold ONE of the problem's components)
   const uint32_t NC = (uint32_t)C.size.size();
   std::vector<int32_t> item_of_comp(NC, -1);
   std::vector<CholBatchItem> items;
@@ -101,7 +102,7 @@ void comps_enqueue_dense(gsfm_rot_problem* P, hipStream_t st) {
   DenseArgs a{};
   a.n_rows = P->n_rows; a.row_ptr = P->row_ptr.p; a.col = P->col.p; a.h0 = P->h0.p; a.h1 = P->h1.p; a.h2 = P->h2.p; a.h3 = P->h3.p; a.h4 = P->h4.p;
   a.Mblk = P->Mblk.p; a.b = P->b.p; a.A = nullptr; a.n = 0; a.T = 0; a.q = P->q_lin; a.lap = P->lin_is_lap; a.info_slot = P->scal.p + SC_DENSE_INFO; a.rcg = P->r.p;
-  const CompMap cm{C.cam_item.p, C.cam_loc.p};
+  const CompMap cm{C.cam_item.p, C.cam_loc.p, P->own_begin};
   hipLaunchKernelGGL(k_comp_assemble, dim3(P->n_rows), dim3(GSFM_BLOCK), 0, st, a, cm, (const CholBatchItem*)C.items.p);
   for (uint32_t k = 0; k < C.Tmax; ++k) {
     const uint32_t m = C.Tmax - k, nt = chol_step_tiles_per_wg(m);
@@ -122,7 +123,7 @@ void comps_enqueue_dense(gsfm_rot_problem* P, hipStream_t st) {
 // vector and the PCG residual are complete and the status word of the scalar block says whether every factorisation went through.
 int run_component_step(gsfm_rot_problem* P, const gsfm_rot_options& o, double tol_requested, bool pcg_struggles, bool first_step, bool* used, int* cg, double* cg_rel) {
   *used = false; *cg = 0; *cg_rel = 0.0;
-  if (P->sharded || P->n_components <= 1 || o.dense_cholesky_max_cams <= 0 || P->cs.active) return 0;
+  if ((P->sharded && !P->packed) || P->n_components <= 1 || o.dense_cholesky_max_cams <= 0 || P->cs.active) return 0;
   if (!comps_build(P, o.dense_cholesky_max_cams)) return 0;
   auto& C = P->comps;
   if (first_step) {   // a new solve: nobody is at rest, no step has been measured (+inf)
@@ -158,7 +159,7 @@ int run_component_step(gsfm_rot_problem* P, const gsfm_rot_options& o, double to
   else comps_enqueue_dense(P, ds);
   if (beside) HIPCHK(hipEventRecord(C.ev_join, ds));
   P->timer.end(tk);
-  const CompMap cm{C.cam_item.p, C.cam_loc.p};
+  const CompMap cm{C.cam_item.p, C.cam_loc.p, P->own_begin};
   if (!C.all_dense) {
     hipLaunchKernelGGL(k_comp_mask_rhs, dim3(grid_for(P->n_cams)), dim3(GSFM_BLOCK), 0, P->stream, (const double*)P->b.p, cm, P->n_cams, C.b_pcg.p);
     P->b_rhs = C.b_pcg.p;
@@ -173,9 +174,19 @@ int run_component_step(gsfm_rot_problem* P, const gsfm_rot_options& o, double to
   }
   if (beside) HIPCHK(hipStreamWaitEvent(P->stream, C.ev_join, 0));
   hipLaunchKernelGGL(k_comp_scatter, dim3(grid_for(P->n_cams)), dim3(GSFM_BLOCK), 0, P->stream, cm, (const CholBatchItem*)C.items.p, C.n_items, P->n_cams, C.all_dense ? 1 : 0,
-                     P->xcg.p, P->r.p, P->scal.p + SC_DENSE_INFO, (const double*)P->Tinv.p, C.stepmax.p);
+                     P->xcg.p, P->r.p, P->scal.p + SC_DENSE_INFO, (const double*)P->Tinv.p, C.stepmax.p, P->packed ? P->scal.p + SC_COMPBAD : nullptr);
   *used = true;
   return 0;
 }
 
+}  // namespace
+
+namespace {
+// Packed sharded problem, once per evaluated step: every rank's block of the step and of the PCG residual to everybody (the LM scalars are
+// computed replicated from them), and the number of ranks whose component factorisation broke down (they all solve that step again by PCG).
+int packed_exchange(gsfm_rot_problem* P) {
+  if (int st = all_gather(P, P->xcg.p, (size_t)P->shard.slice_width * 3)) return st;
+  if (int st = all_gather(P, P->r.p, (size_t)P->shard.slice_width * 3)) return st;
+  return all_reduce(P, P->scal.p + SC_COMPBAD, 1);
+}
 }  // namespace

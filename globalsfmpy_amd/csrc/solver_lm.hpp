@@ -373,7 +373,8 @@ int lm_solve(gsfm_rot_problem* P, const gsfm_rot_options& o_in, gsfm_rot_summary
     bool dense_failed = false;
     // Disconnected view graph: the small components factorised exactly, side by side, PCG on the large ones (solver_components.hpp)
     bool comp_used = false;
-    if (!dense_used && P->n_components > 1 && !P->sharded) {
+    if (P->packed) (void)hipMemsetAsync(P->scal.p + SC_COMPBAD, 0, sizeof(double), P->stream);
+    if (!dense_used && P->n_components > 1 && (!P->sharded || P->packed)) {
       if (int st = run_component_step(P, o, o_in.cg_relative_tolerance, pcg_struggles, iteration == 1, &comp_used, &cg, &cg_rel)) return st;
       if (comp_used) {
         loose = false;
@@ -382,10 +383,12 @@ int lm_solve(gsfm_rot_problem* P, const gsfm_rot_options& o_in, gsfm_rot_summary
           take_gmax();
           if (gmax <= o.gradient_tolerance) { --iteration; return finish(GSFM_TERM_GRADIENT_TOLERANCE); }
         }
+        if (P->packed) { if (int st = packed_exchange(P)) return st; }
         if (int st = evaluate_trial(P, false, h)) return st;
         int info = 0;
         std::memcpy(&info, &h[SC_DENSE_INFO], sizeof(int));
-        if (info != 0) { comp_used = false; cg_spent += cg; cg = 0; }   // a component's factor broke down: plain PCG solves the whole step
+        if (P->packed) info = h[SC_COMPBAD] != 0.0;   // (any rank's: all of them take the fallback together)
+        if (info != 0) { comp_used = false; cg_spent += cg; cg = 0; if (P->packed) (void)hipMemsetAsync(P->scal.p + SC_COMPBAD, 0, sizeof(double), P->stream); }   // a component's factor broke down: plain PCG solves the whole step
         else { sum->num_dense_solves++; dense_used = P->comps.all_dense; }
       }
     }
@@ -403,7 +406,13 @@ int lm_solve(gsfm_rot_problem* P, const gsfm_rot_options& o_in, gsfm_rot_summary
           if (dense_used) pcg_dearer_than_cholesky = true;
         }
       }
+      if (P->packed && !dense_used) { if (int st = packed_exchange(P)) return st; }
       if (int st = evaluate_trial(P, !dense_used && loose, h)) return st;
+      if (P->packed && attempt == 0 && h[SC_COMPBAD] != 0.0) {   // another rank's component factorisation broke down: it solves this step again by PCG, and so does everybody (one more exchange on every rank)
+        (void)hipMemsetAsync(P->scal.p + SC_COMPBAD, 0, sizeof(double), P->stream);
+        cg_spent += cg; cg = 0;
+        continue;
+      }
       for (int pass = 0; pass < 4 && !dense_used && loose && cg_rel > o.cg_relative_tolerance; ++pass) {
         // The loose step has been evaluated.  Every decision the trust-region loop takes from it must be the one the exact step would give:
         //  * termination (function / parameter tolerance): the decisive quantities -- cost change, step norm -- of the loose step are within

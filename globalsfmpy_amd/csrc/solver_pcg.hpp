@@ -156,11 +156,11 @@ int run_pcg(gsfm_rot_problem* P, const gsfm_rot_options& o, double tol, double e
   const bool resume = resume_iters >= 0;
   // PACKED sharded problem: this rank's own block of a block-diagonal system, solved without a collective -- right-hand side zero outside the
   // rank's cameras (everything the recurrence touches stays zero there), mat-vec without the gather; the step and the residual are gathered
-  // once, behind the solve.  The ranks' solves end after different iteration counts: nothing in the LM loop is decided from them.
+  // once per evaluated step by the caller (solver_components.hpp, packed_exchange).  The ranks' solves end after different iteration counts: nothing in the LM loop is decided from them.
   struct LocalScope { gsfm_rot_problem* P; bool on; ~LocalScope() { if (on) { P->pcg_local = false; P->b_rhs = nullptr; } } } local{P, P->sharded && P->packed};
   if (local.on) {
     if (!P->b_own.p && P->b_own.alloc(3 * (size_t)P->n_cams, true) != hipSuccess) return fail(GSFM_ERR_HIP, "allocating the rank-local right-hand side failed");
-    if (!resume) hipLaunchKernelGGL(k_mask_range, dim3(grid_for(P->n_cams)), dim3(GSFM_BLOCK), 0, P->stream, (const double*)P->b.p, P->own_begin, P->own_end, P->n_cams, P->b_own.p);
+    if (!resume) hipLaunchKernelGGL(k_mask_range, dim3(grid_for(P->n_cams)), dim3(GSFM_BLOCK), 0, P->stream, (const double*)(P->b_rhs ? P->b_rhs : P->b.p), P->own_begin, P->own_end, P->n_cams, P->b_own.p);
     P->b_rhs = P->b_own.p; P->pcg_local = true;
   }
   CgArgs a{};
@@ -267,11 +267,7 @@ int run_pcg(gsfm_rot_problem* P, const gsfm_rot_options& o, double tol, double e
     chunks = std::min(chunks, std::max(1, (o.max_cg_iterations + chunk - launched + chunk - 1) / chunk));
   }
   *iters_out = h.iters; *rel_out = h.last_rel <= h.tol ? std::fmin(h.last_rel, tol) : h.last_rel;   // (converged against the floor-adjusted tolerance: converged)
-  if (local.on) {   // every rank's block of the step and of the residual, to everybody (the LM scalars are computed replicated)
-    if (int st = all_gather(P, P->xcg.p, (size_t)P->shard.slice_width * 3)) return st;
-    if (int st = all_gather(P, P->r.p, (size_t)P->shard.slice_width * 3)) return st;
-  }
-  return 0;
+  return 0;   // (packed: the step and the residual are gathered by the caller, once per evaluated step: packed_exchange)
 }
 
 // single-reduction PCG (Chronopoulos-Gear): 2 kernels per iteration (3 + one all-gather when sharded); the launch-latency regime's

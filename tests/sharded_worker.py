@@ -132,13 +132,14 @@ def packed_case(out, prefer_native):
     prob, part = sharding.make_sharded_problem(g, _abi.ANGLE_AXIS_COVTRACE, loss=loss, prefer_native=prefer_native)
     rot, summ = prob.solve(part.scatter(g["init_aa"]))
     import torch
-    cg = torch.tensor([summ["num_pcg_collectives"], summ["num_cg_iterations"]], dtype=torch.int64)
+    cg = torch.tensor([summ["num_pcg_collectives"], summ["num_cg_iterations"], summ["num_dense_solves"]], dtype=torch.int64)
     lo = cg.clone(); dist.all_reduce(cg, op=dist.ReduceOp.MAX); dist.all_reduce(lo, op=dist.ReduceOp.MIN)
     if dist.get_rank() == 0:
         ref = RotationProblem(g["n_cams"], g["edge_i"], g["edge_j"], g["rel_aa"], _abi.ANGLE_AXIS_COVTRACE, cov6=g["cov6"]); ref.set_loss(loss)
         r1, s1 = ref.solve(g["init_aa"])
         np.savez(out, rot=part.gather(rot), ref_rot=r1, cost=summ["final_cost"], ref_cost=s1["final_cost"], iters=summ["num_iterations"], ref_iters=s1["num_iterations"],
-                 pcg_collectives_max=int(cg[0]), cg_max=int(cg[1]), cg_min=int(lo[1]), collectives=summ["num_collectives"], offs=offs, capped=summ["num_pcg_capped_steps"])
+                 pcg_collectives_max=int(cg[0]), cg_max=int(cg[1]), cg_min=int(lo[1]), collectives=summ["num_collectives"], offs=offs, capped=summ["num_pcg_capped_steps"],
+                 dense=int(cg[2]), ref_dense=s1["num_dense_solves"])
     dist.barrier()
     dist.destroy_process_group()
 

@@ -264,7 +264,9 @@ def test_packed_components_solve_without_a_collective_in_the_pcg_loop(tmp_path, 
     res = _launch(world, "gloo", str(tmp_path / ("packed%d.npz" % world)), case="packed")
     print("packed, %d ranks: %d LM iterations (one GPU: %d), PCG iterations per rank %d..%d, %d collectives per solve, none in the PCG loop" % (
         world, res["iters"], res["ref_iters"], res["cg_min"], res["cg_max"], res["collectives"]))
+    print("   component steps (most on any rank): %d (one GPU: %d)" % (res["dense"], res["ref_dense"]))
     assert int(res["pcg_collectives_max"]) == 0 and int(res["capped"]) == 0
+    assert int(res["dense"]) == int(res["iters"])   # (the ranks that hold scenes of at most 512 cameras factorise them in every LM iteration, like the single GPU)
     assert int(res["iters"]) == int(res["ref_iters"])
     assert abs(float(res["cost"]) - float(res["ref_cost"])) <= 1e-9 * float(res["ref_cost"])
     offs = res["offs"]
