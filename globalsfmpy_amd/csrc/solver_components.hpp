@@ -175,6 +175,17 @@ int run_component_step(gsfm_rot_problem* P, const gsfm_rot_options& o, double to
   if (beside) HIPCHK(hipStreamWaitEvent(P->stream, C.ev_join, 0));
   hipLaunchKernelGGL(k_comp_scatter, dim3(grid_for(P->n_cams)), dim3(GSFM_BLOCK), 0, P->stream, cm, (const CholBatchItem*)C.items.p, C.n_items, P->n_cams, C.all_dense ? 1 : 0,
                      P->xcg.p, P->r.p, P->scal.p + SC_DENSE_INFO, (const double*)P->Tinv.p, C.stepmax.p, P->packed ? P->scal.p + SC_COMPBAD : nullptr);
+  if (o.verbose) {   // which components were live in this step (a read-back: verbose runs only)
+    std::vector<int> act(C.n_items), fr(C.n_items);
+    std::vector<unsigned long long> sm(C.n_items);
+    HIPCHK(hipMemcpyAsync(act.data(), C.active.p, sizeof(int) * C.n_items, hipMemcpyDeviceToHost, P->stream));
+    HIPCHK(hipMemcpyAsync(fr.data(), C.frozen.p, sizeof(int) * C.n_items, hipMemcpyDeviceToHost, P->stream));
+    HIPCHK(hipMemcpyAsync(sm.data(), C.stepmax.p, 8 * C.n_items, hipMemcpyDeviceToHost, P->stream));
+    HIPCHK(hipStreamSynchronize(P->stream));
+    std::string line = "[gsfm] components:";
+    for (uint32_t i = 0; i < C.n_items; ++i) { double v; std::memcpy(&v, &sm[i], 8); char b[64]; snprintf(b, sizeof b, " %s%.1e", fr[i] ? "rest:" : act[i] ? "" : "idle:", v); line += b; }
+    fprintf(stderr, "%s  (largest camera update of each factorised component, rad; PCG %d iterations)\n", line.c_str(), *cg);
+  }
   *used = true;
   return 0;
 }

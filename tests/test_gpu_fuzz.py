@@ -75,11 +75,10 @@ def test_two_level_preconditioner_awkward_cases():
 
 
 def test_randomised_forcing_schedule_vs_exact_schedule(oracle):
-    """Short fixed-seed pass of tests/manual/fuzz_forcing.py: 600-6000-camera graphs, every LM step a PCG solve, the default (forcing) schedule
-    against pcg_forcing = 0 and the oracle.  (The 100-trial tally is in profiles/r04_fuzz_forcing.txt: 86 same, 9 within the bar, 3 beyond PCG's
-    reach on either schedule, 2 genuine misses -- Tukey / MAGSAC from far starts, where a 1e-8 rad difference flips an edge's cut-off.)"""
+    """Short fixed-seed pass of tests/manual/fuzz_forcing.py with DEFAULT options: 600-6000-camera graphs, the default schedule against
+    pcg_forcing = 0 and the oracle.  (420-trial tally of the round-5 schedule: profiles/r05_fuzz_forcing.txt -- none beyond the bar; the trials the
+    round-4 schedule missed run by number in tests/test_gpu_round5.py.)"""
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "manual"))
     import fuzz_forcing
     assert fuzz_forcing.run(trials=14, seed=3) == 0
-
