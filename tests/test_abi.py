@@ -96,3 +96,32 @@ def test_shared_libraries_depend_on_nothing_but_the_hip_runtime_and_libc():
         assert needed, name
         for lib in needed:
             assert lib.startswith(allowed + extra), (name, lib)
+
+
+def test_summary_carries_the_abi_v4_fields_and_the_auxiliary_libraries_export_their_entry_points():
+    """ABI v4: num_pcg_capped_steps, worst_accepted_cg_residual, num_forcing_restarts appended to gsfm_rot_summary (the C header, the ctypes
+    mirror and the pybind summary agree); the peer-store library exports the error entry points of round 5, and bench.py's crash-line handler
+    lives in its own bench-only library, not in a product one."""
+    import ctypes as C
+    from globalsfmpy_amd import _abi
+    hdr = open(os.path.join(ROOT, "include", "gsfm_rot.h")).read()
+    body = hdr[hdr.index("typedef struct {\n  int32_t termination;"):hdr.index("} gsfm_rot_summary;")]
+    names_h = re.findall(r"^\s+(?:int32_t|uint64_t|double)\s+(\w+);", body, flags=re.M)
+    names_py = [n for n, _ in _abi.Summary._fields_]
+    assert names_h == names_py, (names_h, names_py)
+    for n in ("num_pcg_capped_steps", "worst_accepted_cg_residual", "num_forcing_restarts"):
+        assert n in names_py
+    assert "#define GSFM_ROT_ABI_VERSION 4" in hdr
+    mod = open(os.path.join(ROOT, "globalsfmpy_amd", "host", "module.cpp")).read()
+    for n in ("num_pcg_capped_steps", "worst_accepted_cg_residual", "num_forcing_restarts", "num_inexact_steps"):
+        assert 'd["%s"]' % n in mod
+    peer = os.path.join(ROOT, "globalsfmpy_amd", "libgsfm_peer.so")
+    guard = os.path.join(ROOT, "globalsfmpy_amd", "libgsfm_benchguard.so")
+    if not (os.path.exists(peer) and os.path.exists(guard)):
+        pytest.skip("auxiliary libraries not built")
+    _abi.preload_hip_runtime()
+    lp, lg = C.CDLL(peer), C.CDLL(guard)
+    for n in ("gsfm_peer_create", "gsfm_peer_connect", "gsfm_peer_all_gather", "gsfm_peer_all_reduce_sum", "gsfm_peer_error", "gsfm_peer_error_take", "gsfm_peer_inject_error"):
+        assert hasattr(lp, n), n
+    assert not hasattr(lp, "gsfm_crash_line_arm")
+    assert hasattr(lg, "gsfm_crash_line_arm") and hasattr(lg, "gsfm_crash_line_disarm")
