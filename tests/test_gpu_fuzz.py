@@ -82,3 +82,11 @@ def test_randomised_forcing_schedule_vs_exact_schedule(oracle):
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "manual"))
     import fuzz_forcing
     assert fuzz_forcing.run(trials=14, seed=3) == 0
+
+
+def test_randomised_disconnected_problems_vs_oracle(oracle):
+    """Short pass of tests/manual/fuzz_components.py: 2-6 scenes as one disconnected problem (contiguous or interleaved numbering, near / far starts,
+    every error type, smooth losses and MAGSAC) through the per-component step of round 5, against the oracle component by component."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "manual"))
+    import fuzz_components
+    assert fuzz_components.run(trials=10, seed=4) == 0
