@@ -434,7 +434,7 @@ int lm_solve(gsfm_rot_problem* P, const gsfm_rot_options& o_in, gsfm_rot_summary
         // which of their edges enter the inlier band (fuzz seed 2 trial 45: 553 / 84 / 11 / 9 loose against 1 253 / 295 / 146 / 176 tight
         // iterations, every step contracting, a handful of cameras 1.7e-2 rad elsewhere).  The solve continues to the tight tolerance and the
         // schedule is off for the rest of the run; a run that had applied an inexact step before is redone.
-        if (!tight && P->loss_staircase && cg > 64) {
+        if (!tight && P->loss_staircase && cg > 64 && o.pcg_forcing != 3) {
           tight = true; forcing_live = false;
           if (loose_applied) { finish(GSFM_TERM_NO_CONVERGENCE); return GSFM_INTERNAL_RESTART; }
         }
