@@ -101,21 +101,39 @@ def test_a_capped_pcg_solve_is_reported_and_rescued_by_the_exact_step(oracle):
 
 
 def test_forcing_schedule_is_abandoned_and_the_solve_redone_on_a_slow_trajectory():
-    """Far start under a redescending loss: the steps shrink by less than 0.3 x per iteration, the contraction gate trips after inexact steps
-    were applied, and the solve is redone from the initial rotations with exact steps -- the rotations, the trace and the iteration counts are
-    those of pcg_forcing = 0 bit for bit, the summary says what happened and bills the abandoned attempt."""
-    g = synth.make_graph(2500, 30000, seed=91, outlier_frac=0.25)
-    init = g["init_aa"] + 0.2 * np.random.default_rng(5).standard_normal(g["init_aa"].shape)
-    p = _problem(g, _abi.ANGLE_AXIS_COVARIANCE, LF.MAGSACWeightBasedLoss(0.02))
+    """A slow trajectory under a smooth loss (trial 21 of seed 2 of tests/manual/fuzz_forcing.py: SoftL1, 2 326 cameras / 11 085 edges, 15 LM iterations):
+    the steps shrink by less than 0.3 x per iteration, the contraction gate trips after inexact steps were applied, and the solve is redone from
+    the initial rotations with exact steps -- the rotations, the trace and the iteration counts are those of pcg_forcing = 0 bit for bit, the
+    summary says what happened and bills the abandoned attempt."""
+    import fuzz_forcing
+    (t, g, et, loss, init, coherent), = list(fuzz_forcing.cases(22, 2, [21]))
+    p = _problem(g, et, loss)
     kw = dict(dense_cholesky_auto_cams=0)
     r0, s0 = p.solve(init, pcg_forcing=0, **kw)
     t0 = p.trace()
     r1, s1 = p.solve(init, **kw)
     t1 = p.trace()
-    print("exact schedule %d LM / %d PCG; default: restarts %d, %d PCG in total" % (s0["num_iterations"], s0["num_cg_iterations"], s1["num_forcing_restarts"], s1["num_cg_iterations"]))
+    print("%s: exact schedule %d LM / %d PCG; default: restarts %d, %d PCG in total" % (type(loss).__name__, s0["num_iterations"], s0["num_cg_iterations"], s1["num_forcing_restarts"], s1["num_cg_iterations"]))
     assert s1["num_forcing_restarts"] == 1 and s1["num_inexact_steps"] == 0
     assert np.array_equal(r0, r1) and np.array_equal(t0, t1)
     assert s1["num_cg_iterations"] > s0["num_cg_iterations"] and s1["num_cg_iterations"] < 1.5 * s0["num_cg_iterations"]
+
+
+def test_forcing_schedule_is_given_up_before_its_first_step_on_an_ill_conditioned_magsac_problem():
+    """The conditioning gate: far start under MAGSAC, the first loose solve needs more than 64 iterations -- it is continued to the tight tolerance
+    and every later step is exact; nothing inexact was ever applied, so nothing is redone, and the run IS pcg_forcing = 0's (same PCG iterations)."""
+    g = synth.make_graph(2500, 30000, seed=91, outlier_frac=0.25)
+    init = g["init_aa"] + 0.2 * np.random.default_rng(5).standard_normal(g["init_aa"].shape)
+    p = _problem(g, _abi.ANGLE_AXIS_COVARIANCE, LF.MAGSACWeightBasedLoss(0.02))
+    kw = dict(dense_cholesky_auto_cams=0)
+    r0, s0 = p.solve(init, pcg_forcing=0, **kw)
+    r1, s1 = p.solve(init, **kw)
+    r3, s3 = p.solve(init, pcg_forcing=3, **kw)
+    print("exact schedule %d LM / %d PCG; default %d PCG, %d restarts; pcg_forcing = 3: %d PCG, %d restarts, %d inexact steps" % (
+        s0["num_iterations"], s0["num_cg_iterations"], s1["num_cg_iterations"], s1["num_forcing_restarts"], s3["num_cg_iterations"], s3["num_forcing_restarts"], s3["num_inexact_steps"]))
+    assert s1["num_forcing_restarts"] == 0 and s1["num_inexact_steps"] == 0 and s1["num_cg_iterations"] == s0["num_cg_iterations"]
+    assert np.array_equal(r0, r1)
+    assert s3["num_forcing_restarts"] == 1 or s3["num_inexact_steps"] > 0   # (without the gate the schedule is tried: kept, or abandoned by the contraction gate)
 
 
 def test_forcing_schedule_stays_on_where_steps_contract():
