@@ -46,11 +46,12 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_comp_activity(const uint32_t* __
     active[c] = !fr && (!(B > 0.0) || t * B > floor2);
   }
 }
-__global__ void __launch_bounds__(GSFM_BLOCK) k_comp_assemble(DenseArgs a, CompMap cm, const CholBatchItem* items) {
-  const uint32_t lrow = blockIdx.x;                 // row of the stored blocks
-  if (lrow >= a.n_rows) return;
-  const uint32_t row = cm.row_base + lrow;          // its camera
-  if (lrow == 0 && threadIdx.x == 3) *a.info_slot = 0.0;
+// (one workgroup per camera of a factorised component -- `cams`, the list k_comp_activity walks -- not per row of the problem: at C4 2 168 of 14 019)
+__global__ void __launch_bounds__(GSFM_BLOCK) k_comp_assemble(DenseArgs a, CompMap cm, const CholBatchItem* items, const uint32_t* __restrict__ cams) {
+  if (blockIdx.x == 0 && threadIdx.x == 3) *a.info_slot = 0.0;
+  const uint32_t row = cams[blockIdx.x];            // the camera,
+  const uint32_t lrow = row - cm.row_base;          // its row of the stored blocks
+  if (row < cm.row_base || lrow >= a.n_rows) return;
   const int32_t ci = cm.item[row];
   if (ci < 0) return;
   const CholBatchItem it = items[ci];
@@ -107,6 +108,13 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_mask_range(const double* b, uint
 // the scalar block's status word (the caller then solves the whole step by PCG)
 __global__ void __launch_bounds__(GSFM_BLOCK) k_comp_scatter(CompMap cm, const CholBatchItem* items, uint32_t n_items, uint32_t n, int all_dense, double* eta, double* rcg, double* info_slot,
                                                              const double* __restrict__ Tinv, unsigned long long* stepmax, double* bad_flag) {
+  // (the maxima first per workgroup in LDS -- 16 slots claimed by component number, a workgroup's 256 consecutive cameras belong to a few
+  // components at most; a component that finds its slot taken goes to memory directly --, then one atomic per slot: 2 168 atomics on six words
+  // were 15 of the kernel's 18 us at C4)
+  __shared__ int tag[16];
+  __shared__ unsigned long long smax[16];
+  if (threadIdx.x < 16) { tag[threadIdx.x] = -1; smax[threadIdx.x] = 0ull; }
+  __syncthreads();
   const uint32_t k = blockIdx.x * GSFM_BLOCK + threadIdx.x;
   if (k == 0) {
     int bad = 0;
@@ -114,8 +122,7 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_comp_scatter(CompMap cm, const C
     __builtin_memcpy(info_slot, &bad, sizeof(int));
     if (bad_flag) *bad_flag = bad ? 1.0 : 0.0;   // (packed sharded problems: summed over the ranks, so that all of them fall back together)
   }
-  if (k >= n) return;
-  const int32_t ci = cm.item[k];
+  const int32_t ci = k < n ? cm.item[k] : -1;
   if (ci >= 0) {
     const bool live = *items[ci].active != 0;
     const double* x = items[ci].x + 3 * (size_t)cm.loc[k];
@@ -124,12 +131,17 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_comp_scatter(CompMap cm, const C
     if (live) {   // the component's largest camera update (delta = Tinv eta, radians; half-angles for the quaternion state): positive doubles order like their bits
       const double* Ti = Tinv + 9 * (size_t)k;
       const double d0 = Ti[0] * x[0] + Ti[1] * x[1] + Ti[2] * x[2], d1 = Ti[3] * x[0] + Ti[4] * x[1] + Ti[5] * x[2], d2 = Ti[6] * x[0] + Ti[7] * x[1] + Ti[8] * x[2];
-      atomicMax(stepmax + ci, (unsigned long long)__double_as_longlong(2.0 * sqrt(d0 * d0 + d1 * d1 + d2 * d2)));
+      const unsigned long long v = (unsigned long long)__double_as_longlong(2.0 * sqrt(d0 * d0 + d1 * d1 + d2 * d2));
+      const int slot = ci & 15, prev = atomicCAS(&tag[slot], -1, ci);
+      if (prev == -1 || prev == ci) atomicMax(&smax[slot], v);
+      else atomicMax(stepmax + ci, v);
     }
-  } else if (all_dense) {
+  } else if (all_dense && k < n) {
 #pragma unroll
     for (int c = 0; c < 3; ++c) { eta[3 * (size_t)k + c] = 0.0; rcg[3 * (size_t)k + c] = 0.0; }
   }
+  __syncthreads();
+  if (threadIdx.x < 16 && tag[threadIdx.x] >= 0) atomicMax(stepmax + tag[threadIdx.x], smax[threadIdx.x]);
 }
 
 }  // namespace gsfm

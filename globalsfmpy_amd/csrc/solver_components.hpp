@@ -103,7 +103,7 @@ void comps_enqueue_dense(gsfm_rot_problem* P, hipStream_t st) {
   a.n_rows = P->n_rows; a.row_ptr = P->row_ptr.p; a.col = P->col.p; a.h0 = P->h0.p; a.h1 = P->h1.p; a.h2 = P->h2.p; a.h3 = P->h3.p; a.h4 = P->h4.p;
   a.Mblk = P->Mblk.p; a.b = P->b.p; a.A = nullptr; a.n = 0; a.T = 0; a.q = P->q_lin; a.lap = P->lin_is_lap; a.info_slot = P->scal.p + SC_DENSE_INFO; a.rcg = P->r.p;
   const CompMap cm{C.cam_item.p, C.cam_loc.p, P->own_begin};
-  hipLaunchKernelGGL(k_comp_assemble, dim3(P->n_rows), dim3(GSFM_BLOCK), 0, st, a, cm, (const CholBatchItem*)C.items.p);
+  hipLaunchKernelGGL(k_comp_assemble, dim3((uint32_t)C.item_cams.n), dim3(GSFM_BLOCK), 0, st, a, cm, (const CholBatchItem*)C.items.p, (const uint32_t*)C.item_cams.p);
   for (uint32_t k = 0; k < C.Tmax; ++k) {
     const uint32_t m = C.Tmax - k, nt = chol_step_tiles_per_wg(m);
     const dim3 grid(chol_step_grid(m, nt), C.n_items);
