@@ -4,7 +4,7 @@ the DEFAULT options (small components factorised side by side, PCG on the large 
 tolerance) against the CPU oracle, component by component (each has its own gauge).  A trial passes with the oracle's LM iteration count, no
 capped step and every component within 1e-6 rad (mean); trials whose ORACLE moves by a comparable amount under 1-ulp perturbations of the
 measurements -- or when started 1e-13 rad away, the size of what separates two correct linear solvers -- are reported as ill-posed.
-usage: python tests/manual/fuzz_components.py [trials] [seed]"""
+usage: python tests/manual/fuzz_components.py [trials] [seed] [only: trial,trial...]   (FUZZ_PROBE=1: the chosen trials row by row against the one-PCG path)"""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -17,15 +17,13 @@ ETS = [_abi.ROTATION_MAT_FNORM, _abi.QUATERNION_COSINE, _abi.ANGLE_AXIS_COVARIAN
        _abi.ANGLE_AXIS_COVTRACE, _abi.ANGLE_AXIS_COVNORM]
 
 
-def run(trials=30, seed=1, only=None, **solve_kw):
-    from oracle import pyoracle
-    from sensitivity import ulp_perturbed
+def cases(trials, seed, only=None):
+    """The trials of run(trials, seed), generated without touching the device: (t, N, ei, ej, rel, cov, inl, init, comp, sizes, shuffled, et, loss)."""
     rng = np.random.default_rng(seed)
-    bad = 0
     for t in range(trials):
         k = int(rng.integers(2, 7))
         sizes = [int(np.exp(rng.uniform(np.log(40), np.log(1500)))) for _ in range(k)]
-        scenes = [synth.make_graph(n, int(n * rng.uniform(6, 20)), int(rng.integers(1, 1 << 30)), outlier_frac=float(rng.uniform(0, 0.3))) for n in sizes]
+        scenes = [synth.make_graph(n, min(int(n * rng.uniform(6, 20)), 2 * n * (n - 1) // 5), int(rng.integers(1, 1 << 30)), outlier_frac=float(rng.uniform(0, 0.3))) for n in sizes]   # (at most 80 % of the pairs: a 40-camera scene has 780)
         offs = np.cumsum([0] + sizes)
         N = int(offs[-1])
         ei = np.concatenate([g["edge_i"] + o for o, g in zip(offs, scenes)]).astype(np.int64)
@@ -48,14 +46,36 @@ def run(trials=30, seed=1, only=None, **solve_kw):
         a = float(np.exp(rng.uniform(np.log(0.05), np.log(1.0))))
         loss = [LF.HuberLoss(a), LF.SoftLOneLoss(a), LF.CauchyLoss(a), LF.GemanMcClureLoss(a, 1.0), LF.TrivialLoss(), LF.TukeyLoss(max(a, 0.3)),
                 LF.MAGSACWeightBasedLoss(0.02)][int(rng.integers(7))]
-        ei, ej = ei.astype(np.uint32), ej.astype(np.uint32)
         if only is not None and t not in only:
             continue
+        yield t, N, ei.astype(np.uint32), ej.astype(np.uint32), rel, cov, inl, init, comp, sizes, shuffled, et, loss
+
+
+def run(trials=30, seed=1, only=None, **solve_kw):
+    from oracle import pyoracle
+    from sensitivity import ulp_perturbed
+    bad = 0
+    for t, N, ei, ej, rel, cov, inl, init, comp, sizes, shuffled, et, loss in cases(trials, seed, only):
+        k = len(sizes)
         p = RotationProblem(N, ei, ej, rel, et, cov6=cov, inlier_weight=inl); p.set_loss(loss)
         rd, sd = p.solve(init, **solve_kw)
+        if os.environ.get("FUZZ_PROBE"):   # one trial under the lens: the component step against the device's own one-PCG-over-everything path, row by row
+            tr1 = p.trace()
+            ra, sa = p.solve(init, dense_cholesky_max_cams=0, dense_cholesky_auto_cams=0)
+            tr2 = p.trace()
+            per = lambda x, y: np.array([synth.angular_distance(synth.align_rotations(x[comp == c], y[comp == c]), y[comp == c]).mean() for c in range(k)])
+            print("   component step %d it, one PCG %d it; per component, component step vs one PCG: %s" % (sd["num_iterations"], sa["num_iterations"], " ".join("%.1e" % v for v in per(rd, ra))))
+            os.makedirs(os.path.join(ROOT, "gpurun_out", "r05"), exist_ok=True)
+            np.savez(os.path.join(ROOT, "gpurun_out", "r05", "comp_probe_%d_%d.npz" % (seed, t)), component_step=rd, one_pcg=ra, comp=comp, trace_component_step=tr1, trace_one_pcg=tr2)
+            print("   [it, cost, |dx|, rel_dec, radius, cg] component step | one PCG")
+            for i in range(min(len(tr1), len(tr2))):
+                a1, a2 = tr1[i], tr2[i]
+                print("   %3d %.12e %.3e %.6f %.2e %4d | %.12e %.3e %.6f %.2e %4d%s" % (a1[0], a1[1], a1[4], a1[5], a1[6], a1[7], a2[1], a2[4], a2[5], a2[6], a2[7], "" if abs(a1[1] - a2[1]) <= 1e-9 * abs(a2[1]) else "  <"))
         p.close()
         o = pyoracle.OracleProblem(N, ei, ej, rel, et, cov6=cov, inlier_weight=inl); o.set_loss(loss)
         ro, so = o.solve(init)
+        if os.environ.get("FUZZ_PROBE"):
+            print("   oracle %d it; per component, one PCG vs oracle: %s; component step vs oracle: %s" % (so["num_iterations"], " ".join("%.1e" % v for v in per(ra, ro)), " ".join("%.1e" % v for v in per(rd, ro))))
         d = np.array([synth.angular_distance(synth.align_rotations(rd[comp == c], ro[comp == c]), ro[comp == c]).mean() for c in range(k)])
         ok = sd["num_iterations"] == so["num_iterations"] and sd["num_pcg_capped_steps"] == 0 and d.max() <= 1e-6
         verdict = "ok" if ok else "MISMATCH"
@@ -92,4 +112,4 @@ def run(trials=30, seed=1, only=None, **solve_kw):
 
 
 if __name__ == "__main__":
-    sys.exit(min(1, run(int(sys.argv[1]) if len(sys.argv) > 1 else 30, int(sys.argv[2]) if len(sys.argv) > 2 else 1)))
+    sys.exit(min(1, run(int(sys.argv[1]) if len(sys.argv) > 1 else 30, int(sys.argv[2]) if len(sys.argv) > 2 else 1, only=[int(v) for v in sys.argv[3].split(",")] if len(sys.argv) > 3 else None)))
