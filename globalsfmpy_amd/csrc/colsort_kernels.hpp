@@ -49,7 +49,17 @@ struct ColLayoutDev {
   const uint16_t* kcnt;
   uint32_t cbits, cmax;
   uint32_t n_wg, nch;
+  // The 2-byte, delta-coded form of the same record (round 5; built where it pays: problem_create.hpp, build_colsort): the positions of a block are
+  // sorted by camera, so the camera of a position is the camera of its wavefront's first lane (kbase: one word per 64 positions) plus the
+  // sum of the steps up to it -- a DPP prefix sum over the wavefront.  k16 = slot (bits 0-8) | row count (bits 9-11; 7: read kcnt) | step from
+  // the previous lane's camera (bits 12-15; 15: read kdel; lane 0: 0).  Padding positions repeat the last camera (their block is zero and
+  // no row reads their slot).  50 B per position instead of 52; the sums are the same numbers added in the same order.  Null: not built.
+  const uint16_t* k16;
+  const uint32_t* kbase;
+  const uint32_t* kdel;
 };
+#define GSFM_K16_CNT_ESC 7u
+#define GSFM_K16_DEL_ESC 15u
 // the record's second word: slot (SLOT_BITS) | count of row p (SLOT_BITS + 1) | row of the entry inside its block (SLOT_BITS)
 __host__ __device__ constexpr uint32_t col_pack(uint32_t slot, uint32_t rowcount, uint32_t rowl) { return slot | (rowcount << GSFM_COL_SLOT_BITS) | (rowl << (2 * GSFM_COL_SLOT_BITS + 1)); }
 __host__ __device__ __forceinline__ uint32_t col_slot(uint32_t y) { return y & ((1u << GSFM_COL_SLOT_BITS) - 1u); }
@@ -84,7 +94,7 @@ struct ColMatvecArgs {
 };
 // `stop_after_request`: evaluated once the first sub-chunk's streams are in flight (the single-reduction PCG decides about convergence
 // there, behind the loads instead of in front of them); true = leave without touching anything.
-template <typename Stop>
+template <bool K16, typename Stop>
 __device__ __forceinline__ void mv_col_body(const ColMatvecArgs& a, Stop stop_after_request) {
   constexpr int RB = GSFM_COL_RB, EPL = GSFM_COL_EPL;
   // plane-major: the slot-contiguous reads of one row are conflict-free; two buffers, so one barrier per iteration suffices (a buffer is
@@ -94,14 +104,16 @@ __device__ __forceinline__ void mv_col_body(const ColMatvecArgs& a, Stop stop_af
   const ColWg w = a.L.wg[blockIdx.x];
   const uint32_t r = threadIdx.x, wave = r >> 6;
   double y0 = 0.0, y1 = 0.0, y2 = 0.0;
-  uint32_t m[EPL], pos[EPL]; double2 A[EPL], B[EPL], C[EPL];
+  uint32_t m[EPL], pos[EPL], cbase[EPL]; double2 A[EPL], B[EPL], C[EPL];
   const uint32_t cmask = (1u << a.L.cbits) - 1u, cshift = a.L.cbits + GSFM_COL_SLOT_BITS, cmax = a.L.cmax;
   auto request = [&](uint32_t s) {   // the streams of sub-chunks s .. s + EPL - 1 of this workgroup (past its end: the last one again, discarded)
 #pragma unroll
     for (int k = 0; k < EPL; ++k) {
       const uint32_t sc = w.first_sub + min(s + (uint32_t)k, w.n_sub - 1);
       const size_t e = (size_t)sc * RB + r;
-      m[k] = __builtin_nontemporal_load(a.L.kcol + e); pos[k] = (uint32_t)e;
+      pos[k] = (uint32_t)e;
+      if constexpr (K16) { m[k] = __builtin_nontemporal_load(a.L.k16 + e); cbase[k] = a.L.kbase[(size_t)sc * (RB / 64) + __builtin_amdgcn_readfirstlane(wave)]; }
+      else { m[k] = __builtin_nontemporal_load(a.L.kcol + e); cbase[k] = 0u; }
       A[k] = nt_load2(a.b0 + e); B[k] = nt_load2(a.b1 + e); C[k] = nt_load2(a.b2 + e);
     }
   };
@@ -112,15 +124,25 @@ __device__ __forceinline__ void mv_col_body(const ColMatvecArgs& a, Stop stop_af
     uint32_t cnt[EPL], inc[EPL];
 #pragma unroll
     for (int k = 0; k < EPL; ++k) {
-      const uint32_t cam = (m[k] & cmask) == cmask ? 0u : (m[k] & cmask), pm = (m[k] >> a.L.cbits) & ((1u << GSFM_COL_SLOT_BITS) - 1u);
+      uint32_t cam, pm, c;
+      if constexpr (K16) {
+        uint32_t dl = m[k] >> 12;
+        if (dl == GSFM_K16_DEL_ESC) dl = a.L.kdel[pos[k]];
+        cam = cbase[k] + wave_incl_scan(dl);
+        pm = m[k] & ((1u << GSFM_COL_SLOT_BITS) - 1u);
+        c = (m[k] >> GSFM_COL_SLOT_BITS) & 7u;
+        if (c == GSFM_K16_CNT_ESC) c = a.L.kcnt[pos[k]];
+      } else {
+        cam = (m[k] & cmask) == cmask ? 0u : (m[k] & cmask); pm = (m[k] >> a.L.cbits) & ((1u << GSFM_COL_SLOT_BITS) - 1u);
+        c = m[k] >> cshift;
+        if (c == cmax) c = a.L.kcnt[pos[k]];   // (saturated: a row with very many entries in this sub-chunk, or no room for counts in the word)
+      }
       const double* um = a.u + 3 * (size_t)cam;
       const double u0 = um[0], u1 = um[1], u2 = um[2];
       slots[buf][k][0][pm] = A[k].x * u0 + A[k].y * u1 + B[k].x * u2;
       slots[buf][k][1][pm] = A[k].y * u0 + B[k].y * u1 + C[k].x * u2;
       slots[buf][k][2][pm] = B[k].x * u0 + C[k].x * u1 + C[k].y * u2;
       // slot range of row r: prefix sum of the rows' counts, inside the wavefront here, across wavefronts after the barrier
-      uint32_t c = m[k] >> cshift;
-      if (c == cmax) c = a.L.kcnt[pos[k]];   // (saturated: a row with very many entries in this sub-chunk, or no room for counts in the word)
       cnt[k] = s + (uint32_t)k < w.n_sub ? c : 0u;
       inc[k] = wave_incl_scan(cnt[k]);
       if ((r & 63u) == 63u) wtot[buf][k][wave] = inc[k];
@@ -139,18 +161,20 @@ __device__ __forceinline__ void mv_col_body(const ColMatvecArgs& a, Stop stop_af
 }
 // (a 256-lane form of the same product -- more, smaller barrier groups per CU -- measured equal or slower, profiles/r04b_k3c_threads_ab.txt, and was removed in round 5)
 #define GSFM_K3C_THREADS GSFM_COL_RB
+template <bool K16>
 __global__ void __launch_bounds__(GSFM_K3C_THREADS) k_mv_col(ColMatvecArgs a) {
   if (a.done && *a.done) return;
-  mv_col_body(a, [] { return false; });
+  mv_col_body<K16>(a, [] { return false; });
 }
 // The same product as the mat-vec of the single-reduction PCG (run_pcg2): the convergence decision of k_matvec_cg at its entry -- every
 // workgroup re-sums the gamma partials in the order and with the reduction tree of the 256-lane kernels, so all of them, and the vector
 // kernel that follows, see bit-identical scalars -- then the rows.  The delta partials come from k_mv_col_finish (dot_part).
 struct ColMatvecCgArgs { ColMatvecArgs mv; Cg2Args cg; };
+template <bool K16>
 __global__ void __launch_bounds__(GSFM_K3C_THREADS) k_mv_col_cg(ColMatvecCgArgs aa) {
   __shared__ double lds[4];
   const Cg2Args& c = aa.cg;
-  mv_col_body(aa.mv, [&]() -> bool {
+  mv_col_body<K16>(aa.mv, [&]() -> bool {
     const int done = c.sc->done, iters = c.sc->iters;
     const double gamma0 = c.sc->gamma0, tol = c.sc->tol;
     const bool estop = cg_energy_stop(c.sc->einc, c.sc->esum, c.sc->etol2, iters);

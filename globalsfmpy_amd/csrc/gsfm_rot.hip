@@ -506,10 +506,10 @@ gsfm_status gsfm_rot_matvec_bytes(gsfm_rot_problem* P, double* layout_bytes, dou
   const double N = (double)P->n_rows;
   const bool lap = P->lap_capable;
   if (lap && P->cs.active) {
-    // mat-vec, per position: its 4- or 6-byte record (column | slot | row count) + body-frame block 48; partial sums written and
+    // mat-vec, per position: its 2-, 4- or 6-byte record (column | slot | row count; 2: delta-coded, ColLayoutDev::k16) + body-frame block 48; partial sums written and
     // read once; the gathered vector, the diagonal blocks, p, q in, y out once per camera.  Linearisation, per position: record 8 +
     // q_rel 32 + whitening 48 in, block 48 out; nine partial sums per row and workgroup
-    if (layout_bytes) *layout_bytes = (P->cs.cmax ? 52.0 : 54.0) * (double)P->cs.n_pos + 2.0 * 24.0 * P->cs.n_wg * GSFM_COL_RB + (24.0 + 48.0 + 24.0 + 32.0 + 24.0) * N;
+    if (layout_bytes) *layout_bytes = (P->cs.k16_active ? 50.0 : P->cs.cmax ? 52.0 : 54.0) * (double)P->cs.n_pos + 2.0 * 24.0 * P->cs.n_wg * GSFM_COL_RB + (24.0 + 48.0 + 24.0 + 32.0 + 24.0) * N;
     if (lin_bytes) *lin_bytes = (8.0 + 32.0 + (P->wmode == W_MATRIX ? 48.0 : P->wmode == W_SCALAR ? 8.0 : 0.0) + 48.0) * (double)P->cs.n_pos + 2.0 * 72.0 * P->cs.n_wg * GSFM_COL_RB + (32.0 + 72.0) * N;
     if (form) *form = 2;
   } else {

@@ -346,7 +346,11 @@ struct gsfm_rot_problem {
     DevBuf<uint16_t> kcnt;
     uint32_t cbits = 0, cmax = 0;
     DevBuf<double> part;      // 9 planes of [n_wg * RB] (K2c; K3c uses the first three)
-    ColLayoutDev dev() const { return ColLayoutDev{wg.p, meta.p, kcol.p, kcnt.p, cbits, cmax, n_wg, nch}; }
+    // K3c's 2-byte delta-coded record (colsort_kernels.hpp, ColLayoutDev::k16): built where its escapes are rare
+    bool k16_active = false;
+    DevBuf<uint16_t> k16;
+    DevBuf<uint32_t> kbase, kdel;
+    ColLayoutDev dev() const { return ColLayoutDev{wg.p, meta.p, kcol.p, kcnt.p, cbits, cmax, n_wg, nch, k16_active ? k16.p : nullptr, kbase.p, kdel.p}; }
   } cs;
 
   // sigma consensus (gsfm_rot_solve_sigma_consensus): the weights are computed inside the first cost sweep / linearisation of a solve

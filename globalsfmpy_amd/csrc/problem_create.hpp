@@ -140,6 +140,12 @@ int build_colsort(gsfm_rot_problem* P, const std::vector<uint32_t>& rp, hvec<uin
   hvec<uint32_t> h_col(n_pos), h_eid(n_pos), h_kcol(n_pos);   // (every position is written below)
   hvec<uint2> h_meta(n_pos);
   hvec<uint16_t> h_kcnt(n_pos);
+  // K3c's 2-byte record (ColLayoutDev::k16): GSFM_K3C_K16=0 keeps the 4-byte one (A/B), =1 forces it whatever its escapes cost
+  const char* k16_env = getenv("GSFM_K3C_K16");
+  const int k16_mode = k16_env && *k16_env ? atoi(k16_env) : -1;
+  hvec<uint16_t> h_k16(k16_mode != 0 ? n_pos : 0);
+  hvec<uint32_t> h_kbase(k16_mode != 0 ? n_sub * (SUB / 64) : 0), h_kdel(k16_mode != 0 ? n_pos : 0);
+  std::atomic<uint64_t> k16_escapes{0};
   std::vector<ColWg> h_wg((size_t)nblk * C.nch);
   // (graded only where the tasks outnumber the chip's resident workgroups several times over -- K2c holds 512, K3c 1024: with a single round,
   // as on one rank's share of a sharded problem (400 tasks), the kernel takes as long as its LARGEST task, and grading made K3c 33 -> 40 us there)
@@ -197,6 +203,21 @@ int build_colsort(gsfm_rot_problem* P, const std::vector<uint32_t>& rp, hvec<uin
           h_kcol[o] = (h_meta[o].x == GSFM_COL_PAD ? kpad : (h_meta[o].x & 0x7fffffffu)) | (col_slot(h_meta[o].y) << cbits) | (std::min(rc, cmax) << (cbits + GSFM_COL_SLOT_BITS));
           h_kcnt[o] = (uint16_t)rc;
         }
+        if (k16_mode != 0) {   // the same sub-chunk once more: cameras as steps inside each wavefront's 64 positions
+          uint32_t prev = 0, esc = 0;
+          for (uint32_t p = 0; p < SUB; ++p) {
+            const size_t o = base + p;
+            const uint32_t cam = h_meta[o].x == GSFM_COL_PAD ? prev : (h_meta[o].x & 0x7fffffffu);   // (position 0 of a sub-chunk is never padding)
+            uint32_t step = 0;
+            if ((p & 63u) == 0) h_kbase[(sub_off[b] + s) * (SUB / 64) + (p >> 6)] = cam; else step = cam - prev;
+            prev = cam;
+            const uint32_t rc = h_kcnt[o];
+            h_kdel[o] = step;
+            esc += (step >= GSFM_K16_DEL_ESC) + (rc >= GSFM_K16_CNT_ESC);
+            h_k16[o] = (uint16_t)(col_slot(h_meta[o].y) | (std::min(rc, GSFM_K16_CNT_ESC) << GSFM_COL_SLOT_BITS) | (std::min(step, GSFM_K16_DEL_ESC) << 12));
+          }
+          k16_escapes.fetch_add(esc, std::memory_order_relaxed);
+        }
       }
     }
   });
@@ -207,6 +228,13 @@ int build_colsort(gsfm_rot_problem* P, const std::vector<uint32_t>& rp, hvec<uin
     C = gsfm_rot_problem::ColSort();   // out of memory: the row-major form needs none of this
     return 0;
   }
+  // The 2-byte record pays where an escape (a step of 15 cameras or more, a row with 7 or more entries in one sub-chunk: each its own 32-byte
+  // sector) is rare: below one position in a hundred -- the benchmark graph has 2e-4 --; an allocation that fails leaves the 4-byte record in use.
+  if (k16_mode != 0 && (k16_mode > 0 || (double)k16_escapes.load() <= 0.01 * (double)n_pos)) {
+    if (C.k16.upload(h_k16) == hipSuccess && C.kbase.upload(h_kbase) == hipSuccess && C.kdel.upload(h_kdel) == hipSuccess) C.k16_active = true;
+    else { (void)hipGetLastError(); C.k16.release(); C.kbase.release(); C.kdel.release(); }
+  }
+  if (getenv("GSFM_CREATE_TIMING")) fprintf(stderr, "gsfm create: column-sorted layout, %zu positions, 2-byte record %s (%llu escapes)\n", n_pos, C.k16_active ? "on" : "off", (unsigned long long)k16_escapes.load());
   col.swap(h_col); deid.swap(h_eid);
   C.active = true;
   return 0;

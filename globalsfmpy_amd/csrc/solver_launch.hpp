@@ -366,7 +366,8 @@ int launch_matvec(gsfm_rot_problem* P, const double* Mblk, const double* p, doub
     ColMatvecArgs m{};
     m.L = c.dev(); m.b0 = P->h0.p; m.b1 = P->h1.p; m.b2 = P->h2.p; m.u = P->u_rot.p; m.part = c.part.p; m.done = done;
     // (occupancy: four workgroups per CU; holding it at 3 / 2 / 1 with unused dynamic LDS measured 215 / 226 / 306 us against 196)
-    hipLaunchKernelGGL(k_mv_col, dim3(c.n_wg), dim3(GSFM_K3C_THREADS), 0, P->stream, m);
+    if (c.k16_active) hipLaunchKernelGGL(k_mv_col<true>, dim3(c.n_wg), dim3(GSFM_K3C_THREADS), 0, P->stream, m);
+    else hipLaunchKernelGGL(k_mv_col<false>, dim3(c.n_wg), dim3(GSFM_K3C_THREADS), 0, P->stream, m);
     ColFinishArgs f{};
     f.n_rows = P->n_rows; f.row_base = P->own_begin; f.nch = c.nch; f.n_wg = c.n_wg; f.part = c.part.p; f.Mblk = Mblk; f.p = p; f.q = P->q_lin; f.y = y; f.done = done;
     if (dot_part && !P->sharded) { f.dot_part = dot_part; *dot_done = true; }   // (one GPU: rows = cameras, the finish grid is the camera kernels' grid)

@@ -311,7 +311,8 @@ int run_pcg2(gsfm_rot_problem* P, const gsfm_rot_options& o, double tol, double 
       auto& L = P->cs;
       ColMatvecCgArgs cm{};
       cm.mv.L = L.dev(); cm.mv.b0 = P->h0.p; cm.mv.b1 = P->h1.p; cm.mv.b2 = P->h2.p; cm.mv.u = P->u_rot.p; cm.mv.part = L.part.p; cm.mv.done = nullptr; cm.cg = c;
-      hipLaunchKernelGGL(k_mv_col_cg, dim3(L.n_wg), dim3(GSFM_K3C_THREADS), 0, P->stream, cm);
+      if (L.k16_active) hipLaunchKernelGGL(k_mv_col_cg<true>, dim3(L.n_wg), dim3(GSFM_K3C_THREADS), 0, P->stream, cm);
+      else hipLaunchKernelGGL(k_mv_col_cg<false>, dim3(L.n_wg), dim3(GSFM_K3C_THREADS), 0, P->stream, cm);
       ColFinishArgs f{};
       f.n_rows = P->n_rows; f.row_base = P->own_begin; f.nch = L.nch; f.n_wg = L.n_wg; f.part = L.part.p; f.Mblk = P->Mblk.p; f.p = P->z.p; f.q = P->q_lin; f.y = w_own;
       f.done = &P->cg2sc.p->done; f.dot_part = dots_own;

@@ -210,3 +210,56 @@ def test_disconnected_problem_small_components_factorised_exactly(oracle, sizes,
         m = comp == c
         for other in (ro, r1):
             assert synth.angular_distance(synth.align_rotations(rd[m], other[m]), other[m]).mean() <= 1e-6, c
+
+
+class _EnvVars:
+    def __init__(self, **kw): self.kw = {k: str(v) for k, v in kw.items()}
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.kw}
+        os.environ.update(self.kw)
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            if v is None: os.environ.pop(k, None)
+            else: os.environ[k] = v
+
+
+@pytest.mark.parametrize("n,e,hub,forced", [
+    (3000, 90000, 0, False),        # dense blocks (30 k entries over 3 000 cameras): steps of 0 / 1, the record is chosen by itself
+    (1100, 20000, 0, False),        # 2 full row blocks + a ragged one, padding at the end of every block's last sub-chunk
+    (70000, 300000, 40000, True),   # sparse blocks (4 k entries over 70 k cameras): most steps escape (>= 15), the hub row's counts escape (>= 7)
+    (513, 4000, 0, True),           # one row in the second block
+])
+def test_k3c_two_byte_record_gives_the_same_bits(n, e, hub, forced):
+    """K3c's 2-byte delta-coded record (colsort_kernels.hpp, ColLayoutDev::k16: slot | row count | camera step, the camera rebuilt by a DPP
+    prefix sum from the wavefront's base) against the 4-byte record it replaces (GSFM_K3C_K16=0): the mat-vec adds the same products in the
+    same order, so the product, the textbook PCG and the single-reduction PCG (k_mv_col_cg) must come out BIT FOR BIT -- including where
+    the escapes carry the record (forced on a layout the builder would not choose it for) -- and the layout's bytes fall by 2 per position."""
+    g = synth.make_graph(n_cams=n, n_edges=e, seed=21, outlier_frac=0.15)
+    rng = np.random.default_rng(4)
+    ei, ej, rel, c6 = g["edge_i"], g["edge_j"], g["rel_aa"], g["cov6"]
+    if hub:
+        others = rng.choice(np.arange(6, n, dtype=np.uint32), size=hub, replace=False)
+        ei = np.concatenate([ei, np.full(hub, 5, dtype=np.uint32)]); ej = np.concatenate([ej, others])
+        rel = np.concatenate([rel, 0.3 * rng.standard_normal((hub, 3))]); c6 = np.concatenate([c6, c6[:hub]])
+    v = rng.standard_normal((n, 3))
+    out = {}
+    for k16 in (0, 1):
+        env = dict(GSFM_K3_COLSORT=1, GSFM_PCG_COARSE=0, GSFM_REORDER=0)
+        if k16 == 0 or forced: env["GSFM_K3C_K16"] = k16
+        with _EnvVars(**env):
+            dev = RotationProblem(n, ei, ej, rel, _abi.ANGLE_AXIS_COVARIANCE, cov6=c6)
+            dev.set_loss(LF.HuberLoss(0.05))
+            lb, form = dev.matvec_bytes()[:2]
+            assert form == 2
+            dev.linearize(g["init_aa"])
+            y = dev.normal_matvec(v)
+            sols = [dev.solve(g["init_aa"], dense_cholesky_max_cams=0, pcg_single_reduction=sr, pcg_forcing=0, max_num_iterations=4) for sr in (0, 1)]
+            out[k16] = (lb, y, sols)
+            dev.close()
+    assert out[0][0] > out[1][0], "the 2-byte record was not built (or not reported)"
+    n_pos = (out[0][0] - out[1][0]) / 2.0
+    assert n_pos == int(n_pos) and n_pos >= 2 * len(ei)
+    assert np.array_equal(out[0][1], out[1][1])
+    for (r0, s0), (r1, s1) in zip(out[0][2], out[1][2]):
+        assert np.array_equal(r0, r1)
+        assert s0["num_cg_iterations"] == s1["num_cg_iterations"] and s0["final_cost"] == s1["final_cost"]
