@@ -478,7 +478,8 @@ def main():
         nd = 2.0 * e_local if part is None else float(part.entries_per_rank[rank])   # (sharded: rank 0's rows)
         mv_bytes = mv_layout_bytes      # this rank's mat-vec as laid out (gsfm_rot_matvec_bytes): row-major 52 B per directed entry, column-sorted 54 B per position + ...
         mv_kernel = {0: "k_matvec<false> (K3: general 9-value blocks, row-major)", 1: "k_matvec<LAP> (K3: Laplacian form, row-major, 52 B per directed entry)",
-                     2: "k_mv_col + k_mv_col_finish (K3c: Laplacian form, column-sorted row blocks, 52 B per position (48 block + 4-byte record); csrc/colsort_kernels.hpp)"}[mv_form]
+                     2: ("k_mv_col + k_mv_col_finish (K3c: Laplacian form, column-sorted row blocks, 52 B per position (48 block + 4-byte record: GSFM_K3C_K16=0); csrc/colsort_kernels.hpp)" if os.environ.get("GSFM_K3C_K16") == "0" else
+                         "k_mv_col + k_mv_col_finish (K3c: Laplacian form, column-sorted row blocks, 50 B per position (48 block + 2-byte delta-coded record, round 5; 52 where the layout is too sparse for it); csrc/colsort_kernels.hpp)")}[mv_form]
         lin_bytes = lin_layout_bytes    # the linearisation as laid out (row-major: col 4 + q_rel 32 + whitening + block per directed entry; column-sorted: 8 + 32 + whitening + 48 per position)
         sweep_bytes = e_local * lay_b + 32.0 * n_cams          # as laid out: idx 8 + q_rel 32 + Lt 48 per edge, the quaternions once
 

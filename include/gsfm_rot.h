@@ -476,8 +476,9 @@ gsfm_status gsfm_rot_time_sweep_variants(gsfm_rot_problem* p, const double* rot_
 gsfm_status gsfm_rot_time_kernels(gsfm_rot_problem* p, const double* rot_aa, int32_t reps, double* out_ms4);
 
 /* Bytes one mat-vec / one linearisation streams as laid out in HBM, and which form the problem uses: 0 = general 9-value blocks (76 B per
- * directed entry in the mat-vec), 1 = Laplacian form, row-major (52 B), 2 = Laplacian form, column-sorted row blocks (54 B per position
- * + slot offsets + partial sums; large graphs without locality, csrc/colsort_kernels.hpp).  Any output may be NULL.  For roofline reporting. */
+ * directed entry in the mat-vec), 1 = Laplacian form, row-major (52 B), 2 = Laplacian form, column-sorted row blocks (50 B per position with
+ * the 2-byte delta-coded record -- graphs whose row blocks are dense in the cameras, e.g. the benchmark graph --, else 52, 54 from 2^19 cameras on;
+ * + partial sums; large graphs without locality, csrc/colsort_kernels.hpp).  Any output may be NULL.  For roofline reporting. */
 gsfm_status gsfm_rot_matvec_bytes(gsfm_rot_problem* p, double* matvec_bytes, double* linearize_bytes, int32_t* form);
 
 /* Bytes moved per edge by one K1 sweep as laid out in HBM / as counted
