@@ -222,17 +222,17 @@ int build_colsort(gsfm_rot_problem* P, const std::vector<uint32_t>& rp, hvec<uin
     }
   });
   C.n_wg = (uint32_t)h_wg.size(); C.n_pos = n_pos; C.cbits = cbits; C.cmax = cmax;
-  if (C.wg.upload(h_wg) != hipSuccess || C.meta.upload(h_meta) != hipSuccess || C.kcol.upload(h_kcol) != hipSuccess || C.kcnt.upload(h_kcnt) != hipSuccess ||
+  // The 2-byte record pays where an escape (a step of 15 cameras or more, a row with 7 or more entries in one sub-chunk: each its own 32-byte
+  // sector) is rare: below one position in a hundred -- the benchmark graph has 1e-4 --; an allocation that fails leaves the 4-byte record in use.
+  if (k16_mode != 0 && (k16_mode > 0 || (double)k16_escapes.load() <= 0.01 * (double)n_pos)) {
+    if (C.k16.upload(h_k16) == hipSuccess && C.kbase.upload(h_kbase) == hipSuccess && C.kdel.upload(h_kdel) == hipSuccess) C.k16_active = true;
+    else { (void)hipGetLastError(); C.k16.release(); C.kbase.release(); C.kdel.release(); }
+  }
+  if (C.wg.upload(h_wg) != hipSuccess || C.meta.upload(h_meta) != hipSuccess || (!C.k16_active && C.kcol.upload(h_kcol) != hipSuccess) || C.kcnt.upload(h_kcnt) != hipSuccess ||
       C.part.alloc((size_t)9 * C.n_wg * RB) != hipSuccess) {
     (void)hipGetLastError();
     C = gsfm_rot_problem::ColSort();   // out of memory: the row-major form needs none of this
     return 0;
-  }
-  // The 2-byte record pays where an escape (a step of 15 cameras or more, a row with 7 or more entries in one sub-chunk: each its own 32-byte
-  // sector) is rare: below one position in a hundred -- the benchmark graph has 2e-4 --; an allocation that fails leaves the 4-byte record in use.
-  if (k16_mode != 0 && (k16_mode > 0 || (double)k16_escapes.load() <= 0.01 * (double)n_pos)) {
-    if (C.k16.upload(h_k16) == hipSuccess && C.kbase.upload(h_kbase) == hipSuccess && C.kdel.upload(h_kdel) == hipSuccess) C.k16_active = true;
-    else { (void)hipGetLastError(); C.k16.release(); C.kbase.release(); C.kdel.release(); }
   }
   if (getenv("GSFM_CREATE_TIMING")) fprintf(stderr, "gsfm create: column-sorted layout, %zu positions, 2-byte record %s (%llu escapes)\n", n_pos, C.k16_active ? "on" : "off", (unsigned long long)k16_escapes.load());
   col.swap(h_col); deid.swap(h_eid);
