@@ -1,4 +1,5 @@
 # A/B: K2c with 512-lane workgroups (one position per lane: 104-124 VGPRs, 4 waves per SIMD) against the product's 256-lane form (two positions per lane: 216 VGPRs, 2 waves per SIMD)
+# (build the second library first: hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -DGSFM_COLLIN_THREADS=512 -o globalsfmpy_amd/libgsfm_rot_t512.so.alt globalsfmpy_amd/csrc/gsfm_rot.hip -ldl)
 set -x
 cd "$(dirname "$0")/.."
 L=globalsfmpy_amd/libgsfm_rot.so
