@@ -350,16 +350,30 @@ def main():
         """W untimed + exactly K timed solves bracketed by barrier + synchronize; returns (seconds, max over ranks; sweeps; last summary; last rotations)."""
         prob = problem if problem is not None else prob_main
         summ_, rot_ = None, None
+        resident = opts.pop("resident", True)
+        if resident:
+            # Inputs resident in HBM when the timed region starts (the contract): the start rotations are a device buffer, refreshed from a
+            # second device buffer before every solve (a 2.4 MB device-to-device copy inside the timed region), the result stays on the device
+            # until the clock has stopped.  resident=False: host arrays in and out through gsfm_rot_solve (the PCIe-inclusive figure).
+            init_d = torch.tensor(np.ascontiguousarray(init), dtype=torch.float64, device="cuda")
+            work_d = torch.empty_like(init_d)
+            def one(**kw):
+                work_d.copy_(init_d)
+                torch.cuda.current_stream().synchronize()   # (the problem runs on its own stream: the buffer must be complete before it reads it)
+                return prob.solve_resident(work_d, **kw)
         for _ in range(n_warm):
-            _, summ_ = prob.solve(init, verbose=args.verbose if rank == 0 else 0, **opts)
+            if resident: summ_ = one(verbose=args.verbose if rank == 0 else 0, **opts)
+            else: _, summ_ = prob.solve(init, verbose=args.verbose if rank == 0 else 0, **opts)
         barrier()
         t0 = time.perf_counter()
         sweeps_ = 0
         for _ in range(n_steps):
-            rot_, summ_ = prob.solve(init, **opts)
+            if resident: summ_ = one(**opts)
+            else: rot_, summ_ = prob.solve(init, **opts)
             sweeps_ += summ_["num_residual_sweeps"]
         barrier()
         el = time.perf_counter() - t0
+        if resident: rot_ = work_d.cpu().numpy()
         if dist is not None:
             t = torch.tensor([el], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -372,6 +386,9 @@ def main():
     sharded_capture = part is not None and getattr(comm, "backend", "") == "rccl-native" and os.environ.get("GSFM_PCG_GRAPH_COLLECTIVES", "1") != "0"
     base_opts = dict(pcg_hip_graph=0) if sharded_capture else {}
     elapsed, sweeps, summ, rot = timed_solves(args.warmup, args.steps, **base_opts)
+    el_h, sw_h, _, rot_h = timed_solves(1, args.steps, resident=False, **base_opts)   # (every rank: the sharded solve is a collective)
+    host_leg = {"what": "gsfm_rot_solve: host arrays in and out (the reference's calling convention), PCIe-inclusive -- reported, never `value`",
+                "ms_per_step": 1e3 * el_h / args.steps, "value": n_edges * sw_h / el_h, "same_rotations_as_value": bool(np.array_equal(rot, rot_h))}
     if watchdog is not None:
         watchdog.cancel()
 
@@ -519,6 +536,11 @@ def main():
                              traffic=pmc_bytes("k_matvec"), traffic_unit="bytes per launch (mat-vec + its finishing kernel, as kernel_ms)", traffic_source=(pmc[1] if pmc else pmc_note),
                              directed_entries_per_launch=int(nd), launches_per_solve=summ["num_cg_iterations"]),
         }
+        # What `value` times (the contract: inputs resident in HBM when the timed region starts): the graph, the measurements and the covariances live
+        # on the device since create; the camera rotations -- 2.4 MB in, 2.4 MB out -- enter and leave as a device buffer (gsfm_rot_solve_resident).
+        # The same K steps through gsfm_rot_solve, host arrays in and out (the reference's calling convention, PCIe-inclusive), ride along.
+        out["state_transfer"] = {"value_times": "gsfm_rot_solve_resident: start rotations and result are device buffers (inputs resident in HBM); a 2.4 MB device-to-device refresh of the start per step is inside the timed region",
+                                 "host_buffers": host_leg}
         kept = summ["num_inexact_steps"] > 0 and summ["num_forcing_restarts"] == 0
         out["pcg_schedule"] = {"pcg_forcing": 1, "pcg_forcing_tolerance_rad": 1e-8, "inexact_steps_per_solve": summ["num_inexact_steps"], "continued_solves_per_solve": summ["num_forcing_refinements"],
                                "forcing_restarts_per_solve": summ["num_forcing_restarts"], "pcg_capped_steps_per_solve": summ["num_pcg_capped_steps"],

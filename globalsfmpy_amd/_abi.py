@@ -191,6 +191,7 @@ def load_library():
     lib.gsfm_rot_problem_create.restype = C.c_int
     declare_solver_signatures(lib, "gsfm_rot_")
     lib.gsfm_rot_set_stream.argtypes = [C.c_void_p, C.c_void_p]; lib.gsfm_rot_set_stream.restype = C.c_int
+    lib.gsfm_rot_solve_resident.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Options), C.POINTER(Summary)]; lib.gsfm_rot_solve_resident.restype = C.c_int
     lib.gsfm_rot_residual_dim.argtypes = [C.c_int32]; lib.gsfm_rot_residual_dim.restype = C.c_int32
     lib.gsfm_rot_time_sweep.argtypes = [C.c_void_p, _DP, C.c_int32, _DP]; lib.gsfm_rot_time_sweep.restype = C.c_int
     lib.gsfm_rot_time_kernels.argtypes = [C.c_void_p, _DP, C.c_int32, _DP]; lib.gsfm_rot_time_kernels.restype = C.c_int

@@ -102,13 +102,27 @@ gsfm_status gsfm_rot_set_edge_weights(gsfm_rot_problem* P, const double* w) {
   return (gsfm_status)sync_check(P, "set_edge_weights");
 }
 
-gsfm_status gsfm_rot_solve(gsfm_rot_problem* P, double* rot, const gsfm_rot_options* opt, gsfm_rot_summary* summary) {
+static gsfm_status solve_impl(gsfm_rot_problem* P, double* rot, const gsfm_rot_options* opt, gsfm_rot_summary* summary, bool resident);
+gsfm_status gsfm_rot_solve(gsfm_rot_problem* P, double* rot, const gsfm_rot_options* opt, gsfm_rot_summary* summary) { return solve_impl(P, rot, opt, summary, false); }
+// rot: DEVICE memory on the problem's device, caller numbering, 3 doubles per camera, in / out.  Returns with the problem's stream synchronised.
+gsfm_status gsfm_rot_solve_resident(gsfm_rot_problem* P, double* rot_dev, const gsfm_rot_options* opt, gsfm_rot_summary* summary) {
+  if (P && rot_dev) {
+    DeviceGuard g(P->device);
+    hipPointerAttribute_t at{};
+    if (hipPointerGetAttributes(&at, rot_dev) != hipSuccess || (at.type != hipMemoryTypeDevice && at.type != hipMemoryTypeManaged)) {
+      (void)hipGetLastError();
+      return (gsfm_status)fail(GSFM_ERR_INVALID_ARG, "gsfm_rot_solve_resident: rot_aa_dev_inout is not device memory (host arrays go to gsfm_rot_solve)");
+    }
+  }
+  return solve_impl(P, rot_dev, opt, summary, true);
+}
+static gsfm_status solve_impl(gsfm_rot_problem* P, double* rot, const gsfm_rot_options* opt, gsfm_rot_summary* summary, bool resident) {
   if (!P || !rot) return (gsfm_status)fail(GSFM_ERR_INVALID_ARG, "NULL argument");
   DeviceGuard g(P->device);
   const gsfm_rot_options o = opt ? *opt : default_options();
   gsfm_rot_summary local; if (!summary) summary = &local;
   const double t0 = now_ms();
-  if (int st = upload_state(P, rot)) return (gsfm_status)st;
+  if (int st = resident ? upload_state_resident(P, rot) : upload_state(P, rot)) return (gsfm_status)st;
   int st = lm_solve(P, o, summary);
   if (st == GSFM_INTERNAL_RESTART) {
     // The forcing schedule gave up on this trajectory after inexact steps had been applied (solver_lm.hpp, the contraction gate): the solve is
@@ -117,7 +131,7 @@ gsfm_status gsfm_rot_solve(gsfm_rot_problem* P, double* rot, const gsfm_rot_opti
     gsfm_rot_options o2 = o;
     o2.pcg_forcing = 0;
     if (o.verbose) fprintf(stderr, "[gsfm] forcing schedule abandoned after %d LM iterations (steps stopped contracting): restarting with exact steps\n", spent.num_iterations);
-    if (int st2 = upload_state(P, rot)) return (gsfm_status)st2;
+    if (int st2 = resident ? upload_state_resident(P, rot) : upload_state(P, rot)) return (gsfm_status)st2;
     st = lm_solve(P, o2, summary);
     summary->num_forcing_restarts = 1;
     summary->num_cg_iterations += spent.num_cg_iterations; summary->num_residual_sweeps += spent.num_residual_sweeps; summary->num_linearizations += spent.num_linearizations;
@@ -125,7 +139,7 @@ gsfm_status gsfm_rot_solve(gsfm_rot_problem* P, double* rot, const gsfm_rot_opti
     summary->num_pcg_launched += spent.num_pcg_launched; summary->t_linearize_ms += spent.t_linearize_ms; summary->t_sweep_ms += spent.t_sweep_ms; summary->t_cg_ms += spent.t_cg_ms;
   }
   if (st) return (gsfm_status)st;
-  if (int st2 = download_state(P, rot)) return (gsfm_status)st2;
+  if (int st2 = resident ? download_state_resident(P, rot) : download_state(P, rot)) return (gsfm_status)st2;
   summary->t_total_ms = now_ms() - t0;
   return GSFM_OK;
 }

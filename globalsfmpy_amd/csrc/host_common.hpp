@@ -259,6 +259,7 @@ struct gsfm_rot_problem {
   // locality relabelling adopted at create (empty = identity): internal id = perm[external id]
   std::vector<uint32_t> perm;
   std::vector<double> h_cam;   // staging for permuted per-camera transfers
+  DevBuf<uint32_t> d_perm;     // perm on the device (gsfm_rot_solve_resident; uploaded on first use)
   int cost_direct = 0;        // 1: K1 gathers the quaternions directly (thin tiles), 0: 2-D LDS tiles
   EdgePlanes dir;             // directed entries (rows = owned cameras)
   DevBuf<uint32_t> row_ptr, col;

@@ -3,6 +3,17 @@
 #pragma once
 #include "host_common.hpp"
 
+namespace gsfm {
+// Per-camera 3-vectors between the caller's numbering and the internal one (the locality relabelling adopted at create), on the device:
+// to_internal: dst[perm[k]] = src[k]; otherwise dst[k] = src[perm[k]].  (gsfm_rot_solve_resident; the host entry points permute on the host.)
+__global__ void __launch_bounds__(GSFM_BLOCK) k_cam_permute3(const double* __restrict__ src, const uint32_t* __restrict__ perm, uint32_t n, int to_internal, double* __restrict__ dst) {
+  const uint32_t k = blockIdx.x * GSFM_BLOCK + threadIdx.x;
+  if (k >= n) return;
+  const size_t a = to_internal ? k : perm[k], b = to_internal ? perm[k] : k;
+  dst[3 * b] = src[3 * a]; dst[3 * b + 1] = src[3 * a + 1]; dst[3 * b + 2] = src[3 * a + 2];
+}
+}  // namespace gsfm
+
 namespace {
 
 // lm_solve's private verdict "the forcing schedule must not be trusted on this trajectory: redo the solve from the initial rotations with every
@@ -79,6 +90,30 @@ int upload_state(gsfm_rot_problem* P, const double* rot_aa) {
   }
   launch_cache(P, P->x.p, P->q.p);
   return 0;
+}
+// The same two transfers for a caller whose rotations live in device memory (gsfm_rot_solve_resident): nothing crosses PCIe.
+int upload_state_resident(gsfm_rot_problem* P, const double* d_rot_aa) {
+  const size_t N = P->n_cams;
+  if (P->perm.empty()) { HIPCHK(hipMemcpyAsync(P->aa_io.p, d_rot_aa, 24 * N, hipMemcpyDeviceToDevice, P->stream)); }
+  else {
+    if (!P->d_perm.p && P->d_perm.upload(P->perm) != hipSuccess) { (void)hipGetLastError(); return fail(GSFM_ERR_HIP, "uploading the camera relabelling failed"); }
+    hipLaunchKernelGGL(k_cam_permute3, dim3(grid_for(N)), dim3(GSFM_BLOCK), 0, P->stream, d_rot_aa, (const uint32_t*)P->d_perm.p, P->n_cams, 1, P->aa_io.p);
+  }
+  if (P->param_dim == 3) { HIPCHK(hipMemcpyAsync(P->x.p, P->aa_io.p, 24 * N, hipMemcpyDeviceToDevice, P->stream)); }
+  else hipLaunchKernelGGL(k_cam_cache, dim3(grid_for(N)), dim3(GSFM_BLOCK), 0, P->stream, P->aa_io.p, P->n_cams, 3, (double2*)P->x.p);
+  launch_cache(P, P->x.p, P->q.p);
+  return 0;
+}
+int download_state_resident(gsfm_rot_problem* P, double* d_rot_aa) {
+  const size_t N = P->n_cams;
+  const double* src = P->x.p;
+  if (P->param_dim != 3) {
+    hipLaunchKernelGGL(k_quat_to_aa, dim3(grid_for(N)), dim3(GSFM_BLOCK), 0, P->stream, P->x.p, P->active.p, P->n_cams, P->aa_io.p);
+    src = P->aa_io.p;
+  }
+  if (P->perm.empty()) { HIPCHK(hipMemcpyAsync(d_rot_aa, src, 24 * N, hipMemcpyDeviceToDevice, P->stream)); }
+  else hipLaunchKernelGGL(k_cam_permute3, dim3(grid_for(N)), dim3(GSFM_BLOCK), 0, P->stream, src, (const uint32_t*)P->d_perm.p, P->n_cams, 0, d_rot_aa);
+  return sync_check(P, "rotations (device-resident)");
 }
 int download_state(gsfm_rot_problem* P, double* rot_aa) {
   const size_t N = P->n_cams;

@@ -178,6 +178,22 @@ class ProblemBase(object):
         return out
 
 
+def _device_rotations(rot_dev, n_cams):
+    """Device address of a (n_cams, 3) float64 buffer: a contiguous torch CUDA tensor, anything with __cuda_array_interface__, or an int."""
+    if isinstance(rot_dev, int):
+        return rot_dev
+    if hasattr(rot_dev, "data_ptr"):   # torch
+        if not rot_dev.is_cuda or str(rot_dev.dtype) != "torch.float64" or not rot_dev.is_contiguous() or rot_dev.numel() != 3 * n_cams:
+            raise ValueError("solve_resident needs a contiguous float64 CUDA tensor of %d x 3" % n_cams)
+        return int(rot_dev.data_ptr())
+    cai = getattr(rot_dev, "__cuda_array_interface__", None)
+    if cai is None:
+        raise TypeError("solve_resident needs device memory (a torch CUDA tensor, __cuda_array_interface__ or a raw address); host arrays go to solve()")
+    if cai["typestr"] not in ("<f8", "=f8") or int(np.prod(cai["shape"])) != 3 * n_cams or cai.get("strides") is not None:
+        raise ValueError("solve_resident needs a contiguous float64 device buffer of %d x 3" % n_cams)
+    return int(cai["data"][0])
+
+
 def _prep_edges(n_cams, edge_i, edge_j, rel_aa, cov6, inlier_weight):
     ei = np.ascontiguousarray(edge_i, dtype=np.uint32)
     ej = np.ascontiguousarray(edge_j, dtype=np.uint32)
@@ -213,6 +229,18 @@ class RotationProblem(ProblemBase):
 
     def _options_default(self, o):
         self._lib.gsfm_rot_options_default(C.byref(o))
+
+    def solve_resident(self, rot_dev, **options):
+        """gsfm_rot_solve_resident: `rot_dev` is DEVICE memory on the problem's device ((n_cams, 3) float64, contiguous: a torch CUDA tensor,
+        an object with __cuda_array_interface__, or a raw address), read as the start and overwritten with the result -- nothing but the
+        summary crosses PCIe.  Returns the summary; the stream is synchronised on return."""
+        ptr = _device_rotations(rot_dev, self.n_cams)
+        o = self._options(options)
+        s = _abi.Summary()
+        st = self._lib.gsfm_rot_solve_resident(self._h, C.c_void_p(ptr), C.byref(o), C.byref(s))
+        self._reraise_callback_error()
+        self._check(st, "solve_resident")
+        return s.as_dict()
 
     def time_sweep(self, rot_aa, reps=20):
         rot = np.ascontiguousarray(rot_aa, dtype=np.float64).reshape(self.n_cams, 3)

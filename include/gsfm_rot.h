@@ -382,6 +382,15 @@ gsfm_status gsfm_rot_set_edge_weights(gsfm_rot_problem* p, const double* w /* n_
 gsfm_status gsfm_rot_solve(gsfm_rot_problem* p, double* rot_aa_inout,
                            const gsfm_rot_options* opt, gsfm_rot_summary* summary);
 
+/* The same solve for a caller whose rotations already live in device memory (a pipeline stage that runs on the GPU; bench.py's timed
+ * region): rot_aa_dev_inout is a DEVICE pointer on the problem's device -- 3 doubles per camera, the caller's camera numbering, read at
+ * entry, overwritten with the result -- and nothing crosses PCIe but the summary's scalars.  The buffer is read and written on the
+ * PROBLEM's stream (gsfm_rot_set_stream): its producer must have finished, or be ordered before that stream.  Returns with the problem's stream
+ * synchronised.  GSFM_ERR_INVALID_ARG for a host pointer.  (The reference's entry points take host maps, estimator.cpp:72-78: they map
+ * to gsfm_rot_solve; this one has no counterpart there.)                                                                        */
+gsfm_status gsfm_rot_solve_resident(gsfm_rot_problem* p, double* rot_aa_dev_inout,
+                                    const gsfm_rot_options* opt, gsfm_rot_summary* summary);
+
 /* EstimateRotationsWithSigmaConsensus (estimator.cpp:314-457): outer IRLS with
  * MAGSAC (nu = 3) weights from the residual norm, inner full LM solve.  The
  * problem must have been created with GSFM_ROT_ANGLE_AXIS.                      */

@@ -263,3 +263,51 @@ def test_k3c_two_byte_record_gives_the_same_bits(n, e, hub, forced):
     for (r0, s0), (r1, s1) in zip(out[0][2], out[1][2]):
         assert np.array_equal(r0, r1)
         assert s0["num_cg_iterations"] == s1["num_cg_iterations"] and s0["final_cost"] == s1["final_cost"]
+
+
+@pytest.mark.parametrize("case", ["coherent_relabelled", "random", "quaternion_state", "restart"])
+def test_device_resident_solve_equals_the_host_buffer_solve(case):
+    """gsfm_rot_solve_resident: the rotations enter and leave as a DEVICE buffer in the caller's numbering (permuted on the device where create
+    adopted the locality relabelling) -- the same state reaches the same solver, so rotations, cost and iteration counts equal
+    gsfm_rot_solve's bit for bit: angle-axis and quaternion states, isolated cameras (their input value must survive), a solve that is
+    redone from the caller's buffer (the forcing schedule's restart reads it a second time); a host pointer is refused."""
+    import torch
+    if case == "coherent_relabelled":
+        g = synth.make_graph(n_cams=3000, n_edges=30000, seed=3, outlier_frac=0.1, local_window=40)
+        perm = np.random.default_rng(0).permutation(3000).astype(np.uint32)     # shuffled ids: create adopts the locality order
+        g["edge_i"], g["edge_j"] = perm[g["edge_i"]], perm[g["edge_j"]]
+        inv = np.argsort(perm)
+        g["init_aa"] = g["init_aa"][inv]
+        et, loss, opts = _abi.ANGLE_AXIS_COVARIANCE, LF.MAGSACWeightBasedLoss(0.02), {}
+    elif case == "random":
+        g = synth.make_graph(n_cams=2500, n_edges=40000, seed=4, outlier_frac=0.2)
+        et, loss, opts = _abi.ANGLE_AXIS, LF.SoftLOneLoss(0.1), {}
+    elif case == "quaternion_state":
+        g = synth.make_graph(n_cams=900, n_edges=9000, seed=5, outlier_frac=0.1)
+        keep = (g["edge_i"] != 17) & (g["edge_j"] != 17)                         # camera 17: no edge, keeps its input value
+        for k in ("edge_i", "edge_j", "rel_aa", "cov6", "inlier_weight"):
+            g[k] = g[k][keep]
+        et, loss, opts = _abi.QUATERNION_COSINE, LF.HuberLoss(0.1), {}
+    else:
+        g = synth.make_graph(n_cams=1500, n_edges=9000, seed=11, outlier_frac=0.3)
+        g["init_aa"] = g["init_aa"] + 0.25 * np.random.default_rng(2).standard_normal(g["init_aa"].shape)
+        et, loss, opts = _abi.ANGLE_AXIS, LF.CauchyLoss(0.05), dict(dense_cholesky_max_cams=0)
+    p = RotationProblem(g["n_cams"], g["edge_i"], g["edge_j"], g["rel_aa"], et, cov6=g["cov6"] if et == _abi.ANGLE_AXIS_COVARIANCE else None)
+    p.set_loss(loss)
+    rot_h, s_h = p.solve(g["init_aa"], **opts)
+    d = torch.tensor(np.ascontiguousarray(g["init_aa"]), dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    s_d = p.solve_resident(d, **opts)
+    rot_d = d.cpu().numpy()
+    assert np.array_equal(rot_d, rot_h)
+    for k in ("num_iterations", "num_cg_iterations", "final_cost", "termination", "num_forcing_restarts"):
+        assert s_d[k] == s_h[k], k
+    if case == "quaternion_state":
+        assert np.array_equal(rot_d[17], g["init_aa"][17])
+    if case == "restart":
+        assert s_d["num_forcing_restarts"] in (0, 1)
+    with pytest.raises(Exception):
+        p._check(p._lib.gsfm_rot_solve_resident(p._h, rot_h.ctypes.data, None, None), "solve_resident")
+    with pytest.raises((TypeError, ValueError)):
+        p.solve_resident(rot_h)
+    p.close()
