@@ -552,7 +552,7 @@ def main():
                                "what": "every LM step is solved loosely first (estimated deviation from the exact step <= 1e-8 rad rms, no camera's block-Jacobi estimate above 1e-7); "
                                        "decisions are taken from it only when a factor two away from their thresholds, otherwise PCG continues towards cg_relative_tolerance 1e-12; "
                                        "the schedule is kept only while every accepted step is below 0.3 x its predecessor (and, under MAGSAC, no loose solve needs more than 64 iterations) -- otherwise the run is redone with exact steps "
-                                       "(include/gsfm_rot.h: pcg_forcing; tests/manual/fuzz_forcing.py: 0 mismatches in 840 default-option trials, profiles/r05_fuzz_forcing.txt)"}
+                                       "(include/gsfm_rot.h: pcg_forcing; tests/manual/fuzz_forcing.py: 0 mismatches in 4 840 default-option trials, profiles/r05_fuzz_forcing.txt)"}
         if exact is not None:
             out["exact_schedule"] = exact
         if tree is not None:
