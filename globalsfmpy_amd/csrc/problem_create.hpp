@@ -133,6 +133,11 @@ int build_colsort(gsfm_rot_problem* P, const std::vector<uint32_t>& rp, hvec<uin
   {
     const double per_block = (double)n_sub / nblk;
     uint32_t nch = std::max<uint32_t>((uint32_t)std::lround(per_block / 22.0), (400 + nblk - 1) / nblk);
+    // A layout that is ONE round of workgroups (fewer than the 1280 tasks from which the sizes are graded: a rank's share of a sharded problem, a
+    // mid-size graph) runs as long as its most loaded CU: about two workgroups per CU -- 500 tasks -- measured best for K3c AND K2c on the
+    // shares of the benchmark graph (profiles/r05_rank_wgs.txt: 2 ranks 882 -> 490 tasks K3c 106.6 -> 86.2 us; 8 ranks 400 -> 500 tasks K2c
+    // 114.1 -> 104.6 us, K3c 34.6 -> 33.9; 525 or 750 tasks lose 15 %: a third workgroup on some CUs).
+    if ((size_t)nblk * nch < 1280) nch = std::max<uint32_t>(1u, (uint32_t)std::lround(500.0 / nblk));
     if (const char* e = getenv("GSFM_COL_WGS")) { const int v = atoi(e); if (v > 0) nch = ((uint32_t)v + nblk - 1) / nblk; }
     C.nch = std::min<uint32_t>(32, std::max<uint32_t>(1, nch));
   }
