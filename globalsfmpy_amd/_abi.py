@@ -49,7 +49,7 @@ class Options(C.Structure):
         ("pcg_single_reduction", C.c_int32), ("cg_stall_iterations", C.c_int32),
         ("dense_cholesky_max_cams", C.c_int32), ("pcg_hip_graph", C.c_int32),
         ("pcg_forcing", C.c_int32), ("dense_cholesky_auto_cams", C.c_int32), ("pcg_forcing_tolerance", C.c_double),
-        ("lm_device_control", C.c_int32), ("reserved1_", C.c_int32),
+        ("lm_device_control", C.c_int32), ("component_rest", C.c_int32),
     ]
 
 

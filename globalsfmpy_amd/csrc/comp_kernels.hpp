@@ -26,7 +26,7 @@ struct CompMap {
 // alone.  Never under the MAGSAC losses (freeze_below = 0): there an iterate 1e-10 rad off can sit in another table cell.
 __global__ void __launch_bounds__(GSFM_BLOCK) k_comp_activity(const uint32_t* __restrict__ cam_ptr, const uint32_t* __restrict__ cams, const double* __restrict__ b,
                                                               const double* __restrict__ Minv, const double* zbound, double floor2, int* active,
-                                                              unsigned long long* stepmax, int* frozen, double freeze_below) {
+                                                              unsigned long long* stepmax, int* frozen, double freeze_below, const double* freeze_ok) {
   __shared__ double lds[8];
   const uint32_t c = blockIdx.x;
   double v = 0.0;
@@ -41,9 +41,15 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_comp_activity(const uint32_t* __
   if (threadIdx.x == 0) {
     const double B = *zbound;
     int fr = frozen[c];
-    if (!fr && freeze_below > 0.0 && __longlong_as_double((long long)stepmax[c]) <= freeze_below) fr = 1;   // (last iteration's exact step; +inf before the first)
-    frozen[c] = fr; stepmax[c] = 0ull;
-    active[c] = !fr && (!(B > 0.0) || t * B > floor2);
+    // (last iteration's exact step; +inf before the first and after an iteration in which the component was idle -- an idle component was not
+    // factorised, nothing was measured, and block-Jacobi's estimate, which idles it, is no bound on an ill-conditioned scene's true step.
+    // *freeze_ok: the host allows freezing only while the damping is not what makes the step small -- trust radius at or above its initial
+    // value -- : after a run of rejections caused by ANOTHER scene the shared radius collapses and an unconverged scene's damped step can fall
+    // below the threshold without the scene having converged; the reference keeps solving every block.  Round-5 advisor.)
+    if (!fr && freeze_below > 0.0 && *freeze_ok != 0.0 && __longlong_as_double((long long)stepmax[c]) <= freeze_below) fr = 1;
+    const int act = !fr && (!(B > 0.0) || t * B > floor2);
+    frozen[c] = fr; stepmax[c] = act ? 0ull : 0x7ff0000000000000ull;
+    active[c] = act;
   }
 }
 // (one workgroup per camera of a factorised component -- `cams`, the list k_comp_activity walks -- not per row of the problem: at C4 2 168 of 14 019)

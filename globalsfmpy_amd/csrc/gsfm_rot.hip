@@ -23,7 +23,7 @@ void gsfm_rot_options_default(gsfm_rot_options* o) {
   o->initial_trust_region_radius = 1e4; o->max_trust_region_radius = 1e16; o->min_trust_region_radius = 1e-32;
   o->min_relative_decrease = 1e-3; o->min_lm_diagonal = 1e-6; o->max_lm_diagonal = 1e32;
   o->jacobi_scaling = 1; o->max_cg_iterations = 20000; o->cg_relative_tolerance = 1e-12; o->cg_check_interval = 8; o->verbose = 0; o->pcg_single_reduction = -1; o->cg_stall_iterations = 0; o->dense_cholesky_max_cams = 512; o->pcg_hip_graph = 1;
-  o->pcg_forcing = 1; o->pcg_forcing_tolerance = 1e-8; o->dense_cholesky_auto_cams = 5333; o->lm_device_control = 1;
+  o->pcg_forcing = 1; o->pcg_forcing_tolerance = 1e-8; o->dense_cholesky_auto_cams = 5333; o->lm_device_control = 1; o->component_rest = 1;
 }
 
 int32_t gsfm_rot_residual_dim(int32_t t) { return t == GSFM_ROT_QUATERNION_NORM ? 4 : t == GSFM_ROT_ROTATION_MAT_FNORM ? 9 : 3; }

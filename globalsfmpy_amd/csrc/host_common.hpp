@@ -250,6 +250,7 @@ struct gsfm_rot_problem {
   } pcg_graph, pcg2_graph;
 
   EdgePlanes cost;            // cost-owned edges
+  double cost_n_global = 0.0; // edges counted in the cost over ALL ranks (= cost.n unsharded; sharded: summed in the create-time agreement, identical on every rank)
   DevBuf<uint2> cost_idx;
   DevBuf<CostTile> cost_tiles;
   // Laplacian form of the normal matrix (kernels.hpp, lin_rows): chosen per linearisation; u_rot = R^T p for the mat-vec
@@ -288,6 +289,7 @@ struct gsfm_rot_problem {
     std::vector<uint32_t> comp_of;     // per camera (internal numbering): component index, 0xffffffff for a camera without edges
     std::vector<uint32_t> size;        // cameras per component
     int built_cap = -1;                // the size limit the batch below was built for (-1: not built)
+    bool fresh_solve = true;           // set at the top of every solve: the first component step of the solve resets `frozen` / `stepmax` (not "LM iteration 1": a step can reach this path later, e.g. behind a failed dense factorisation)
     uint32_t n_items = 0, Tmax = 0, n_dense_cams = 0, n_pcg_comps = 0;
     size_t a_words = 0;                // doubles of the A tiles (the head of the slab: one memset clears them)
     bool all_dense = false;            // every camera with an edge lies in a factorised component: no PCG at all
@@ -321,6 +323,7 @@ struct gsfm_rot_problem {
   bool packed = false;        // sharded: no rank holds an edge that leaves its slice (whole components per rank): every rank runs its own PCG, no collective in the loop
   bool pcg_local = false;     //   ... set while such a PCG runs: the mat-vec does not gather
   DevBuf<double> b_own;       //   ... its right-hand side: b with the other ranks' cameras zeroed
+  bool component_rest = true; // gsfm_rot_options::component_rest of the solve in hand (lm_solve): converged components of a disconnected problem are put to rest
   uint32_t n_components = 1;  // connected components of the view graph (1 when sharded: a rank sees only its own edges)
   DevBuf<double> part_a, part_b, part_cost, part_cam, part_gauge, scal;
   DevBuf<CgScalars> cgsc;

@@ -2269,6 +2269,7 @@ __device__ __forceinline__ double lm_cube(double t) {
 }
 // `it_dev`: the number of the LM iteration the next k_lm_after stamps its record with -- on the device, so that no kernel of an iteration takes a
 // per-iteration argument and the whole iteration replays as one hipGraph (solver_lm.hpp)
+__global__ void k_set_double(double* p, double v) { *p = v; }   // one device word from a host value, in stream order (no staging buffer to keep alive)
 __global__ void k_lm_set(double* ctl, double radius, double df, double x_cost, double x_norm, double gmax, double n_invalid, double* it_dev, double iteration) {
   *it_dev = iteration;
   ctl[CT_RADIUS] = radius; ctl[CT_DF] = df; ctl[CT_XCOST] = x_cost; ctl[CT_XNORM] = x_norm; ctl[CT_GMAX] = gmax; ctl[CT_NINVALID] = n_invalid;

@@ -275,14 +275,18 @@ static gsfm_status problem_create_impl(uint32_t n_cams, uint64_t n_edges, const 
   bool agreed = false;
   DevBuf<double> agree_buf;
   double coarse_votes_against = 0.0;
+  // The agreement also carries the number of edges this rank counts in the cost: their sum -- the problem's edge count, the same exact
+  // double on every rank -- is what every LM decision that depends on "how many edges" is taken from (solver_lm.hpp: the staircase band of
+  // the forcing schedule).  A rank-local count there would let one rank restart while the others enter a collective (round-5 advisor).
   auto agree = [&](double my_flag, double my_vote) -> int {   // number of ranks that failed, or -1 if the agreement itself could not be run
     agreed = true;
     if (!P->sharded) return 0;
-    double h[2] = {my_flag, my_vote};
-    if (agree_buf.alloc(2) != hipSuccess || hipMemcpy(agree_buf.p, h, 16, hipMemcpyHostToDevice) != hipSuccess) return -1;
-    if (all_reduce(P, agree_buf.p, 2) != 0) return -1;
-    if (hipStreamSynchronize(P->stream) != hipSuccess || hipMemcpy(h, agree_buf.p, 16, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    double h[3] = {my_flag, my_vote, (double)P->cost.n};
+    if (agree_buf.alloc(3) != hipSuccess || hipMemcpy(agree_buf.p, h, 24, hipMemcpyHostToDevice) != hipSuccess) return -1;
+    if (all_reduce(P, agree_buf.p, 3) != 0) return -1;
+    if (hipStreamSynchronize(P->stream) != hipSuccess || hipMemcpy(h, agree_buf.p, 24, hipMemcpyDeviceToHost) != hipSuccess) return -1;
     coarse_votes_against = h[1];
+    P->cost_n_global = h[2];
     return (int)(h[0] + 0.5);
   };
   auto bail = [&](int st) {

@@ -88,6 +88,7 @@ bool comps_build(gsfm_rot_problem* P, int cap) {
   }
   for (size_t i = 0; i < items.size(); ++i) { items[i].A = C.slab.p + offA[i]; items[i].L = C.slab.p + offL[i]; items[i].x = C.slab.p + offX[i]; items[i].info = C.info.p + i; items[i].active = C.active.p + i; }
   if (C.items.upload(items) != hipSuccess || C.cam_item.upload(cam_item) != hipSuccess || C.cam_loc.upload(cam_loc) != hipSuccess) { (void)hipGetLastError(); return false; }
+  { std::vector<unsigned long long> inf(items.size(), 0x7ff0000000000000ull); if (hipMemcpy(C.stepmax.p, inf.data(), 8 * items.size(), hipMemcpyHostToDevice) != hipSuccess) { (void)hipGetLastError(); return false; } }   // nothing measured yet
   C.n_items = (uint32_t)items.size(); C.Tmax = Tmax; C.n_dense_cams = n_dense; C.all_dense = pcg_comps == 0;
   C.a_words = a_words; C.n_pcg_comps = pcg_comps;
   return true;
@@ -98,7 +99,7 @@ void comps_enqueue_dense(gsfm_rot_problem* P, hipStream_t st) {
   auto& C = P->comps;
   (void)hipMemsetAsync(C.slab.p, 0, 8 * C.a_words, st);
   hipLaunchKernelGGL(k_comp_activity, dim3(C.n_items), dim3(GSFM_BLOCK), 0, st, (const uint32_t*)C.item_ptr.p, (const uint32_t*)C.item_cams.p, (const double*)P->b.p,
-                     (const double*)P->Minv.p, (const double*)(P->scal.p + SC_ZBOUND), pcg_abs_floor2(P), C.active.p, C.stepmax.p, C.frozen.p, comp_freeze_below(P));
+                     (const double*)P->Minv.p, (const double*)(P->scal.p + SC_ZBOUND), pcg_abs_floor2(P), C.active.p, C.stepmax.p, C.frozen.p, comp_freeze_below(P), (const double*)(P->scal.p + SC_FREEZE_OK));
   DenseArgs a{};
   a.n_rows = P->n_rows; a.row_ptr = P->row_ptr.p; a.col = P->col.p; a.h0 = P->h0.p; a.h1 = P->h1.p; a.h2 = P->h2.p; a.h3 = P->h3.p; a.h4 = P->h4.p;
   a.Mblk = P->Mblk.p; a.b = P->b.p; a.A = nullptr; a.n = 0; a.T = 0; a.q = P->q_lin; a.lap = P->lin_is_lap; a.info_slot = P->scal.p + SC_DENSE_INFO; a.rcg = P->r.p;
@@ -121,17 +122,20 @@ void comps_enqueue_dense(gsfm_rot_problem* P, hipStream_t st) {
 
 // The step of a disconnected problem: *used = false if the path does not apply (the caller then runs its generic one).  On return the step
 // vector and the PCG residual are complete and the status word of the scalar block says whether every factorisation went through.
-int run_component_step(gsfm_rot_problem* P, const gsfm_rot_options& o, double tol_requested, bool pcg_struggles, bool first_step, bool* used, int* cg, double* cg_rel) {
+// freeze_ok: this step's damping is not what would make a component's step small (lm_solve: the trust radius is at or above its initial value)
+int run_component_step(gsfm_rot_problem* P, const gsfm_rot_options& o, double tol_requested, bool pcg_struggles, bool freeze_ok, bool* used, int* cg, double* cg_rel) {
   *used = false; *cg = 0; *cg_rel = 0.0;
   if ((P->sharded && !P->packed) || P->n_components <= 1 || o.dense_cholesky_max_cams <= 0 || P->cs.active) return 0;
   if (!comps_build(P, o.dense_cholesky_max_cams)) return 0;
   auto& C = P->comps;
-  if (first_step) {   // a new solve: nobody is at rest, no step has been measured (+inf)
+  if (C.fresh_solve) {   // the first component step of a solve, whichever LM iteration reaches it (lm_solve sets the flag at its top): nobody is at rest, no step has been measured (+inf)
+    C.fresh_solve = false;
     std::vector<unsigned long long> inf(C.n_items, 0x7ff0000000000000ull);
     HIPCHK(hipMemsetAsync(C.frozen.p, 0, sizeof(int) * C.n_items, P->stream));
     HIPCHK(hipMemcpyAsync(C.stepmax.p, inf.data(), 8 * C.n_items, hipMemcpyHostToDevice, P->stream));
     HIPCHK(hipStreamSynchronize(P->stream));   // (the staging vector dies with this scope)
   }
+  hipLaunchKernelGGL(k_set_double, dim3(1), dim3(1), 0, P->stream, P->scal.p + SC_FREEZE_OK, freeze_ok ? 1.0 : 0.0);
   // The factorisations and the PCG solve of the large components touch disjoint outputs and read the same inputs: with something left for PCG
   // the chain of the factorisations runs on a stream of its own beside it (fork behind the damping's kernels, join in front of the scatter).
   if (C.side_state == 0) {

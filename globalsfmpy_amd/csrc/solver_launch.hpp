@@ -205,7 +205,7 @@ int all_reduce(gsfm_rot_problem* P, double* buf, size_t count) {
 }
 
 // ---- launches -----------------------------------------------------------------------------
-enum { SC_COST = 0, SC_GMAX = 1, SC_STEP = 2 /* ..6 */, SC_XNORM2 = 7, SC_TRIAL = 8, SC_ZL8 = 9 /* k_cam_step's sixth sum (loose steps) */, SC_ZBOUND = 10 /* k_cam_bound's B: the absolute floor of the PCG tolerance */, SC_COMPBAD = 11 /* packed sharded problems: ranks whose component factorisation broke down (all-reduced) */, SC_DENSE_INFO = 15 /* an int: status of the Cholesky factorisation */, SC_N = 16,
+enum { SC_COST = 0, SC_GMAX = 1, SC_STEP = 2 /* ..6 */, SC_XNORM2 = 7, SC_TRIAL = 8, SC_ZL8 = 9 /* k_cam_step's sixth sum (loose steps) */, SC_ZBOUND = 10 /* k_cam_bound's B: the absolute floor of the PCG tolerance */, SC_COMPBAD = 11 /* packed sharded problems: ranks whose component factorisation broke down (all-reduced) */, SC_FREEZE_OK = 12 /* component step: 1.0 while a small exact step may put a component to rest (k_comp_activity) */, SC_DENSE_INFO = 15 /* an int: status of the Cholesky factorisation */, SC_N = 16,
        SC_CTL = 16 /* .. 31: the device-side LM control block (kernels.hpp, CT_*) */, SC_REC = 32 /* .. 95: ring of four per-iteration records of it */, SC_ALL = 96 };
 enum { T_LIN = 0, T_SWEEP = 1, T_CG = 2 };
 

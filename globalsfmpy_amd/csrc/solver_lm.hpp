@@ -149,6 +149,8 @@ int lm_solve(gsfm_rot_problem* P, const gsfm_rot_options& o_in, gsfm_rot_summary
   P->graph_launches = 0;
   P->n_collectives = P->n_pcg_collectives = P->n_pcg_launched = 0;
   P->lap = P->lap_capable;
+  P->comps.fresh_solve = true;
+  P->component_rest = o.component_rest != 0;
   double h[SC_N];
   double radius = o.initial_trust_region_radius, decrease_factor = 2.0;
   int num_invalid = 0, iteration = 0;
@@ -410,7 +412,7 @@ int lm_solve(gsfm_rot_problem* P, const gsfm_rot_options& o_in, gsfm_rot_summary
     bool comp_used = false;
     if (P->packed) (void)hipMemsetAsync(P->scal.p + SC_COMPBAD, 0, sizeof(double), P->stream);
     if (!dense_used && P->n_components > 1 && (!P->sharded || P->packed)) {
-      if (int st = run_component_step(P, o, o_in.cg_relative_tolerance, pcg_struggles, iteration == 1, &comp_used, &cg, &cg_rel)) return st;
+      if (int st = run_component_step(P, o, o_in.cg_relative_tolerance, pcg_struggles, radius >= o.initial_trust_region_radius, &comp_used, &cg, &cg_rel)) return st;
       if (comp_used) {
         loose = false;
         if (gmax_deferred) {
@@ -553,7 +555,10 @@ int lm_solve(gsfm_rot_problem* P, const gsfm_rot_options& o_in, gsfm_rot_summary
       const double pt = o.parameter_tolerance * (x_norm + o.parameter_tolerance), ft = o.function_tolerance * x_cost, acc = std::fabs(cost_change);
       // (the staircase's noise in a cost change falls with the number of edges that make it up: 0.9 against 1.1 at 44k edges, 1.797 against
       // 1.815 at 300k -- the band is +- 100 / sqrt(E) relative, at most the factor two)
-      const double n_e = (double)std::max<size_t>(1, P->cost.n) * (P->sharded ? (double)P->shard.world_size : 1.0);
+      // (the GLOBAL edge count, bit-identical on every rank of a sharded problem -- summed in the create-time agreement: with a rank-local count
+      // the band would differ from rank to rank, and a decision inside the sliver between two ranks' bands would send one rank into the restart
+      // while the others enter the next collective)
+      const double n_e = std::fmax(1.0, P->sharded ? P->cost_n_global : (double)P->cost.n);
       const double w = P->loss_staircase ? std::fmin(1.0, 100.0 / std::sqrt(n_e)) : 1e-3, lo = 1.0 / (1.0 + w), hi = 1.0 + w;
       if (cost_change > 0.0 && ((step_norm > lo * pt && step_norm <= hi * pt) || (acc > lo * ft && acc <= hi * ft) || (rel_dec > lo * o.min_relative_decrease && rel_dec <= hi * o.min_relative_decrease))) {
         record(x_cost, cost_change, step_norm, rel_dec, cg); finish(GSFM_TERM_NO_CONVERGENCE); return GSFM_INTERNAL_RESTART;

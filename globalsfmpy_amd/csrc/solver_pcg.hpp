@@ -144,9 +144,10 @@ struct PcgStagnation {
 // For a DISCONNECTED problem under a smooth loss the floor is 1e-11 rad: its scenes are independent problems that converge at their own pace,
 // and the ones that have converged must stop costing iterations while the slowest iterates on (C4: 13 of 14); what they are left short of is
 // their conditioning times 1e-11 rad, five orders inside the bar.  (Not under MAGSAC: an iterate 1e-11 rad off can sit in another table cell.)
-double pcg_abs_floor2(const gsfm_rot_problem* P) { const double f = (P->n_components > 1 && !P->loss_staircase && !P->cb) ? 1e-11 : 2e-14; return f * f; }
+// (gsfm_rot_options::component_rest = 0 switches both departures from the reference's single global stopping rule off: P->component_rest, set by lm_solve)
+double pcg_abs_floor2(const gsfm_rot_problem* P) { const double f = (P->n_components > 1 && !P->loss_staircase && !P->cb && P->component_rest) ? 1e-11 : 2e-14; return f * f; }
 // ... and a factorised component whose exact step has fallen below this is put to rest for the remainder of the solve (comp_kernels.hpp, k_comp_activity)
-double comp_freeze_below(const gsfm_rot_problem* P) { return (!P->loss_staircase && !P->cb) ? 1e-10 : 0.0; }
+double comp_freeze_below(const gsfm_rot_problem* P) { return (!P->loss_staircase && !P->cb && P->component_rest) ? 1e-10 : 0.0; }
 
 // block-Jacobi PCG on (J^T J + Lambda) eta = -g to the relative residual `tol` -- or, etol2 > 0 (a loose solve of the forcing schedule), until the
 // estimated relative energy-norm error squared falls below etol2 (kernels.hpp, cg_energy_stop); returns iterations.  resume_iters >= 0: continue the solve
@@ -388,6 +389,9 @@ int run_pcg2(gsfm_rot_problem* P, const gsfm_rot_options& o, double tol, double 
 // graphs (tools/small_graph_pcg.py: 22 -> 14 -> 8 us per iteration at C2 size); from ~1M directed entries on the kernels dominate
 // and the textbook recurrence is kept (its residual is the recursively updated one of the reference description).
 bool use_single_reduction(const gsfm_rot_problem* P, const gsfm_rot_options& o) {
+  // A PACKED sharded problem runs every rank's own PCG without a collective (run_pcg's LocalScope); run_pcg2 has no such scope -- its all-gather
+  // sits inside the loop and the ranks' iteration counts differ -- so not even an explicit pcg_single_reduction = 1 selects it there (round-5 advisor).
+  if (P->packed) return false;
   if (o.pcg_single_reduction >= 0) return o.pcg_single_reduction != 0;
   if (o.cg_stall_iterations > 0) return false;   // stagnation detection lives in the textbook variant's scalar kernel
   // (On the column-sorted layout the variant exists too -- k_mv_col_cg, one vector kernel instead of two -- and measures the same as the

@@ -213,6 +213,15 @@ typedef struct {
                                           are left short of into another set of inlier edges (fuzz seed 2 trial 45).  The benchmark graph from the
                                           spanning-tree start is such a run (308 loose iterations in its first step): 218 ms with exact steps by
                                           default, 106 ms and 1.5e-9 rad from it with pcg_forcing = 3.
+                                          EXCEPTION, documented (round-5 review): what the schedule keeps is the ROTATIONS, not in every case the LM
+                                          iteration COUNT ("IRLS iterations to 1e-6", gsfm_rot_summary::num_iterations / iters_to_1e6).  A MAGSAC run
+                                          that ends on REJECTED candidates hovering at the function tolerance -- cost changes of 0.9 against 1.1 x
+                                          1e-6 of the cost, each a sum of table-cell jumps -- ends one to seven rejections earlier or later than the
+                                          exact schedule does, the state not moving in between (<= 5e-9 rad): 7 of 4 840 fuzz trials, LM 7 against 14
+                                          once.  A rejected candidate changes nothing whichever iteration the run ends at, so such a run is NOT
+                                          redone (only decisions on cost-LOWERING candidates inside the noise band are, above); a caller who needs
+                                          the reference's iteration count under MAGSAC sets pcg_forcing = 0.  On every BASELINE configuration the two
+                                          schedules give the same count (bench.py prints both, tests/test_gpu_bench.py asserts it on C5).
                                           0: every step at cg_relative_tolerance (rounds 1-3).  3: as 1 without the exclusions by loss (Tukey, callback)
                                           and by conditioning -- the contraction gate and the restarts stay -- for callers who know their graphs.
                                           2 (a testing aid): every loose solve is continued
@@ -239,7 +248,20 @@ typedef struct {
                                           radius it wrote, so an iteration costs ONE host read-back instead of two and no host decision sits between
                                           its kernels.  Same formulas in the same order as the host loop: bit-identical trajectories
                                           (tests/test_gpu_round4.py).  0: the host loop everywhere. */
-  int32_t reserved1_;
+  int32_t component_rest;              /* default 1.  A DEPARTURE from Ceres' single global stopping rule, for disconnected view graphs (several
+                                          scenes batched as one problem; csrc/solver_components.hpp) under a smooth loss: a connected component of at
+                                          most dense_cholesky_max_cams cameras is PUT TO REST for the remainder of the solve once its exact
+                                          (factorised) step has fallen below 1e-10 rad on every one of its cameras while the trust radius is at or
+                                          above its initial value, and the PCG tolerance of such a problem has an absolute floor of 1e-11 rad per
+                                          camera instead of 2e-14.  The reference has no such notion: ceres::Solve factorises every block of the
+                                          block-diagonal system in every iteration until the GLOBAL function / gradient / parameter test fires
+                                          (estimator.cpp:299-305).  The scenes of a batch are independent problems, a scene whose Newton step is
+                                          1e-10 rad has at most ~1e-9 rad left to go, and resting it is what keeps 13 converged scenes from being
+                                          factorised 30 more times while the 14th iterates on (BASELINE C4: 61 -> 46 ms); each component stays within
+                                          1e-6 rad of the reference's answer (tests/test_gpu_round5.py, tests/manual/fuzz_components.py).  Never under
+                                          the MAGSAC losses or a host-callback loss (1e-10 rad can be another table cell).
+                                          0: off -- every component is solved in every LM iteration and the floor is 2e-14 rad, as on a connected graph.
+                                          (This field was `reserved1_` until round 6: a caller that zero-filled it gets the reference's semantics.) */
 } gsfm_rot_options;
 
 typedef enum {

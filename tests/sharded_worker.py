@@ -114,6 +114,40 @@ def big_coherent_case(out, prefer_native):
     dist.destroy_process_group()
 
 
+def magsac_restart_case(out, prefer_native):
+    """Round-5 advisor: a MAGSAC solve on which the forcing schedule is abandoned and the run redone (seed 9 trial 93 of tests/manual/fuzz_forcing.py:
+    1 388 cameras / 12 999 edges, 14 LM iterations), on ranks whose shares of the edges differ widely (random cut points).  Every rank must take the
+    restart in the same LM iteration -- the staircase band of that decision is taken from the GLOBAL edge count (create-time agreement), not from a
+    rank's own -- otherwise one rank re-enters the solve while the others wait in a collective and the run hangs."""
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.join(ROOT, "tests", "manual"))
+    import fuzz_forcing
+    from globalsfmpy_amd.solver import RotationProblem
+    (t, g, et, loss, init, coherent), = list(fuzz_forcing.cases(94, 9, [93]))
+    world, rank = dist.get_world_size(), dist.get_rank()
+    n = g["n_cams"]
+    rng = np.random.default_rng(5)
+    cuts = [0] + sorted(int(c) for c in rng.integers(n // 10, n, world - 1)) + [n]
+    width = max(1, max(cuts[r + 1] - cuts[r] for r in range(world)))
+    new_id = np.empty(n, dtype=np.int64)
+    for r in range(world):
+        new_id[cuts[r]:cuts[r + 1]] = r * width + np.arange(cuts[r + 1] - cuts[r])
+    part = sharding.Partition(n, world, width, new_id, [0] * world)
+    prob, part = sharding.make_sharded_problem(g, et, loss=loss, prefer_native=prefer_native, part=part)
+    rot, summ = prob.solve(part.scatter(init))
+    mine = (int(summ["num_forcing_restarts"]), int(summ["num_iterations"]), int(summ["num_edges_used"]))
+    everyone = [None] * world
+    dist.all_gather_object(everyone, mine)
+    if rank == 0:
+        ref = RotationProblem(n, g["edge_i"], g["edge_j"], g["rel_aa"], et, cov6=g["cov6"], inlier_weight=g["inlier_weight"]); ref.set_loss(loss)
+        r1, s1 = ref.solve(init, dense_cholesky_max_cams=0, dense_cholesky_auto_cams=0)
+        np.savez(out, rot=part.gather(rot), ref_rot=r1, cost=summ["final_cost"], ref_cost=s1["final_cost"], iters=summ["num_iterations"], ref_iters=s1["num_iterations"],
+                 restarts=np.array([e[0] for e in everyone]), rank_iters=np.array([e[1] for e in everyone]), rank_edges=np.array([e[2] for e in everyone]),
+                 ref_restarts=s1["num_forcing_restarts"], loss=type(loss).__name__, n_edges=len(g["edge_i"]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def packed_case(out, prefer_native):
     """Six scenes as one disconnected problem, whole components per rank (sharding.pack_components): the library finds that no rank holds an
     edge leaving its slice (PACKED) and every rank solves its own block with its own PCG -- no collective inside the PCG loop."""
@@ -200,6 +234,8 @@ def main():
         return packed_case(out, len(sys.argv) > 3 and sys.argv[3] == "native")
     if case == "peererror":
         return peer_error_case(out)
+    if case == "magsacrestart":
+        return magsac_restart_case(out, len(sys.argv) > 3 and sys.argv[3] == "native")
     if case.startswith("random"):
         return random_case(int(case.split(":")[1]), out, len(sys.argv) > 3 and sys.argv[3] == "native", big=case.startswith("randomcoarse"))
     g = synth.make_graph(1203, 40000, seed=23, outlier_frac=0.3)

@@ -41,6 +41,10 @@ def test_bench_single_gpu_contract_line():
     assert out["pcg_schedule"]["pcg_forcing"] == 1 and out["exact_schedule"]["pcg_forcing"] == 0
     assert out["exact_schedule"]["default_schedule_vs_this"]["mean_angular_difference_rad"] <= 1e-6
     assert out["exact_schedule"]["cg_iterations"] >= out["cg_iterations_per_solve"]
+    # BASELINE's second metric, on both schedules: the same count on the benchmark graph; and the line names the start `value` used
+    its = out["iters_to_1e-6_by_schedule"]
+    assert its["default"] == its["exact"] == out["iters_to_1e-6"] and its["lm_iterations_default"] == its["lm_iterations_exact"], its
+    assert "init" in out["config"] and "spanning" in out["config"]["init"]
 
 
 def test_bench_two_ranks_on_one_gpu_over_gloo():

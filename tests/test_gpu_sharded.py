@@ -249,6 +249,23 @@ def test_sharded_equals_unsharded_at_the_default_tolerance_on_a_large_ill_condit
     assert d.mean() <= 1e-6
 
 
+def test_a_forcing_restart_under_magsac_is_taken_by_every_rank_together(tmp_path):
+    """Round-5 advisor (medium): the staircase band of the restart decision was computed from a rank's OWN edge count, so ranks with unequal
+    shares could disagree on it -- one restarting, the others entering the next all-gather.  Three ranks with random cut points on a MAGSAC
+    problem whose default solve is redone (fuzz seed 9 trial 93): every rank reports the same restart and iteration counts, the run ends, and it
+    equals the unsharded default solve."""
+    res = _launch(3, "gloo", str(tmp_path / "restart.npz"), case="magsacrestart")
+    print("%s, %d edges; per rank: cost edges %s, restarts %s, LM iterations %s; unsharded: %d restarts, %d iterations" % (
+        res["loss"], res["n_edges"], res["rank_edges"].tolist(), res["restarts"].tolist(), res["rank_iters"].tolist(), res["ref_restarts"], res["ref_iters"]))
+    assert str(res["loss"]) == "MAGSACWeightBasedLoss"
+    assert len(set(res["rank_edges"].tolist())) == 3 and int(res["rank_edges"].sum()) == int(res["n_edges"])   # unequal shares, every edge counted once
+    assert len(set(res["restarts"].tolist())) == 1 and len(set(res["rank_iters"].tolist())) == 1
+    assert int(res["restarts"][0]) == int(res["ref_restarts"]) == 1
+    assert int(res["iters"]) == int(res["ref_iters"])
+    assert abs(float(res["cost"]) - float(res["ref_cost"])) <= 1e-9 * float(res["ref_cost"])
+    assert synth.angular_distance(synth.align_rotations(res["rot"], res["ref_rot"]), res["ref_rot"]).mean() <= 1e-6
+
+
 def test_peer_store_time_out_fails_the_solve_and_the_next_one_runs_on_the_fallback(tmp_path):
     res = _launch(2, "gloo", str(tmp_path / "peererr.npz"), mode="peer", case="peererror")
     failed, flagged, same, few_peer_calls, fallback_used = [int(v) for v in res["flags"]]
