@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--small-graphs", type=int, default=1, help="also time the latency-regime configurations (C1 Madrid, C2), each beside the CPU oracle")
     ap.add_argument("--coherent", type=int, default=0, help="also time the spatially coherent 100k / 2M graph with and without the two-level preconditioner (not a BASELINE config)")
     ap.add_argument("--tree-init", type=int, default=1, help="also solve from the maximum-spanning-tree initialisation of SURVEY 8(d)")
+    ap.add_argument("--weak-leg", type=int, default=1, help="N > 1, --scaling strong: also time the weak-scaling point (cams x N, edges x N) and report it as `weak_scaling` on the same line")
     return ap.parse_args()
 
 
@@ -293,36 +294,42 @@ def main():
     n_cams, n_edges = args.cams, args.edges
     if args.scaling == "weak":
         n_cams, n_edges = args.cams * world, args.edges * world
+    def shared_graph(n_cams, n_edges):
+        """The synthetic graph, generated once per node (the contract is one node): rank 0 generates it and the others map its arrays from shared memory."""
+        g = None
+        if dist is not None and world > 1:
+            # one node (the contract): rank 0 generates the graph once and the others map its arrays from shared memory instead of
+            # generating 8 copies (6 s and 3 GB each); any failure falls back to generating locally -- the generator is deterministic
+            shm = "/dev/shm" if os.path.isdir("/dev/shm") else None
+            path = None if shm is None else os.path.join(shm, "gsfm_bench_%s_%d_%d_%d" % (os.environ.get("MASTER_PORT", "0"), n_cams, n_edges, args.seed))
+            ok = torch.zeros(1, dtype=torch.int32, device="cuda" if backend == "nccl" else "cpu")
+            if rank == 0 and path is not None:
+                try:
+                    g = synth.make_graph(n_cams, n_edges, args.seed, outlier_frac=args.outliers)
+                    os.makedirs(path, exist_ok=True)
+                    for k, v in g.items():
+                        np.save(os.path.join(path, k + ".npy"), np.asarray(v))
+                    ok += 1
+                except OSError:
+                    pass
+            dist.broadcast(ok, src=0)
+            if int(ok.item()) == 1 and rank != 0:
+                try:
+                    g = {f[:-4]: np.load(os.path.join(path, f), mmap_mode="r") for f in os.listdir(path) if f.endswith(".npy")}
+                    g = {k: (v if v.ndim else v.item()) for k, v in g.items()}
+                except (OSError, ValueError):
+                    g = None
+            dist.barrier()
+            if rank == 0 and path is not None and int(ok.item()) == 1:
+                import shutil
+                shutil.rmtree(path, ignore_errors=True)   # (the others hold their mappings; the pages live until they drop them)
+        if g is None:
+            g = synth.make_graph(n_cams, n_edges, args.seed, outlier_frac=args.outliers)
+
+        return g
+
     t_gen = time.perf_counter()
-    g = None
-    if dist is not None and world > 1:
-        # one node (the contract): rank 0 generates the graph once and the others map its arrays from shared memory instead of
-        # generating 8 copies (6 s and 3 GB each); any failure falls back to generating locally -- the generator is deterministic
-        shm = "/dev/shm" if os.path.isdir("/dev/shm") else None
-        path = None if shm is None else os.path.join(shm, "gsfm_bench_%s_%d_%d_%d" % (os.environ.get("MASTER_PORT", "0"), n_cams, n_edges, args.seed))
-        ok = torch.zeros(1, dtype=torch.int32, device="cuda" if backend == "nccl" else "cpu")
-        if rank == 0 and path is not None:
-            try:
-                g = synth.make_graph(n_cams, n_edges, args.seed, outlier_frac=args.outliers)
-                os.makedirs(path, exist_ok=True)
-                for k, v in g.items():
-                    np.save(os.path.join(path, k + ".npy"), np.asarray(v))
-                ok += 1
-            except OSError:
-                pass
-        dist.broadcast(ok, src=0)
-        if int(ok.item()) == 1 and rank != 0:
-            try:
-                g = {f[:-4]: np.load(os.path.join(path, f), mmap_mode="r") for f in os.listdir(path) if f.endswith(".npy")}
-                g = {k: (v if v.ndim else v.item()) for k, v in g.items()}
-            except (OSError, ValueError):
-                g = None
-        dist.barrier()
-        if rank == 0 and path is not None and int(ok.item()) == 1:
-            import shutil
-            shutil.rmtree(path, ignore_errors=True)   # (the others hold their mappings; the pages live until they drop them)
-    if g is None:
-        g = synth.make_graph(n_cams, n_edges, args.seed, outlier_frac=args.outliers)
+    g = shared_graph(n_cams, n_edges)
     t_gen = time.perf_counter() - t_gen
 
     t_create = time.perf_counter()
@@ -338,7 +345,7 @@ def main():
     torch.cuda.synchronize()
     t_create = time.perf_counter() - t_create
 
-    prob_main = prob
+    prob_main, init_main = prob, init
 
     def barrier():
         torch.cuda.synchronize()
@@ -351,6 +358,7 @@ def main():
         prob = problem if problem is not None else prob_main
         summ_, rot_ = None, None
         resident = opts.pop("resident", True)
+        init = opts.pop("init", init_main)
         if resident:
             # Inputs resident in HBM when the timed region starts (the contract): the start rotations are a device buffer, refreshed from a
             # second device buffer before every solve (a 2.4 MB device-to-device copy inside the timed region), the result stays on the device
@@ -683,6 +691,48 @@ def main():
         wd.cancel()
         if rank == 0:
             out["peer_store_exchange"] = info
+    if part is not None and world > 1 and args.scaling == "strong" and args.weak_leg:
+        # The WEAK-scaling point next to the strong-scaling line (round-5 review, item 1c): the graph grown with the rank count so that a rank's
+        # share is the one-GPU workload (cams x world, edges x world: 800k cameras / 80 M edges at 8 ranks), same generator, same options, same
+        # timing rules -- so that the first run on a real node yields both curves.  Own watchdog: whatever happens here, the line measured so far is printed.
+        import threading
+        limit = float(os.environ.get("GSFM_BENCH_WEAK_WATCHDOG_S", "900"))
+
+        def _fall_back_weak():
+            sys.stderr.write("bench.py rank %d: the weak-scaling leg did not finish within %.0f s: reporting what was measured before\n" % (rank, limit))
+            if rank == 0:
+                out["weak_scaling"] = {"status": "no result within %.0f s (watchdog)" % limit}
+                os.write(real_stdout, (json.dumps(out) + "\n").encode())
+            os._exit(0)
+        wd = threading.Timer(limit, _fall_back_weak)
+        wd.daemon = True
+        wd.start()
+        info = {"status": "unavailable"}
+        try:
+            t_w = time.perf_counter()
+            prob.close()   # (the strong-scaling problem: its planes make room for the larger graph's)
+            del g
+            wc, we = args.cams * world, args.edges * world
+            gw = shared_graph(wc, we)
+            prob_w, part_w = sharding.make_sharded_problem(gw, error_type, loss=loss_ctor())
+            init_w = part_w.scatter(gw["init_aa"])
+            t_w = time.perf_counter() - t_w
+            el_w, sw_w, s_w, rot_w = timed_solves(args.warmup, args.steps, problem=prob_w, init=init_w, **base_opts)
+            info = {"status": "ok", "scaling": "weak", "cams": wc, "edges": we, "value": we * sw_w / el_w, "unit": "edge-residuals/s", "ms_per_step": 1e3 * el_w / args.steps,
+                    "lm_iterations": s_w["num_iterations"], "cg_iterations": s_w["num_cg_iterations"], "residual_sweeps_per_solve": s_w["num_residual_sweeps"],
+                    "final_cost": s_w["final_cost"], "termination": s_w["termination_name"], "collectives": prob_w._comm.backend,
+                    "matvec_layout_form_rank0": prob_w.matvec_bytes()[1], "setup_s": t_w,
+                    "what": "the same generator and options on a graph grown with the rank count (a rank's share = the one-GPU workload); value = all ranks' edges x sweeps / max-over-ranks time; "
+                            "efficiency against the one-GPU line is for the reader to compute (layout form 2 = column-sorted K2c / K3c on rank 0, 1 = row-major)"}
+            if rank == 0:
+                ew = synth.angular_distance(synth.align_rotations(part_w.gather(rot_w), gw["gt_aa"]), gw["gt_aa"])
+                info["mean_angular_error_vs_ground_truth_deg"] = float(np.rad2deg(ew.mean()))
+            prob_w.close()
+        except Exception as e:  # noqa: BLE001  (the extra leg never takes the line down with it)
+            info = {"status": "failed: %r" % (e,)}
+        wd.cancel()
+        if rank == 0:
+            out["weak_scaling"] = info
     if crash_lib is not None:
         crash_lib.gsfm_crash_line_disarm()
     if rank == 0:

@@ -215,7 +215,20 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_mv_col_finish(ColFinishArgs a) {
   const uint32_t blk = row / GSFM_COL_RB, r = row % GSFM_COL_RB;
   const size_t plane = (size_t)a.n_wg * GSFM_COL_RB;
   double t0 = 0.0, t1 = 0.0, t2 = 0.0;
-  for (uint32_t c = 0; c < a.nch; ++c) { const size_t o = ((size_t)blk * a.nch + c) * GSFM_COL_RB + r; t0 += a.part[o]; t1 += a.part[plane + o]; t2 += a.part[2 * plane + o]; }
+  // (the partials of eight chunks are requested together, then added in chunk order -- the same sums as a plain loop, bit for bit; as a plain loop
+  // the 3 x nch loads of a lane went out one dependent round trip after the other: 8.2-9.6 us for the 12.5 k rows of one rank of 8 under
+  // rocprofv3, a quarter of its mat-vec, profiles/r06_rank8_kernel_stats.txt)
+  constexpr uint32_t FB = 8;
+  for (uint32_t c0 = 0; c0 < a.nch; c0 += FB) {
+    double v0[FB], v1[FB], v2[FB];
+#pragma unroll
+    for (uint32_t j = 0; j < FB; ++j) {
+      const size_t o = ((size_t)blk * a.nch + min(c0 + j, a.nch - 1)) * GSFM_COL_RB + r;
+      v0[j] = a.part[o]; v1[j] = a.part[plane + o]; v2[j] = a.part[2 * plane + o];
+    }
+#pragma unroll
+    for (uint32_t j = 0; j < FB; ++j) if (c0 + j < a.nch) { t0 += v0[j]; t1 += v1[j]; t2 += v2[j]; }
+  }
   const size_t k = a.row_base + row;
   double R[9], mp[3];
   qmat(load_q(a.q, (uint32_t)k), R);
@@ -450,10 +463,20 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_lin_col_finish(uint32_t n_rows, 
   const uint32_t blk = row / GSFM_COL_RB, r = row % GSFM_COL_RB;
   const size_t plane = (size_t)n_wg * GSFM_COL_RB;
   double v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-  for (uint32_t c = 0; c < nch; ++c) {
-    const size_t o = ((size_t)blk * nch + c) * GSFM_COL_RB + r;
+  constexpr uint32_t FB = 4;   // (the nine partials of four chunks in flight together, added in chunk order: the same sums as a plain loop -- see k_mv_col_finish)
+  for (uint32_t c0 = 0; c0 < nch; c0 += FB) {
+    double w[FB][9];
 #pragma unroll
-    for (int x = 0; x < 9; ++x) v[x] += part[(size_t)x * plane + o];
+    for (uint32_t j = 0; j < FB; ++j) {
+      const size_t o = ((size_t)blk * nch + min(c0 + j, nch - 1)) * GSFM_COL_RB + r;
+#pragma unroll
+      for (int x = 0; x < 9; ++x) w[j][x] = part[(size_t)x * plane + o];
+    }
+#pragma unroll
+    for (uint32_t j = 0; j < FB; ++j) if (c0 + j < nch) {
+#pragma unroll
+      for (int x = 0; x < 9; ++x) v[x] += w[j][x];
+    }
   }
   double* out = gD + 9 * (size_t)(row_base + row);
   if (q) {

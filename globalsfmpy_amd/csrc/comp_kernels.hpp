@@ -26,7 +26,7 @@ struct CompMap {
 // alone.  Never under the MAGSAC losses (freeze_below = 0): there an iterate 1e-10 rad off can sit in another table cell.
 __global__ void __launch_bounds__(GSFM_BLOCK) k_comp_activity(const uint32_t* __restrict__ cam_ptr, const uint32_t* __restrict__ cams, const double* __restrict__ b,
                                                               const double* __restrict__ Minv, const double* zbound, double floor2, int* active,
-                                                              unsigned long long* stepmax, int* frozen, double freeze_below, const double* freeze_ok) {
+                                                              unsigned long long* stepmax, unsigned long long* stepprev, int* frozen, double freeze_below, const double* freeze_ok) {
   __shared__ double lds[8];
   const uint32_t c = blockIdx.x;
   double v = 0.0;
@@ -41,14 +41,18 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_comp_activity(const uint32_t* __
   if (threadIdx.x == 0) {
     const double B = *zbound;
     int fr = frozen[c];
-    // (last iteration's exact step; +inf before the first and after an iteration in which the component was idle -- an idle component was not
-    // factorised, nothing was measured, and block-Jacobi's estimate, which idles it, is no bound on an ill-conditioned scene's true step.
-    // *freeze_ok: the host allows freezing only while the damping is not what makes the step small -- trust radius at or above its initial
-    // value -- : after a run of rejections caused by ANOTHER scene the shared radius collapses and an unconverged scene's damped step can fall
-    // below the threshold without the scene having converged; the reference keeps solving every block.  Round-5 advisor.)
-    if (!fr && freeze_below > 0.0 && *freeze_ok != 0.0 && __longlong_as_double((long long)stepmax[c]) <= freeze_below) fr = 1;
+    // cur: last iteration's exact step of this component (+inf before the first and after an iteration in which it was idle -- an idle component
+    // was not factorised, nothing was measured, and block-Jacobi's estimate, which idles it, is no bound on an ill-conditioned scene's true step);
+    // prev: the one measured before it.  A component goes to rest when its step is below the threshold AND there is evidence that it is small
+    // because the scene has converged, not because the shared trust region has collapsed under ANOTHER scene's rejections (round-5 advisor: a
+    // damped step can fall below any threshold on an unconverged scene): either the step has at least halved against the previous measurement --
+    // steps near convergence contract fast (C4: by 4-10 x per accepted step), a damping-limited scene's barely move, and a REJECTED iteration
+    // re-solves the same point (ratio ~ 1) -- or the damping is no stronger than at the start of the solve (*freeze_ok: radius >= its initial value).
+    const double cur = __longlong_as_double((long long)stepmax[c]), prev = __longlong_as_double((long long)stepprev[c]);
+    const bool contracted = prev < __longlong_as_double(0x7ff0000000000000ll) && cur <= 0.5 * prev;
+    if (!fr && freeze_below > 0.0 && cur <= freeze_below && (contracted || *freeze_ok != 0.0)) fr = 1;
     const int act = !fr && (!(B > 0.0) || t * B > floor2);
-    frozen[c] = fr; stepmax[c] = act ? 0ull : 0x7ff0000000000000ull;
+    frozen[c] = fr; stepprev[c] = stepmax[c]; stepmax[c] = act ? 0ull : 0x7ff0000000000000ull;
     active[c] = act;
   }
 }

@@ -299,7 +299,7 @@ struct gsfm_rot_problem {
     DevBuf<double> slab, b_pcg;
     DevBuf<int> info, active;          // per item: factorisation status; has anything to solve in this LM step (k_comp_activity)
     DevBuf<uint32_t> item_ptr, item_cams;   // the cameras of every item, item by item
-    DevBuf<unsigned long long> stepmax;     // per item: bits of the largest camera update (rad) of its last exact step
+    DevBuf<unsigned long long> stepmax, stepprev;   // per item: bits of the largest camera update (rad) of its last exact step, and of the one measured before it
     DevBuf<int> frozen;                      // per item: put to rest for the remainder of the solve (k_comp_activity)
     double graph_freeze = -1.0;
     hipGraphExec_t graph = nullptr;

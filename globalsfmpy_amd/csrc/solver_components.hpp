@@ -82,13 +82,13 @@ bool comps_build(gsfm_rot_problem* P, int cap) {
   item_cams.resize(item_ptr.back());
   { std::vector<uint32_t> fill(item_ptr.begin(), item_ptr.end() - 1); for (uint32_t k = 0; k < P->n_cams; ++k) if (cam_item[k] >= 0) item_cams[fill[cam_item[k]]++] = k; }
   if (C.slab.alloc(words, true) != hipSuccess || C.info.alloc(items.size(), true) != hipSuccess || C.active.alloc(items.size(), true) != hipSuccess ||
-      C.stepmax.alloc(items.size(), true) != hipSuccess || C.frozen.alloc(items.size(), true) != hipSuccess ||
+      C.stepmax.alloc(items.size(), true) != hipSuccess || C.stepprev.alloc(items.size(), true) != hipSuccess || C.frozen.alloc(items.size(), true) != hipSuccess ||
       C.item_ptr.upload(item_ptr) != hipSuccess || C.item_cams.upload(item_cams) != hipSuccess || C.b_pcg.alloc(3 * (size_t)P->n_cams, true) != hipSuccess) {
     (void)hipGetLastError(); C.slab.release(); return false;
   }
   for (size_t i = 0; i < items.size(); ++i) { items[i].A = C.slab.p + offA[i]; items[i].L = C.slab.p + offL[i]; items[i].x = C.slab.p + offX[i]; items[i].info = C.info.p + i; items[i].active = C.active.p + i; }
   if (C.items.upload(items) != hipSuccess || C.cam_item.upload(cam_item) != hipSuccess || C.cam_loc.upload(cam_loc) != hipSuccess) { (void)hipGetLastError(); return false; }
-  { std::vector<unsigned long long> inf(items.size(), 0x7ff0000000000000ull); if (hipMemcpy(C.stepmax.p, inf.data(), 8 * items.size(), hipMemcpyHostToDevice) != hipSuccess) { (void)hipGetLastError(); return false; } }   // nothing measured yet
+  { std::vector<unsigned long long> inf(items.size(), 0x7ff0000000000000ull); if (hipMemcpy(C.stepmax.p, inf.data(), 8 * items.size(), hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(C.stepprev.p, inf.data(), 8 * items.size(), hipMemcpyHostToDevice) != hipSuccess) { (void)hipGetLastError(); return false; } }   // nothing measured yet
   C.n_items = (uint32_t)items.size(); C.Tmax = Tmax; C.n_dense_cams = n_dense; C.all_dense = pcg_comps == 0;
   C.a_words = a_words; C.n_pcg_comps = pcg_comps;
   return true;
@@ -99,7 +99,7 @@ void comps_enqueue_dense(gsfm_rot_problem* P, hipStream_t st) {
   auto& C = P->comps;
   (void)hipMemsetAsync(C.slab.p, 0, 8 * C.a_words, st);
   hipLaunchKernelGGL(k_comp_activity, dim3(C.n_items), dim3(GSFM_BLOCK), 0, st, (const uint32_t*)C.item_ptr.p, (const uint32_t*)C.item_cams.p, (const double*)P->b.p,
-                     (const double*)P->Minv.p, (const double*)(P->scal.p + SC_ZBOUND), pcg_abs_floor2(P), C.active.p, C.stepmax.p, C.frozen.p, comp_freeze_below(P), (const double*)(P->scal.p + SC_FREEZE_OK));
+                     (const double*)P->Minv.p, (const double*)(P->scal.p + SC_ZBOUND), pcg_abs_floor2(P), C.active.p, C.stepmax.p, C.stepprev.p, C.frozen.p, comp_freeze_below(P), (const double*)(P->scal.p + SC_FREEZE_OK));
   DenseArgs a{};
   a.n_rows = P->n_rows; a.row_ptr = P->row_ptr.p; a.col = P->col.p; a.h0 = P->h0.p; a.h1 = P->h1.p; a.h2 = P->h2.p; a.h3 = P->h3.p; a.h4 = P->h4.p;
   a.Mblk = P->Mblk.p; a.b = P->b.p; a.A = nullptr; a.n = 0; a.T = 0; a.q = P->q_lin; a.lap = P->lin_is_lap; a.info_slot = P->scal.p + SC_DENSE_INFO; a.rcg = P->r.p;
@@ -133,6 +133,7 @@ int run_component_step(gsfm_rot_problem* P, const gsfm_rot_options& o, double to
     std::vector<unsigned long long> inf(C.n_items, 0x7ff0000000000000ull);
     HIPCHK(hipMemsetAsync(C.frozen.p, 0, sizeof(int) * C.n_items, P->stream));
     HIPCHK(hipMemcpyAsync(C.stepmax.p, inf.data(), 8 * C.n_items, hipMemcpyHostToDevice, P->stream));
+    HIPCHK(hipMemcpyAsync(C.stepprev.p, inf.data(), 8 * C.n_items, hipMemcpyHostToDevice, P->stream));
     HIPCHK(hipStreamSynchronize(P->stream));   // (the staging vector dies with this scope)
   }
   hipLaunchKernelGGL(k_set_double, dim3(1), dim3(1), 0, P->stream, P->scal.p + SC_FREEZE_OK, freeze_ok ? 1.0 : 0.0);

@@ -251,8 +251,9 @@ typedef struct {
   int32_t component_rest;              /* default 1.  A DEPARTURE from Ceres' single global stopping rule, for disconnected view graphs (several
                                           scenes batched as one problem; csrc/solver_components.hpp) under a smooth loss: a connected component of at
                                           most dense_cholesky_max_cams cameras is PUT TO REST for the remainder of the solve once its exact
-                                          (factorised) step has fallen below 1e-10 rad on every one of its cameras while the trust radius is at or
-                                          above its initial value, and the PCG tolerance of such a problem has an absolute floor of 1e-11 rad per
+                                          (factorised) step has fallen below 1e-10 rad on every one of its cameras -- and has at least halved against
+                                          the step measured before it, or the trust radius is at or above its initial value: a step that is small
+                                          because the scene converged, not because another scene's rejections collapsed the shared radius --, and the PCG tolerance of such a problem has an absolute floor of 1e-11 rad per
                                           camera instead of 2e-14.  The reference has no such notion: ceres::Solve factorises every block of the
                                           block-diagonal system in every iteration until the GLOBAL function / gradient / parameter test fires
                                           (estimator.cpp:299-305).  The scenes of a batch are independent problems, a scene whose Newton step is

@@ -61,6 +61,10 @@ def test_bench_two_ranks_on_one_gpu_over_gloo():
     assert out["collectives_per_pcg_iteration"] == 1.0 and out["collectives_per_solve"] > out["cg_iterations_per_solve"]   # exactly one collective per PCG iteration
     ps = out["peer_store_exchange"]
     assert ps["status"] == "ok" and ps["reproduces_the_collective_run"] and ps["backend"] == "peer-store+gloo" and ps["pcg_chunks_replayed_as_hipgraphs"] > 0, ps
+    # the weak-scaling point rides on the same line (round-5 review, 1c): the graph grown with the rank count, same options, converged
+    ws = out["weak_scaling"]
+    assert ws["status"] == "ok" and ws["cams"] == 2 * out["config"]["cams"] and ws["edges"] == 2 * out["config"]["edges"] and ws["value"] > 0, ws
+    assert ws["termination"] == out["termination"] and ws["mean_angular_error_vs_ground_truth_deg"] < 1.0, ws
     one = _json_line(subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + SMALL + ["--sigma-pass", "0"], cwd=ROOT, capture_output=True, text=True, timeout=900).stdout)
     assert out["lm_iterations"] == one["lm_iterations"] and out["residual_sweeps_per_solve"] == one["residual_sweeps_per_solve"]
     assert abs(out["final_cost"] - one["final_cost"]) <= 1e-6 * one["final_cost"]
