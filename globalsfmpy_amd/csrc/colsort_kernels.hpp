@@ -262,8 +262,9 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_col_s(ColRowSArgs a) {
     const uint2 mt = col_load_meta(a.L.meta + d);
     if (mt.x == GSFM_COL_PAD) continue;
     const Quat qk = load_q(a.q, a.row_base + w.row0 + col_rowl(mt.y)), qm = load_q(a.q, mt.x & 0x7fffffffu);
-    const double2 r0 = a.qr0[d], r1 = a.qr1[d];
-    const Quat qr{r0.x, r0.y, r1.x, r1.y};
+    double2 r0, r1;
+    qrel_load<WM>(a.qr0, a.qr1, d, r0, r1);
+    const Quat qr = qrel_quat<WM>(r0, r1);
     const EdgeW W = load_w<WM>(a.w0, a.w1, a.w2, a.ws, d);
     double r[R];
     if (mt.x >> 31) edge_residual<F, WM>(qm, qk, qr, W, r);

@@ -273,16 +273,88 @@ __device__ __forceinline__ Quat load_q(const double2* __restrict__ q2, uint32_t 
 }
 
 // ------------------------------------------------------------------------------------------
+// The measured relative rotation of an edge / a directed entry: 24 bytes per position on covariance-whitened problems (round 6; SURVEY 8(d)
+// counts the measurement at 24 B).  A unit quaternion is three numbers and a sign: the component of LARGEST magnitude (>= 1/2) is dropped and
+// rebuilt as +-sqrt(1 - a^2 - b^2 - c^2); dropping the largest keeps the rebuilt one accurate to an ulp (dropping w outright would lose
+// ~1e-16 / w: a third of the benchmark's edges are uniformly random rotations, |w| < 1e-4 on hundreds of them).  Which component was dropped
+// (0..3 = x, y, z, w) rides in bit 62 of the first two stored doubles -- the top bit of the exponent field, zero for every |value| < 2 -- and
+// its sign in bit 62 of the third (q and -q are the same rotation, but the quaternion-cosine residual, quat.hpp:86-103, carries the sign of
+// q_ij into the sign of r: the stored quaternion is the one ceres::AngleAxisToQuaternion gives, not a normalised one).
+// Planes: qr0 = (a, b) as double2, qr1 = c as double (the buffer is still handed around as a double2 pointer).
+// WHERE: the W_MATRIX problems (ANGLE_AXIS_COVARIANCE / COV_INLIERS: 88 -> 80 B streamed per edge).  Measured at C5, same box, alternating
+// (profiles/r06_qrel3_ab.txt): reweight sweep 180 -> 168.5 us (0.61 -> 0.65 of the roofline on SURVEY 8(d)'s bytes), full sweep 221 -> 213.5, s-only
+// 172 -> 166.5, K2c 580-593 -> 583-587 (its own stream is not what binds it), the trial-cost sweep 137.4 -> 142.2 (it stores nothing and is bound
+// by instruction issue: the ~45 VALU operations of the decode show), a whole solve 12.01 -> 11.94 ms with the final cost equal to the last bit.  The
+// unit- and scalar-weight sweeps (40-48 B per edge) are bound by instruction issue throughout -- 98.6 -> 108.4 us with three components -- and
+// keep the full quaternion, 32 B.  -DGSFM_QREL3=0: the full quaternion everywhere (rounds 1-5).
+#ifndef GSFM_QREL3
+#define GSFM_QREL3 1
+#endif
+__host__ __device__ constexpr bool qrel_three(int wm) { return GSFM_QREL3 != 0 && wm == W_MATRIX; }
+__host__ __device__ constexpr int qrel_bytes(int wm) { return qrel_three(wm) ? 24 : 32; }
+__device__ __forceinline__ void qrel_encode(const Quat& q, double* ab_c /* [3] */) {
+  const double v[4] = {q.x, q.y, q.z, q.w};
+  if (!(isfinite(v[0]) && isfinite(v[1]) && isfinite(v[2]) && isfinite(v[3]))) { ab_c[0] = ab_c[1] = ab_c[2] = 1.5; return; }   // a non-finite measurement decodes to NaN (1 - 3 x 2.25 < 0)
+  int k = 3;
+  double m = fabs(v[3]);
+#pragma unroll
+  for (int c = 2; c >= 0; --c) if (fabs(v[c]) > m) { m = fabs(v[c]); k = c; }
+  double o[3];
+  int n = 0;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) if (c != k) o[n++] = v[c];
+  unsigned long long b0 = (unsigned long long)__double_as_longlong(o[0]), b1 = (unsigned long long)__double_as_longlong(o[1]), b2 = (unsigned long long)__double_as_longlong(o[2]);
+  b0 |= (unsigned long long)(k & 1) << 62; b1 |= (unsigned long long)(k >> 1) << 62; b2 |= (unsigned long long)(v[k] < 0.0 ? 1 : 0) << 62;
+  ab_c[0] = __longlong_as_double((long long)b0); ab_c[1] = __longlong_as_double((long long)b1); ab_c[2] = __longlong_as_double((long long)b2);
+}
+// raw: the full quaternion (x, y) (z, w) -- or, three components: (a, b) in r0, c in r1.x (r1.y unused)
+template <int WM>
+__device__ __forceinline__ Quat qrel_quat(const double2& r0, const double2& r1) {
+  if constexpr (!qrel_three(WM)) return Quat{r0.x, r0.y, r1.x, r1.y};
+  else {
+    const unsigned ha = (unsigned)__double2hiint(r0.x), hb = (unsigned)__double2hiint(r0.y), hc = (unsigned)__double2hiint(r1.x);
+    const unsigned k = ((ha >> 30) & 1u) | (((hb >> 30) & 1u) << 1);
+    const double a = __hiloint2double((int)(ha & 0xbfffffffu), __double2loint(r0.x)), b = __hiloint2double((int)(hb & 0xbfffffffu), __double2loint(r0.y)),
+                 c = __hiloint2double((int)(hc & 0xbfffffffu), __double2loint(r1.x));
+    const double mp = sqrt(1.0 - a * a - b * b - c * c);   // (>= 1/4 for a unit quaternion; negative -> NaN for what qrel_encode made of a non-finite one)
+    const double m = __hiloint2double(__double2hiint(mp) ^ (int)((hc << 1) & 0x80000000u), __double2loint(mp));   // (bit 30 of the third's high word -> the sign bit)
+    Quat q;   // stored order = (x, y, z, w) with component k removed
+    q.x = k == 0u ? m : a;
+    q.y = k == 0u ? a : (k == 1u ? m : b);
+    q.z = k == 3u ? c : (k == 2u ? m : b);
+    q.w = k == 3u ? m : c;
+    return q;
+  }
+}
+template <int WM>
+__device__ __forceinline__ void qrel_load_nt(const double2* __restrict__ qr0, const double2* __restrict__ qr1, size_t e, double2& r0, double2& r1) {
+  r0 = nt_load2(qr0 + e);
+  if constexpr (qrel_three(WM)) { r1.x = __builtin_nontemporal_load((const double*)qr1 + e); r1.y = 0.0; } else r1 = nt_load2(qr1 + e);
+}
+template <int WM>
+__device__ __forceinline__ void qrel_load(const double2* __restrict__ qr0, const double2* __restrict__ qr1, size_t e, double2& r0, double2& r1) {
+  r0 = qr0[e];
+  if constexpr (qrel_three(WM)) { r1.x = ((const double*)qr1)[e]; r1.y = 0.0; } else r1 = qr1[e];
+}
+
+// ------------------------------------------------------------------------------------------
 // K0': measured relative rotations, angle-axis -> unit quaternion planes, gathered into entry order on the device
 // (ceres::AngleAxisToQuaternion, estimator.cpp:132; one upload of the 3E doubles instead of a host gather per entry)
 __global__ void __launch_bounds__(GSFM_BLOCK) k_build_qrel(const double* __restrict__ rel_aa, const uint32_t* __restrict__ eid, size_t n,
-                                                           double2* __restrict__ qr0, double2* __restrict__ qr1) {
+                                                           double2* __restrict__ qr0, double2* __restrict__ qr1, int three) {
   const size_t t = (size_t)blockIdx.x * GSFM_BLOCK + threadIdx.x;
   if (t >= n) return;
   const double* aa = rel_aa + 3 * (size_t)eid[t];
   const Quat q = aa_to_quat(aa[0], aa[1], aa[2]);
-  qr0[t] = make_double2(q.x, q.y);
-  qr1[t] = make_double2(q.z, q.w);
+  if (three) {   // (qrel_three: the W_MATRIX problems)
+    double v[3];
+    qrel_encode(q, v);
+    qr0[t] = make_double2(v[0], v[1]);
+    ((double*)qr1)[t] = v[2];
+  } else {
+    qr0[t] = make_double2(q.x, q.y);
+    qr1[t] = make_double2(q.z, q.w);
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -446,8 +518,9 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_row_s(RowSArgs a) {
   for (uint32_t d = a.row_ptr[row] + lane; d < end; d += a.G) {
     const uint32_t cr = a.col[d];
     const Quat qm = load_q(a.q, cr & 0x7fffffffu);
-    const double2 r0 = a.qr0[d], r1 = a.qr1[d];
-    const Quat qr{r0.x, r0.y, r1.x, r1.y};
+    double2 r0, r1;
+    qrel_load<WM>(a.qr0, a.qr1, d, r0, r1);
+    const Quat qr = qrel_quat<WM>(r0, r1);
     EdgeW W = load_w<WM>(a.w0, a.w1, a.w2, a.ws, d);
     if (UNIT) W.l00 = 1.0;
     double r[R];
@@ -570,7 +643,7 @@ __global__ void __launch_bounds__(GSFM_TILE_THREADS) k_cost(CostArgs a) {
       const uint32_t eu = e0 + u * GSFM_TILE_THREADS;
       const uint32_t e = eu < tile.end ? eu : e0;   // lanes past the end re-read their first edge and discard it
       ij[u] = a.idx[e];
-      r0[u] = nt_load2(a.qr0 + e); r1[u] = nt_load2(a.qr1 + e);
+      qrel_load_nt<WM>(a.qr0, a.qr1, e, r0[u], r1[u]);
       Wm[u] = load_w<WM>(a.w0, a.w1, a.w2, a.ws, e);
       if (WM == W_SCALAR && a.unit_w) Wm[u].l00 = 1.0;
     }
@@ -578,7 +651,7 @@ __global__ void __launch_bounds__(GSFM_TILE_THREADS) k_cost(CostArgs a) {
     for (int u = 0; u < U; ++u) {
       const uint32_t e = e0 + u * GSFM_TILE_THREADS;
       if (e >= tile.end) continue;
-      const Quat qr{r0[u].x, r0[u].y, r1[u].x, r1[u].y};
+      const Quat qr = qrel_quat<WM>(r0[u], r1[u]);
       const double2 i0 = qi_xy[ij[u].x], i1 = qi_zw[ij[u].x], j0 = qj_xy[ij[u].y], j1 = qj_zw[ij[u].y];
       const Quat qi{i0.x, i0.y, i1.x, i1.y}, qj{j0.x, j0.y, j1.x, j1.y};
       acc += cost_edge<F, WM, LM, MODE>(a, lv, e, qi, qj, qr, Wm[u], dw);
@@ -618,11 +691,12 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_cost_direct(CostArgs a) {
   double acc = 0.0, dw = 0.0;
   for (uint32_t e = tile.begin + threadIdx.x; e < tile.end; e += GSFM_BLOCK) {
     const uint2 ij = a.idx[e];
-    const double2 r0 = nt_load2(a.qr0 + e), r1 = nt_load2(a.qr1 + e);
+    double2 r0, r1;
+    qrel_load_nt<WM>(a.qr0, a.qr1, e, r0, r1);
     EdgeW W = load_w<WM>(a.w0, a.w1, a.w2, a.ws, e);
     if (WM == W_SCALAR && a.unit_w) W.l00 = 1.0;
     const Quat qi = load_q(a.q, ij.x), qj = load_q(a.q, ij.y);
-    acc += cost_edge<F, WM, LM, MODE>(a, lv, e, qi, qj, Quat{r0.x, r0.y, r1.x, r1.y}, W, dw);
+    acc += cost_edge<F, WM, LM, MODE>(a, lv, e, qi, qj, qrel_quat<WM>(r0, r1), W, dw);
   }
   acc = wave_sum(acc);
   if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = acc;
@@ -718,8 +792,9 @@ __device__ __forceinline__ void lin_rows(const LinArgs& a) {
       const uint32_t cr = __builtin_nontemporal_load(a.col + d);
       const uint32_t m = cr & 0x7fffffffu;
       const bool row_is_second = (cr >> 31) != 0;
-      const double2 r0 = nt_load2(a.qr0 + d), r1 = nt_load2(a.qr1 + d);
-      const Quat qr{r0.x, r0.y, r1.x, r1.y};
+      double2 r0, r1;
+      qrel_load_nt<WM>(a.qr0, a.qr1, d, r0, r1);
+      const Quat qr = qrel_quat<WM>(r0, r1);
       EdgeW W = load_w<WM>(a.w0, a.w1, a.w2, a.ws, d);
       const bool sig = F == F_AA && WM == W_SCALAR && a.sigma.on;
       if (sig) W.l00 = 1.0;
@@ -811,7 +886,7 @@ struct LinStreams { double2 r0, r1; EdgeW W; };
 template <int WM>
 __device__ __forceinline__ LinStreams lin_load_streams(const LinArgs& a, uint32_t d) {
   LinStreams S;
-  S.r0 = nt_load2(a.qr0 + d); S.r1 = nt_load2(a.qr1 + d);
+  qrel_load_nt<WM>(a.qr0, a.qr1, d, S.r0, S.r1);
   S.W = load_w<WM>(a.w0, a.w1, a.w2, a.ws, d);
   return S;
 }
@@ -862,7 +937,7 @@ __device__ __forceinline__ void edge_lin_row(const Quat& qk, const Quat& qm, con
 // general one (both Jacobians, full Corrector, host-callback rho) restricted to the row camera's block -- the Laplacian form needs no more.
 template <int F, int WM, int LM, bool FAST>
 __device__ __forceinline__ void lin_entry_eval(const LinArgs& a, const LossView<LM>& lv, uint32_t d, uint32_t cr, const Quat& qk, const Quat& qm, LinStreams S, double* g3, double* G6) {
-  const Quat qr{S.r0.x, S.r0.y, S.r1.x, S.r1.y};
+  const Quat qr = qrel_quat<WM>(S.r0, S.r1);
   const bool row_is_second = (cr >> 31) != 0;
   if (FAST) {
     double r[3], Ar[9];
@@ -926,7 +1001,7 @@ __device__ __forceinline__ void lin_entry_eval(const LinArgs& a, const LossView<
 #endif
 template <int WM, int LM>
 __device__ __forceinline__ void lin_entry_body_aa(const LinArgs& a, const LossView<LM>& lv, uint32_t d, uint32_t cr, const Quat& qk, const Quat& qm, LinStreams S, double* gb3, double* B6) {
-  const Quat qr{S.r0.x, S.r0.y, S.r1.x, S.r1.y};
+  const Quat qr = qrel_quat<WM>(S.r0, S.r1);
   const bool row_is_second = (cr >> 31) != 0;
   const Quat qi = row_is_second ? qm : qk, qj = row_is_second ? qk : qm;
   const Quat qe = qmul(qmul(qj, qconj(qi)), qconj(qr));

@@ -7,7 +7,7 @@ namespace {
 
 // Reverse Cuthill-McKee style relabelling (plain BFS from a minimum-degree camera of every component, reversed).  The p[col]
 // and q[col] gathers of K3/K2 are bound by uncoalesced lane requests; when the neighbours of a camera sit within a few
-// hundred indices of each other the lanes of a row share 128-byte lines and the gather becomes free (tools/bench_matvec.hip:
+// hundred indices of each other the lanes of a row share 128-byte lines and the gather becomes free (tools/archive/bench_matvec.hip:
 // 346 us -> 235 us at a window of 400, 284 us at 2000, no gain at 20000).  View graphs of real scenes are spatially
 // coherent but their ids are arbitrary; a uniformly random graph (the C5 benchmark) has nothing to recover.  The
 // relabelling is therefore adopted only if it shrinks the mean |i - j| over the edges by more than half AND brings it
@@ -98,9 +98,11 @@ struct DeviceGuard {
 template <typename EidVec>
 int upload_planes(gsfm_rot_problem* P, EdgePlanes& pl, const EidVec& eid, const double* d_rel_aa) {
   pl.n = eid.size();
-  if (pl.eid.upload(eid) != hipSuccess || pl.qr0.alloc(pl.n) != hipSuccess || pl.qr1.alloc(pl.n) != hipSuccess)
+  // (qr1: the third stored component, one double per position, on the W_MATRIX problems -- kernels.hpp, qrel_three; the full quaternion's (z, w) pairs otherwise)
+  const bool three = qrel_three(P->wmode);
+  if (pl.eid.upload(eid) != hipSuccess || pl.qr0.alloc(pl.n) != hipSuccess || pl.qr1.alloc(three ? (pl.n + 1) / 2 : pl.n) != hipSuccess)
     return fail(GSFM_ERR_HIP, "uploading edge planes failed (out of memory?)");
-  if (pl.n) hipLaunchKernelGGL(k_build_qrel, dim3(grid_for(pl.n)), dim3(GSFM_BLOCK), 0, P->stream, d_rel_aa, pl.eid.p, pl.n, pl.qr0.p, pl.qr1.p);
+  if (pl.n) hipLaunchKernelGGL(k_build_qrel, dim3(grid_for(pl.n)), dim3(GSFM_BLOCK), 0, P->stream, d_rel_aa, pl.eid.p, pl.n, pl.qr0.p, pl.qr1.p, three ? 1 : 0);
   if (P->wmode == W_MATRIX) {
     if (pl.w0.alloc(pl.n) != hipSuccess || pl.w1.alloc(pl.n) != hipSuccess || pl.w2.alloc(pl.n) != hipSuccess) return fail(GSFM_ERR_HIP, "alloc whitening planes");
   } else if (P->wmode == W_SCALAR) {

@@ -91,7 +91,7 @@ int sync_check(gsfm_rot_problem* P, const char* what) {
 }
 
 // Read `bytes` (<= 256) from the device and wait.  The LM / PCG control reads ~100 bytes two to five times per iteration; a copy into
-// pageable memory costs 22 us per read on this platform, into pinned memory 14 us (tools/bench_sync.hip), which is what small graphs feel.
+// pageable memory costs 22 us per read on this platform, into pinned memory 14 us (tools/archive/bench_sync.hip), which is what small graphs feel.
 int read_back(gsfm_rot_problem* P, void* dst, const void* src_dev, size_t bytes, const char* what) {
   void* stage = (P->pin && bytes <= 256) ? P->pin : dst;
   HIPCHK(hipMemcpyAsync(stage, src_dev, bytes, hipMemcpyDeviceToHost, P->stream));

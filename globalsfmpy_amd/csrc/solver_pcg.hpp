@@ -396,7 +396,7 @@ bool use_single_reduction(const gsfm_rot_problem* P, const gsfm_rot_options& o) 
   if (o.cg_stall_iterations > 0) return false;   // stagnation detection lives in the textbook variant's scalar kernel
   // (On the column-sorted layout the variant exists too -- k_mv_col_cg, one vector kernel instead of two -- and measures the same as the
   // textbook recurrence at C5: 30.69 against 30.63 ms per solve, 129 iterations both; the entry decision of its mat-vec costs what the
-  // saved launch gains.  tools/r03_pcg_variants.py)
+  // saved launch gains.  tools/archive/r03_pcg_variants.py)
   // Sharded: always -- there every launch counts (the per-rank kernels shrink with the rank count, the launches do not), and the variant is
   // 3 kernels + 1 collective per iteration (mat-vec, finish, [all-gather of A u with the delta partials in its tail], vector step) against
   // 5 + 1 for the textbook recurrence; except at tolerances below 1e-13 (disconnected graphs, lm_solve), where the recursively updated

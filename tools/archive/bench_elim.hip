@@ -20,7 +20,7 @@ using namespace gsfm;
 // Four columns at a time go through LDS (T) into the row-per-lane form, are factored there exactly as chol_eliminate64 factors them (6
 // multiplier broadcasts per four pivots instead of ~64), go back through LDS, and are applied to all remaining columns as ONE rank-4 MFMA per
 // 16 x 16 block: the matrix core adds its four products in k order with FMA rounding, which is the order and the rounding of the row-per-lane
-// loop -- every entry anyone reads comes out with the same bits (tools/bench_elim.hip checks that).
+// loop -- every entry anyone reads comes out with the same bits (tools/archive/bench_elim.hip checks that).
 struct ElimC { chol_d4 v[4][2]; };
 #define GSFM_WAVE_LDS_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 __device__ __forceinline__ void elimc_load(ElimC& V, const double* __restrict__ diag, const double* __restrict__ panel, uint32_t lane) {

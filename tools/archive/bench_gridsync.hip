@@ -2,7 +2,7 @@
 // persistent PCG kernel can beat two dependent launches per iteration in the latency regime.
 // Each round: every workgroup writes a slice of a vector, barrier, reads a slice written by a workgroup on another XCD and checks it.
 // Spins are bounded: a barrier that is not passed within LIMIT polls raises an error flag and the kernel exits.
-// build: hipcc -O3 --offload-arch=gfx950 -o tools/bench_gridsync tools/bench_gridsync.hip
+// build: hipcc -O3 --offload-arch=gfx950 -o tools/bench_gridsync tools/archive/bench_gridsync.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>

@@ -1,5 +1,5 @@
 // Host cost of reading a few scalars back from the device (LM control reads ~100 bytes two or three times per iteration; DESIGN.md section 6, latency regime).
-// build: hipcc -O3 --offload-arch=gfx950 -o tools/bench_sync tools/bench_sync.hip
+// build: hipcc -O3 --offload-arch=gfx950 -o tools/bench_sync tools/archive/bench_sync.hip
 #include <hip/hip_runtime.h>
 #include <chrono>
 #include <cstdio>

@@ -1,4 +1,4 @@
-"""C2 (10k cameras / 200k edges), covariance + MAGSAC: a few solves; run under rocprofv3 --kernel-trace, then tools/r03_gaps.py on the db."""
+"""C2 (10k cameras / 200k edges), covariance + MAGSAC: a few solves; run under rocprofv3 --kernel-trace, then tools/archive/r03_gaps.py on the db."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from globalsfmpy_amd import _abi, synth

@@ -15,7 +15,7 @@ done
 python profiles/make_pmc_traffic.py "$(find $OUT/pmc_FETCH_SIZE -name '*.db' | head -1)" "$(find $OUT/pmc_WRITE_SIZE -name '*.db' | head -1)" "$OUT/r03_pmc_traffic.json" > "$OUT/pmc_traffic.log" 2>&1
 python profiles/summarize_pmc.py "$(find $OUT/pmc_FETCH_SIZE -name '*.db' | head -1)" "$(find $OUT/pmc_WRITE_SIZE -name '*.db' | head -1)" > "$OUT/r03_pmc_hbm_traffic.txt" 2>&1
 find "$OUT" -name '*.db' -size +30M -delete
-K3_PMC_OUT="$OUT/k3c_pmc" K3_PMC_GROUPS="tcp_req tcp_stall tcc_hit tcc_ea sq_a" bash tools/r03_k3_pmc.sh > "$OUT/k3c_pmc.log" 2>&1
+K3_PMC_OUT="$OUT/k3c_pmc" K3_PMC_GROUPS="tcp_req tcp_stall tcc_hit tcc_ea sq_a" bash tools/archive/r03_k3_pmc.sh > "$OUT/k3c_pmc.log" 2>&1
 cp "$OUT/r03_pmc_traffic.json" profiles/r03_pmc_traffic.json   # so that the bench run below reports it (same kernel sources)
 timeout 900 python bench.py > "$OUT/r03_bench.json" 2> "$OUT/r03_bench.err"
 head -5 "$OUT/r03_kernel_stats.txt"; head -c 600 "$OUT/r03_bench.json"

@@ -2,11 +2,11 @@
 # Round 3: counter evidence for K3 (k_matvec<LAP>) on the C5 problem -- which resource binds the u[col] gather.
 # One rocprofv3 --pmc pass per counter group (separate runs, kernel trace only); a failing group (unknown counter, too many for the
 # block's slots) does not stop the others.  Outputs: gpurun_out/r03_k3_pmc/<group>/ + a summary text per group.
-#   usage (on the GPU box, from the repo root):  bash tools/r03_k3_pmc.sh [probe.py]
+#   usage (on the GPU box, from the repo root):  bash tools/archive/r03_k3_pmc.sh [probe.py]
 set -u
 cd "$(dirname "$0")/.."
 ROOT=$PWD
-PROBE=${1:-tools/r03_k3_probe.py}
+PROBE=${1:-tools/archive/r03_k3_probe.py}
 OUT=${K3_PMC_OUT:-$ROOT/gpurun_out/r03_k3_pmc}
 mkdir -p "$OUT"
 export TMPDIR=/tmp
