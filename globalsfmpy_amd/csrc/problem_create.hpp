@@ -550,10 +550,17 @@ static gsfm_status problem_create_impl(uint32_t n_cams, uint64_t n_edges, const 
     const char* env = getenv("GSFM_K3_COLSORT");
     const int mode = env && *env ? atoi(env) : -1;
     const bool lap_ok = (P->functor == F_AA || P->functor == F_QCOS) && !(getenv("GSFM_LAPLACIAN") && atoi(getenv("GSFM_LAPLACIAN")) == 0);
-    // What makes it pay is line sharing in the gathers: about one entry per camera and row block, i.e. rows of 512 * mean degree >= ~n_cams / 2
-    // entries (C5: 102k entries per block for 100k cameras, on one GPU and on every rank of a sharded run alike); sparser blocks gain nothing.
-    const double per_block = P->n_rows ? (double)GSFM_COL_RB * (double)nd / (double)P->n_rows : 0.0;
-    if (lap_ok && nd > 0 && (mode > 0 || (mode < 0 && nd >= (size_t)1000000 && per_block >= 0.5 * (double)n_cams && P->coarse_want == 0 && P->perm.empty()))) {
+    // ROUND 6: no density condition any more.  Rounds 3-5 also asked for 512 rows x mean degree >= cameras / 2 ("sparser blocks gain nothing": the
+    // gathers of a block then share no lines) -- a rule set when the layout was first built and never re-measured.  Measured on the current kernels
+    // (tools/r06_density_probe.py, profiles/r06_density_rule.txt; same generator, default choice against the forced layout, whole solves):
+    //   400k cameras / 40 M edges   86.8 -> 52.1 ms   (mat-vec 19.2 -> 9.2 ns per 1000 directed entries; C5: 9.35)
+    //   800k / 80 M                198.2 -> 121.7 ms   (22.5 -> 11.7)        1.5 M / 150 M   423.8 -> 245.1 ms   (24.3 -> 11.4)
+    //   1 M / 10 M (degree 20)     376 -> 244 ms       500k / 12.5 M (degree 50)   51.1 -> 32.8 ms     2 M / 10 M (degree 10)   12.6 -> 9.5 s
+    // with the final cost equal to the last bit every time.  (Why the sorted order wins even where a wavefront's 64 gathers touch 64 different
+    // lines was not chased with counters: those lines are neighbours in memory, a row-major row's are scattered over the whole vector.)
+    // What remains of the rule: at least 1 M directed entries (below, the launch-latency regime, the row-major
+    // kernels with their 2-kernel PCG iteration are the faster ones) and no locality found by the relabelling / no coarse space (coherent graphs).
+    if (lap_ok && nd > 0 && (mode > 0 || (mode < 0 && nd >= (size_t)1000000 && P->coarse_want == 0 && P->perm.empty()))) {
       if (int st = build_colsort(P, rp, col, deid, n_host_threads)) return bail(st);
       if (P->cs.active) { P->coarse_want = 0; P->coarse_adaptive = false; }
     }
