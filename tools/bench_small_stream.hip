@@ -41,7 +41,7 @@ int main() {
   auto time = [&](auto launch) { for (int k = 0; k < 5; ++k) launch(); CHK(hipEventRecord(e0, st)); for (int k = 0; k < 50; ++k) launch(); CHK(hipEventRecord(e1, st)); CHK(hipStreamSynchronize(st)); float ms; CHK(hipEventElapsedTime(&ms, e0, e1)); return 1e3 * ms / 50; };
   printf("empty kernel, 256 x 256, back to back: %.2f us per launch\n", time([&] { hipLaunchKernelGGL(k_empty, dim3(256), dim3(256), 0, st, sink); }));
   struct Case { const char* what; double mb_in; int out_every; };
-  const Case cases[] = {{"K3c, one rank of 8: 125 MB in", 125.0, 0}, {"K1, one rank of 8: 120 MB in", 120.0, 0}, {"K2c, one rank of 8: 243 MB in + 121 MB out", 243.0, 2},
+  const Case cases[] = {{"half of one rank of 8's K3c: 62.5 MB in", 62.5, 0}, {"K3c, one rank of 8: 125 MB in", 125.0, 0}, {"K1, one rank of 8: 120 MB in", 120.0, 0}, {"K2c, one rank of 8: 243 MB in + 121 MB out", 243.0, 2},
                         {"K3c, one rank of 4: 250 MB in", 250.0, 0}, {"K3c, one rank of 2: 500 MB in", 500.0, 0}, {"K3c, one GPU: 1000 MB in", 1000.0, 0}};
   for (const Case& c : cases) {
     const size_t n16 = (size_t)(c.mb_in * 1e6 / 16);
