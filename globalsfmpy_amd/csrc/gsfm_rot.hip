@@ -524,12 +524,12 @@ gsfm_status gsfm_rot_matvec_bytes(gsfm_rot_problem* P, double* layout_bytes, dou
     // read once; the gathered vector, the diagonal blocks, p, q in, y out once per camera.  Linearisation, per position: record 8 +
     // q_rel 32 + whitening 48 in, block 48 out; nine partial sums per row and workgroup
     if (layout_bytes) *layout_bytes = (P->cs.k16_active ? 50.0 : P->cs.cmax ? 52.0 : 54.0) * (double)P->cs.n_pos + 2.0 * 24.0 * P->cs.n_wg * GSFM_COL_RB + (24.0 + 48.0 + 24.0 + 32.0 + 24.0) * N;
-    if (lin_bytes) *lin_bytes = (8.0 + (double)qrel_bytes(P->wmode) + (P->wmode == W_MATRIX ? 48.0 : P->wmode == W_SCALAR ? 8.0 : 0.0) + 48.0) * (double)P->cs.n_pos + 2.0 * 72.0 * P->cs.n_wg * GSFM_COL_RB + (32.0 + 72.0) * N;
+    if (lin_bytes) *lin_bytes = (8.0 + (P->q3 ? 24.0 : 32.0) + (P->wmode == W_MATRIX ? 48.0 : P->wmode == W_SCALAR ? 8.0 : 0.0) + 48.0) * (double)P->cs.n_pos + 2.0 * 72.0 * P->cs.n_wg * GSFM_COL_RB + (32.0 + 72.0) * N;
     if (form) *form = 2;
   } else {
     if (layout_bytes) *layout_bytes = (double)P->dir.n * (lap ? 52.0 : 76.0) + 2.0 * 24.0 * N;
     const double w = P->wmode == W_MATRIX ? 48.0 : P->wmode == W_SCALAR ? 8.0 : 0.0;
-    if (lin_bytes) *lin_bytes = (double)P->dir.n * (4.0 + (double)qrel_bytes(P->wmode) + w + (lap ? 48.0 : 72.0)) + (32.0 + 72.0) * N;
+    if (lin_bytes) *lin_bytes = (double)P->dir.n * (4.0 + (P->q3 ? 24.0 : 32.0) + w + (lap ? 48.0 : 72.0)) + (32.0 + 72.0) * N;
     if (form) *form = lap ? 1 : 0;
   }
   return GSFM_OK;
@@ -540,8 +540,8 @@ gsfm_status gsfm_rot_sweep_bytes(gsfm_rot_problem* P, double* algorithmic, doubl
   // indices 8 B + measurement 24 B (32 B for the quaternion types) + whitening 48/8/0 B + weight out 8 B
   const double w = P->wmode == W_MATRIX ? 48.0 : P->wmode == W_SCALAR ? 8.0 : 0.0;
   if (algorithmic) *algorithmic = 8.0 + (P->functor == F_AA ? 24.0 : 32.0) + w + 8.0;
-  // as laid out: uint2 idx + the measurement (24 B on the W_MATRIX problems since round 6: three quaternion components, kernels.hpp qrel_three; 32 B otherwise) + whitening planes; the weight is consumed in-kernel (no per-edge store)
-  if (layout) *layout = 8.0 + (double)qrel_bytes(P->wmode) + w;
+  // as laid out: uint2 idx + the measurement (24 B on the W_MATRIX problems of >= 1 M edges since round 6: three quaternion components, kernels.hpp qrel_three; 32 B otherwise) + whitening planes; the weight is consumed in-kernel (no per-edge store)
+  if (layout) *layout = 8.0 + (P->q3 ? 24.0 : 32.0) + w;
   return GSFM_OK;
 }
 

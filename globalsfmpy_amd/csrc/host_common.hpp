@@ -249,6 +249,7 @@ struct gsfm_rot_problem {
     void reset() { if (exec) (void)hipGraphExecDestroy(exec); exec = nullptr; }
   } pcg_graph, pcg2_graph;
 
+  bool q3 = false;            // the measurement planes hold three quaternion components, 24 B (kernels.hpp qrel_three: W_MATRIX problems of >= 1 M edges)
   EdgePlanes cost;            // cost-owned edges
   double cost_n_global = 0.0; // edges counted in the cost over ALL ranks (= cost.n unsharded; sharded: summed in the create-time agreement, identical on every rank)
   DevBuf<uint2> cost_idx;

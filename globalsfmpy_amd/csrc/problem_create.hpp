@@ -99,7 +99,7 @@ template <typename EidVec>
 int upload_planes(gsfm_rot_problem* P, EdgePlanes& pl, const EidVec& eid, const double* d_rel_aa) {
   pl.n = eid.size();
   // (qr1: the third stored component, one double per position, on the W_MATRIX problems -- kernels.hpp, qrel_three; the full quaternion's (z, w) pairs otherwise)
-  const bool three = qrel_three(P->wmode);
+  const bool three = P->q3;
   if (pl.eid.upload(eid) != hipSuccess || pl.qr0.alloc(pl.n) != hipSuccess || pl.qr1.alloc(three ? (pl.n + 1) / 2 : pl.n) != hipSuccess)
     return fail(GSFM_ERR_HIP, "uploading edge planes failed (out of memory?)");
   if (pl.n) hipLaunchKernelGGL(k_build_qrel, dim3(grid_for(pl.n)), dim3(GSFM_BLOCK), 0, P->stream, d_rel_aa, pl.eid.p, pl.n, pl.qr0.p, pl.qr1.p, three ? 1 : 0);
@@ -545,6 +545,11 @@ static gsfm_status problem_create_impl(uint32_t n_cams, uint64_t n_edges, const 
 
   lap("cost tiles");
   P->timer.apply_rule(nd);
+  {  // the measurement planes as three quaternion components (kernels.hpp, qrel_three): covariance-whitened problems whose sweeps are bound by the
+     // stream -- at least a million edges held by this process; GSFM_QREL3=0/1 overrides (tests force it on small graphs)
+    const char* e = getenv("GSFM_QREL3");
+    P->q3 = qrel_three(P->wmode) && (e && *e ? atoi(e) != 0 : n_edges >= (uint64_t)1000000);
+  }
   {  // K2c / K3c, the column-sorted layout of the directed entries: for large graphs whose rows offer the gathers no locality -- i.e. where
      // neither the relabelling nor the two-level preconditioner (both for spatially coherent graphs) applies.  GSFM_K3_COLSORT=0/1 overrides.
     const char* env = getenv("GSFM_K3_COLSORT");

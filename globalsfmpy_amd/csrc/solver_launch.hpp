@@ -217,7 +217,7 @@ void launch_cache(gsfm_rot_problem* P, const double* x, double2* q) {
 int launch_row_s(gsfm_rot_problem* P, const double2* q, double* s_out, bool unit_weights) {
   if (P->cs.active) {   // column-sorted layout (Laplacian-capable functors only); unit_weights is no longer asked for by any caller
     ColRowSArgs ca{};
-    ca.L = P->cs.dev(); ca.row_base = P->own_begin; ca.n_rows = P->n_rows; ca.eid = P->dir.eid.p; ca.qr0 = P->dir.qr0.p; ca.qr1 = P->dir.qr1.p;
+    ca.L = P->cs.dev(); ca.row_base = P->own_begin; ca.n_rows = P->n_rows; ca.eid = P->dir.eid.p; ca.qr0 = P->dir.qr0.p; ca.qr1 = P->dir.qr1.p; ca.q3 = P->q3;
     ca.w0 = P->dir.w0.p; ca.w1 = P->dir.w1.p; ca.w2 = P->dir.w2.p; ca.ws = P->dir.ws.p; ca.q = q; ca.s_out = s_out;
     const dim3 grid(P->cs.n_wg), blk(GSFM_BLOCK);
     if (unit_weights) return fail(GSFM_ERR_UNSUPPORTED, "unit-weight row sweep on the column-sorted layout");
@@ -230,7 +230,7 @@ int launch_row_s(gsfm_rot_problem* P, const double2* q, double* s_out, bool unit
   }
   RowSArgs ra{};
   ra.n_rows = P->n_rows; ra.row_base = P->own_begin; ra.G = P->G; ra.row_ptr = P->row_ptr.p; ra.col = P->col.p; ra.eid = P->dir.eid.p;
-  ra.qr0 = P->dir.qr0.p; ra.qr1 = P->dir.qr1.p; ra.w0 = P->dir.w0.p; ra.w1 = P->dir.w1.p; ra.w2 = P->dir.w2.p; ra.ws = P->dir.ws.p; ra.q = q; ra.s_out = s_out;
+  ra.qr0 = P->dir.qr0.p; ra.qr1 = P->dir.qr1.p; ra.q3 = P->q3; ra.w0 = P->dir.w0.p; ra.w1 = P->dir.w1.p; ra.w2 = P->dir.w2.p; ra.ws = P->dir.ws.p; ra.q = q; ra.s_out = s_out;
   const dim3 grid(grid_for((size_t)P->n_rows * P->G)), blk(GSFM_BLOCK);
   const int f = P->functor, w = P->wmode;
 #define GSFM_ROWS(F, W, U) hipLaunchKernelGGL((k_row_s<F, W, U>), grid, blk, 0, P->stream, ra)
@@ -248,7 +248,7 @@ int launch_row_s(gsfm_rot_problem* P, const double2* q, double* s_out, bool unit
 
 CostArgs cost_args(gsfm_rot_problem* P, const double2* q) {
   CostArgs a{};
-  a.tiles = P->cost_tiles.p; a.direct = P->cost_direct; a.n_cams = P->n_cams; a.n = P->cost.n; a.idx = P->cost_idx.p; a.qr0 = P->cost.qr0.p; a.qr1 = P->cost.qr1.p;
+  a.tiles = P->cost_tiles.p; a.direct = P->cost_direct; a.n_cams = P->n_cams; a.n = P->cost.n; a.idx = P->cost_idx.p; a.qr0 = P->cost.qr0.p; a.qr1 = P->cost.qr1.p; a.q3 = P->q3;
   a.w0 = P->cost.w0.p; a.w1 = P->cost.w1.p; a.w2 = P->cost.w2.p; a.ws = P->cost.ws.p; a.ws_rw = P->cost.ws.p;
   a.q = q; a.loss = P->d_loss.p; a.eid = P->cost.eid.p; a.partials = P->part_cost.p;
   return a;
@@ -317,7 +317,7 @@ int launch_lin(gsfm_rot_problem* P, const double2* q, const double* go) {
   if (P->cb) { if (int st = refresh_external_rho(P, q)) return st; }
   LinArgs a{};
   a.n_rows = P->n_rows; a.row_base = P->own_begin; a.G = P->G; a.row_ptr = P->row_ptr.p; a.col = P->col.p; a.eid = P->dir.eid.p;
-  a.qr0 = P->dir.qr0.p; a.qr1 = P->dir.qr1.p; a.w0 = P->dir.w0.p; a.w1 = P->dir.w1.p; a.w2 = P->dir.w2.p; a.ws = P->dir.ws.p; a.ws_rw = P->dir.ws.p;
+  a.qr0 = P->dir.qr0.p; a.qr1 = P->dir.qr1.p; a.q3 = P->q3; a.w0 = P->dir.w0.p; a.w1 = P->dir.w1.p; a.w2 = P->dir.w2.p; a.ws = P->dir.ws.p; a.ws_rw = P->dir.ws.p;
   a.q = q; a.loss = P->d_loss.p; a.rho_ext = P->cb ? P->rho_ext.p : nullptr; a.fast_ok = k2_fast_path(P) ? 1 : 0; a.go = go;
   if (P->sigma_pending_lin) { a.sigma = P->sigma; a.sigma.on = 1; P->sigma_pending_lin = false; }
   if (!P->lap && !P->h3.p && (P->h3.alloc(P->dir.n) != hipSuccess || P->h4.alloc(P->dir.n) != hipSuccess)) return fail(GSFM_ERR_HIP, "allocating the general normal-equation blocks failed");

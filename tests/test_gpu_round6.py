@@ -29,7 +29,7 @@ class _Env:
 
 @pytest.mark.parametrize("et", [_abi.ANGLE_AXIS_COVARIANCE, _abi.ANGLE_AXIS_COV_INLIERS])
 def test_three_component_measurement_planes_on_the_rotations_that_stress_the_decode(oracle, et):
-    """csrc/kernels.hpp, qrel_three: on the W_MATRIX problems the measured rotation is stored as three quaternion components, the largest one
+    """csrc/kernels.hpp, qrel_three: on W_MATRIX problems of a million edges or more the measured rotation is stored as three quaternion components, the largest one
     dropped (its index in bit 62 of the first two, its sign in bit 62 of the third) and rebuilt by a square root.  Measurements built to hit
     every dropped index and both signs: half-turns about each axis and about diagonals (w ~ 0: x, y or z is the largest), angles of
     pi +- 1e-9 and pi +- 1e-4, rotation vectors LONGER than pi (ceres::AngleAxisToQuaternion then gives w < 0), tiny and exactly-zero
@@ -53,9 +53,13 @@ def test_three_component_measurement_planes_on_the_rotations_that_stress_the_dec
     ora = oracle.OracleProblem(n, g["edge_i"], g["edge_j"], rel, et, cov6=g["cov6"], inlier_weight=g["inlier_weight"])
     ora.set_loss(LF.MAGSACWeightBasedLoss(0.02))
     ro, lo = ora.residuals(x, want_residuals=True), ora.linearize(x)
+    small = RotationProblem(n, g["edge_i"], g["edge_j"], rel, et, cov6=g["cov6"], inlier_weight=g["inlier_weight"])
+    assert small.sweep_bytes()[1] == 8 + 32 + 48   # below a million edges the full quaternion stays (the small configurations keep their last bits)
+    small.close()
     for colsort in (0, 1):
-        with _Env(GSFM_K3_COLSORT=colsort):
+        with _Env(GSFM_K3_COLSORT=colsort, GSFM_QREL3=1):   # (forced: by itself the compact form starts at a million edges)
             dev = RotationProblem(n, g["edge_i"], g["edge_j"], rel, et, cov6=g["cov6"], inlier_weight=g["inlier_weight"])
+        assert dev.sweep_bytes()[1] == 8 + 24 + 48
         dev.set_loss(LF.MAGSACWeightBasedLoss(0.02))
         rd, ld = dev.residuals(x, want_residuals=True), dev.linearize(x)
         scale = np.maximum(1.0, ro["s"])
@@ -76,7 +80,9 @@ def test_a_non_finite_measurement_fails_a_covariance_problem_like_ceres(oracle):
     for bad in (np.nan, np.inf):
         rel = g["rel_aa"].copy(); rel[17, 1] = bad
         for cls in (RotationProblem, oracle.OracleProblem):
-            p = cls(g["n_cams"], g["edge_i"], g["edge_j"], rel, _abi.ANGLE_AXIS_COVARIANCE, cov6=g["cov6"]); p.set_loss(LF.HuberLoss(0.1))
+            with _Env(GSFM_QREL3=1):
+                p = cls(g["n_cams"], g["edge_i"], g["edge_j"], rel, _abi.ANGLE_AXIS_COVARIANCE, cov6=g["cov6"])
+            p.set_loss(LF.HuberLoss(0.1))
             r, s = p.solve(g["init_aa"])
             assert s["termination_name"] == "FAILURE" and s["num_iterations"] == 0 and np.array_equal(r, g["init_aa"])
 
