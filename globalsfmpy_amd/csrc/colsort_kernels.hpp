@@ -253,7 +253,6 @@ struct ColRowSArgs {
   const double* ws;
   const double2* q;
   double* s_out;
-  int q3;
 };
 template <int F, int WM>
 __global__ void __launch_bounds__(GSFM_BLOCK) k_col_s(ColRowSArgs a) {
@@ -264,8 +263,8 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_col_s(ColRowSArgs a) {
     if (mt.x == GSFM_COL_PAD) continue;
     const Quat qk = load_q(a.q, a.row_base + w.row0 + col_rowl(mt.y)), qm = load_q(a.q, mt.x & 0x7fffffffu);
     double2 r0, r1;
-    qrel_load<WM>(a.qr0, a.qr1, d, r0, r1, a.q3);
-    const Quat qr = qrel_quat<WM>(r0, r1, a.q3);
+    qrel_load<WM>(a.qr0, a.qr1, d, r0, r1);
+    const Quat qr = qrel_quat<WM>(r0, r1);
     const EdgeW W = load_w<WM>(a.w0, a.w1, a.w2, a.ws, d);
     double r[R];
     if (mt.x >> 31) edge_residual<F, WM>(qm, qk, qr, W, r);

@@ -25,7 +25,7 @@
 namespace gsfm {
 
 enum { F_AA = 0, F_QCOS = 1, F_QNORM = 2, F_RFNORM = 3 };
-enum { W_NONE = 0, W_SCALAR = 1, W_MATRIX = 2 };
+enum { W_NONE = 0, W_SCALAR = 1, W_MATRIX = 2, W_MATRIX3 = 3 /* W_MATRIX with the measurement planes as three quaternion components (qrel_three below): a kernel template value only, never a problem's wmode */ };
 
 template <int F> struct ResDim { static constexpr int R = (F == F_QNORM) ? 4 : (F == F_RFNORM) ? 9 : 3; };
 
@@ -261,7 +261,7 @@ __device__ __forceinline__ EdgeW load_w(const double2* __restrict__ w0, const do
   EdgeW W;
   W.l00 = 1.0; W.l01 = W.l02 = W.l12 = 0.0; W.l11 = W.l22 = 1.0;
   if (WM == W_SCALAR) { W.l00 = __builtin_nontemporal_load(ws + e); }
-  else if (WM == W_MATRIX) {
+  else if (WM == W_MATRIX || WM == W_MATRIX3) {
     const double2 a = nt_load2(w0 + e), b = nt_load2(w1 + e), c = nt_load2(w2 + e);
     W.l00 = a.x; W.l01 = a.y; W.l02 = b.x; W.l11 = b.y; W.l12 = c.x; W.l22 = c.y;
   }
@@ -282,7 +282,8 @@ __device__ __forceinline__ Quat load_q(const double2* __restrict__ q2, uint32_t 
 // q_ij into the sign of r: the stored quaternion is the one ceres::AngleAxisToQuaternion gives, not a normalised one).
 // Planes: qr0 = (a, b) as double2, qr1 = c as double (the buffer is still handed around as a double2 pointer).
 // WHERE: the W_MATRIX problems (ANGLE_AXIS_COVARIANCE / COV_INLIERS: 88 -> 80 B streamed per edge) of at least one million edges -- where the
-// sweeps are bound by the stream (gsfm_rot_problem::q3, decided at create; GSFM_QREL3=0/1 in the environment overrides).  Below that size the
+// sweeps are bound by the stream (gsfm_rot_problem::q3, decided at create: such a problem launches the W_MATRIX3 instantiations; GSFM_QREL3=0/1 in the
+// environment overrides).  Below that size the
 // launches are bound by latency, the 8 bytes buy nothing, and the rebuilt component -- within an ulp of ceres::AngleAxisToQuaternion's, not always
 // equal to it -- would move the small configurations' last bits for no gain: on the real Madrid graph under MAGSAC, whose outcome is bimodal under
 // one-ulp changes of the measurements, it was enough to land the run in the other cluster (62 instead of 63 LM iterations, 2.0e-4
@@ -295,8 +296,10 @@ __device__ __forceinline__ Quat load_q(const double2* __restrict__ q2, uint32_t 
 #ifndef GSFM_QREL3
 #define GSFM_QREL3 1
 #endif
-__host__ __device__ constexpr bool qrel_three(int wm) { return GSFM_QREL3 != 0 && wm == W_MATRIX; }
-__host__ __device__ constexpr int qrel_bytes(int wm) { return qrel_three(wm) ? 24 : 32; }
+// (A compile-time property of the kernels -- the template value W_MATRIX3 -- not a runtime branch inside the W_MATRIX ones: with the branch compiled
+// in, the compiler scheduled the W_MATRIX kernels' arithmetic differently, last bits of the small configurations moved, and Madrid / MAGSAC -- bimodal
+// under one-ulp changes, DESIGN section 2 -- landed in its other cluster, 62 instead of 63 LM iterations: profiles/r06_madrid_bits.txt.)
+__host__ __device__ constexpr bool qrel_three(int wm) { return GSFM_QREL3 != 0 && wm == W_MATRIX3; }
 __device__ __forceinline__ void qrel_encode(const Quat& q, double* ab_c /* [3] */) {
   const double v[4] = {q.x, q.y, q.z, q.w};
   if (!(isfinite(v[0]) && isfinite(v[1]) && isfinite(v[2]) && isfinite(v[3]))) { ab_c[0] = ab_c[1] = ab_c[2] = 1.5; return; }   // a non-finite measurement decodes to NaN (1 - 3 x 2.25 < 0)
@@ -314,10 +317,9 @@ __device__ __forceinline__ void qrel_encode(const Quat& q, double* ab_c /* [3] *
 }
 // raw: the full quaternion (x, y) (z, w) -- or, three components: (a, b) in r0, c in r1.x (r1.y unused)
 template <int WM>
-__device__ __forceinline__ Quat qrel_quat(const double2& r0, const double2& r1, int three) {
+__device__ __forceinline__ Quat qrel_quat(const double2& r0, const double2& r1) {
   if constexpr (!qrel_three(WM)) return Quat{r0.x, r0.y, r1.x, r1.y};
   else {
-    if (!three) return Quat{r0.x, r0.y, r1.x, r1.y};   // (uniform over the launch: a kernel argument)
     const unsigned ha = (unsigned)__double2hiint(r0.x), hb = (unsigned)__double2hiint(r0.y), hc = (unsigned)__double2hiint(r1.x);
     const unsigned k = ((ha >> 30) & 1u) | (((hb >> 30) & 1u) << 1);
     const double a = __hiloint2double((int)(ha & 0xbfffffffu), __double2loint(r0.x)), b = __hiloint2double((int)(hb & 0xbfffffffu), __double2loint(r0.y)),
@@ -333,16 +335,14 @@ __device__ __forceinline__ Quat qrel_quat(const double2& r0, const double2& r1, 
   }
 }
 template <int WM>
-__device__ __forceinline__ void qrel_load_nt(const double2* __restrict__ qr0, const double2* __restrict__ qr1, size_t e, double2& r0, double2& r1, int three) {
+__device__ __forceinline__ void qrel_load_nt(const double2* __restrict__ qr0, const double2* __restrict__ qr1, size_t e, double2& r0, double2& r1) {
   r0 = nt_load2(qr0 + e);
-  if constexpr (qrel_three(WM)) { if (three) { r1.x = __builtin_nontemporal_load((const double*)qr1 + e); r1.y = 0.0; } else r1 = nt_load2(qr1 + e); }
-  else r1 = nt_load2(qr1 + e);
+  if constexpr (qrel_three(WM)) { r1.x = __builtin_nontemporal_load((const double*)qr1 + e); r1.y = 0.0; } else r1 = nt_load2(qr1 + e);
 }
 template <int WM>
-__device__ __forceinline__ void qrel_load(const double2* __restrict__ qr0, const double2* __restrict__ qr1, size_t e, double2& r0, double2& r1, int three) {
+__device__ __forceinline__ void qrel_load(const double2* __restrict__ qr0, const double2* __restrict__ qr1, size_t e, double2& r0, double2& r1) {
   r0 = qr0[e];
-  if constexpr (qrel_three(WM)) { if (three) { r1.x = ((const double*)qr1)[e]; r1.y = 0.0; } else r1 = qr1[e]; }
-  else r1 = qr1[e];
+  if constexpr (qrel_three(WM)) { r1.x = ((const double*)qr1)[e]; r1.y = 0.0; } else r1 = qr1[e];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -514,7 +514,6 @@ struct RowSArgs {
   const double* ws;
   const double2* q;
   double* s_out;          // per local edge
-  int q3;                 // the measurement planes hold three components (qrel_three problems of >= 1 M edges)
 };
 template <int F, int WM, bool UNIT>
 __global__ void __launch_bounds__(GSFM_BLOCK) k_row_s(RowSArgs a) {
@@ -528,8 +527,8 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_row_s(RowSArgs a) {
     const uint32_t cr = a.col[d];
     const Quat qm = load_q(a.q, cr & 0x7fffffffu);
     double2 r0, r1;
-    qrel_load<WM>(a.qr0, a.qr1, d, r0, r1, a.q3);
-    const Quat qr = qrel_quat<WM>(r0, r1, a.q3);
+    qrel_load<WM>(a.qr0, a.qr1, d, r0, r1);
+    const Quat qr = qrel_quat<WM>(r0, r1);
     EdgeW W = load_w<WM>(a.w0, a.w1, a.w2, a.ws, d);
     if (UNIT) W.l00 = 1.0;
     double r[R];
@@ -559,8 +558,7 @@ struct CostArgs {
   uint32_t n_cams;
   size_t n;                  // edges, ordered by tile; idx holds BLOCK-LOCAL camera indices
   const uint2* idx;          // (i, j)
-  const double2 *qr0, *qr1;  // q_rel planes (x,y) (z,w) -- or (a,b), c: q3
-  int q3;                    // the measurement planes hold three components (qrel_three problems of >= 1 M edges)
+  const double2 *qr0, *qr1;  // q_rel planes (x,y) (z,w) -- or (a,b), c in the W_MATRIX3 kernels
   const double2 *w0, *w1, *w2;
   const double* ws;
   const double2* q;          // camera quaternions
@@ -653,7 +651,7 @@ __global__ void __launch_bounds__(GSFM_TILE_THREADS) k_cost(CostArgs a) {
       const uint32_t eu = e0 + u * GSFM_TILE_THREADS;
       const uint32_t e = eu < tile.end ? eu : e0;   // lanes past the end re-read their first edge and discard it
       ij[u] = a.idx[e];
-      qrel_load_nt<WM>(a.qr0, a.qr1, e, r0[u], r1[u], a.q3);
+      qrel_load_nt<WM>(a.qr0, a.qr1, e, r0[u], r1[u]);
       Wm[u] = load_w<WM>(a.w0, a.w1, a.w2, a.ws, e);
       if (WM == W_SCALAR && a.unit_w) Wm[u].l00 = 1.0;
     }
@@ -661,7 +659,7 @@ __global__ void __launch_bounds__(GSFM_TILE_THREADS) k_cost(CostArgs a) {
     for (int u = 0; u < U; ++u) {
       const uint32_t e = e0 + u * GSFM_TILE_THREADS;
       if (e >= tile.end) continue;
-      const Quat qr = qrel_quat<WM>(r0[u], r1[u], a.q3);
+      const Quat qr = qrel_quat<WM>(r0[u], r1[u]);
       const double2 i0 = qi_xy[ij[u].x], i1 = qi_zw[ij[u].x], j0 = qj_xy[ij[u].y], j1 = qj_zw[ij[u].y];
       const Quat qi{i0.x, i0.y, i1.x, i1.y}, qj{j0.x, j0.y, j1.x, j1.y};
       acc += cost_edge<F, WM, LM, MODE>(a, lv, e, qi, qj, qr, Wm[u], dw);
@@ -702,11 +700,11 @@ __global__ void __launch_bounds__(GSFM_BLOCK) k_cost_direct(CostArgs a) {
   for (uint32_t e = tile.begin + threadIdx.x; e < tile.end; e += GSFM_BLOCK) {
     const uint2 ij = a.idx[e];
     double2 r0, r1;
-    qrel_load_nt<WM>(a.qr0, a.qr1, e, r0, r1, a.q3);
+    qrel_load_nt<WM>(a.qr0, a.qr1, e, r0, r1);
     EdgeW W = load_w<WM>(a.w0, a.w1, a.w2, a.ws, e);
     if (WM == W_SCALAR && a.unit_w) W.l00 = 1.0;
     const Quat qi = load_q(a.q, ij.x), qj = load_q(a.q, ij.y);
-    acc += cost_edge<F, WM, LM, MODE>(a, lv, e, qi, qj, qrel_quat<WM>(r0, r1, a.q3), W, dw);
+    acc += cost_edge<F, WM, LM, MODE>(a, lv, e, qi, qj, qrel_quat<WM>(r0, r1), W, dw);
   }
   acc = wave_sum(acc);
   if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = acc;
@@ -761,7 +759,6 @@ struct LinArgs {
   const uint32_t* col;       // neighbour camera | role << 31 (role 1: the row camera is `second`)
   const uint32_t* eid;
   const double2 *qr0, *qr1;
-  int q3;                    // the measurement planes hold three components (qrel_three problems of >= 1 M edges)
   const double2 *w0, *w1, *w2;
   const double* ws;
   const double2* q;
@@ -804,8 +801,8 @@ __device__ __forceinline__ void lin_rows(const LinArgs& a) {
       const uint32_t m = cr & 0x7fffffffu;
       const bool row_is_second = (cr >> 31) != 0;
       double2 r0, r1;
-      qrel_load_nt<WM>(a.qr0, a.qr1, d, r0, r1, a.q3);
-      const Quat qr = qrel_quat<WM>(r0, r1, a.q3);
+      qrel_load_nt<WM>(a.qr0, a.qr1, d, r0, r1);
+      const Quat qr = qrel_quat<WM>(r0, r1);
       EdgeW W = load_w<WM>(a.w0, a.w1, a.w2, a.ws, d);
       const bool sig = F == F_AA && WM == W_SCALAR && a.sigma.on;
       if (sig) W.l00 = 1.0;
@@ -897,7 +894,7 @@ struct LinStreams { double2 r0, r1; EdgeW W; };
 template <int WM>
 __device__ __forceinline__ LinStreams lin_load_streams(const LinArgs& a, uint32_t d) {
   LinStreams S;
-  qrel_load_nt<WM>(a.qr0, a.qr1, d, S.r0, S.r1, a.q3);
+  qrel_load_nt<WM>(a.qr0, a.qr1, d, S.r0, S.r1);
   S.W = load_w<WM>(a.w0, a.w1, a.w2, a.ws, d);
   return S;
 }
@@ -948,7 +945,7 @@ __device__ __forceinline__ void edge_lin_row(const Quat& qk, const Quat& qm, con
 // general one (both Jacobians, full Corrector, host-callback rho) restricted to the row camera's block -- the Laplacian form needs no more.
 template <int F, int WM, int LM, bool FAST>
 __device__ __forceinline__ void lin_entry_eval(const LinArgs& a, const LossView<LM>& lv, uint32_t d, uint32_t cr, const Quat& qk, const Quat& qm, LinStreams S, double* g3, double* G6) {
-  const Quat qr = qrel_quat<WM>(S.r0, S.r1, a.q3);
+  const Quat qr = qrel_quat<WM>(S.r0, S.r1);
   const bool row_is_second = (cr >> 31) != 0;
   if (FAST) {
     double r[3], Ar[9];
@@ -1012,7 +1009,7 @@ __device__ __forceinline__ void lin_entry_eval(const LinArgs& a, const LossView<
 #endif
 template <int WM, int LM>
 __device__ __forceinline__ void lin_entry_body_aa(const LinArgs& a, const LossView<LM>& lv, uint32_t d, uint32_t cr, const Quat& qk, const Quat& qm, LinStreams S, double* gb3, double* B6) {
-  const Quat qr = qrel_quat<WM>(S.r0, S.r1, a.q3);
+  const Quat qr = qrel_quat<WM>(S.r0, S.r1);
   const bool row_is_second = (cr >> 31) != 0;
   const Quat qi = row_is_second ? qm : qk, qj = row_is_second ? qk : qm;
   const Quat qe = qmul(qmul(qj, qconj(qi)), qconj(qr));

@@ -548,7 +548,7 @@ static gsfm_status problem_create_impl(uint32_t n_cams, uint64_t n_edges, const 
   {  // the measurement planes as three quaternion components (kernels.hpp, qrel_three): covariance-whitened problems whose sweeps are bound by the
      // stream -- at least a million edges held by this process; GSFM_QREL3=0/1 overrides (tests force it on small graphs)
     const char* e = getenv("GSFM_QREL3");
-    P->q3 = qrel_three(P->wmode) && (e && *e ? atoi(e) != 0 : n_edges >= (uint64_t)1000000);
+    P->q3 = GSFM_QREL3 != 0 && P->wmode == W_MATRIX && (e && *e ? atoi(e) != 0 : n_edges >= (uint64_t)1000000);
   }
   {  // K2c / K3c, the column-sorted layout of the directed entries: for large graphs whose rows offer the gathers no locality -- i.e. where
      // neither the relabelling nor the two-level preconditioner (both for spatially coherent graphs) applies.  GSFM_K3_COLSORT=0/1 overrides.

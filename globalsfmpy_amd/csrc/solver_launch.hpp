@@ -19,10 +19,10 @@ int loss_mode(const gsfm_rot_problem* P) {
 }
 template <typename ArgsT, template <int, int, int> class Launcher>
 int dispatch(const gsfm_rot_problem* P, const ArgsT& args, int grid) {
-  const int f = P->functor, w = P->wmode, l = loss_mode(P);
+  const int f = P->functor, w = (P->wmode == W_MATRIX && P->q3) ? W_MATRIX3 : P->wmode, l = loss_mode(P);   // (W_MATRIX3: the same kernels on three-component measurement planes)
 #define GSFM_CASE3(F, W, L) if (f == F && w == W && l == L) { Launcher<F, W, L>::go(args, grid, P->stream); return 0; }
 #define GSFM_CASE(F, W) GSFM_CASE3(F, W, LM_PROGRAM) GSFM_CASE3(F, W, LM_SIMPLE) GSFM_CASE3(F, W, LM_MAGSAC)
-  GSFM_CASE(F_AA, W_NONE) GSFM_CASE(F_AA, W_SCALAR) GSFM_CASE(F_AA, W_MATRIX)
+  GSFM_CASE(F_AA, W_NONE) GSFM_CASE(F_AA, W_SCALAR) GSFM_CASE(F_AA, W_MATRIX) GSFM_CASE(F_AA, W_MATRIX3)
   GSFM_CASE(F_QCOS, W_NONE) GSFM_CASE(F_QNORM, W_NONE) GSFM_CASE(F_RFNORM, W_NONE)
 #undef GSFM_CASE
 #undef GSFM_CASE3
@@ -217,12 +217,13 @@ void launch_cache(gsfm_rot_problem* P, const double* x, double2* q) {
 int launch_row_s(gsfm_rot_problem* P, const double2* q, double* s_out, bool unit_weights) {
   if (P->cs.active) {   // column-sorted layout (Laplacian-capable functors only); unit_weights is no longer asked for by any caller
     ColRowSArgs ca{};
-    ca.L = P->cs.dev(); ca.row_base = P->own_begin; ca.n_rows = P->n_rows; ca.eid = P->dir.eid.p; ca.qr0 = P->dir.qr0.p; ca.qr1 = P->dir.qr1.p; ca.q3 = P->q3;
+    ca.L = P->cs.dev(); ca.row_base = P->own_begin; ca.n_rows = P->n_rows; ca.eid = P->dir.eid.p; ca.qr0 = P->dir.qr0.p; ca.qr1 = P->dir.qr1.p;
     ca.w0 = P->dir.w0.p; ca.w1 = P->dir.w1.p; ca.w2 = P->dir.w2.p; ca.ws = P->dir.ws.p; ca.q = q; ca.s_out = s_out;
     const dim3 grid(P->cs.n_wg), blk(GSFM_BLOCK);
     if (unit_weights) return fail(GSFM_ERR_UNSUPPORTED, "unit-weight row sweep on the column-sorted layout");
     if (P->functor == F_AA && P->wmode == W_NONE) hipLaunchKernelGGL((k_col_s<F_AA, W_NONE>), grid, blk, 0, P->stream, ca);
     else if (P->functor == F_AA && P->wmode == W_SCALAR) hipLaunchKernelGGL((k_col_s<F_AA, W_SCALAR>), grid, blk, 0, P->stream, ca);
+    else if (P->functor == F_AA && P->wmode == W_MATRIX && P->q3) hipLaunchKernelGGL((k_col_s<F_AA, W_MATRIX3>), grid, blk, 0, P->stream, ca);
     else if (P->functor == F_AA && P->wmode == W_MATRIX) hipLaunchKernelGGL((k_col_s<F_AA, W_MATRIX>), grid, blk, 0, P->stream, ca);
     else if (P->functor == F_QCOS) hipLaunchKernelGGL((k_col_s<F_QCOS, W_NONE>), grid, blk, 0, P->stream, ca);
     else return fail(GSFM_ERR_UNSUPPORTED, "no kernel for this error type");
@@ -230,13 +231,14 @@ int launch_row_s(gsfm_rot_problem* P, const double2* q, double* s_out, bool unit
   }
   RowSArgs ra{};
   ra.n_rows = P->n_rows; ra.row_base = P->own_begin; ra.G = P->G; ra.row_ptr = P->row_ptr.p; ra.col = P->col.p; ra.eid = P->dir.eid.p;
-  ra.qr0 = P->dir.qr0.p; ra.qr1 = P->dir.qr1.p; ra.q3 = P->q3; ra.w0 = P->dir.w0.p; ra.w1 = P->dir.w1.p; ra.w2 = P->dir.w2.p; ra.ws = P->dir.ws.p; ra.q = q; ra.s_out = s_out;
+  ra.qr0 = P->dir.qr0.p; ra.qr1 = P->dir.qr1.p; ra.w0 = P->dir.w0.p; ra.w1 = P->dir.w1.p; ra.w2 = P->dir.w2.p; ra.ws = P->dir.ws.p; ra.q = q; ra.s_out = s_out;
   const dim3 grid(grid_for((size_t)P->n_rows * P->G)), blk(GSFM_BLOCK);
   const int f = P->functor, w = P->wmode;
 #define GSFM_ROWS(F, W, U) hipLaunchKernelGGL((k_row_s<F, W, U>), grid, blk, 0, P->stream, ra)
   if (f == F_AA && w == W_SCALAR && unit_weights) GSFM_ROWS(F_AA, W_SCALAR, true);
   else if (f == F_AA && w == W_NONE) GSFM_ROWS(F_AA, W_NONE, false);
   else if (f == F_AA && w == W_SCALAR) GSFM_ROWS(F_AA, W_SCALAR, false);
+  else if (f == F_AA && w == W_MATRIX && P->q3) GSFM_ROWS(F_AA, W_MATRIX3, false);
   else if (f == F_AA && w == W_MATRIX) GSFM_ROWS(F_AA, W_MATRIX, false);
   else if (f == F_QCOS) GSFM_ROWS(F_QCOS, W_NONE, false);
   else if (f == F_QNORM) GSFM_ROWS(F_QNORM, W_NONE, false);
@@ -248,7 +250,7 @@ int launch_row_s(gsfm_rot_problem* P, const double2* q, double* s_out, bool unit
 
 CostArgs cost_args(gsfm_rot_problem* P, const double2* q) {
   CostArgs a{};
-  a.tiles = P->cost_tiles.p; a.direct = P->cost_direct; a.n_cams = P->n_cams; a.n = P->cost.n; a.idx = P->cost_idx.p; a.qr0 = P->cost.qr0.p; a.qr1 = P->cost.qr1.p; a.q3 = P->q3;
+  a.tiles = P->cost_tiles.p; a.direct = P->cost_direct; a.n_cams = P->n_cams; a.n = P->cost.n; a.idx = P->cost_idx.p; a.qr0 = P->cost.qr0.p; a.qr1 = P->cost.qr1.p;
   a.w0 = P->cost.w0.p; a.w1 = P->cost.w1.p; a.w2 = P->cost.w2.p; a.ws = P->cost.ws.p; a.ws_rw = P->cost.ws.p;
   a.q = q; a.loss = P->d_loss.p; a.eid = P->cost.eid.p; a.partials = P->part_cost.p;
   return a;
@@ -317,7 +319,7 @@ int launch_lin(gsfm_rot_problem* P, const double2* q, const double* go) {
   if (P->cb) { if (int st = refresh_external_rho(P, q)) return st; }
   LinArgs a{};
   a.n_rows = P->n_rows; a.row_base = P->own_begin; a.G = P->G; a.row_ptr = P->row_ptr.p; a.col = P->col.p; a.eid = P->dir.eid.p;
-  a.qr0 = P->dir.qr0.p; a.qr1 = P->dir.qr1.p; a.q3 = P->q3; a.w0 = P->dir.w0.p; a.w1 = P->dir.w1.p; a.w2 = P->dir.w2.p; a.ws = P->dir.ws.p; a.ws_rw = P->dir.ws.p;
+  a.qr0 = P->dir.qr0.p; a.qr1 = P->dir.qr1.p; a.w0 = P->dir.w0.p; a.w1 = P->dir.w1.p; a.w2 = P->dir.w2.p; a.ws = P->dir.ws.p; a.ws_rw = P->dir.ws.p;
   a.q = q; a.loss = P->d_loss.p; a.rho_ext = P->cb ? P->rho_ext.p : nullptr; a.fast_ok = k2_fast_path(P) ? 1 : 0; a.go = go;
   if (P->sigma_pending_lin) { a.sigma = P->sigma; a.sigma.on = 1; P->sigma_pending_lin = false; }
   if (!P->lap && !P->h3.p && (P->h3.alloc(P->dir.n) != hipSuccess || P->h4.alloc(P->dir.n) != hipSuccess)) return fail(GSFM_ERR_HIP, "allocating the general normal-equation blocks failed");
