@@ -19,8 +19,10 @@ def per_kernel(db, counter):
     return {r[0]: {"calls": r[1], "avg": r[2], "dur_us": r[3] / 1e3} for r in rows}
 
 
-KEYS = [("k_matvec", ["k_mv_col<", "k_mv_col(", "k_matvec<"]), ("k_matvec_finish", ["k_mv_col_finish"]), ("k_lin", ["k_lin_col<0, 2, 2, true>", "k_lin_col<", "k_lin_fast<", "k_lin3<", "k_lin<"]),
-        ("k_cost", ["k_cost<0, 2, 2, 0>", "k_cost<0, 2, 2, false>", "k_cost_direct<0, 2, 2, 0>"]), ("k_cost_reweight", ["k_cost<0, 2, 2, 2>"]), ("k_cost_full", ["k_cost<0, 2, 2, 1>", "k_cost<0, 2, 2, true>"]), ("k_cost_unit_weights", ["k_cost<0, 0, 1, 0>", "k_cost<0, 0, 1, false>"]),
+# (the C5 problem launches the W_MATRIX3 = 3 instantiations since round 6 -- three-component measurement planes; `2` = the full-quaternion ones of rounds 1-5)
+KEYS = [("k_matvec", ["k_mv_col<", "k_mv_col(", "k_matvec<"]), ("k_matvec_finish", ["k_mv_col_finish"]), ("k_lin", ["k_lin_col<0, 3, 2, true>", "k_lin_col<0, 2, 2, true>", "k_lin_col<", "k_lin_fast<", "k_lin3<", "k_lin<"]),
+        ("k_cost", ["k_cost<0, 3, 2, 0>", "k_cost<0, 2, 2, 0>", "k_cost<0, 2, 2, false>", "k_cost_direct<0, 3, 2, 0>", "k_cost_direct<0, 2, 2, 0>"]), ("k_cost_reweight", ["k_cost<0, 3, 2, 2>", "k_cost<0, 2, 2, 2>"]),
+        ("k_cost_full", ["k_cost<0, 3, 2, 1>", "k_cost<0, 2, 2, 1>", "k_cost<0, 2, 2, true>"]), ("k_cost_unit_weights", ["k_cost<0, 0, 1, 0>", "k_cost<0, 0, 1, false>"]),
         ("k_lin_unit_weights", ["k_lin_col<0, 0, 1, true>"]), ("k_lin_scalar_weights", ["k_lin_col<0, 1, 1, true>"])]
 
 
