@@ -132,3 +132,33 @@ def test_component_rest_option_and_the_freeze_rule(oracle):
         m = comp == c
         for r in (r1, r0):
             assert synth.angular_distance(synth.align_rotations(r[m], ro[m]), ro[m]).mean() <= 1e-6, c
+
+
+@pytest.mark.parametrize("case", ["single_small", "single_one_tile", "single_odd", "components", "components_all_small"])
+def test_one_launch_per_block_column_gives_the_fused_steps_bits(case):
+    """dense_kernels.hpp, k_chol_look (round 6): the exact step's factorisation as one launch per block column -- the panel of column k + 1
+    beside the update with column k, one elimination per block row -- against the fused step kernel it replaces (GSFM_CHOL_FUSED=1), for the
+    single dense matrix (solver_dense.hpp: 1, 2, an odd and an even number of block columns) and for the components of a disconnected graph
+    factorised side by side (solver_components.hpp): every tile receives the same updates in the same order from the same instructions, so
+    whole solves agree to the last bit -- rotations, cost, iteration counts."""
+    from test_gpu_round5 import _batch_of_scenes
+    if case.startswith("single"):
+        n = {"single_small": 150, "single_one_tile": 10, "single_odd": 331}[case]
+        g = synth.make_graph(n, 12 * n if n > 20 else 30, seed=77 + n, outlier_frac=0.1)
+        N, ei, ej, rel, cov, init = g["n_cams"], g["edge_i"], g["edge_j"], g["rel_aa"], g["cov6"], g["init_aa"]
+    else:
+        sizes = (300, 700, 120, 450, 64) if case == "components" else (200, 260, 150, 90, 21)
+        N, ei, ej, rel, cov, init, _ = _batch_of_scenes(sizes, 900)
+    out = []
+    for fused in (1, 0):
+        with _Env(GSFM_CHOL_FUSED=fused):
+            p = RotationProblem(N, ei, ej, rel, _abi.ANGLE_AXIS_COVTRACE, cov6=cov)
+            p.set_loss(LF.HuberLoss(0.1))
+            r, s = p.solve(init)
+            out.append((r, s, p.trace().copy()))
+    (rf, sf, tf), (rl, sl, tl) = out
+    print("%s: %d cameras, %d LM iterations, %d exact steps, final cost %.17g" % (case, N, sl["num_iterations"], sl["num_dense_solves"], sl["final_cost"]))
+    assert sl["num_dense_solves"] == sl["num_iterations"] > 0 and sf["num_dense_solves"] == sf["num_iterations"]
+    assert sf["num_iterations"] == sl["num_iterations"] and sf["final_cost"] == sl["final_cost"]
+    assert np.array_equal(tf, tl)
+    assert np.array_equal(rf, rl)
