@@ -6,10 +6,14 @@
 // length of the dependent chain instead of the arithmetic:
 //   * the matrix lives as 32 x 32 tiles of the lower triangle (8 KiB, contiguous), plus one extra tile row holding the right-hand
 //     side, so the forward substitution L y = b falls out of the factorisation (y is the last row of L);
-//   * ONE kernel per block column k (right-looking): every workgroup factors the 32 x 32 diagonal block A_kk itself (one wavefront,
-//     rows in registers, v_readlane broadcasts: no inter-workgroup dependency inside a step), solves the two panel tiles it needs by
-//     substitution and updates its own trailing tile A_ij -= L_ik L_jk^T.  The redundant work is ~3x the flops of the textbook
-//     schedule and irrelevant here; the chain per step is one kernel instead of three (round 1: 111 launches, 2.2 ms at 3N = 1182);
+//   * ONE launch per TWO block columns (round 6, k_chol_look2): the launch produces the columns c0 and c0 + 1 and applies the two before them.
+//     Its panel workgroups -- one per block row -- give their own five tiles the pending updates on the fly (left-looking), then run the
+//     64-row elimination (one wavefront, rows in registers, v_readlane broadcasts: the diagonal block's factorisation in the lower lanes IS
+//     the substitution of the panel tile in the upper lanes) once per column; its update workgroups fold both pending columns into two
+//     trailing tiles each on the matrix cores.  No dependency inside a launch, one elimination per block row and column.  Rounds 3-5 ran
+//     ONE fused kernel per column in which every trailing tile's workgroup repeated the eliminations it needed (two to three per tile:
+//     k_chol_step, kept behind GSFM_CHOL_FUSED=1 as the reference of the bit-identity test) -- the six scenes of C4 side by side 985 -> 660 us
+//     per factorisation + solve, Madrid's matrix alone 519 -> 444, every double of L, y and x the same (tools/bench_chol_batch.hip);
 //   * L goes to a second buffer (a workgroup's inputs A_kk, A_ik, A_jk are never written during step k, so there is no race);
 //   * the backward substitution L^T x = y is one workgroup sweeping the block rows of L bottom-up.
 // fp64 VALU throughout at these sizes.  Beyond ~50 block columns (more than 512 cameras) the redundancy of that schedule (every trailing
@@ -55,14 +59,44 @@ struct CholArgs {
 // The 64-row elimination (lanes 0..31: rows of A_kk, lanes 32..63: rows of a panel tile): entries above the diagonal of the diagonal rows
 // (lane < c) are never read by anyone, so they may hold anything; the multipliers L[c][c0] (held by lane c) are fetched in batches -- all
 // v_readlane of a batch first, then the FMAs: one SGPR-hazard wait per batch instead of one per multiplier.
+// 1 / sqrt(x) with the instructions of the device library's rsqrt(double) -- v_rsq_f64, then y0 + (y0 e)(0.375 e + 0.5) with e = 1 - x y0^2 -- minus
+// its closing special-case select (x = 0, inf, nan: never a pivot that is used).  The same bits for every positive finite x
+// (tools/check_devmath.hip compares 2^26 of them; tools/bench_chol_batch.hip every double of the factors).
+__device__ __forceinline__ double chol_rsqrt(double x) {
+  const double y0 = __builtin_amdgcn_rsq(x);
+  const double e = __builtin_fma(-x * y0, y0, 1.0);
+  return __builtin_fma(y0 * e, __builtin_fma(e, 0.375, 0.5), y0);
+}
+#ifndef GSFM_ELIM_SHORT
+#define GSFM_ELIM_SHORT 1     // 0: the loop of rounds 1-5 (tools/bench_chol_batch.hip -DGSFM_ELIM_SHORT=0 for the A/B)
+#endif
 __device__ __forceinline__ int chol_eliminate64(double* r, uint32_t lane) {
+  (void)lane;
+  // The elimination is what a launch of the factorisation costs (tools/bench_chol_batch.hip -DGSFM_LOOK_TIMING: 4.4 us of a 9.4 us launch until
+  // round 6: ~2 100 instructions in one wavefront, 137 ns per pivot).  Round 6 takes three things out of every pivot, none of which changes
+  // a bit of a factor that is used -- 3.65 us:
+  //   * the pivot test's select: rsqrt runs on the pivot as it comes, the test sets the status beside it -- after a non-positive pivot the
+  //     rows hold garbage either way, the factor is refused (info) and the step solved again by PCG;
+  //   * the select that gave lane c0 "piv * inv" and the others "r * inv": in lane c0 r[c0] IS the pivot;
+  //   * rsqrt's special-case select (chol_rsqrt).
+  // Measured and not adopted (the same bits each, profiles/r06b_chol_look.txt): the multipliers broadcast through LDS instead of v_readlane
+  // pairs -- half the instructions, but their latency lands on the chain: 4.95 us as written, 4.27 software-pipelined by one pivot,
+  // against 4.38 --; the next pivot computed in every lane from two early broadcasts (no trip through the scalar unit between two
+  // pivots, four instructions more per pivot): 4.00 against 3.65.
   int bad = 0;
 #pragma unroll
   for (int c0 = 0; c0 < GSFM_CB; ++c0) {
+#if GSFM_ELIM_SHORT
+    const double piv = readlane_f64(r[c0], c0);
+    if (!(piv > 0.0) && !bad) bad = c0 + 1;
+    const double inv = chol_rsqrt(piv);
+    r[c0] = r[c0] * inv;
+#else
     double piv = readlane_f64(r[c0], c0);
     if (!(piv > 0.0)) { if (!bad) bad = c0 + 1; piv = 1.0; }
     const double inv = rsqrt(piv);
     r[c0] = (lane == (uint32_t)c0) ? piv * inv : r[c0] * inv;
+#endif
 #pragma unroll
     for (int cb = c0 + 1; cb < GSFM_CB; cb += GSFM_CHOL_BATCH) {
       double m[GSFM_CHOL_BATCH];
@@ -219,191 +253,212 @@ __device__ __forceinline__ void chol_panel_body(const CholArgs& a) {
 }
 __global__ void __launch_bounds__(64) k_chol_panel(CholArgs a) { chol_panel_body(a); }
 
-// The trailing update of step k in the FUSED step's arithmetic (round 6; the batched factorisation of several components, where the fused
-// step's repeated eliminations -- two or more per trailing tile -- are what a launch costs once 3 000 tiles of six scenes share it): tile
-// (i, j), k < j <= i <= T, becomes A_ij - L_ik L_jk^T exactly as chol_step_body computes it -- the product first, from zero, eight
-// v_mfma_f64_16x16x4_f64 per 16 x 16 quadrant with the contraction index dealt as 4 kk + g, then own - product -- from the panel tiles
-// k_chol_panel has written (the rows chol_step_body holds in Pi / Pj: the same instructions on the same inputs).  A factor built from
-// k_chol_panel + this kernel is therefore bit-identical to one built by k_chol_step, step by step, and the host may choose per step and per
-// LM iteration.  One workgroup per trailing tile: row t = i - k - 1 has t + 1 of them.
-__device__ __forceinline__ void chol_update_exact_body(const CholArgs& a) {
-  __shared__ double Pi[GSFM_CB][GSFM_CB + 1], Pj[GSFM_CB][GSFM_CB + 1];
-  const uint32_t k = a.k, T = a.T, tid = threadIdx.x;
-  uint32_t b = blockIdx.x, t = 0;
-  while (b >= t + 1) { b -= t + 1; ++t; }
-  const uint32_t i = k + 1 + t, j = k + 1 + b;
-  if (i == T && j == T) return;    // the right-hand side has no diagonal tile
+// TWO block columns per launch (round 6, the form the product runs): launch c0 PRODUCES the columns c0 and c0 + 1 and APPLIES the two columns
+// before them (the previous launch's).  Half the launches of k_chol_look for the same work per block row plus one redundant panel tile:
+//   * panel workgroups -- the diagonal one, then one per block row i = c0 + 2 .. T -- hold the tiles (c0, c0), (c0 + 1, c0), (c0 + 1, c0 + 1),
+//     (i, c0), (i, c0 + 1) in registers (16 x 16 quadrants per wavefront), give them the two pending columns' updates on the fly, run the
+//     64-row elimination of column c0 for the rows c0 + 1 and i on two wavefronts at once, fold column c0 into (c0 + 1, c0 + 1) and
+//     (i, c0 + 1) and eliminate column c0 + 1;
+//   * update workgroups, one per two neighbouring trailing tiles (i, j), j >= c0 + 2: both pending columns in one pass, in ascending order.
+// PROD = 1: a matrix's LAST column when it has an odd number of them (one column produced).  PEND = 0: the first launch (nothing pending, no
+// update workgroups).  Per tile the updates arrive in ascending column order, each as "product from zero, then own - product" with the
+// contraction index dealt as 4 kk + g, and the eliminations are chol_eliminate64 on the same rows: the factor is bit-identical to k_chol_step's
+// and k_chol_look's (tools/bench_chol_batch.hip compares every double).
+#define GSFM_LOOK2_NT 2       // trailing tiles per update workgroup: P_i and P_j of two columns for two tiles = the panel's six LDS tiles
+#define GSFM_LOOK2_LDS 6
+template <int PEND, int PROD>
+__device__ __forceinline__ void chol_look2_body(const CholArgs& a, double (*S)[GSFM_CB][GSFM_CB + 1]) {
+  static_assert((PEND == 0 || PEND == 2) && (PROD == 1 || PROD == 2), "pending columns: none or two; produced: one or two");
+  const uint32_t c0 = a.k, T = a.T, tid = threadIdx.x;
+  const uint32_t n_panel = T - c0 + 2 - PROD;     // the diagonal workgroup + the block rows c0 + PROD .. T
   const uint32_t ur = tid / 8, uc4 = (tid % 8) * 4, wave = tid >> 6, lane = tid & 63;
-  const uint32_t mq = (16 * (wave >> 1) + (lane >> 4)) * GSFM_CB + 16 * (wave & 1) + (lane & 15);
-  chol_d4 own;
-  {
-    const double* so = a.A + chol_tile_off(i, j) + mq;
+  const uint32_t qa = wave >> 1, qb = wave & 1, qc = lane & 15, g = lane >> 4, ri = 16 * qa + qc, rj = 16 * qb + qc;
+  const uint32_t mq = (16 * qa + g) * GSFM_CB + 16 * qb + qc;
+  auto own_load = [&](uint32_t i, uint32_t j) {   // this lane's four elements of its wavefront's quadrant of tile (i, j) of A
+    chol_d4 v; const double* s = a.A + chol_tile_off(i, j) + mq;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) own[q] = so[4 * q * GSFM_CB];
-  }
-  {
-    const double2* li = (const double2*)(a.L + chol_tile_off(i, k) + ur * GSFM_CB + uc4);
-    const double2 v0 = li[0], v1 = li[1];
-    Pi[ur][uc4] = v0.x; Pi[ur][uc4 + 1] = v0.y; Pi[ur][uc4 + 2] = v1.x; Pi[ur][uc4 + 3] = v1.y;
-    if (j != i) {
-      const double2* lj = (const double2*)(a.L + chol_tile_off(j, k) + ur * GSFM_CB + uc4);
-      const double2 w0 = lj[0], w1 = lj[1];
-      Pj[ur][uc4] = w0.x; Pj[ur][uc4 + 1] = w0.y; Pj[ur][uc4 + 2] = w1.x; Pj[ur][uc4 + 3] = w1.y;
-    }
-  }
-  __syncthreads();
-  const uint32_t c = lane & 15, g = lane >> 4, ri = 16 * (wave >> 1) + c, rj = 16 * (wave & 1) + c;
-  double (*Q)[GSFM_CB + 1] = (j == i) ? Pi : Pj;
-  chol_d4 acc = {0.0, 0.0, 0.0, 0.0};
+    for (int q = 0; q < 4; ++q) v[q] = s[4 * q * GSFM_CB];
+    return v;
+  };
+  auto own_store = [&](uint32_t i, uint32_t j, chol_d4 v) {
+    double* d = a.A + chol_tile_off(i, j) + mq;
 #pragma unroll
-  for (int kk = 0; kk < 8; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Pi[ri][4 * kk + g], Q[rj][4 * kk + g], acc, 0, 0, 0);
-  double* d = a.A + chol_tile_off(i, j) + mq;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) d[4 * q * GSFM_CB] = own[q] - acc[q];
-}
-__global__ void __launch_bounds__(256) k_chol_update_exact(CholArgs a) { chol_update_exact_body(a); }
-// ONE launch per block column without the fused step's repeated eliminations (round 6): launch k APPLIES column k and PRODUCES column k + 1.
-//   * panel workgroups, one per block row i = k + 1 .. T (row T: the right-hand side), first in the grid: the tiles (k + 1, k + 1) and
-//     (i, k + 1) receive column k's update on the fly (left-looking: nobody else needs them any more), then wavefront 0 runs the 64-row
-//     elimination on them -- L_{k+1,k+1} from workgroup 0, L_{i,k+1} from the others;
-//   * update workgroups, one per trailing tile (i, j), k + 2 <= j <= i <= T: A_ij - L_ik L_jk^T as above.
-// The two kinds touch disjoint tiles (the panel reads column k + 1 of A and writes column k + 1 of L, the update writes columns >= k + 2 of A
-// and reads column k of L, which the PREVIOUS launch produced), so there is no dependency inside a launch, one elimination per block row
-// instead of two to three per trailing tile, and the chain is still one launch per column: k_chol_panel for column 0, then launches
-// 0 .. T - 2.  Every tile sees the same updates in the same order with the same instructions as under k_chol_step: the factor is
-// bit-identical (tools/bench_chol_batch.hip checks every double).
-// GSFM_LOOK_NT: trailing tiles per update workgroup, 1 or 3 (they share P_i).  Measured (tools/bench_chol_batch.hip, profiles/r06b_chol_look.txt):
-// six matrices side by side 708 -> 682 us with three, Madrid's matrix alone 470 -> 477: three for the batched form, one for the single matrix.
-template <int GSFM_LOOK_NT>
-__device__ __forceinline__ void chol_look_body(const CholArgs& a) {
-  static_assert(GSFM_LOOK_NT >= 1 && GSFM_LOOK_NT <= 3, "the update workgroup's P_j tiles share the panel's four LDS tiles");
-  constexpr int GSFM_LOOK_LDS = 4;
-  __shared__ double S[GSFM_LOOK_LDS][GSFM_CB][GSFM_CB + 1];   // panel workgroups: P_{k+1}, P_i and the updated tiles (k + 1, k + 1), (i, k + 1); update workgroups: P_i and up to three P_j
-  // (the panel's four tiles in TWO -- the updated tiles in the place of their operands, one more barrier -- measured slower, 493 against 468 us for Madrid's matrix alone: profiles/r06b_chol_look.txt)
-  const uint32_t k = a.k, T = a.T, c = k + 1, tid = threadIdx.x, n_panel = T - k;
-  const uint32_t ur = tid / 8, uc4 = (tid % 8) * 4, wave = tid >> 6, lane = tid & 63;
-  const uint32_t mq = (16 * (wave >> 1) + (lane >> 4)) * GSFM_CB + 16 * (wave & 1) + (lane & 15);
-  const uint32_t qc = lane & 15, g = lane >> 4, ri = 16 * (wave >> 1) + qc, rj = 16 * (wave & 1) + qc;
-  auto stage = [&](double (*P)[GSFM_CB + 1], const double* tile) {   // a 32 x 32 tile into LDS, 4 doubles per lane
-    const double2* t = (const double2*)(tile + ur * GSFM_CB + uc4);
+    for (int q = 0; q < 4; ++q) d[4 * q * GSFM_CB] = v[q];
+  };
+  auto tile_regs = [&](uint32_t i, uint32_t j) {   // tile (i, j) of L, four consecutive doubles per lane
+    const double2* t = (const double2*)(a.L + chol_tile_off(i, j) + ur * GSFM_CB + uc4);
     const double2 v0 = t[0], v1 = t[1];
-    P[ur][uc4] = v0.x; P[ur][uc4 + 1] = v0.y; P[ur][uc4 + 2] = v1.x; P[ur][uc4 + 3] = v1.y;
+    chol_d4 v = {v0.x, v0.y, v1.x, v1.y};
+    return v;
+  };
+  auto tile_put = [&](double (*P)[GSFM_CB + 1], chol_d4 v) { P[ur][uc4] = v[0]; P[ur][uc4 + 1] = v[1]; P[ur][uc4 + 2] = v[2]; P[ur][uc4 + 3] = v[3]; };
+  auto tile_publish = [&](uint32_t i, uint32_t j, const double (*P)[GSFM_CB + 1]) {
+    double* d = a.L + chol_tile_off(i, j) + ur * GSFM_CB + uc4;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) d[q] = P[ur][uc4 + q];
+  };
+  auto quad_put = [&](double (*P)[GSFM_CB + 1], chol_d4 v) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) P[16 * qa + g + 4 * q][16 * qb + qc] = v[q];
+  };
+  auto minus_prod = [&](chol_d4 o, const double (*X)[GSFM_CB + 1], const double (*Y)[GSFM_CB + 1]) {   // own - X Y^T: the product first, from zero
+    chol_d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(X[ri][4 * kk + g], Y[rj][4 * kk + g], acc, 0, 0, 0);
+    chol_d4 r;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) r[q] = o[q] - acc[q];
+    return r;
+  };
+  // one wavefront: the 64-row elimination of [D | X] (X == D for the diagonal workgroup's own factor); the upper lanes' rows go back into X,
+  // the lower lanes' -- the Cholesky factor of D -- to tile (cd, cd) of L where asked
+  auto eliminate = [&](double (*D)[GSFM_CB + 1], double (*X)[GSFM_CB + 1], bool write_diag, uint32_t cd) {
+    const uint32_t rr = lane & 31;
+    const double (*src)[GSFM_CB + 1] = lane < 32 ? D : X;
+    double r[GSFM_CB];
+#pragma unroll
+    for (int q = 0; q < GSFM_CB; ++q) r[q] = src[rr][q];
+    const int bad = chol_eliminate64(r, lane);
+    if (lane >= 32) {
+      if (X != D) {
+#pragma unroll
+        for (int q = 0; q < GSFM_CB; ++q) X[rr][q] = r[q];
+      }
+    } else if (write_diag) {
+      double2* dl = (double2*)(a.L + chol_tile_off(cd, cd) + rr * GSFM_CB);
+#pragma unroll
+      for (int q = 0; q < GSFM_CB / 2; ++q) dl[q] = make_double2((uint32_t)(2 * q) <= lane ? r[2 * q] : 0.0, (uint32_t)(2 * q + 1) <= lane ? r[2 * q + 1] : 0.0);
+      if (lane == 0 && bad && *a.info == 0) *a.info = (int)(cd * GSFM_CB + bad);
+    }
   };
   if (blockIdx.x < n_panel) {
-    const uint32_t i = c + blockIdx.x;
-    const bool diag = blockIdx.x == 0;             // block row k + 1 itself: L_{k+1,k+1}
     __builtin_amdgcn_s_setprio(3);                 // the chain runs through these wavefronts: ahead of the update workgroups that share the CU
-    double (*Pd)[GSFM_CB + 1] = S[0], (*Pi)[GSFM_CB + 1] = S[1], (*Dd)[GSFM_CB + 1] = S[2], (*Ci)[GSFM_CB + 1] = S[3];
-    chol_d4 ownD, ownC = {0.0, 0.0, 0.0, 0.0};
-    {
-      const double* sd = a.A + chol_tile_off(c, c) + mq;
+    const bool diag = blockIdx.x == 0;
+    const uint32_t i = c0 + PROD - 1 + blockIdx.x;  // (not used by the diagonal workgroup)
+    chol_d4 D00 = own_load(c0, c0), D10 = {0.0, 0.0, 0.0, 0.0}, D11 = D10, R0 = D10, R1 = D10;
+    if (PROD == 2) { D10 = own_load(c0 + 1, c0); D11 = own_load(c0 + 1, c0 + 1); }
+    if (!diag) { R0 = own_load(i, c0); if (PROD == 2) R1 = own_load(i, c0 + 1); }
+    if (PEND == 2) {
+      chol_d4 st[2][3];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) ownD[q] = sd[4 * q * GSFM_CB];
-      if (!diag) {
-        const double* sc = a.A + chol_tile_off(i, c) + mq;
+      for (int p = 0; p < 2; ++p) {
+        const uint32_t col = c0 - 2 + p;
+        st[p][0] = tile_regs(c0, col);
+        st[p][1] = PROD == 2 ? tile_regs(c0 + 1, col) : st[p][0];
+        st[p][2] = !diag ? tile_regs(i, col) : st[p][0];
+      }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) ownC[q] = sc[4 * q * GSFM_CB];
+      for (int p = 0; p < 2; ++p) {
+        if (p) __syncthreads();                    // (the first pending column's operands have been read)
+        tile_put(S[0], st[p][0]);
+        if (PROD == 2) tile_put(S[1], st[p][1]);
+        if (!diag) tile_put(S[2], st[p][2]);
+        __syncthreads();
+        D00 = minus_prod(D00, S[0], S[0]);
+        if (PROD == 2) { D10 = minus_prod(D10, S[1], S[0]); D11 = minus_prod(D11, S[1], S[1]); }
+        if (!diag) { R0 = minus_prod(R0, S[2], S[0]); if (PROD == 2) R1 = minus_prod(R1, S[2], S[1]); }
       }
     }
-    stage(Pd, a.L + chol_tile_off(c, k));
-    if (!diag) stage(Pi, a.L + chol_tile_off(i, k));
+    quad_put(S[3], D00);
+    if (PROD == 2) quad_put(S[4], D10);
+    if (!diag) quad_put(S[5], R0);
     __syncthreads();
-    chol_d4 accD = {0.0, 0.0, 0.0, 0.0}, accC = {0.0, 0.0, 0.0, 0.0};
+    if (PROD == 1) {                               // the last column of a matrix with an odd number of them: as k_chol_panel
+      if (wave == 0) {
+        const uint32_t rr = lane & 31;
+        const double (*src)[GSFM_CB + 1] = (lane < 32 || diag) ? S[3] : S[5];
+        double r[GSFM_CB];
 #pragma unroll
-    for (int kk = 0; kk < 8; ++kk) accD = __builtin_amdgcn_mfma_f64_16x16x4f64(Pd[ri][4 * kk + g], Pd[rj][4 * kk + g], accD, 0, 0, 0);
-    if (!diag) {
+        for (int q = 0; q < GSFM_CB; ++q) r[q] = src[rr][q];
+        const int bad = chol_eliminate64(r, lane);
+        if (diag) {
+          if (lane < 32) {
+            double2* dl = (double2*)(a.L + chol_tile_off(c0, c0) + rr * GSFM_CB);
 #pragma unroll
-      for (int kk = 0; kk < 8; ++kk) accC = __builtin_amdgcn_mfma_f64_16x16x4f64(Pi[ri][4 * kk + g], Pd[rj][4 * kk + g], accC, 0, 0, 0);
+            for (int q = 0; q < GSFM_CB / 2; ++q) dl[q] = make_double2((uint32_t)(2 * q) <= lane ? r[2 * q] : 0.0, (uint32_t)(2 * q + 1) <= lane ? r[2 * q + 1] : 0.0);
+            if (lane == 0 && bad && *a.info == 0) *a.info = (int)(c0 * GSFM_CB + bad);
+          }
+        } else if (lane >= 32) {
+          double2* dl = (double2*)(a.L + chol_tile_off(i, c0) + rr * GSFM_CB);
+#pragma unroll
+          for (int q = 0; q < GSFM_CB / 2; ++q) dl[q] = make_double2(r[2 * q], r[2 * q + 1]);
+        }
+      }
+      return;
     }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) Dd[16 * (wave >> 1) + g + 4 * q][16 * (wave & 1) + qc] = ownD[q] - accD[q];
-    if (!diag) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) Ci[16 * (wave >> 1) + g + 4 * q][16 * (wave & 1) + qc] = ownC[q] - accC[q];
-    }
+    // column c0: the rows c0 + 1 (wavefront 0; the diagonal workgroup's lower lanes give L_{c0,c0}) and i (wavefront 1) side by side
+    if (wave == 0) eliminate(S[3], S[4], diag, c0);
+    else if (wave == 1 && !diag) eliminate(S[3], S[5], false, c0);
+    __syncthreads();
+    // column c0 into (c0 + 1, c0 + 1) and (i, c0 + 1), then column c0 + 1
+    D11 = minus_prod(D11, S[4], S[4]);
+    if (!diag) R1 = minus_prod(R1, S[5], S[4]);
+    quad_put(S[0], D11);
+    if (!diag) quad_put(S[1], R1);
+    if (diag) tile_publish(c0 + 1, c0, S[4]); else tile_publish(i, c0, S[5]);
     __syncthreads();
     if (wave == 0) {
-      const uint32_t rr = lane & 31;
-      const double (*src)[GSFM_CB + 1] = (lane < 32 || diag) ? Dd : Ci;
-      double r[GSFM_CB];
+      if (diag) eliminate(S[0], S[0], true, c0 + 1);
+      else {
+        const uint32_t rr = lane & 31;
+        const double (*src)[GSFM_CB + 1] = lane < 32 ? S[0] : S[1];
+        double r[GSFM_CB];
 #pragma unroll
-      for (int q = 0; q < GSFM_CB; ++q) r[q] = src[rr][q];
-      const int bad = chol_eliminate64(r, lane);
-      if (diag) {
-        if (lane < 32) {
-          double2* dl = (double2*)(a.L + chol_tile_off(c, c) + rr * GSFM_CB);
+        for (int q = 0; q < GSFM_CB; ++q) r[q] = src[rr][q];
+        (void)chol_eliminate64(r, lane);
+        if (lane >= 32) {
+          double2* dl = (double2*)(a.L + chol_tile_off(i, c0 + 1) + rr * GSFM_CB);
 #pragma unroll
-          for (int q = 0; q < GSFM_CB / 2; ++q) dl[q] = make_double2((uint32_t)(2 * q) <= lane ? r[2 * q] : 0.0, (uint32_t)(2 * q + 1) <= lane ? r[2 * q + 1] : 0.0);
-          if (lane == 0 && bad && *a.info == 0) *a.info = (int)(c * GSFM_CB + bad);
+          for (int q = 0; q < GSFM_CB / 2; ++q) dl[q] = make_double2(r[2 * q], r[2 * q + 1]);
         }
-      } else if (lane >= 32) {
-        double2* dl = (double2*)(a.L + chol_tile_off(i, c) + rr * GSFM_CB);
-#pragma unroll
-        for (int q = 0; q < GSFM_CB / 2; ++q) dl[q] = make_double2(r[2 * q], r[2 * q + 1]);
       }
     }
     return;
   }
-  // update workgroups: up to GSFM_LOOK_NT neighbouring tiles (i, j0 ..) of one block row (they share P_i; a third of the workgroups of the one-tile form)
+  if (PEND == 0) return;
+  // update workgroups: up to two neighbouring tiles (i, j0), (i, j0 + 1) of one block row, both pending columns
   uint32_t b = blockIdx.x - n_panel, t = 0;
-  while (b >= (t + GSFM_LOOK_NT) / GSFM_LOOK_NT) { b -= (t + GSFM_LOOK_NT) / GSFM_LOOK_NT; ++t; }
-  const uint32_t i = k + 2 + t, j0 = k + 2 + GSFM_LOOK_NT * b;
+  while (b >= (t + GSFM_LOOK2_NT) / GSFM_LOOK2_NT) { b -= (t + GSFM_LOOK2_NT) / GSFM_LOOK2_NT; ++t; }
+  const uint32_t i = c0 + PROD + t, j0 = c0 + PROD + GSFM_LOOK2_NT * b;
   if (i > T) return;
-  uint32_t nt = min((uint32_t)GSFM_LOOK_NT, i - j0 + 1);
+  uint32_t nt = min((uint32_t)GSFM_LOOK2_NT, i - j0 + 1);
   if (i == T && j0 + nt - 1 == T) --nt;    // the right-hand side has no diagonal tile
   if (nt == 0) return;
-  chol_d4 own[GSFM_LOOK_NT];
+  chol_d4 own[GSFM_LOOK2_NT];
 #pragma unroll
-  for (int u = 0; u < GSFM_LOOK_NT; ++u) if ((uint32_t)u < nt) {
-    const double* so = a.A + chol_tile_off(i, j0 + u) + mq;
+  for (int u = 0; u < GSFM_LOOK2_NT; ++u) if ((uint32_t)u < nt) own[u] = own_load(i, j0 + u);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) own[u][q] = so[4 * q * GSFM_CB];
+  for (int p = 0; p < 2; ++p) {
+    tile_put(S[p], tile_regs(i, c0 - 2 + p));
+#pragma unroll
+    for (int u = 0; u < GSFM_LOOK2_NT; ++u) if ((uint32_t)u < nt && j0 + u != i) tile_put(S[2 + 2 * u + p], tile_regs(j0 + u, c0 - 2 + p));
   }
-  stage(S[0], a.L + chol_tile_off(i, k));
-#pragma unroll
-  for (int u = 0; u < GSFM_LOOK_NT; ++u) if ((uint32_t)u < nt && j0 + u != i) stage(S[1 + u], a.L + chol_tile_off(j0 + u, k));
   __syncthreads();
-  double aop[8];
 #pragma unroll
-  for (int kk = 0; kk < 8; ++kk) aop[kk] = S[0][ri][4 * kk + g];
+  for (int u = 0; u < GSFM_LOOK2_NT; ++u) if ((uint32_t)u < nt) {
 #pragma unroll
-  for (int u = 0; u < GSFM_LOOK_NT; ++u) if ((uint32_t)u < nt) {
-    double (*Q)[GSFM_CB + 1] = (j0 + u == i) ? S[0] : S[1 + u];
-    chol_d4 acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int kk = 0; kk < 8; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[kk], Q[rj][4 * kk + g], acc, 0, 0, 0);
-    double* d = a.A + chol_tile_off(i, j0 + u) + mq;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) d[4 * q * GSFM_CB] = own[u][q] - acc[q];
+    for (int p = 0; p < 2; ++p) own[u] = minus_prod(own[u], S[p], (j0 + u == i) ? S[p] : S[2 + 2 * u + p]);
+    own_store(i, j0 + u, own[u]);
   }
 }
-// workgroups of launch k for a matrix of T block rows (k <= T - 2): T - k panel rows + the trailing tiles of the block rows k + 2 .. T
-__host__ __device__ inline uint32_t chol_look_grid(uint32_t T, uint32_t k, uint32_t nt) { return (T - k) + chol_step_grid(T - k - 1, nt) - 1; }
-template <int GSFM_LOOK_NT>
-__global__ void __launch_bounds__(256) k_chol_look(CholArgs a) { chol_look_body<GSFM_LOOK_NT>(a); }
-template <int GSFM_LOOK_NT>
-__global__ void __launch_bounds__(256) k_chol_look_batch(const CholBatchItem* items, uint32_t k) {
-  const CholBatchItem it = items[blockIdx.y];
-  if (k + 2 > it.T || blockIdx.x >= chol_look_grid(it.T, k, GSFM_LOOK_NT) || !*it.active) return;
-  const CholArgs a{it.A, it.L, it.T, k, it.info};
-  chol_look_body<GSFM_LOOK_NT>(a);
+// workgroups of the launch that produces the columns c0 (, c0 + 1) of a matrix of T block rows
+__host__ __device__ inline uint32_t chol_look2_grid(uint32_t T, uint32_t c0, bool pending) {
+  const uint32_t prod = T - c0 >= 2 ? 2 : 1, n_panel = T - c0 + 2 - prod;
+  return n_panel + (pending ? chol_step_grid(T - c0 - prod + 1, GSFM_LOOK2_NT) - 1 : 0);
 }
-// The batched step (k_chol_step_batch) as these two launches: blockIdx.y is the matrix, the grid is the LARGEST matrix's
-__global__ void __launch_bounds__(64) k_chol_panel_batch(const CholBatchItem* items, uint32_t k) {
-  const CholBatchItem it = items[blockIdx.y];
-  if (k >= it.T || blockIdx.x > it.T - k || !*it.active) return;
-  const CholArgs a{it.A, it.L, it.T, k, it.info};
-  chol_panel_body(a);
+template <int PEND>
+__global__ void __launch_bounds__(256) k_chol_look2(CholArgs a) {
+  __shared__ double S[GSFM_LOOK2_LDS][GSFM_CB][GSFM_CB + 1];
+  if (a.T - a.k >= 2) chol_look2_body<PEND, 2>(a, S); else chol_look2_body<PEND, 1>(a, S);
 }
-__global__ void __launch_bounds__(256) k_chol_update_exact_batch(const CholBatchItem* items, uint32_t k) {
+template <int PEND>
+__global__ void __launch_bounds__(256) k_chol_look2_batch(const CholBatchItem* items, uint32_t c0) {
+  __shared__ double S[GSFM_LOOK2_LDS][GSFM_CB][GSFM_CB + 1];
   const CholBatchItem it = items[blockIdx.y];
-  if (k >= it.T) return;
-  const uint32_t m = it.T - k;
-  if (blockIdx.x >= m * (m + 1) / 2 || !*it.active) return;
-  const CholArgs a{it.A, it.L, it.T, k, it.info};
-  chol_update_exact_body(a);
+  if (c0 >= it.T || blockIdx.x >= chol_look2_grid(it.T, c0, PEND != 0) || !*it.active) return;
+  const CholArgs a{it.A, it.L, it.T, c0, it.info};
+  if (it.T - c0 >= 2) chol_look2_body<PEND, 2>(a, S); else chol_look2_body<PEND, 1>(a, S);
 }
-
 // Second half: A_ij -= L_ik L_jk^T for every trailing tile k < j <= i <= T ((T, T) does not exist), one wavefront per tile, on the matrix
 // cores: v_mfma_f64_16x16x4_f64 computes D(16x16) = A(16x4) B(4x16) + C; lane l supplies A[l & 15][l >> 4] and B[l >> 4][l & 15] and holds
 // C/D[(l >> 4) + 4 reg][l & 15], reg = 0..3 (MI355X guide, fragment layout of the f64 form).  A 32 x 32 tile is 2 x 2 such blocks times

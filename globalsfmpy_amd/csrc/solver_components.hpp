@@ -105,14 +105,15 @@ void comps_enqueue_dense(gsfm_rot_problem* P, hipStream_t st) {
   a.Mblk = P->Mblk.p; a.b = P->b.p; a.A = nullptr; a.n = 0; a.T = 0; a.q = P->q_lin; a.lap = P->lin_is_lap; a.info_slot = P->scal.p + SC_DENSE_INFO; a.rcg = P->r.p;
   const CompMap cm{C.cam_item.p, C.cam_loc.p, P->own_begin};
   hipLaunchKernelGGL(k_comp_assemble, dim3((uint32_t)C.item_cams.n), dim3(GSFM_BLOCK), 0, st, a, cm, (const CholBatchItem*)C.items.p, (const uint32_t*)C.item_cams.p);
-  // one launch per block column: the panel of column k + 1 beside the update with column k (dense_kernels.hpp, k_chol_look_batch; round 6: the fused
-  // step's bits at one elimination per block row -- the six scenes of C4 side by side 985 -> 682 us per factorisation + solve); GSFM_CHOL_FUSED=1: the fused step
+  // one launch per TWO block columns: their panels beside the update with the two columns before them (dense_kernels.hpp, k_chol_look2_batch; round 6: the
+  // fused step's bits at one elimination per block row and column -- the six scenes of C4 side by side 985 -> 660 us per factorisation + solve);
+  // GSFM_CHOL_FUSED=1: the fused step
   const char* fused_env = getenv("GSFM_CHOL_FUSED");
   const bool fused = fused_env && fused_env[0] == '1';
   if (!fused) {
-    hipLaunchKernelGGL(k_chol_panel_batch, dim3(C.Tmax + 1, C.n_items), dim3(64), 0, st, (const CholBatchItem*)C.items.p, 0u);
-    for (uint32_t k = 0; k + 2 <= C.Tmax; ++k)
-      hipLaunchKernelGGL(k_chol_look_batch<3>, dim3(chol_look_grid(C.Tmax, k, 3), C.n_items), dim3(256), 0, st, (const CholBatchItem*)C.items.p, k);
+    hipLaunchKernelGGL(k_chol_look2_batch<0>, dim3(chol_look2_grid(C.Tmax, 0, false), C.n_items), dim3(256), 0, st, (const CholBatchItem*)C.items.p, 0u);
+    for (uint32_t c0 = 2; c0 < C.Tmax; c0 += 2)
+      hipLaunchKernelGGL(k_chol_look2_batch<2>, dim3(chol_look2_grid(C.Tmax, c0, true), C.n_items), dim3(256), 0, st, (const CholBatchItem*)C.items.p, c0);
   } else for (uint32_t k = 0; k < C.Tmax; ++k) {
     const uint32_t m = C.Tmax - k, nt = chol_step_tiles_per_wg(m);
     const dim3 grid(chol_step_grid(m, nt), C.n_items);

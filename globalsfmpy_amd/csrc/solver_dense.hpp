@@ -29,18 +29,15 @@ int run_dense(gsfm_rot_problem* P, bool* used, bool plain = false) {
     a.Mblk = P->Mblk.p; a.b = P->b.p; a.A = P->denseA.p; a.n = n; a.T = T; a.q = P->q_lin; a.lap = P->lin_is_lap; a.info_slot = P->scal.p + SC_DENSE_INFO; a.rcg = P->r.p;
     if (P->cs.active) hipLaunchKernelGGL(k_dense_assemble_col, dim3(P->cs.n_wg), dim3(GSFM_BLOCK), 0, P->stream, a, P->cs.dev());
     else hipLaunchKernelGGL(k_dense_assemble, dim3(P->n_rows), dim3(GSFM_BLOCK), 0, P->stream, a);
-    // Up to 64 block columns: ONE launch per block column, the panel of column k + 1 beside the update with column k (dense_kernels.hpp,
-    // k_chol_look; round 6: the same bits as the fused step it replaces -- one elimination per block row instead of two or three per trailing
-    // tile -- Madrid's 37 columns 519 -> 470 us per factorisation + solve).  GSFM_CHOL_FUSED=1: the fused step (A/B, the bit-identity test).
+    // Up to 64 block columns: one launch per TWO block columns, the panels of the columns c0, c0 + 1 beside the update with the two columns before
+    // them (dense_kernels.hpp, k_chol_look2; round 6: the same bits as the fused step it replaces at one elimination per block row and
+    // column -- Madrid's 37 columns 519 -> 444 us per factorisation + solve).  GSFM_CHOL_FUSED=1: the fused step (A/B, the bit-identity test).
     const char* fused_env = getenv("GSFM_CHOL_FUSED");
     const bool fused = fused_env && fused_env[0] == '1';
     if (T <= split_T && !fused) {
-      CholArgs c0{P->denseA.p, P->denseL.p, T, 0, info};
-      hipLaunchKernelGGL(k_chol_panel, dim3(T + 1), dim3(64), 0, P->stream, c0);
-      for (uint32_t k = 0; k + 2 <= T; ++k) {
-        CholArgs c{P->denseA.p, P->denseL.p, T, k, info};
-        hipLaunchKernelGGL(k_chol_look<1>, dim3(chol_look_grid(T, k, 1)), dim3(256), 0, P->stream, c);
-      }
+      CholArgs c{P->denseA.p, P->denseL.p, T, 0, info};
+      hipLaunchKernelGGL(k_chol_look2<0>, dim3(chol_look2_grid(T, 0, false)), dim3(256), 0, P->stream, c);
+      for (c.k = 2; c.k < T; c.k += 2) hipLaunchKernelGGL(k_chol_look2<2>, dim3(chol_look2_grid(T, c.k, true)), dim3(256), 0, P->stream, c);
     } else if (T <= split_T) {
       for (uint32_t k = 0; k < T; ++k) {
         CholArgs c{P->denseA.p, P->denseL.p, T, k, info};

@@ -10,7 +10,7 @@
 #include <vector>
 #include <random>
 #include <algorithm>
-#include "../globalsfmpy_amd/csrc/dense_kernels.hpp"
+#include "chol_variants.hpp"
 using namespace gsfm;
 #define CHK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
 
@@ -45,7 +45,7 @@ int main() {
   for (uint32_t c = 0; c < NI; ++c) { items[c].A = slab + offA[c]; items[c].L = slab + offL[c]; items[c].x = slab + offX[c]; items[c].info = dinfo + c; items[c].active = dactive + c; }
   CHK(hipMemcpy(ditems, items.data(), sizeof(CholBatchItem) * NI, hipMemcpyHostToDevice));
   hipStream_t st; CHK(hipStreamCreate(&st));
-  const uint32_t NEVER = 0xffffffffu, LOOK = 0xfffffffeu;
+  const uint32_t NEVER = 0xffffffffu, LOOK = 0xfffffffeu, LOOK2 = 0xfffffffdu;
   // split_above_tiles: steps whose trailing tile count (of the LARGEST matrix) is above this run as panel + update
   const int look_nt = getenv("LOOK_NT") ? atoi(getenv("LOOK_NT")) : 3;   // trailing tiles per update workgroup of the one-launch-per-column form
   auto enqueue = [&](uint32_t split_above_tiles) {
@@ -58,6 +58,9 @@ int main() {
         if (look_nt == 3) hipLaunchKernelGGL(k_chol_look_batch<3>, dim3(chol_look_grid(Tmax, k, 3), NI), dim3(256), 0, st, (const CholBatchItem*)ditems, k);
         else hipLaunchKernelGGL(k_chol_look_batch<1>, dim3(chol_look_grid(Tmax, k, 1), NI), dim3(256), 0, st, (const CholBatchItem*)ditems, k);
       }
+    } else if (split_above_tiles == LOOK2) {   // two columns per launch
+      hipLaunchKernelGGL(k_chol_look2_batch<0>, dim3(chol_look2_grid(Tmax, 0, false), NI), dim3(256), 0, st, (const CholBatchItem*)ditems, 0u);
+      for (uint32_t c0 = 2; c0 < Tmax; c0 += 2) hipLaunchKernelGGL(k_chol_look2_batch<2>, dim3(chol_look2_grid(Tmax, c0, true), NI), dim3(256), 0, st, (const CholBatchItem*)ditems, c0);
     } else for (uint32_t k = 0; k < Tmax; ++k) {
       const uint32_t m = Tmax - k, tiles = m * (m + 1) / 2;
       if (tiles > split_above_tiles) {
@@ -78,7 +81,7 @@ int main() {
       if (k0) hipLaunchKernelGGL(k_chol_back_update_batch<GR>, dim3(k0, NI), dim3(32 * GR), 0, st, (const CholBatchItem*)ditems, g);
     }
   };
-  const std::vector<std::pair<const char*, uint32_t>> forms = {{"fused step everywhere", NEVER}, {"panel + update where > 256 trailing tiles", 256}, {"panel + update where > 512 trailing tiles", 512}, {"panel + update everywhere", 0}, {"one launch per column: panel k + 1 beside update k", LOOK}};
+  const std::vector<std::pair<const char*, uint32_t>> forms = {{"fused step everywhere", NEVER}, {"panel + update where > 256 trailing tiles", 256}, {"panel + update everywhere", 0}, {"one launch per column: panel k + 1 beside update k", LOOK}, {"one launch per TWO columns", LOOK2}};
   const std::vector<std::vector<int>> live = {{1, 1, 1, 1, 1, 1}, {0, 1, 1, 0, 0, 1}, {0, 1, 0, 0, 0, 0}};
   std::vector<double> ref;
   for (const auto& lv : live) {
@@ -91,6 +94,8 @@ int main() {
       std::vector<double> out(words - a_words); std::vector<int> info(NI);
       CHK(hipMemcpy(out.data(), slab + a_words, 8 * (words - a_words), hipMemcpyDeviceToHost)); CHK(hipMemcpy(info.data(), dinfo, 4 * NI, hipMemcpyDeviceToHost));
       size_t diff = 0;
+      unsigned long long fnv = 1469598103934665603ull;   // checksum of every double of L, y and x (to compare BUILDS, e.g. -DGSFM_ELIM_LDS=0 against 1)
+      { const unsigned char* pb = (const unsigned char*)out.data(); for (size_t q = 0; q < 8 * out.size(); ++q) { fnv ^= pb[q]; fnv *= 1099511628211ull; } }
       if (f == 0) ref = out; else for (size_t q = 0; q < out.size(); ++q) diff += std::memcmp(&out[q], &ref[q], 8) != 0;
       // residual of the first live matrix
       double rmax = 0.0;
@@ -104,9 +109,25 @@ int main() {
       const int reps = 30;
       CHK(hipEventRecord(e0, st)); for (int k = 0; k < reps; ++k) CHK(hipGraphLaunch(ge, st)); CHK(hipEventRecord(e1, st)); CHK(hipEventSynchronize(e1));
       float ms; CHK(hipEventElapsedTime(&ms, e0, e1));
-      printf("  %-52s: %8.1f us per factorisation + solve (graph replay)  info %d  |Ax - b| sampled %.1e  doubles of L, y, x differing from the fused form: %zu\n", forms[f].first, 1e3 * ms / reps, *std::max_element(info.begin(), info.end()), rmax, diff);
+      printf("  %-52s: %8.1f us per factorisation + solve (graph replay)  info %d  |Ax - b| sampled %.1e  doubles of L, y, x differing from the fused form: %zu  fnv %016llx\n", forms[f].first, 1e3 * ms / reps, *std::max_element(info.begin(), info.end()), rmax, diff, fnv);
       CHK(hipGraphExecDestroy(ge)); CHK(hipGraphDestroy(g));
     }
   }
+#ifdef GSFM_LOOK_TIMING
+  {   // phase stamps of the first row workgroup of matrix 1 (Madrid's size) in every launch of the one-launch-per-column form (last run: that matrix alone)
+    const std::vector<int> only = {0, 1, 0, 0, 0, 0};
+    CHK(hipMemcpy(dactive, only.data(), 4 * NI, hipMemcpyHostToDevice));
+    enqueue(LOOK); CHK(hipStreamSynchronize(st));
+    static unsigned long long ts[128][8];
+    CHK(hipMemcpyFromSymbol(ts, HIP_SYMBOL(gsfm_look_ts), sizeof(ts)));
+    double acc[6] = {0, 0, 0, 0, 0, 0}; int n = 0;
+    for (uint32_t k = 0; k + 3 <= items[1].T; ++k, ++n) {
+      for (int q = 1; q < 6; ++q) acc[q] += (double)(ts[k][q] - ts[k][q - 1]) * 10.0;   // 100 MHz
+      if (k + 4 <= items[1].T) acc[0] += (double)(ts[k + 1][0] - ts[k][5]) * 10.0;
+    }
+    printf("row workgroup of the one-launch-per-column form, matrix 1182 alone, mean over %d launches (ns): loads + stage + barrier %.0f | two products + LDS + barrier %.0f | rows from LDS %.0f | elimination %.0f | store %.0f | end of one -> start of the next %.0f\n",
+           n, acc[1] / n, acc[2] / n, acc[3] / n, acc[4] / n, acc[5] / n, acc[0] / std::max(1, n - 1));
+  }
+#endif
   return 0;
 }

@@ -38,7 +38,7 @@ c4 = dict(n=int(offs[-1]), ei=np.concatenate([g["edge_i"] + o for o, g in zip(of
 res = {}
 for fused in ("1", "0"):
     os.environ["GSFM_CHOL_FUSED"] = fused
-    name = "fused step (until round 6)" if fused == "1" else "one launch per block column"
+    name = "fused step (until round 6)" if fused == "1" else "two block columns per launch"
     for et, loss, what in ((_abi.ANGLE_AXIS_COVARIANCE, LF.MAGSACWeightBasedLoss(0.02), "Madrid cov + MAGSAC"), (_abi.ANGLE_AXIS, LF.SoftLOneLoss(0.1), "Madrid SoftL1 (EstimateRotations)")):
         p = RotationProblem(len(ids), ei, ej, m["rel_aa"], et, cov6=c6); p.set_loss(loss)
         t, r, s = best(p, x0)
