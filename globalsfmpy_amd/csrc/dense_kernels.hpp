@@ -16,11 +16,9 @@
 //     per factorisation + solve, Madrid's matrix alone 519 -> 444, every double of L, y and x the same (tools/bench_chol_batch.hip);
 //   * L goes to a second buffer (a workgroup's inputs A_kk, A_ik, A_jk are never written during step k, so there is no race);
 //   * the backward substitution L^T x = y is one workgroup sweeping the block rows of L bottom-up.
-// fp64 VALU throughout at these sizes.  Beyond ~50 block columns (more than 512 cameras) the redundancy of that schedule (every trailing
-// workgroup repeating the diagonal factorisation) and its per-lane 1 x 4 update dominate, and the work is done by two kernels per step
-// instead: k_chol_panel (one wavefront per panel tile: the same fused factorisation + substitution, once per tile ROW instead of once per
-// trailing tile) and k_chol_update_mfma (one wavefront per trailing tile: A_ij -= L_ik L_jk^T as 2 x 2 x 8 v_mfma_f64_16x16x4_f64 -- the
-// one dense contraction on this path, on the matrix cores).
+// The same schedule serves every size up to GSFM_DENSE_MAX_T block columns (round 6; until then matrices beyond 64 block columns ran a panel
+// kernel and a separate trailing update per step: 3N = 2400 / 4500 / 9000 1.25 -> 0.89, 3.11 -> 2.25, 13.2 -> 11.8 ms per factorise + solve,
+// tools/bench_chol_large.hip -- those kernels now live in tools/chol_variants.hpp).  The trailing updates are fp64 MFMA, everything else fp64 VALU.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -33,8 +31,7 @@ namespace gsfm {
 #define GSFM_CHOL_BATCH 8
 #endif
 #define GSFM_DENSE_MAX_T 500   // block rows whose right-hand side the backward kernel keeps in LDS (125 KB of the 160): 3N <= 16000, 5333 cameras
-#define GSFM_CHOL_SPLIT_T 64   // LDS capacity (block rows) of the single-workgroup backward kernel kept for A/B runs: the fused schedule is never used beyond
-#define GSFM_CHOL_SPLIT_DEFAULT 64   // more block columns than this: the two-kernel MFMA schedule (see run_dense; crossover measured at ~68: 3N = 2048 1.06 vs 1.10 ms, 2304 1.30 vs 1.27)
+#define GSFM_CHOL_FUSED_MAX_T 64   // the fused step of rounds 2-5 (GSFM_CHOL_FUSED=1: the reference of the bit-identity test) is never used beyond
 
 __host__ __device__ inline size_t chol_tile_off(uint32_t i, uint32_t j) { return ((size_t)i * (i + 1) / 2 + j) * GSFM_TILE_ELEMS; }
 __host__ __device__ inline size_t chol_num_tiles(uint32_t T) { return (size_t)(T + 1) * (T + 2) / 2; }   // block rows 0..T (row T = rhs)
@@ -227,32 +224,6 @@ __global__ void __launch_bounds__(256) k_chol_step_batch(const CholBatchItem* it
   const CholArgs a{it.A, it.L, it.T, k, it.info};
   chol_step_body<GSFM_CHOL_NT>(a);
 }
-// Step k of the two-kernel schedule, first half: workgroup 0 (one wavefront) factors A_kk and writes L_kk; workgroup b >= 1 factors A_kk
-// again in its lower lanes and, with the same instructions, turns the panel tile A_ik, i = k + b (block row T = the right-hand side), into
-// L_ik = A_ik L_kk^-T in its upper lanes.  Reads A, writes L: no race with anything in this step.
-__device__ __forceinline__ void chol_panel_body(const CholArgs& a) {
-  const uint32_t k = a.k, lane = threadIdx.x, rr = lane & 31, b = blockIdx.x;
-  const uint32_t i = k + b;   // b == 0: the diagonal tile itself in both halves
-  const double2* src = (const double2*)(a.A + (lane < 32 ? chol_tile_off(k, k) : chol_tile_off(i, k)) + rr * GSFM_CB);
-  double r[GSFM_CB];
-#pragma unroll
-  for (int q = 0; q < GSFM_CB / 2; ++q) { const double2 v = src[q]; r[2 * q] = v.x; r[2 * q + 1] = v.y; }
-  const int bad = chol_eliminate64(r, lane);
-  if (b == 0) {
-    if (lane < 32) {
-      double2* dl = (double2*)(a.L + chol_tile_off(k, k) + rr * GSFM_CB);
-#pragma unroll
-      for (int q = 0; q < GSFM_CB / 2; ++q) dl[q] = make_double2((uint32_t)(2 * q) <= lane ? r[2 * q] : 0.0, (uint32_t)(2 * q + 1) <= lane ? r[2 * q + 1] : 0.0);
-      if (lane == 0 && bad && *a.info == 0) *a.info = (int)(k * GSFM_CB + bad);
-    }
-  } else if (lane >= 32) {
-    double2* dl = (double2*)(a.L + chol_tile_off(i, k) + rr * GSFM_CB);
-#pragma unroll
-    for (int q = 0; q < GSFM_CB / 2; ++q) dl[q] = make_double2(r[2 * q], r[2 * q + 1]);
-  }
-}
-__global__ void __launch_bounds__(64) k_chol_panel(CholArgs a) { chol_panel_body(a); }
-
 // TWO block columns per launch (round 6, the form the product runs): launch c0 PRODUCES the columns c0 and c0 + 1 and APPLIES the two columns
 // before them (the previous launch's).  Half the launches of k_chol_look for the same work per block row plus one redundant panel tile:
 //   * panel workgroups -- the diagonal one, then one per block row i = c0 + 2 .. T -- hold the tiles (c0, c0), (c0 + 1, c0), (c0 + 1, c0 + 1),
@@ -459,74 +430,6 @@ __global__ void __launch_bounds__(256) k_chol_look2_batch(const CholBatchItem* i
   const CholArgs a{it.A, it.L, it.T, c0, it.info};
   if (it.T - c0 >= 2) chol_look2_body<PEND, 2>(a, S); else chol_look2_body<PEND, 1>(a, S);
 }
-// Second half: A_ij -= L_ik L_jk^T for every trailing tile k < j <= i <= T ((T, T) does not exist), one wavefront per tile, on the matrix
-// cores: v_mfma_f64_16x16x4_f64 computes D(16x16) = A(16x4) B(4x16) + C; lane l supplies A[l & 15][l >> 4] and B[l >> 4][l & 15] and holds
-// C/D[(l >> 4) + 4 reg][l & 15], reg = 0..3 (MI355X guide, fragment layout of the f64 form).  A 32 x 32 tile is 2 x 2 such blocks times
-// 8 steps of K = 4; the A operand is -L_ik, the B operand L_jk read row-wise (= L_jk^T column-wise).
-// Block columns k .. k + ncol - 1 of L (ncol = 1 or 2) are folded into the tiles (i, j), j0 <= j <= i <= T -- or, col_only, into the tiles
-// (i, j0) of one block column alone.  Two columns per pass read and write every trailing tile once instead of twice (the update is bound by
-// those 16 KB per tile from ~100 block rows on); the accumulation order per tile -- column k, then column k + 1 -- is the one two separate
-// passes have, so the factor is bit-identical whichever way the host pairs the columns.
-struct CholUpdArgs { double* A; const double* L; uint32_t T, k, j0, col_only; };
-template <int NCOL>
-__global__ void __launch_bounds__(256) k_chol_update_mfma(CholUpdArgs a) {
-  const uint32_t T = a.T, lane = threadIdx.x & 63, j0 = a.j0;
-  const uint64_t b = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  const uint32_t m = T - j0 + 1;                          // block rows j0 .. T
-  uint32_t i, j;
-  if (a.col_only) {
-    if (b >= m) return;
-    i = j0 + (uint32_t)b; j = j0;
-  } else {
-    if (b >= (uint64_t)m * (m + 1) / 2) return;
-    uint32_t t = (uint32_t)((sqrt(8.0 * (double)b + 1.0) - 1.0) * 0.5);
-    while ((uint64_t)(t + 1) * (t + 2) / 2 <= b) ++t;
-    while ((uint64_t)t * (t + 1) / 2 > b) --t;
-    i = j0 + t; j = j0 + (uint32_t)(b - (uint64_t)t * (t + 1) / 2);
-  }
-  if (i == T && j == T) return;
-  const uint32_t c = lane & 15, g = lane >> 4;
-  double* Aij = a.A + chol_tile_off(i, j);
-  chol_d4 acc[2][2];
-#pragma unroll
-  for (int si = 0; si < 2; ++si)
-#pragma unroll
-    for (int sj = 0; sj < 2; ++sj)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) acc[si][sj][r] = Aij[(16 * si + g + 4 * r) * GSFM_CB + 16 * sj + c];
-#pragma unroll
-  for (uint32_t cc = 0; cc < (uint32_t)NCOL; ++cc) {
-    const double* Li = a.L + chol_tile_off(i, a.k + cc);
-    const double* Lj = a.L + chol_tile_off(j, a.k + cc);
-    // The contraction index may be dealt to (MFMA step kk, lane group g) in any way, as long as A and B agree: lane group g takes
-    // k = 8 g .. 8 g + 7, eight CONSECUTIVE doubles of a tile row, so the operand loads are 64 contiguous bytes per lane (whole rows per
-    // 4 lanes) instead of eight 8-byte pieces 32 bytes apart.
-    double aop[2][8], bop[2][8];
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const double2* ra = (const double2*)(Li + (16 * s + c) * GSFM_CB + 8 * g);
-      const double2* rb = (const double2*)(Lj + (16 * s + c) * GSFM_CB + 8 * g);
-#pragma unroll
-      for (int h = 0; h < 4; ++h) {
-        const double2 va = ra[h], vb = rb[h];
-        aop[s][2 * h] = -va.x; aop[s][2 * h + 1] = -va.y; bop[s][2 * h] = vb.x; bop[s][2 * h + 1] = vb.y;
-      }
-    }
-#pragma unroll
-    for (int si = 0; si < 2; ++si)
-#pragma unroll
-      for (int sj = 0; sj < 2; ++sj)
-#pragma unroll
-        for (int kk = 0; kk < 8; ++kk) acc[si][sj] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[si][kk], bop[sj][kk], acc[si][sj], 0, 0, 0);
-  }
-#pragma unroll
-  for (int si = 0; si < 2; ++si)
-#pragma unroll
-    for (int sj = 0; sj < 2; ++sj)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) Aij[(16 * si + g + 4 * r) * GSFM_CB + 16 * sj + c] = acc[si][sj][r];
-}
-
 // x_k = L_kk^-T y_k for one block: the 32-step substitution of one wavefront (running right-hand side in lane registers, solved components
 // broadcast with v_readlane).
 __device__ __forceinline__ void chol_back_block(const double (*Lk)[GSFM_CB + 1], double v, uint32_t lane, double* xk_out, double* x, uint32_t g0, uint32_t n) {

@@ -16,11 +16,6 @@ int run_dense(gsfm_rot_problem* P, bool* used, bool plain = false) {
   if (!P->denseA.p) {
     if (P->denseA.alloc(elems) != hipSuccess || P->denseL.alloc(elems, true) != hipSuccess || P->dense_x.alloc((size_t)T * GSFM_CB, true) != hipSuccess) { P->denseA.release(); return 0; }
   }
-  // schedule: one fused kernel per block column (shortest chain for tiny matrices), or panel + MFMA update + one backward launch per block
-  // row.  Measured (tools/bench_chol.hip, profiles/r03_bench_chol.txt): 1.42 vs 2.7 ms at 3N = 2400, 3.45 vs 10.2 ms at 4500; at Madrid's
-  // 1182 the fused schedule is the faster one inside the solver (37.7 vs 39.3 ms of linear solves per 63 LM iterations), and up to
-  // ~68 block columns in the benchmark (2048: 1.06 vs 1.10 ms), so the switch is at 64 block columns (682 cameras).
-  constexpr uint32_t split_T = GSFM_CHOL_SPLIT_DEFAULT;
   auto enqueue = [&]() {
     (void)hipMemsetAsync(P->denseA.p, 0, 8 * elems, P->stream);
     int* const info = (int*)(P->scal.p + SC_DENSE_INFO);
@@ -29,46 +24,23 @@ int run_dense(gsfm_rot_problem* P, bool* used, bool plain = false) {
     a.Mblk = P->Mblk.p; a.b = P->b.p; a.A = P->denseA.p; a.n = n; a.T = T; a.q = P->q_lin; a.lap = P->lin_is_lap; a.info_slot = P->scal.p + SC_DENSE_INFO; a.rcg = P->r.p;
     if (P->cs.active) hipLaunchKernelGGL(k_dense_assemble_col, dim3(P->cs.n_wg), dim3(GSFM_BLOCK), 0, P->stream, a, P->cs.dev());
     else hipLaunchKernelGGL(k_dense_assemble, dim3(P->n_rows), dim3(GSFM_BLOCK), 0, P->stream, a);
-    // Up to 64 block columns: one launch per TWO block columns, the panels of the columns c0, c0 + 1 beside the update with the two columns before
-    // them (dense_kernels.hpp, k_chol_look2; round 6: the same bits as the fused step it replaces at one elimination per block row and
-    // column -- Madrid's 37 columns 519 -> 444 us per factorisation + solve).  GSFM_CHOL_FUSED=1: the fused step (A/B, the bit-identity test).
+    // One launch per TWO block columns, the panels of the columns c0, c0 + 1 beside the update with the two columns before them
+    // (dense_kernels.hpp, k_chol_look2; round 6).  Up to 64 block columns it gives the bits of the fused step it replaces at one
+    // elimination per block row and column -- Madrid's 37 columns 519 -> 444 us per factorisation + solve; GSFM_CHOL_FUSED=1: the
+    // fused step (A/B, the bit-identity test).  Beyond, it replaces the panel + MFMA-update pairs of rounds 3-5 (another summation order
+    // in the update: the last bits of those factors changed): 3N = 2400 / 4500 / 9000 1.25 -> 0.89, 3.11 -> 2.25, 13.2 -> 11.8 ms.
     const char* fused_env = getenv("GSFM_CHOL_FUSED");
-    const bool fused = fused_env && fused_env[0] == '1';
-    if (T <= split_T && !fused) {
+    const bool fused = fused_env && fused_env[0] == '1' && T <= GSFM_CHOL_FUSED_MAX_T;
+    if (!fused) {
       CholArgs c{P->denseA.p, P->denseL.p, T, 0, info};
       hipLaunchKernelGGL(k_chol_look2<0>, dim3(chol_look2_grid(T, 0, false)), dim3(256), 0, P->stream, c);
       for (c.k = 2; c.k < T; c.k += 2) hipLaunchKernelGGL(k_chol_look2<2>, dim3(chol_look2_grid(T, c.k, true)), dim3(256), 0, P->stream, c);
-    } else if (T <= split_T) {
+    } else {
       for (uint32_t k = 0; k < T; ++k) {
         CholArgs c{P->denseA.p, P->denseL.p, T, k, info};
-        const uint64_t m = T - k;
-        { const uint32_t nt = chol_step_tiles_per_wg((uint32_t)m); const dim3 grid(chol_step_grid((uint32_t)m, nt));
-          if (nt == 3) hipLaunchKernelGGL(k_chol_step<3>, grid, dim3(256), 0, P->stream, c); else if (nt == 2) hipLaunchKernelGGL(k_chol_step<2>, grid, dim3(256), 0, P->stream, c); else hipLaunchKernelGGL(k_chol_step<1>, grid, dim3(256), 0, P->stream, c); }
-      }
-    } else {
-      // larger matrices: panel (one wavefront per tile row), then the trailing update on the matrix cores -- block columns in GROUPS of two (four beyond 192 block columns):
-      // inside a group the finished columns are folded into the NEXT block column alone, so that its panel can run, and after the group all
-      // of them are folded into the rest in one pass (every trailing tile read and written once per group instead of once per column; same
-      // launch count; per tile the columns are still applied in ascending order, so the factor is bit-identical to the column-by-column schedule)
-      auto update = [&](uint32_t k, uint32_t ncol, uint32_t j0, bool col_only) {
-        CholUpdArgs u{P->denseA.p, P->denseL.p, T, k, j0, col_only ? 1u : 0u};
-        const uint64_t m = T - j0 + 1, tiles = col_only ? m : m * (m + 1) / 2;
-        if (j0 > T || !tiles) return;
-        const dim3 grid((uint32_t)((tiles + 3) / 4)), blk(256);
-        if (ncol == 4) hipLaunchKernelGGL(k_chol_update_mfma<4>, grid, blk, 0, P->stream, u);
-        else if (ncol == 3) hipLaunchKernelGGL(k_chol_update_mfma<3>, grid, blk, 0, P->stream, u);
-        else if (ncol == 2) hipLaunchKernelGGL(k_chol_update_mfma<2>, grid, blk, 0, P->stream, u);
-        else hipLaunchKernelGGL(k_chol_update_mfma<1>, grid, blk, 0, P->stream, u);
-      };
-      const uint32_t GROUP = T > 192 ? 4 : 2;   // (3N = 2400 / 4500 / 9000: pairs 1.42 / 3.44 / 14.7 ms, fours 1.48 / 3.50 / 13.8; column by column 1.48 / 3.75 / 17.4)
-      for (uint32_t k = 0; k < T; k += GROUP) {
-        const uint32_t g = std::min(GROUP, T - k);
-        for (uint32_t c = 0; c < g; ++c) {
-          CholArgs pc{P->denseA.p, P->denseL.p, T, k + c, info};
-          hipLaunchKernelGGL(k_chol_panel, dim3(T - (k + c) + 1), dim3(64), 0, P->stream, pc);
-          if (c + 1 < g) update(k, c + 1, k + c + 1, true);    // columns k .. k + c into block column k + c + 1 alone: the next panel's input
-        }
-        update(k, g, k + g, false);                            // all g columns into the rest (for the last group: the right-hand side row only)
+        const uint32_t m = T - k, nt = chol_step_tiles_per_wg(m);
+        const dim3 grid(chol_step_grid(m, nt));
+        if (nt == 3) hipLaunchKernelGGL(k_chol_step<3>, grid, dim3(256), 0, P->stream, c); else if (nt == 2) hipLaunchKernelGGL(k_chol_step<2>, grid, dim3(256), 0, P->stream, c); else hipLaunchKernelGGL(k_chol_step<1>, grid, dim3(256), 0, P->stream, c);
       }
     }
     // backward substitution, L^T x = y (y = block row T of L), in groups of 8 block rows: one workgroup solves a group, one launch

@@ -204,9 +204,10 @@ int lm_solve(gsfm_rot_problem* P, const gsfm_rot_options& o_in, gsfm_rot_summary
   if (gmax <= o.gradient_tolerance) return finish(GSFM_TERM_GRADIENT_TOLERANCE);
   bool last_successful = false, pcg_struggles = false, pcg_dearer_than_cholesky = false;
   // What one exact step (assemble + factorise + both substitutions, one hipGraph replay) takes on MI355X as a function of 3N: measured
-  // (tools/bench_chol.hip, profiles/r03_bench_chol.txt: 1182 -> 0.45 ms, 2400 -> 1.33, 4500 -> 3.27, 9000 -> 13.5), log-log interpolated.
+  // (tools/bench_chol_large.hip, profiles/r06b_chol_look.txt: 1182 -> 0.40 ms, 2400 -> 0.89, 4500 -> 2.25, 9000 -> 11.8 with the schedule
+  // of round 6; rounds 3-5: 0.45 / 1.33 / 3.27 / 13.5), log-log interpolated.
   auto dense_cost_ms = [](double n3) {
-    static const double pts[5][2] = {{600.0, 0.20}, {1182.0, 0.45}, {2400.0, 1.33}, {4500.0, 3.27}, {9000.0, 13.5}};
+    static const double pts[5][2] = {{600.0, 0.18}, {1182.0, 0.40}, {2400.0, 0.89}, {4500.0, 2.25}, {9000.0, 11.8}};
     int k = 0;
     while (k < 3 && n3 > pts[k + 1][0]) ++k;
     const double t = std::log(n3 / pts[k][0]) / std::log(pts[k + 1][0] / pts[k][0]);

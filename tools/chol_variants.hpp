@@ -4,6 +4,102 @@
 #pragma once
 #include "../globalsfmpy_amd/csrc/dense_kernels.hpp"
 namespace gsfm {
+// ---- the two-kernel schedule of matrices beyond 64 block columns until round 6 (tools/bench_chol_large.hip)
+// Step k of the two-kernel schedule, first half: workgroup 0 (one wavefront) factors A_kk and writes L_kk; workgroup b >= 1 factors A_kk
+// again in its lower lanes and, with the same instructions, turns the panel tile A_ik, i = k + b (block row T = the right-hand side), into
+// L_ik = A_ik L_kk^-T in its upper lanes.  Reads A, writes L: no race with anything in this step.
+__device__ __forceinline__ void chol_panel_body(const CholArgs& a) {
+  const uint32_t k = a.k, lane = threadIdx.x, rr = lane & 31, b = blockIdx.x;
+  const uint32_t i = k + b;   // b == 0: the diagonal tile itself in both halves
+  const double2* src = (const double2*)(a.A + (lane < 32 ? chol_tile_off(k, k) : chol_tile_off(i, k)) + rr * GSFM_CB);
+  double r[GSFM_CB];
+#pragma unroll
+  for (int q = 0; q < GSFM_CB / 2; ++q) { const double2 v = src[q]; r[2 * q] = v.x; r[2 * q + 1] = v.y; }
+  const int bad = chol_eliminate64(r, lane);
+  if (b == 0) {
+    if (lane < 32) {
+      double2* dl = (double2*)(a.L + chol_tile_off(k, k) + rr * GSFM_CB);
+#pragma unroll
+      for (int q = 0; q < GSFM_CB / 2; ++q) dl[q] = make_double2((uint32_t)(2 * q) <= lane ? r[2 * q] : 0.0, (uint32_t)(2 * q + 1) <= lane ? r[2 * q + 1] : 0.0);
+      if (lane == 0 && bad && *a.info == 0) *a.info = (int)(k * GSFM_CB + bad);
+    }
+  } else if (lane >= 32) {
+    double2* dl = (double2*)(a.L + chol_tile_off(i, k) + rr * GSFM_CB);
+#pragma unroll
+    for (int q = 0; q < GSFM_CB / 2; ++q) dl[q] = make_double2(r[2 * q], r[2 * q + 1]);
+  }
+}
+__global__ void __launch_bounds__(64) k_chol_panel(CholArgs a) { chol_panel_body(a); }
+
+// Second half: A_ij -= L_ik L_jk^T for every trailing tile k < j <= i <= T ((T, T) does not exist), one wavefront per tile, on the matrix
+// cores: v_mfma_f64_16x16x4_f64 computes D(16x16) = A(16x4) B(4x16) + C; lane l supplies A[l & 15][l >> 4] and B[l >> 4][l & 15] and holds
+// C/D[(l >> 4) + 4 reg][l & 15], reg = 0..3 (MI355X guide, fragment layout of the f64 form).  A 32 x 32 tile is 2 x 2 such blocks times
+// 8 steps of K = 4; the A operand is -L_ik, the B operand L_jk read row-wise (= L_jk^T column-wise).
+// Block columns k .. k + ncol - 1 of L (ncol = 1 or 2) are folded into the tiles (i, j), j0 <= j <= i <= T -- or, col_only, into the tiles
+// (i, j0) of one block column alone.  Two columns per pass read and write every trailing tile once instead of twice (the update is bound by
+// those 16 KB per tile from ~100 block rows on); the accumulation order per tile -- column k, then column k + 1 -- is the one two separate
+// passes have, so the factor is bit-identical whichever way the host pairs the columns.
+struct CholUpdArgs { double* A; const double* L; uint32_t T, k, j0, col_only; };
+template <int NCOL>
+__global__ void __launch_bounds__(256) k_chol_update_mfma(CholUpdArgs a) {
+  const uint32_t T = a.T, lane = threadIdx.x & 63, j0 = a.j0;
+  const uint64_t b = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const uint32_t m = T - j0 + 1;                          // block rows j0 .. T
+  uint32_t i, j;
+  if (a.col_only) {
+    if (b >= m) return;
+    i = j0 + (uint32_t)b; j = j0;
+  } else {
+    if (b >= (uint64_t)m * (m + 1) / 2) return;
+    uint32_t t = (uint32_t)((sqrt(8.0 * (double)b + 1.0) - 1.0) * 0.5);
+    while ((uint64_t)(t + 1) * (t + 2) / 2 <= b) ++t;
+    while ((uint64_t)t * (t + 1) / 2 > b) --t;
+    i = j0 + t; j = j0 + (uint32_t)(b - (uint64_t)t * (t + 1) / 2);
+  }
+  if (i == T && j == T) return;
+  const uint32_t c = lane & 15, g = lane >> 4;
+  double* Aij = a.A + chol_tile_off(i, j);
+  chol_d4 acc[2][2];
+#pragma unroll
+  for (int si = 0; si < 2; ++si)
+#pragma unroll
+    for (int sj = 0; sj < 2; ++sj)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[si][sj][r] = Aij[(16 * si + g + 4 * r) * GSFM_CB + 16 * sj + c];
+#pragma unroll
+  for (uint32_t cc = 0; cc < (uint32_t)NCOL; ++cc) {
+    const double* Li = a.L + chol_tile_off(i, a.k + cc);
+    const double* Lj = a.L + chol_tile_off(j, a.k + cc);
+    // The contraction index may be dealt to (MFMA step kk, lane group g) in any way, as long as A and B agree: lane group g takes
+    // k = 8 g .. 8 g + 7, eight CONSECUTIVE doubles of a tile row, so the operand loads are 64 contiguous bytes per lane (whole rows per
+    // 4 lanes) instead of eight 8-byte pieces 32 bytes apart.
+    double aop[2][8], bop[2][8];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const double2* ra = (const double2*)(Li + (16 * s + c) * GSFM_CB + 8 * g);
+      const double2* rb = (const double2*)(Lj + (16 * s + c) * GSFM_CB + 8 * g);
+#pragma unroll
+      for (int h = 0; h < 4; ++h) {
+        const double2 va = ra[h], vb = rb[h];
+        aop[s][2 * h] = -va.x; aop[s][2 * h + 1] = -va.y; bop[s][2 * h] = vb.x; bop[s][2 * h + 1] = vb.y;
+      }
+    }
+#pragma unroll
+    for (int si = 0; si < 2; ++si)
+#pragma unroll
+      for (int sj = 0; sj < 2; ++sj)
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) acc[si][sj] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[si][kk], bop[sj][kk], acc[si][sj], 0, 0, 0);
+  }
+#pragma unroll
+  for (int si = 0; si < 2; ++si)
+#pragma unroll
+    for (int sj = 0; sj < 2; ++sj)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Aij[(16 * si + g + 4 * r) * GSFM_CB + 16 * sj + c] = acc[si][sj][r];
+}
+
+// ---- forms of the step of the small matrices measured in round 6 (tools/bench_chol_batch.hip)
 // The trailing update of step k in the FUSED step's arithmetic (round 6; the batched factorisation of several components, where the fused
 // step's repeated eliminations -- two or more per trailing tile -- are what a launch costs once 3 000 tiles of six scenes share it): tile
 // (i, j), k < j <= i <= T, becomes A_ij - L_ik L_jk^T exactly as chol_step_body computes it -- the product first, from zero, eight
