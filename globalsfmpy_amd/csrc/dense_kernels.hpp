@@ -435,10 +435,15 @@ __global__ void __launch_bounds__(256) k_chol_look2_batch(const CholBatchItem* i
 __device__ __forceinline__ void chol_back_block(const double (*Lk)[GSFM_CB + 1], double v, uint32_t lane, double* xk_out, double* x, uint32_t g0, uint32_t n) {
   const uint32_t l = lane & 31;
   const double rinv = 1.0 / Lk[l][l];   // all reciprocals at once, off the dependent chain
+  // (round 6: this lane's column of L_kk in registers before the chain starts -- read inside it, every step waited for its LDS read: 1.64 us per
+  // block row, of which the 32 dependent multiply / broadcast / FMA steps are a third; tools/bench_chol_batch.hip -DGSFM_BACK_TIMING)
+  double col[GSFM_CB];
+#pragma unroll
+  for (int t = 0; t < GSFM_CB; ++t) col[t] = Lk[t][l];
 #pragma unroll
   for (int t = GSFM_CB - 1; t >= 0; --t) {
     const double xt = readlane_f64(v * rinv, t);
-    if (l < (uint32_t)t) v -= Lk[t][l] * xt;
+    if (l < (uint32_t)t) v -= col[t] * xt;
   }
   if (lane < GSFM_CB) { const double mine = v * rinv; xk_out[lane] = mine; if (g0 + lane < n) x[g0 + lane] = mine; }   // lane t was never modified after step t
 }
@@ -450,6 +455,12 @@ __device__ __forceinline__ void chol_back_block(const double (*Lk)[GSFM_CB + 1],
 // did them: the same bits.  That kernel streamed all of L through one CU (135 us at 3N = 1182, 21 % of a Madrid LM iteration); here a group
 // costs its 8 or 16 dependent block rows inside one launch and the bulk of L is read by many CUs at once (2 launches per group).
 struct CholBackGroupArgs { double* L; double* x; uint32_t n, T, k0, k1; };   // x: T * 32 doubles (padded); y_j = first row of tile (T, j) of L
+#ifdef GSFM_BACK_TIMING   // (tools/bench_chol_batch.hip -DGSFM_BACK_TIMING: stamps of wavefront 0 of matrix 1's group kernel, per block row)
+__device__ unsigned long long gsfm_back_ts[64][4];
+#define GSFM_BACK_STAMP(row, n) do { if (blockIdx.y == 1 && threadIdx.x == 0) gsfm_back_ts[row][n] = wall_clock64(); } while (0)
+#else
+#define GSFM_BACK_STAMP(row, n) do { } while (0)
+#endif
 template <int GR>   // block rows per group = wavefronts of the workgroup (8 or 16)
 __device__ __forceinline__ void chol_back_group_body(const CholBackGroupArgs& a) {
   constexpr uint32_t NT = 64 * GR, LOADERS = 32 * (GR - 1), PER = (GSFM_TILE_ELEMS + LOADERS - 1) / LOADERS;
@@ -477,8 +488,11 @@ __device__ __forceinline__ void chol_back_group_body(const CholBackGroupArgs& a)
 #pragma unroll
       for (int i = 0; i < (int)PER; ++i) { const uint32_t e = e0 + LOADERS * i; dv[i] = e < GSFM_TILE_ELEMS ? d[e] : 0.0; }
     }
+    GSFM_BACK_STAMP(k, 0);
     if (wave == 0) chol_back_block(Lk[k & 1], yg[k - k0][c], lane, xk[k & 1], a.x, k * GSFM_CB, a.T * GSFM_CB);
+    GSFM_BACK_STAMP(k, 1);
     __syncthreads();
+    GSFM_BACK_STAMP(k, 2);
     if (tile) {
       double s2 = 0.0;
 #pragma unroll
@@ -490,6 +504,7 @@ __device__ __forceinline__ void chol_back_group_body(const CholBackGroupArgs& a)
       for (int i = 0; i < (int)PER; ++i) { const uint32_t e = e0 + LOADERS * i; if (e < GSFM_TILE_ELEMS) Lk[(k - 1) & 1][e / GSFM_CB][e % GSFM_CB] = dv[i]; }
     }
     __syncthreads();
+    GSFM_BACK_STAMP(k, 3);
   }
 }
 template <int GR>

@@ -113,6 +113,18 @@ int main() {
       CHK(hipGraphExecDestroy(ge)); CHK(hipGraphDestroy(g));
     }
   }
+#ifdef GSFM_BACK_TIMING
+  {   // the backward substitution's group kernel, wavefront 0 of matrix 1 (Madrid's size) alone: per block row
+    const std::vector<int> only = {0, 1, 0, 0, 0, 0};
+    CHK(hipMemcpy(dactive, only.data(), 4 * NI, hipMemcpyHostToDevice));
+    enqueue(LOOK2); CHK(hipStreamSynchronize(st));
+    static unsigned long long ts[64][4];
+    CHK(hipMemcpyFromSymbol(ts, HIP_SYMBOL(gsfm_back_ts), sizeof(ts)));
+    double acc[3] = {0, 0, 0}; int n = 0;
+    for (uint32_t k = 0; k < items[1].T; ++k, ++n) for (int q = 0; q < 3; ++q) acc[q] += (double)(ts[k][q + 1] - ts[k][q]) * 10.0;   // 100 MHz
+    printf("backward substitution, group kernel, matrix 1182 alone, mean per block row over %d rows (ns): 32-step substitution %.0f | barrier %.0f | fold into the group's rows + next diagonal tile into LDS + barrier %.0f\n", n, acc[0] / n, acc[1] / n, acc[2] / n);
+  }
+#endif
 #ifdef GSFM_LOOK_TIMING
   {   // phase stamps of the first row workgroup of matrix 1 (Madrid's size) in every launch of the one-launch-per-column form (last run: that matrix alone)
     const std::vector<int> only = {0, 1, 0, 0, 0, 0};
