@@ -235,6 +235,12 @@ __global__ void __launch_bounds__(256) k_chol_step_batch(const CholBatchItem* it
 // update workgroups).  Per tile the updates arrive in ascending column order, each as "product from zero, then own - product" with the
 // contraction index dealt as 4 kk + g, and the eliminations are chol_eliminate64 on the same rows: the factor is bit-identical to k_chol_step's
 // and k_chol_look's (tools/bench_chol_batch.hip compares every double).
+#ifdef GSFM_LOOK_TIMING   // (tools/bench_chol_batch.hip -DGSFM_LOOK_TIMING: phase stamps of the first row workgroup of matrix 1 in every launch)
+__device__ unsigned long long gsfm_look2_ts[64][8];
+#define GSFM_LOOK2_STAMP(n) do { if (blockIdx.x == 1 && blockIdx.y == 1 && threadIdx.x == 0) gsfm_look2_ts[a.k / 2][n] = wall_clock64(); } while (0)
+#else
+#define GSFM_LOOK2_STAMP(n) do { } while (0)
+#endif
 #define GSFM_LOOK2_NT 2       // trailing tiles per update workgroup: P_i and P_j of two columns for two tiles = the panel's six LDS tiles
 #define GSFM_LOOK2_LDS 6
 template <int PEND, int PROD>
@@ -306,6 +312,7 @@ __device__ __forceinline__ void chol_look2_body(const CholArgs& a, double (*S)[G
     __builtin_amdgcn_s_setprio(3);                 // the chain runs through these wavefronts: ahead of the update workgroups that share the CU
     const bool diag = blockIdx.x == 0;
     const uint32_t i = c0 + PROD - 1 + blockIdx.x;  // (not used by the diagonal workgroup)
+    GSFM_LOOK2_STAMP(0);
     chol_d4 D00 = own_load(c0, c0), D10 = {0.0, 0.0, 0.0, 0.0}, D11 = D10, R0 = D10, R1 = D10;
     if (PROD == 2) { D10 = own_load(c0 + 1, c0); D11 = own_load(c0 + 1, c0 + 1); }
     if (!diag) { R0 = own_load(i, c0); if (PROD == 2) R1 = own_load(i, c0 + 1); }
@@ -325,15 +332,18 @@ __device__ __forceinline__ void chol_look2_body(const CholArgs& a, double (*S)[G
         if (PROD == 2) tile_put(S[1], st[p][1]);
         if (!diag) tile_put(S[2], st[p][2]);
         __syncthreads();
+        if (p == 0) GSFM_LOOK2_STAMP(7);
         D00 = minus_prod(D00, S[0], S[0]);
         if (PROD == 2) { D10 = minus_prod(D10, S[1], S[0]); D11 = minus_prod(D11, S[1], S[1]); }
         if (!diag) { R0 = minus_prod(R0, S[2], S[0]); if (PROD == 2) R1 = minus_prod(R1, S[2], S[1]); }
       }
     }
+    GSFM_LOOK2_STAMP(1);
     quad_put(S[3], D00);
     if (PROD == 2) quad_put(S[4], D10);
     if (!diag) quad_put(S[5], R0);
     __syncthreads();
+    GSFM_LOOK2_STAMP(2);
     if (PROD == 1) {                               // the last column of a matrix with an odd number of them: as k_chol_panel
       if (wave == 0) {
         const uint32_t rr = lane & 31;
@@ -360,7 +370,9 @@ __device__ __forceinline__ void chol_look2_body(const CholArgs& a, double (*S)[G
     // column c0: the rows c0 + 1 (wavefront 0; the diagonal workgroup's lower lanes give L_{c0,c0}) and i (wavefront 1) side by side
     if (wave == 0) eliminate(S[3], S[4], diag, c0);
     else if (wave == 1 && !diag) eliminate(S[3], S[5], false, c0);
+    GSFM_LOOK2_STAMP(3);
     __syncthreads();
+    GSFM_LOOK2_STAMP(4);
     // column c0 into (c0 + 1, c0 + 1) and (i, c0 + 1), then column c0 + 1
     D11 = minus_prod(D11, S[4], S[4]);
     if (!diag) R1 = minus_prod(R1, S[5], S[4]);
@@ -368,6 +380,7 @@ __device__ __forceinline__ void chol_look2_body(const CholArgs& a, double (*S)[G
     if (!diag) quad_put(S[1], R1);
     if (diag) tile_publish(c0 + 1, c0, S[4]); else tile_publish(i, c0, S[5]);
     __syncthreads();
+    GSFM_LOOK2_STAMP(5);
     if (wave == 0) {
       if (diag) eliminate(S[0], S[0], true, c0 + 1);
       else {
@@ -383,6 +396,7 @@ __device__ __forceinline__ void chol_look2_body(const CholArgs& a, double (*S)[G
           for (int q = 0; q < GSFM_CB / 2; ++q) dl[q] = make_double2(r[2 * q], r[2 * q + 1]);
         }
       }
+      GSFM_LOOK2_STAMP(6);
     }
     return;
   }

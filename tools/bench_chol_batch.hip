@@ -126,6 +126,21 @@ int main() {
   }
 #endif
 #ifdef GSFM_LOOK_TIMING
+  {   // the two-column launch: the first row workgroup of matrix 1 (Madrid's size) alone
+    const std::vector<int> only = {0, 1, 0, 0, 0, 0};
+    CHK(hipMemcpy(dactive, only.data(), 4 * NI, hipMemcpyHostToDevice));
+    enqueue(LOOK2); CHK(hipStreamSynchronize(st));
+    static unsigned long long ts[64][8];
+    CHK(hipMemcpyFromSymbol(ts, HIP_SYMBOL(gsfm_look2_ts), sizeof(ts)));
+    double acc[7] = {0, 0, 0, 0, 0, 0, 0}, landed = 0; int n = 0;
+    for (uint32_t g = 1; 2 * g + 3 <= items[1].T; ++g, ++n) {   // launches c0 = 2, 4, ...: two pending columns, two produced, a row workgroup exists
+      for (int q = 1; q < 7; ++q) acc[q] += (double)(ts[g][q] - ts[g][q - 1]) * 10.0;
+      landed += (double)(ts[g][7] - ts[g][0]) * 10.0;
+      if (2 * (g + 1) + 3 <= items[1].T) acc[0] += (double)(ts[g + 1][0] - ts[g][6]) * 10.0;
+    }
+    printf("two columns per launch, row workgroup, matrix 1182 alone, mean over %d launches (ns): loads + two pending columns on the fly %.0f (of which until the first operands are in LDS: %.0f) | tiles to LDS + barrier %.0f | elimination of column c0 %.0f | barrier %.0f | column c0 into c0 + 1, publish, barrier %.0f | elimination of column c0 + 1 + store %.0f | end -> start of the next %.0f\n",
+           n, acc[1] / n, landed / n, acc[2] / n, acc[3] / n, acc[4] / n, acc[5] / n, acc[6] / n, acc[0] / std::max(1, n - 1));
+  }
   {   // phase stamps of the first row workgroup of matrix 1 (Madrid's size) in every launch of the one-launch-per-column form (last run: that matrix alone)
     const std::vector<int> only = {0, 1, 0, 0, 0, 0};
     CHK(hipMemcpy(dactive, only.data(), 4 * NI, hipMemcpyHostToDevice));
