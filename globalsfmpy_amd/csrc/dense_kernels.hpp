@@ -14,8 +14,12 @@
 //     ONE fused kernel per column in which every trailing tile's workgroup repeated the eliminations it needed (two to three per tile:
 //     k_chol_step, kept behind GSFM_CHOL_FUSED=1 as the reference of the bit-identity test) -- the six scenes of C4 side by side 985 -> 660 us
 //     per factorisation + solve, Madrid's matrix alone 519 -> 444, every double of L, y and x the same (tools/bench_chol_batch.hip);
-//   * L goes to a second buffer (a workgroup's inputs A_kk, A_ik, A_jk are never written during step k, so there is no race);
-//   * the backward substitution L^T x = y is one workgroup sweeping the block rows of L bottom-up.
+//   * L goes to a second buffer, and what a launch reads of A and L nobody writes in that launch (the panel workgroups read the columns
+//     c0, c0 + 1 of A and the pending columns of L, and write the columns c0, c0 + 1 of L; the update workgroups write the columns >= c0 + 2
+//     of A): no race, no ordering between workgroups;
+//   * the backward substitution L^T x = y runs in groups of 8 block rows: one workgroup solves a group (a wavefront per block row: the
+//     32-step substitution with the diagonal tile's column in registers, the others folding x_k into the group's rows), one launch folds the
+//     group's x into all block rows above it.
 // The same schedule serves every size up to GSFM_DENSE_MAX_T block columns (round 6; until then matrices beyond 64 block columns ran a panel
 // kernel and a separate trailing update per step: 3N = 2400 / 4500 / 9000 1.25 -> 0.89, 3.11 -> 2.25, 13.2 -> 11.8 ms per factorise + solve,
 // tools/bench_chol_large.hip -- those kernels now live in tools/chol_variants.hpp).  The trailing updates are fp64 MFMA, everything else fp64 VALU.
