@@ -231,7 +231,7 @@ typedef struct {
                                           dense_cholesky_max_cams and at most this many cameras start on PCG and switch to exact Cholesky steps --
                                           what the reference does for every graph, estimator.cpp:300 -- from the moment one PCG-solved step has
                                           cost more time (elapsed, host clock around the solve) than 1.25 x the factorisation of their size is measured to take on
-                                          MI355X (0.45 ms at 394 cameras, 1.33 at 800, 3.27 at 1500, 13.5 at 3000; tools/bench_chol.hip).  Easy
+                                          MI355X (0.40 ms at 394 cameras, 0.89 at 800, 2.25 at 1500, 11.8 at 3000; tools/bench_chol_large.hip).  Easy
                                           graphs (a few dozen PCG iterations per step) never switch; Madrid-like ones (hundreds) do after their
                                           first step.  Ignored for sharded problems and when dense_cholesky_max_cams < 0. */
   double pcg_forcing_tolerance;        /* default 1e-8 rad: largest estimated rms deviation of an inexact step from the exact one (or 5e-6 x the squared
