@@ -74,7 +74,10 @@ int main() {
         else hipLaunchKernelGGL(k_chol_step_batch<1>, grid, dim3(256), 0, st, (const CholBatchItem*)ditems, k);
       }
     }
-    constexpr uint32_t GR = 8;
+#ifndef BACK_GR
+#define BACK_GR 8
+#endif
+    constexpr uint32_t GR = BACK_GR;   // (-DBACK_GR=16: groups of 16 block rows, the A/B of rounds 3 and 6)
     for (uint32_t g = 0; g * GR < Tmax; ++g) {
       hipLaunchKernelGGL(k_chol_back_group_batch<GR>, dim3(1, NI), dim3(64 * GR), 0, st, (const CholBatchItem*)ditems, g);
       const uint32_t k1 = Tmax - g * GR, k0 = k1 > GR ? k1 - GR : 0;
